@@ -1,0 +1,706 @@
+/*
+ * gx_oracle.c -- TEST INFRASTRUCTURE ONLY (see gx_oracle.h).
+ *
+ * CPU restatement of guardX safe_rl_envs Engine (reset / step / reset_done)
+ * for the Goal_Point_<N>Hazards family, fp32, one plain loop per env.
+ * "engine.py:NNN" cites /root/reference/safe_rl_envs/safe_rl_envs/envs/engine.py.
+ * "[derived]" marks MuJoCo/MJX/JAX semantics taken from their published
+ * algorithms (third-party, unpinned in requirements.txt:3-4, absent here).
+ *
+ * PARITY UNPINNED except for the PRNG block function / split ordering.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: every fp32 operation
+ * below is a single IEEE operation unless written as fmaf()).
+ */
+#include "gx_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ */
+/* deterministic fp32 math (coefficients: tools/fit_math.py)           */
+/* ------------------------------------------------------------------ */
+static const float TWO_OVER_PI = 0.6366197466850281f;
+static const float PIO2_HI = 1.5707963705062866f;
+static const float PIO2_MID = -4.371138828673793e-08f;
+static const float PIO2_LO = -1.7151245100058819e-15f;
+static const float PI_F = 3.1415927410125732f;
+static const float TWO_PI_F = 6.2831854820251465f; /* f32(2*pi) */
+static const float LOG2E = 1.4426950216293335f;
+static const float LN2_HI = 0.6931471824645996f;
+static const float LN2_LO = -1.9046542121259336e-09f;
+
+static float bits_to_f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static uint32_t f_to_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/* sin/cos by 3-term Cody-Waite reduction to [-pi/4,pi/4] + minimax polys. */
+static void gx_sincos(float x, float* s, float* c)
+{
+    if (!(fabsf(x) <= 16777216.0f)) x = x * 0.0f; /* inf/nan -> nan, huge -> 0 */
+    float k = rintf(x * TWO_OVER_PI);
+    float r = fmaf(-k, PIO2_HI, x);
+    r = fmaf(-k, PIO2_MID, r);
+    r = fmaf(-k, PIO2_LO, r);
+    float z = r * r;
+    float ps = fmaf(z, -0.00019488747f, 0.008331924f);
+    ps = fmaf(z, ps, -0.1666665f);
+    float S = fmaf(r * z, ps, r);
+    float pc = fmaf(z, 2.4431205e-05f, -0.0013887306f);
+    pc = fmaf(z, pc, 0.041666646f);
+    float C = fmaf(z * z, pc, fmaf(z, -0.5f, 1.0f));
+    int q = ((int)k) & 3; /* |k| <= 2^24*0.64: exact */
+    float ss = (q & 1) ? C : S;
+    float cc = (q & 1) ? S : C;
+    if (q == 1 || q == 2) cc = -cc;
+    if (q >= 2) ss = -ss;
+    if (x != x) { ss = x; cc = x; }
+    *s = ss;
+    *c = cc;
+}
+
+/* atan2 with one division and a degree-7 (in a^2) minimax polynomial. */
+static float gx_atan2(float y, float x)
+{
+    if (x != x || y != y) return x + y;
+    float ax = fabsf(x), ay = fabsf(y);
+    float mx = ax > ay ? ax : ay;
+    float mn = ax > ay ? ay : ax;
+    float a;
+    if (mx == 0.0f) a = 0.0f;
+    else if (mx == INFINITY) a = (mn == INFINITY) ? 1.0f : 0.0f;
+    else a = mn / mx;
+    float z = a * a;
+    float p = fmaf(z, 0.0026222442f, -0.015132535f);
+    p = fmaf(z, p, 0.04112186f);
+    p = fmaf(z, p, -0.07366706f);
+    p = fmaf(z, p, 0.10573932f);
+    p = fmaf(z, p, -0.14185975f);
+    p = fmaf(z, p, 0.19990396f);
+    p = fmaf(z, p, -0.33332986f);
+    float t = fmaf(a * z, p, a);
+    if (ay > ax) t = PIO2_HI - t;
+    if (f_to_bits(x) >> 31) t = PI_F - t;
+    return (f_to_bits(y) >> 31) ? -t : t;
+}
+
+/* exp for the lidar sensor.  Values below exp(-87) (< 1.7e-38) flush to 0. */
+static float gx_exp(float x)
+{
+    if (x != x) return x;
+    if (x < -87.0f) return 0.0f;
+    if (x > 88.0f) return INFINITY;
+    float k = rintf(x * LOG2E);
+    float r = fmaf(-k, LN2_HI, x);
+    r = fmaf(-k, LN2_LO, r);
+    float q = fmaf(r, 0.001395172f, 0.008369599f);
+    q = fmaf(r, q, 0.041666187f);
+    q = fmaf(r, q, 0.16666512f);
+    q = fmaf(r, q, 0.5f);
+    float t = fmaf(r * r, q, r);
+    float e = 1.0f + t;
+    int ki = (int)k;
+    return bits_to_f(f_to_bits(e) + ((uint32_t)ki << 23));
+}
+
+/* jnp.maximum: NaN-propagating */
+static float gx_max(float a, float b) { return (a > b || a != a) ? a : b; }
+
+void gxo_math_probe(int32_t n, const float* x, const float* y, float* s, float* c,
+                    float* at2, float* ex)
+{
+    for (int i = 0; i < n; ++i) {
+        gx_sincos(x[i], &s[i], &c[i]);
+        at2[i] = gx_atan2(y[i], x[i]);
+        ex[i] = gx_exp(x[i]);
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* jax.random restatement [derived: jax/_src/prng.py, random.py]        */
+/* ------------------------------------------------------------------ */
+static uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+/* Threefry-2x32, 20 rounds (Salmon et al. 2011; jax threefry2x32_p). */
+static void threefry2x32(uint32_t k0, uint32_t k1, uint32_t x0, uint32_t x1,
+                         uint32_t* o0, uint32_t* o1)
+{
+    static const int R[2][4] = {{13, 15, 26, 6}, {17, 29, 16, 24}};
+    uint32_t ks[3] = {k0, k1, k0 ^ k1 ^ 0x1BD11BDAu};
+    x0 += ks[0];
+    x1 += ks[1];
+    for (int i = 0; i < 5; ++i) {
+        for (int j = 0; j < 4; ++j) {
+            x0 += x1;
+            x1 = rotl32(x1, R[i & 1][j]);
+            x1 ^= x0;
+        }
+        x0 += ks[(i + 1) % 3];
+        x1 += ks[(i + 2) % 3] + (uint32_t)(i + 1);
+    }
+    *o0 = x0;
+    *o1 = x1;
+}
+
+void gxo_threefry2x32(uint32_t k0, uint32_t k1, uint32_t x0, uint32_t x1, uint32_t* out2)
+{
+    threefry2x32(k0, k1, x0, x1, &out2[0], &out2[1]);
+}
+
+/* element i of threefry_2x32(key, iota(n)): the count vector (padded to even
+ * length) is cut in halves that feed the two block inputs; outputs are
+ * concatenated [derived: prng.py threefry_2x32]. */
+static uint32_t tf_bits_at(const uint32_t key[2], uint32_t n, uint32_t i)
+{
+    uint32_t half = (n + 1u) / 2u, o0, o1;
+    if (i < half) {
+        uint32_t hi = i + half;
+        threefry2x32(key[0], key[1], i, hi < n ? hi : 0u, &o0, &o1);
+        return o0;
+    }
+    threefry2x32(key[0], key[1], i - half, i, &o0, &o1);
+    return o1;
+}
+
+/* jax.random.split(key, n)[j] = flat[2j], flat[2j+1], flat = bits over iota(2n) */
+static void split_at(const uint32_t key[2], uint32_t n, uint32_t j, uint32_t out[2])
+{
+    out[0] = tf_bits_at(key, 2u * n, 2u * j);
+    out[1] = tf_bits_at(key, 2u * n, 2u * j + 1u);
+}
+
+void gxo_split(const uint32_t* key, int32_t n, uint32_t* out_2n)
+{
+    for (int32_t j = 0; j < n; ++j) split_at(key, (uint32_t)n, (uint32_t)j, &out_2n[2 * j]);
+}
+
+/* jax.random.uniform(key, (), f32, minval, maxval) [derived: random.py _uniform] */
+static float uniform_f32(const uint32_t key[2], float minval, float maxval)
+{
+    uint32_t bits = tf_bits_at(key, 1u, 0u);
+    float f = bits_to_f((bits >> 9) | 0x3F800000u) - 1.0f;
+    float v = f * (maxval - minval) + minval;
+    return v > minval ? v : minval; /* lax.max(minval, v) */
+}
+
+float gxo_uniform(const uint32_t* key, float minval, float maxval)
+{
+    return uniform_f32(key, minval, maxval);
+}
+
+/* jax.random.randint(key, (n,), 0, span) element i [derived: random.py _randint] */
+static uint32_t randint_at(const uint32_t k1[2], const uint32_t k2[2], uint32_t n,
+                           uint32_t span, uint32_t i)
+{
+    uint32_t hi = tf_bits_at(k1, n, i), lo = tf_bits_at(k2, n, i);
+    uint32_t mult = 65536u % span;
+    mult = (mult * mult) % span;
+    uint32_t off = (hi % span) * mult + (lo % span);
+    return off % span;
+}
+
+void gxo_randint(const uint32_t* key, int32_t n, uint32_t span, int32_t* out_n)
+{
+    uint32_t k1[2], k2[2];
+    split_at(key, 2, 0, k1);
+    split_at(key, 2, 1, k2);
+    if (span == 0) span = 1;
+    for (int32_t i = 0; i < n; ++i)
+        out_n[i] = (int32_t)randint_at(k1, k2, (uint32_t)n, span, (uint32_t)i);
+}
+
+/* ------------------------------------------------------------------ */
+/* engine state                                                         */
+/* ------------------------------------------------------------------ */
+/* Point robot constants [derived from xmls/point.xml:3,5,16-20,37-39; SURVEY
+ * Appendix B]: sphere r=.1 + box half .05 at (.1,0,0), density 1. */
+#define PT_H 0.02f              /* point.xml:3 timestep */
+#define PT_M 0.005188790204786391f
+#define PT_MXC 0.0001f          /* mass * com offset along body x */
+#define PT_IO 2.842182748581224e-05f /* inertia about the hinge axis */
+#define PT_DXY 0.01f            /* point.xml:16-17 damping */
+#define PT_DT 0.005f            /* point.xml:18 */
+#define PT_GEAR 0.3f            /* point.xml:37-39 */
+
+struct gxo_env {
+    gxo_config cfg;
+    int N, H, NOBJ, D, bins;
+    int off_acc, off_ctrl, off_comp, off_glidar, off_hlidar, off_qpos, off_qvel, off_vel;
+    float *qpos, *qvel, *pose0, *pose1, *objs; /* env-major */
+    float *done0, *done1, *done2, *steps, *obs;
+    float* pool; /* valid layouts, rows of (H+2)*2 */
+    int layout_size;
+    uint32_t key[2];
+    int hist; /* number of step() calls so far, saturating at 2 (None-ness) */
+};
+
+static int g_threads = 0;
+void gxo_set_threads(int32_t n) { g_threads = n; }
+int gxo_get_threads(void)
+{
+#ifdef _OPENMP
+    return g_threads > 0 ? g_threads : omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+int gxo_obs_dim(const gxo_env* e) { return e->D; }
+int gxo_layout_size(const gxo_env* e) { return e->layout_size; }
+
+int gxo_create(const gxo_config* cfg, gxo_env** out)
+{
+    if (!cfg || !out || cfg->struct_size != (int32_t)sizeof(gxo_config)) return GXO_ERR_ARG;
+    if (cfg->robot != 0) return GXO_ERR_UNSUPPORTED;
+    if (cfg->env_num < 1 || cfg->hazards_num < 1 || cfg->hazards_num > 64) return GXO_ERR_ARG;
+    if (cfg->lidar_num_bins < 3 || cfg->lidar_num_bins > 64) return GXO_ERR_ARG;
+    if (cfg->env_offset < 0 || cfg->env_offset + cfg->env_num > cfg->env_total) return GXO_ERR_ARG;
+    gxo_env* e = (gxo_env*)calloc(1, sizeof(gxo_env));
+    e->cfg = *cfg;
+    e->N = cfg->env_num;
+    e->H = cfg->hazards_num;
+    e->NOBJ = 1 + e->H;
+    e->bins = cfg->lidar_num_bins;
+    /* flat obs = concat over sorted(obs_space_dict keys)  engine.py:386-409,773-777 */
+    int o = 0;
+    e->off_acc = e->off_ctrl = e->off_comp = e->off_glidar = e->off_hlidar = -1;
+    e->off_qpos = e->off_qvel = e->off_vel = -1;
+    if (cfg->observe_acc) { e->off_acc = o; o += 2; }
+    if (cfg->observe_ctrl) { e->off_ctrl = o; o += 3; }
+    if (cfg->observe_goal_comp) { e->off_comp = o; o += 2; }
+    if (cfg->observe_goal_lidar) { e->off_glidar = o; o += e->bins; }
+    if (cfg->observe_hazards) { e->off_hlidar = o; o += e->bins; }
+    if (cfg->observe_qpos) { e->off_qpos = o; o += 3; }
+    if (cfg->observe_qvel) { e->off_qvel = o; o += 3; }
+    if (cfg->observe_vel) { e->off_vel = o; o += 2; }
+    e->D = o;
+    int N = e->N;
+    e->qpos = (float*)calloc((size_t)N * 3, 4);
+    e->qvel = (float*)calloc((size_t)N * 3, 4);
+    e->pose0 = (float*)calloc((size_t)N * 4, 4);
+    e->pose1 = (float*)calloc((size_t)N * 2, 4);
+    e->objs = (float*)calloc((size_t)N * e->NOBJ * 2, 4);
+    e->done0 = (float*)calloc(N, 4);
+    e->done1 = (float*)calloc(N, 4);
+    e->done2 = (float*)calloc(N, 4);
+    e->steps = (float*)calloc(N, 4);
+    e->obs = (float*)calloc((size_t)N * (e->D > 0 ? e->D : 1), 4);
+    for (int i = 0; i < N; ++i) { e->pose0[4 * i + 2] = 1.0f; }
+    /* PRNGKey(seed) = (seed >> 32, seed & 0xffffffff)  engine.py:216 */
+    e->key[0] = 0u;
+    e->key[1] = cfg->seed;
+    e->hist = 0;
+    *out = e;
+    return GXO_OK;
+}
+
+void gxo_destroy(gxo_env* e)
+{
+    if (!e) return;
+    free(e->qpos); free(e->qvel); free(e->pose0); free(e->pose1); free(e->objs);
+    free(e->done0); free(e->done1); free(e->done2); free(e->steps); free(e->obs);
+    free(e->pool);
+    free(e);
+}
+
+/* ------------------------------------------------------------------ */
+/* layout sampling  engine.py:433-452, 546-621                          */
+/* ------------------------------------------------------------------ */
+static double obj_keepout(const gxo_config* c, int obj, int nobj_total)
+{
+    /* placements order: goal, hazard0.., robot  engine.py:533-544 */
+    if (obj == 0) return c->goal_keepout;
+    if (obj == nobj_total - 1) return c->robot_keepout;
+    return c->hazards_keepout;
+}
+
+/* engine.py:546-572 for one candidate key; xy holds (H+2)*2 floats. */
+static int sample_layout(const gxo_config* c, const uint32_t key[2], float* xy)
+{
+    const int nobj = c->hazards_num + 2;
+    uint32_t rng[2] = {key[0], key[1]};
+    int success = 1;
+    for (int o = 0; o < nobj; ++o) {
+        double k = obj_keepout(c, o, nobj);
+        /* constrain_placement  engine.py:574-577 (python floats -> f32 bounds) */
+        float xmin = (float)(c->extents[0] + k), ymin = (float)(c->extents[1] + k);
+        float xmax = (float)(c->extents[2] - k), ymax = (float)(c->extents[3] - k);
+        int conflicted = 1;
+        float px = -INFINITY, py = -INFINITY;
+        for (int t = 0; t < 10; ++t) { /* engine.py:562 */
+            uint32_t nrng[2], rng1[2], r1[2], r2[2];
+            split_at(rng, 2, 0, nrng); /* rng, rng1 = split(rng, 2)  :563 */
+            split_at(rng, 2, 1, rng1);
+            rng[0] = nrng[0]; rng[1] = nrng[1];
+            split_at(rng1, 2, 0, r1);  /* draw_placement :618 */
+            split_at(rng1, 2, 1, r2);
+            float cx = uniform_f32(r1, xmin, xmax); /* :619 */
+            float cy = uniform_f32(r2, ymin, ymax); /* :620 */
+            int flag = 1; /* placement_is_valid :549-555 */
+            for (int p = 0; p < o; ++p) {
+                float dx = cx - xy[2 * p], dy = cy - xy[2 * p + 1];
+                float dist = sqrtf(dx * dx + dy * dy);
+                float thr = (float)(obj_keepout(c, p, nobj) + c->placements_margin + k);
+                if (dist < thr) flag = 0;
+            }
+            if (flag) { px = cx; py = cy; conflicted = 0; } /* :566-567 */
+        }
+        xy[2 * o] = px; xy[2 * o + 1] = py;
+        if (conflicted) success = 0; /* :569 */
+    }
+    float dx = xy[2 * (nobj - 1)] - xy[0], dy = xy[2 * (nobj - 1) + 1] - xy[1];
+    float d = sqrtf(dx * dx + dy * dy);
+    if (d < c->robot_goal_min_dist) success = 0; /* :570-571 */
+    return success;
+}
+
+/* reset_layout  engine.py:433-444 */
+static int reset_layout(gxo_env* e)
+{
+    const int M = e->cfg.n_candidates, row = (e->H + 2) * 2;
+    unsigned char* ok = (unsigned char*)malloc((size_t)M);
+    float* all = (float*)malloc((size_t)M * row * 4);
+    const uint32_t* key = e->key;
+    const gxo_config* c = &e->cfg;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(gxo_get_threads())
+    for (int j = 0; j < M; ++j) {
+        uint32_t kj[2];
+        split_at(key, (uint32_t)M, (uint32_t)j, kj); /* split(rng, 1e6)  :263 */
+        ok[j] = (unsigned char)sample_layout(c, kj, &all[(size_t)j * row]);
+    }
+    int L = 0;
+    for (int j = 0; j < M; ++j) L += ok[j];
+    free(e->pool);
+    e->pool = (float*)malloc((size_t)(L > 0 ? L : 1) * row * 4);
+    int w = 0;
+    for (int j = 0; j < M; ++j) /* idx = where(success > 0)[0]  :436 */
+        if (ok[j]) memcpy(&e->pool[(size_t)(w++) * row], &all[(size_t)j * row], (size_t)row * 4);
+    e->layout_size = L;
+    free(ok);
+    free(all);
+    return L > e->cfg.env_total ? GXO_OK : GXO_ERR_LAYOUT; /* assert :444 */
+}
+
+/* ------------------------------------------------------------------ */
+/* physics + observation                                                */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    float x, y, th, vx, vy, om;
+} ptstate;
+
+/* One mjx.step for the Point robot [derived, SURVEY Appendix B]:
+ * forward(qpos,qvel,ctrl) -> pose, qacc ; Euler with implicit joint damping. */
+static void point_substep(ptstate* s, const float ctrl[3], float pose[4], float qacc[3])
+{
+    /* kinematics: hinge quaternion (cos th/2, 0,0, sin th/2) -> xmat */
+    float sh, ch;
+    gx_sincos(0.5f * s->th, &sh, &ch);
+    float c = ch * ch - sh * sh;
+    float sn = 2.0f * (ch * sh);
+    pose[0] = s->x; pose[1] = s->y; pose[2] = c; pose[3] = sn;
+    /* joint-space inertia M = [[m,0,b],[0,m,d],[b,d,Io]] */
+    float b = -(PT_MXC * sn), d = PT_MXC * c;
+    float w2 = s->om * s->om;
+    /* qfrc_smooth = passive - bias + actuator */
+    float fx = (-(PT_DXY * s->vx) - (-(d * w2))) + PT_GEAR * ctrl[0];
+    float fy = (-(PT_DXY * s->vy) - (b * w2)) + PT_GEAR * ctrl[1];
+    float ft = (-(PT_DT * s->om) - 0.0f) + PT_GEAR * ctrl[2];
+    float t = b * fx + d * fy;
+    float s2 = b * b + d * d;
+    /* data.qacc = M^-1 f (no damping in M) */
+    {
+        const float ia = (float)(1.0 / 0.005188790204786391);
+        float y3 = ft - t * ia;
+        float d3 = PT_IO - s2 * ia;
+        float q3 = y3 / d3;
+        qacc[0] = (fx - b * q3) * ia;
+        qacc[1] = (fy - d * q3) * ia;
+        qacc[2] = q3;
+    }
+    /* Euler, damping implicit: (M + h D) qa = f */
+    const float ia = (float)(1.0 / (0.005188790204786391 + 0.02 * 0.01));
+    const float ei = (float)(2.842182748581224e-05 + 0.02 * 0.005);
+    float y3 = ft - t * ia;
+    float d3 = ei - s2 * ia;
+    float q3 = y3 / d3;
+    float q1 = (fx - b * q3) * ia;
+    float q2 = (fy - d * q3) * ia;
+    s->vx = s->vx + PT_H * q1;
+    s->vy = s->vy + PT_H * q2;
+    s->om = s->om + PT_H * q3;
+    s->x = s->x + PT_H * s->vx;
+    s->y = s->y + PT_H * s->vy;
+    s->th = s->th + PT_H * s->om;
+}
+
+/* obs_lidar engine.py:846-900 over `n` objects (xy pairs), pose=(x,y,c,s). */
+static void obs_lidar(const gxo_env* e, const float pose[4], const float* objs, int n, float* out)
+{
+    const int B = e->bins;
+    const float bin_size = (float)((M_PI * 2) / B); /* :880 weak-typed python float */
+    for (int b = 0; b < B; ++b) out[b] = 0.0f;
+    for (int o = 0; o < n; ++o) {
+        float dx = objs[2 * o] - pose[0], dy = objs[2 * o + 1] - pose[1];
+        /* ego_xy :817-826: world_3vec @ R, R = [[c,-s,0],[s,c,0],[0,0,1]] */
+        float zx = dx * pose[2] + dy * pose[3];
+        float zy = dx * (-pose[3]) + dy * pose[2];
+        float dist = sqrtf(zx * zx + zy * zy); /* :878 */
+        float ang = gx_atan2(zy, zx);          /* :879 */
+        if (ang != 0.0f && ang < 0.0f) ang = ang + TWO_PI_F; /* jnp.remainder */
+        int bin;
+        float q = ang / bin_size;
+        if (!(q >= 0.0f)) bin = 0; /* NaN: defined as 0 (obs carries NaN anyway) */
+        else if (q >= (float)B) bin = B;
+        else bin = (int)q; /* :882 */
+        float bin_angle = bin_size * (float)bin; /* :883 */
+        float sensor;
+        if (!e->cfg.lidar_max_dist_set)
+            sensor = gx_exp((-e->cfg.lidar_exp_gain) * dist); /* :886 */
+        else
+            sensor = gx_max(0.0f, e->cfg.lidar_max_dist - dist) / e->cfg.lidar_max_dist; /* :888 */
+        /* obs[bin] read clamps, out-of-range scatter is dropped [derived: jnp indexing] */
+        if (bin < B) out[bin] = gx_max(out[bin], sensor); /* :889-890 */
+        if (e->cfg.lidar_alias) {                          /* :893-899 */
+            float alias = (ang - bin_angle) / bin_size;
+            int bp = (bin + 1) % B, bm = (bin - 1 + B) % B;
+            out[bp] = gx_max(out[bp], alias * sensor);
+            out[bm] = gx_max(out[bm], (1.0f - alias) * sensor);
+        }
+    }
+}
+
+/* Engine.obs engine.py:738-778 -> flat row.  vel/acc passed in. */
+static void build_obs(const gxo_env* e, const float pose[4], const float* objs,
+                      const float ctrl[3], const ptstate* s, const float vel[2],
+                      const float acc[2], float* row)
+{
+    if (e->off_acc >= 0) { row[e->off_acc] = acc[0]; row[e->off_acc + 1] = acc[1]; }
+    if (e->off_ctrl >= 0) { for (int i = 0; i < 3; ++i) row[e->off_ctrl + i] = ctrl[i]; }
+    if (e->off_comp >= 0) { /* obs_compass :834-844 */
+        float dx = objs[0] - pose[0], dy = objs[1] - pose[1];
+        row[e->off_comp] = dx * pose[2] + dy * pose[3];
+        row[e->off_comp + 1] = dx * (-pose[3]) + dy * pose[2];
+    }
+    if (e->off_glidar >= 0) obs_lidar(e, pose, objs, 1, &row[e->off_glidar]);
+    if (e->off_hlidar >= 0) obs_lidar(e, pose, objs + 2, e->H, &row[e->off_hlidar]);
+    if (e->off_qpos >= 0) { row[e->off_qpos] = s->x; row[e->off_qpos + 1] = s->y; row[e->off_qpos + 2] = s->th; }
+    if (e->off_qvel >= 0) { row[e->off_qvel] = s->vx; row[e->off_qvel + 1] = s->vy; row[e->off_qvel + 2] = s->om; }
+    if (e->off_vel >= 0) { row[e->off_vel] = vel[0]; row[e->off_vel + 1] = vel[1]; }
+}
+
+static float dist_goal(const float* objs, const float* pose_xy)
+{
+    float dx = objs[0] - pose_xy[0], dy = objs[1] - pose_xy[1]; /* goal_pos :780-785 */
+    return sqrtf(dx * dx + dy * dy);
+}
+
+static void load_layout(gxo_env* e, int i, const float* lay)
+{
+    /* layout2qpos engine.py:623-639: goal, hazards -> their slide joints; robot -> qpos[0:2] */
+    memcpy(&e->objs[(size_t)i * e->NOBJ * 2], lay, (size_t)e->NOBJ * 2 * 4);
+    e->qpos[3 * i] = lay[2 * e->NOBJ];
+    e->qpos[3 * i + 1] = lay[2 * e->NOBJ + 1];
+    e->qpos[3 * i + 2] = 0.0f;
+    e->qvel[3 * i] = e->qvel[3 * i + 1] = e->qvel[3 * i + 2] = 0.0f;
+}
+
+/* get_layout engine.py:446-452: idx = randint(key, (env_num,), 0, layout_size) */
+static void layout_indices(const gxo_env* e, uint32_t* idx)
+{
+    uint32_t k1[2], k2[2];
+    split_at(e->key, 2, 0, k1);
+    split_at(e->key, 2, 1, k2);
+    uint32_t span = e->layout_size > 0 ? (uint32_t)e->layout_size : 1u;
+    for (int i = 0; i < e->N; ++i)
+        idx[i] = randint_at(k1, k2, (uint32_t)e->cfg.env_total, span,
+                            (uint32_t)(e->cfg.env_offset + i));
+}
+
+int gxo_reset(gxo_env* e, float* obs)
+{
+    int rc = reset_layout(e); /* :457 */
+    if (rc != GXO_OK && e->layout_size < 1) return rc;
+    uint32_t* idx = (uint32_t*)malloc((size_t)e->N * 4);
+    layout_indices(e, idx); /* :458 */
+    const int row = (e->H + 2) * 2;
+    const float zero3[3] = {0, 0, 0}, zero2[2] = {0, 0};
+    for (int i = 0; i < e->N; ++i) {
+        load_layout(e, i, &e->pool[(size_t)idx[i] * row]);
+        /* mjx_reset :644-657: ctrl=0, mjx.forward -> pose(qpos), obs without history */
+        ptstate s = {e->qpos[3 * i], e->qpos[3 * i + 1], 0.0f, 0.0f, 0.0f, 0.0f};
+        float sh, ch;
+        gx_sincos(0.5f * s.th, &sh, &ch);
+        float* p0 = &e->pose0[4 * i];
+        p0[0] = s.x; p0[1] = s.y; p0[2] = ch * ch - sh * sh; p0[3] = 2.0f * (ch * sh);
+        build_obs(e, p0, &e->objs[(size_t)i * e->NOBJ * 2], zero3, &s, zero2, zero2,
+                  &e->obs[(size_t)i * e->D]);
+        e->steps[i] = 0.0f; /* :463 */
+    }
+    free(idx);
+    memcpy(obs, e->obs, (size_t)e->N * e->D * 4);
+    return rc;
+}
+
+int gxo_step(gxo_env* e, const float* action, float* obs, float* reward, float* cost,
+             float* done, float* qacc_out)
+{
+    const int N = e->N, D = e->D, H = e->H;
+    /* update_data :426-431 */
+    memcpy(e->done2, e->done1, (size_t)N * 4);
+    memcpy(e->done1, e->done0, (size_t)N * 4);
+    {
+        uint32_t nk[2];
+        split_at(e->key, 2, 0, nk);
+        e->key[0] = nk[0]; e->key[1] = nk[1];
+    }
+    const int have_last = e->hist >= 1, have_last_last = e->hist >= 2;
+    const float dt = PT_H * (float)e->cfg.physics_steps; /* :235 */
+#pragma omp parallel for schedule(static) num_threads(gxo_get_threads()) if (N >= 4096)
+    for (int i = 0; i < N; ++i) {
+        float* p0 = &e->pose0[4 * i];
+        float* p1 = &e->pose1[2 * i];
+        const float* objs = &e->objs[(size_t)i * e->NOBJ * 2];
+        float P1[2] = {p0[0], p0[1]};   /* last_data.xpos */
+        float P2[2] = {p1[0], p1[1]};   /* last_last_data.xpos */
+        /* convert_action :672-685 with the PRE-step xmat */
+        float a0 = action[2 * i], a1 = action[2 * i + 1];
+        float ctrl[3] = {p0[2] * a0, p0[3] * a0, a1};
+        ptstate s = {e->qpos[3 * i], e->qpos[3 * i + 1], e->qpos[3 * i + 2],
+                     e->qvel[3 * i], e->qvel[3 * i + 1], e->qvel[3 * i + 2]};
+        float pose[4], qacc[3];
+        for (int k = 0; k < e->cfg.physics_steps; ++k) point_substep(&s, ctrl, pose, qacc); /* :689 */
+        /* ego_vel_acc :902-929 */
+        float vel[2] = {0, 0}, acc[2] = {0, 0};
+        if (e->off_vel >= 0 || e->off_acc >= 0) {
+            float pl[2] = {pose[0], pose[1]}, pll[2] = {pose[0], pose[1]};
+            float ld = e->done1[i], lld = e->done2[i];
+            if (have_last) {
+                if (!(ld > 0.0f)) { pl[0] = P1[0]; pl[1] = P1[1]; }
+                if (have_last_last) {
+                    if (lld + ld > 0.0f) { pll[0] = pl[0]; pll[1] = pl[1]; }
+                    else { pll[0] = P2[0]; pll[1] = P2[1]; }
+                }
+            }
+            float vw[2], lvw[2], aw[2];
+            for (int k = 0; k < 2; ++k) {
+                vw[k] = (pose[k] - pl[k]) / dt;
+                lvw[k] = (pl[k] - pll[k]) / dt;
+                aw[k] = (vw[k] - lvw[k]) / dt;
+            }
+            vel[0] = vw[0] * pose[2] + vw[1] * pose[3];
+            vel[1] = vw[0] * (-pose[3]) + vw[1] * pose[2];
+            acc[0] = aw[0] * pose[2] + aw[1] * pose[3];
+            acc[1] = aw[0] * (-pose[3]) + aw[1] * pose[2];
+        }
+        float* row = &e->obs[(size_t)i * D];
+        build_obs(e, pose, objs, ctrl, &s, vel, acc, row); /* :690 */
+        /* reward_done :787-802 */
+        float dg = dist_goal(objs, pose);
+        float last = dg;
+        if (have_last && !(e->done1[i] > 0.0f)) last = dist_goal(objs, P1);
+        float dd = last - dg;
+        float r = dd * e->cfg.reward_distance;
+        float dn = dg < e->cfg.goal_size ? 1.0f : 0.0f;
+        if (fabsf(dd) > 1.0f) { dn = 1.0f; r = 0.0f; }
+        /* cost :804-811 */
+        float cs = 0.0f;
+        for (int h = 0; h < H; ++h) {
+            float dx = objs[2 + 2 * h] - pose[0], dy = objs[3 + 2 * h] - pose[1];
+            float dh = sqrtf(dx * dx + dy * dy);
+            float below = dh < e->cfg.hazards_size ? dh : e->cfg.hazards_size; /* jp.minimum */
+            if (dh != dh) below = dh;
+            cs = cs + (e->cfg.hazards_size - below);
+        }
+        /* NaN/Inf guard :696-699 */
+        int bad = 0;
+        for (int k = 0; k < D; ++k) if (!(fabsf(row[k]) <= 3.4028234663852886e38f)) bad = 1;
+        if (bad) { r = 0.0f; dn = 1.0f; }
+        /* timeout + step counter :492-493 */
+        if (e->steps[i] > (float)e->cfg.num_steps) dn = 1.0f;
+        e->steps[i] = dn > 0.0f ? 0.0f : e->steps[i] + 1.0f;
+        /* commit */
+        e->qpos[3 * i] = s.x; e->qpos[3 * i + 1] = s.y; e->qpos[3 * i + 2] = s.th;
+        e->qvel[3 * i] = s.vx; e->qvel[3 * i + 1] = s.vy; e->qvel[3 * i + 2] = s.om;
+        p1[0] = P1[0]; p1[1] = P1[1];
+        p0[0] = pose[0]; p0[1] = pose[1]; p0[2] = pose[2]; p0[3] = pose[3];
+        e->done0[i] = dn;
+        reward[i] = r; cost[i] = cs; done[i] = dn;
+        if (qacc_out) { qacc_out[3 * i] = qacc[0]; qacc_out[3 * i + 1] = qacc[1]; qacc_out[3 * i + 2] = qacc[2]; }
+    }
+    if (e->hist < 2) e->hist++;
+    memcpy(obs, e->obs, (size_t)N * D * 4);
+    return GXO_OK;
+}
+
+int gxo_reset_done(gxo_env* e, float* obs)
+{
+    const int N = e->N, D = e->D, row = (e->H + 2) * 2;
+    if (e->hist == 0) { /* self._done is None: :713 falls through */
+        memcpy(obs, e->obs, (size_t)N * D * 4);
+        return GXO_OK;
+    }
+    if (e->layout_size < 1) return GXO_ERR_LAYOUT;
+    uint32_t* idx = (uint32_t*)malloc((size_t)N * 4);
+    layout_indices(e, idx); /* :500 */
+    memcpy(obs, e->obs, (size_t)N * D * 4); /* self._obs is NOT updated by reset_done (:501) */
+    const float zero3[3] = {0, 0, 0}, zero2[2] = {0, 0};
+    for (int i = 0; i < N; ++i) {
+        if (!(e->done0[i] > 0.0f)) continue; /* :715-717 */
+        load_layout(e, i, &e->pool[(size_t)idx[i] * row]);
+        /* fake step (:719-724) on a scratch copy: its pose/qpos/qvel feed the obs only;
+         * the returned data keeps the stale xpos/xmat (:731). */
+        ptstate s = {e->qpos[3 * i], e->qpos[3 * i + 1], e->qpos[3 * i + 2], 0.0f, 0.0f, 0.0f};
+        float pose[4], qacc[3];
+        for (int k = 0; k < e->cfg.physics_steps; ++k) point_substep(&s, zero3, pose, qacc);
+        build_obs(e, pose, &e->objs[(size_t)i * e->NOBJ * 2], zero3, &s, zero2, zero2,
+                  &obs[(size_t)i * D]); /* :726-729 */
+    }
+    free(idx);
+    return GXO_OK;
+}
+
+int gxo_get_state(const gxo_env* e, float* qpos, float* qvel, float* pose0, float* pose1,
+                  float* objs, float* done0, float* done1, float* steps, uint32_t* key,
+                  int32_t* hist)
+{
+    const size_t N = (size_t)e->N;
+    if (qpos) memcpy(qpos, e->qpos, N * 12);
+    if (qvel) memcpy(qvel, e->qvel, N * 12);
+    if (pose0) memcpy(pose0, e->pose0, N * 16);
+    if (pose1) memcpy(pose1, e->pose1, N * 8);
+    if (objs) memcpy(objs, e->objs, N * e->NOBJ * 8);
+    if (done0) memcpy(done0, e->done0, N * 4);
+    if (done1) memcpy(done1, e->done1, N * 4);
+    if (steps) memcpy(steps, e->steps, N * 4);
+    if (key) { key[0] = e->key[0]; key[1] = e->key[1]; }
+    if (hist) *hist = e->hist;
+    return GXO_OK;
+}
+
+int gxo_set_state(gxo_env* e, const float* qpos, const float* qvel, const float* pose0,
+                  const float* pose1, const float* objs, const float* done0,
+                  const float* done1, const float* steps, const uint32_t* key,
+                  const int32_t* hist)
+{
+    const size_t N = (size_t)e->N;
+    if (qpos) memcpy(e->qpos, qpos, N * 12);
+    if (qvel) memcpy(e->qvel, qvel, N * 12);
+    if (pose0) memcpy(e->pose0, pose0, N * 16);
+    if (pose1) memcpy(e->pose1, pose1, N * 8);
+    if (objs) memcpy(e->objs, objs, N * e->NOBJ * 8);
+    if (done0) memcpy(e->done0, done0, N * 4);
+    if (done1) memcpy(e->done1, done1, N * 4);
+    if (steps) memcpy(e->steps, steps, N * 4);
+    if (key) { e->key[0] = key[0]; e->key[1] = key[1]; }
+    if (hist) e->hist = *hist;
+    return GXO_OK;
+}
+
+int gxo_get_pool(const gxo_env* e, float* pool, int32_t max_rows)
+{
+    int n = e->layout_size < max_rows ? e->layout_size : max_rows;
+    if (n > 0) memcpy(pool, e->pool, (size_t)n * (e->H + 2) * 2 * 4);
+    return n;
+}
