@@ -1,0 +1,90 @@
+"""ctypes binding of libguardx_hip.so (include/guardx.h).
+
+There is no CPU fallback: if the HIP library is missing or fails to load this
+module raises, and every Engine call goes through the C ABI below.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libguardx_hip.so")
+
+GX_OK, GX_ERR_ARG, GX_ERR_UNSUPPORTED, GX_ERR_LAYOUT, GX_ERR_HIP, GX_ERR_STATE = range(6)
+
+
+class GxConfig(C.Structure):
+    """Mirror of `struct gx_config` (include/guardx.h)."""
+    _fields_ = [
+        ("struct_size", C.c_int32), ("robot", C.c_int32), ("env_num", C.c_int32),
+        ("env_total", C.c_int32), ("env_offset", C.c_int32), ("seed", C.c_uint32),
+        ("num_steps", C.c_int32), ("hazards_num", C.c_int32), ("lidar_num_bins", C.c_int32),
+        ("lidar_alias", C.c_int32), ("lidar_max_dist_set", C.c_int32),
+        ("lidar_max_dist", C.c_float), ("lidar_exp_gain", C.c_float),
+        ("goal_size", C.c_float), ("hazards_size", C.c_float), ("reward_distance", C.c_float),
+        ("goal_keepout", C.c_double), ("hazards_keepout", C.c_double),
+        ("robot_keepout", C.c_double), ("placements_margin", C.c_double),
+        ("extents", C.c_double * 4),
+        ("observe_goal_lidar", C.c_int32), ("observe_goal_comp", C.c_int32),
+        ("observe_hazards", C.c_int32), ("observe_qpos", C.c_int32),
+        ("observe_qvel", C.c_int32), ("observe_ctrl", C.c_int32),
+        ("observe_vel", C.c_int32), ("observe_acc", C.c_int32),
+        ("n_candidates", C.c_int32), ("physics_steps", C.c_int32),
+        ("robot_goal_min_dist", C.c_float), ("device", C.c_int32),
+    ]
+
+
+# every symbol include/guardx.h declares: name -> (restype, argtypes)
+_FP = C.c_void_p  # device pointers travel as integers
+_HFP = C.POINTER(C.c_float)
+_U32P = C.POINTER(C.c_uint32)
+_I32P = C.POINTER(C.c_int32)
+SYMBOLS = {
+    "gx_last_error": (C.c_char_p, []),
+    "gx_abi_version": (C.c_int32, []),
+    "gx_create": (C.c_int, [C.POINTER(GxConfig), C.POINTER(C.c_void_p)]),
+    "gx_destroy": (C.c_int, [C.c_void_p]),
+    "gx_obs_dim": (C.c_int32, [C.c_void_p]),
+    "gx_act_dim": (C.c_int32, [C.c_void_p]),
+    "gx_reset": (C.c_int, [C.c_void_p, _FP, C.c_void_p]),
+    "gx_layout_size": (C.c_int, [C.c_void_p, _I32P]),
+    "gx_step": (C.c_int, [C.c_void_p, _FP, _FP, _FP, _FP, _FP, _FP, C.c_void_p]),
+    "gx_reset_done": (C.c_int, [C.c_void_p, _FP, _FP, C.c_void_p]),
+    "gx_rollout": (C.c_int, [C.c_void_p, C.c_int32, _FP, _FP, _FP, _FP, _FP, C.c_void_p]),
+    "gx_get_state": (C.c_int, [C.c_void_p] + [_HFP] * 8 + [_U32P, _I32P]),
+    "gx_set_state": (C.c_int, [C.c_void_p] + [_HFP] * 8 + [_U32P, _I32P]),
+    "gx_get_pool": (C.c_int, [C.c_void_p, _HFP, C.c_int32, _I32P]),
+    "gx_math_probe": (C.c_int, [C.c_int32, _FP, _FP, _FP, _FP, _FP, _FP, C.c_void_p]),
+    "gx_split_probe": (C.c_int, [_U32P, C.c_int32, _FP, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises (never falls back) when it is unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m guardx_amd.build` "
+            "(guardx_amd has no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI drifted
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class GxError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"guardx status {status}: {msg}")
+        self.status = status
+
+
+def check(status):
+    if status != GX_OK:
+        msg = load().gx_last_error()
+        raise GxError(status, msg.decode() if msg else "")

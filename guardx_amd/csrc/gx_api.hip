@@ -1,0 +1,417 @@
+// gx_api.hip -- C ABI (include/guardx.h) over the HIP kernels.  Host side only.
+//
+// The handle owns the SoA environment state and the layout pool; observation,
+// reward, cost, done and action buffers belong to the caller (torch tensors).
+// Reference behaviour cited as engine.py:NNN
+// (/root/reference/safe_rl_envs/safe_rl_envs/envs/engine.py).
+#include "../../include/guardx.h"
+#include "gx_kernels.h"
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace gx;
+
+static thread_local std::string g_err;
+
+static gx_status fail(gx_status st, const std::string& msg)
+{
+    g_err = msg;
+    return st;
+}
+
+#define GX_HIP(call)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(GX_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+struct gx_engine {
+    gx_config cfg;
+    Params p;
+    SampleParams sp;
+    DevBuffers b;
+    int nobj_total;
+    uint32_t key[2];
+    int hist;            // number of step() calls so far, saturating at 2
+    bool have_reset;
+    int* h_layout_size;  // pinned
+    hipEvent_t layout_ev;
+    bool layout_pending;
+    int device;
+};
+
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) {
+            changed = (hipSetDevice(dev) == hipSuccess);
+        }
+    }
+    ~DeviceGuard()
+    {
+        if (changed) (void)hipSetDevice(prev);
+    }
+};
+
+extern "C" const char* gx_last_error(void) { return g_err.c_str(); }
+extern "C" int32_t gx_abi_version(void) { return 1; }
+extern "C" int32_t gx_obs_dim(const gx_engine* e) { return e ? e->p.D : -1; }
+extern "C" int32_t gx_act_dim(const gx_engine* e) { return e ? 2 : -1; }
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
+{
+    if (!cfg || !out) return fail(GX_ERR_ARG, "null argument");
+    if (cfg->struct_size != (int32_t)sizeof(gx_config))
+        return fail(GX_ERR_ARG, "gx_config.struct_size mismatch");
+    if (cfg->robot != 0)
+        return fail(GX_ERR_UNSUPPORTED, "only xmls/point.xml is implemented by the HIP path");
+    if (cfg->env_num < 1 || cfg->env_total < cfg->env_num || cfg->env_offset < 0 ||
+        cfg->env_offset + cfg->env_num > cfg->env_total)
+        return fail(GX_ERR_ARG, "bad env_num/env_total/env_offset");
+    if (cfg->hazards_num < 1 || cfg->hazards_num > 64)
+        return fail(GX_ERR_ARG, "hazards_num must be in [1,64]");
+    if (cfg->lidar_num_bins < 3 || cfg->lidar_num_bins > 64)
+        return fail(GX_ERR_ARG, "lidar_num_bins must be in [3,64]");
+    if (cfg->n_candidates < 1 || cfg->physics_steps < 1) return fail(GX_ERR_ARG, "bad n_candidates/physics_steps");
+
+    int ndev = 0;
+    GX_HIP(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(GX_ERR_ARG, "bad device ordinal");
+    DeviceGuard guard(cfg->device);
+
+    gx_engine* e = new (std::nothrow) gx_engine();
+    if (!e) return fail(GX_ERR_HIP, "out of host memory");
+    e->cfg = *cfg;
+    e->device = cfg->device;
+    Params& p = e->p;
+    p.N = cfg->env_num;
+    p.Npad = (p.N + 255) / 256 * 256;
+    p.H = cfg->hazards_num;
+    p.nobj = 1 + p.H;
+    p.P = (p.nobj + 1) / 2;
+    p.bins = cfg->lidar_num_bins;
+    // flat obs = concat over sorted(obs_space_dict keys)  engine.py:386-409,773-777
+    int o = 0;
+    p.off_acc = p.off_ctrl = p.off_comp = p.off_gl = p.off_hl = p.off_qpos = p.off_qvel = p.off_vel = -1;
+    if (cfg->observe_acc) { p.off_acc = o; o += 2; }
+    if (cfg->observe_ctrl) { p.off_ctrl = o; o += 3; }
+    if (cfg->observe_goal_comp) { p.off_comp = o; o += 2; }
+    if (cfg->observe_goal_lidar) { p.off_gl = o; o += p.bins; }
+    if (cfg->observe_hazards) { p.off_hl = o; o += p.bins; }
+    if (cfg->observe_qpos) { p.off_qpos = o; o += 3; }
+    if (cfg->observe_qvel) { p.off_qvel = o; o += 3; }
+    if (cfg->observe_vel) { p.off_vel = o; o += 2; }
+    p.D = o;
+    if (p.D < 1) { delete e; return fail(GX_ERR_ARG, "empty observation"); }
+    p.lidar_alias = cfg->lidar_alias;
+    p.lidar_max_dist_set = cfg->lidar_max_dist_set;
+    p.lidar_max_dist = cfg->lidar_max_dist;
+    p.neg_gain = -cfg->lidar_exp_gain;
+    p.bin_size = (float)((3.14159265358979323846 * 2) / p.bins); // engine.py:880
+    p.goal_size = cfg->goal_size;
+    p.hazards_size = cfg->hazards_size;
+    p.reward_distance = cfg->reward_distance;
+    p.num_steps_f = (float)cfg->num_steps;
+    p.physics_steps = cfg->physics_steps;
+    p.dt = 0.02f * (float)cfg->physics_steps; // engine.py:235
+    p.env_total = cfg->env_total;
+    p.env_offset = cfg->env_offset;
+    p.have_last = p.have_last_last = 0;
+    p.hist_on = (cfg->observe_vel || cfg->observe_acc) ? 1 : 0;
+
+    // layout sampler constants (python-float arithmetic, then f32: engine.py:554,574-577)
+    SampleParams& sp = e->sp;
+    e->nobj_total = p.H + 2;
+    sp.M = cfg->n_candidates;
+    sp.nobj_total = e->nobj_total;
+    const double ko[3] = {cfg->goal_keepout, cfg->hazards_keepout, cfg->robot_keepout};
+    for (int t = 0; t < 3; ++t) {
+        sp.lo_x[t] = (float)(cfg->extents[0] + ko[t]);
+        sp.lo_y[t] = (float)(cfg->extents[1] + ko[t]);
+        sp.hi_x[t] = (float)(cfg->extents[2] - ko[t]);
+        sp.hi_y[t] = (float)(cfg->extents[3] - ko[t]);
+        for (int q = 0; q < 3; ++q) sp.thr[q][t] = (float)(ko[q] + cfg->placements_margin + ko[t]);
+    }
+    sp.min_rg = cfg->robot_goal_min_dist;
+
+    // PRNGKey(seed)  engine.py:216
+    e->key[0] = 0u;
+    e->key[1] = cfg->seed;
+    e->hist = 0;
+    e->have_reset = false;
+    e->layout_pending = false;
+    e->h_layout_size = nullptr;
+    memset(&e->b, 0, sizeof(e->b));
+
+    const size_t M = (size_t)sp.M, W = (M + 63) / 64;
+    hipError_t err = hipSuccess;
+    auto alloc = [&](void** ptr, size_t bytes) {
+        if (err == hipSuccess) err = hipMalloc(ptr, bytes);
+        if (err == hipSuccess) err = hipMemset(*ptr, 0, bytes);
+    };
+    alloc((void**)&e->b.dyn, sizeof(float4) * 3 * p.Npad);
+    alloc((void**)&e->b.obj, sizeof(float4) * (size_t)p.P * p.Npad);
+    alloc((void**)&e->b.hist, sizeof(float4) * p.Npad);
+    alloc((void**)&e->b.cand_ok, M);
+    alloc((void**)&e->b.cand_xy, sizeof(float2) * M * e->nobj_total);
+    alloc((void**)&e->b.wave_cnt, sizeof(int) * W);
+    alloc((void**)&e->b.wave_off, sizeof(int) * W);
+    alloc((void**)&e->b.cand_of, sizeof(int) * M);
+    alloc((void**)&e->b.layout_size, sizeof(int));
+    if (err == hipSuccess) err = hipHostMalloc((void**)&e->h_layout_size, sizeof(int), hipHostMallocDefault);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->layout_ev, hipEventDisableTiming);
+    if (err == hipSuccess) {
+        // xmat of the zero pose: cos = 1 (engine.py:229 MjData default)
+        std::vector<float4> d2(p.Npad, make_float4(1.f, 0.f, 0.f, 0.f));
+        err = hipMemcpy(e->b.dyn + 2 * (size_t)p.Npad, d2.data(), sizeof(float4) * p.Npad, hipMemcpyHostToDevice);
+    }
+    if (err != hipSuccess) {
+        std::string m = std::string("device allocation failed: ") + hipGetErrorString(err);
+        gx_destroy(e);
+        return fail(GX_ERR_HIP, m);
+    }
+    *e->h_layout_size = 0;
+    *out = e;
+    return GX_OK;
+}
+
+extern "C" gx_status gx_destroy(gx_engine* e)
+{
+    if (!e) return GX_OK;
+    DeviceGuard guard(e->device);
+    (void)hipDeviceSynchronize();
+    void* bufs[] = {e->b.dyn, e->b.obj, e->b.hist, e->b.cand_ok, e->b.cand_xy, e->b.wave_cnt,
+                    e->b.wave_off, e->b.cand_of, e->b.layout_size};
+    for (void* q : bufs)
+        if (q) (void)hipFree(q);
+    if (e->h_layout_size) (void)hipHostFree(e->h_layout_size);
+    if (e->layout_ev) (void)hipEventDestroy(e->layout_ev);
+    delete e;
+    return GX_OK;
+}
+
+static void layout_keys(const gx_engine* e, uint32_t (&k)[4])
+{
+    // get_layout: randint(key, ...) splits the key once  engine.py:447
+    split2(e->key[0], e->key[1], k[0], k[1], k[2], k[3]);
+}
+
+extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
+{
+    if (!e || !d_obs) return fail(GX_ERR_ARG, "null argument");
+    if (!aligned16(d_obs)) return fail(GX_ERR_ARG, "d_obs must be 16-byte aligned");
+    DeviceGuard guard(e->device);
+    hipStream_t s = (hipStream_t)stream;
+    e->sp.k0 = e->key[0];
+    e->sp.k1 = e->key[1];
+    launch_sample(e->sp, e->b, s); // reset_layout  engine.py:433-444
+    uint32_t k[4];
+    layout_keys(e, k);
+    launch_reset_apply(e->p, e->b, e->nobj_total, k[0], k[1], k[2], k[3], d_obs, s);
+    GX_HIP(hipMemcpyAsync(e->h_layout_size, e->b.layout_size, sizeof(int), hipMemcpyDeviceToHost, s));
+    GX_HIP(hipEventRecord(e->layout_ev, s));
+    GX_HIP(hipGetLastError());
+    e->layout_pending = true;
+    e->have_reset = true;
+    return GX_OK;
+}
+
+extern "C" gx_status gx_layout_size(gx_engine* e, int32_t* out)
+{
+    if (!e || !out) return fail(GX_ERR_ARG, "null argument");
+    if (!e->have_reset) return fail(GX_ERR_STATE, "gx_layout_size before gx_reset");
+    DeviceGuard guard(e->device);
+    if (e->layout_pending) {
+        GX_HIP(hipEventSynchronize(e->layout_ev));
+        e->layout_pending = false;
+    }
+    *out = *e->h_layout_size;
+    if (*out <= e->cfg.env_total) {
+        char buf[128];
+        snprintf(buf, sizeof buf, "layout_size %d <= env_num %d (engine.py:444)", *out, e->cfg.env_total);
+        return fail(GX_ERR_LAYOUT, buf);
+    }
+    return GX_OK;
+}
+
+extern "C" gx_status gx_step(gx_engine* e, const float* d_action, float* d_obs, float* d_reward,
+                             float* d_cost, float* d_done, float* d_qacc, void* stream)
+{
+    if (!e || !d_action || !d_obs || !d_reward || !d_cost || !d_done) return fail(GX_ERR_ARG, "null argument");
+    if (!e->have_reset) return fail(GX_ERR_STATE, "gx_step before gx_reset (engine.py: _data is None)");
+    if (!aligned16(d_obs) || (reinterpret_cast<uintptr_t>(d_action) & 7u))
+        return fail(GX_ERR_ARG, "d_obs must be 16-byte and d_action 8-byte aligned");
+    DeviceGuard guard(e->device);
+    // update_data: key, _ = split(key, 2)  engine.py:431
+    uint32_t a0, a1, b0, b1;
+    split2(e->key[0], e->key[1], a0, a1, b0, b1);
+    e->key[0] = a0;
+    e->key[1] = a1;
+    e->p.have_last = e->hist >= 1;
+    e->p.have_last_last = e->hist >= 2;
+    launch_step(e->p, e->b, d_action, d_obs, d_reward, d_cost, d_done, d_qacc, (hipStream_t)stream);
+    if (e->hist < 2) e->hist++;
+    GX_HIP(hipGetLastError());
+    return GX_OK;
+}
+
+extern "C" gx_status gx_reset_done(gx_engine* e, const float* d_obs_in, float* d_obs_out, void* stream)
+{
+    if (!e || !d_obs_in || !d_obs_out) return fail(GX_ERR_ARG, "null argument");
+    if (!e->have_reset) return fail(GX_ERR_STATE, "gx_reset_done before gx_reset");
+    if (!aligned16(d_obs_in) || !aligned16(d_obs_out)) return fail(GX_ERR_ARG, "obs buffers must be 16-byte aligned");
+    DeviceGuard guard(e->device);
+    hipStream_t s = (hipStream_t)stream;
+    if (e->hist == 0) { // self._done is None: mjx_reset_done falls through (engine.py:713)
+        if (d_obs_in != d_obs_out)
+            GX_HIP(hipMemcpyAsync(d_obs_out, d_obs_in, sizeof(float) * (size_t)e->p.N * e->p.D,
+                                  hipMemcpyDeviceToDevice, s));
+        return GX_OK;
+    }
+    uint32_t k[4];
+    layout_keys(e, k);
+    launch_reset_done(e->p, e->b, e->nobj_total, k[0], k[1], k[2], k[3], d_obs_in, d_obs_out, s);
+    GX_HIP(hipGetLastError());
+    return GX_OK;
+}
+
+extern "C" gx_status gx_rollout(gx_engine* e, int32_t T, const float* d_actions, float* d_obs,
+                                float* d_reward, float* d_cost, float* d_done, void* stream)
+{
+    if (!e || !d_actions || !d_obs || !d_reward || !d_cost || !d_done || T < 1)
+        return fail(GX_ERR_ARG, "bad argument");
+    if (!e->have_reset) return fail(GX_ERR_STATE, "gx_rollout before gx_reset");
+    const size_t N = (size_t)e->p.N, D = (size_t)e->p.D;
+    if ((N * D * sizeof(float)) % 16 != 0 || (N * 2 * sizeof(float)) % 8 != 0)
+        return fail(GX_ERR_ARG, "env_num*obs_dim*4 must be a multiple of 16 for time-major outputs");
+    for (int32_t t = 0; t < T; ++t) {
+        float* obs_t = d_obs + (size_t)t * N * D;
+        gx_status st = gx_step(e, d_actions + (size_t)t * N * 2, obs_t, d_reward + (size_t)t * N,
+                               d_cost + (size_t)t * N, d_done + (size_t)t * N, nullptr, stream);
+        if (st != GX_OK) return st;
+        st = gx_reset_done(e, obs_t, obs_t, stream);
+        if (st != GX_OK) return st;
+    }
+    return GX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// state exchange (tests / checkpoints); synchronous
+// ---------------------------------------------------------------------------
+extern "C" gx_status gx_get_state(gx_engine* e, float* qpos, float* qvel, float* pose0, float* pose1,
+                                  float* objs, float* done0, float* done1, float* steps,
+                                  uint32_t* key, int32_t* hist)
+{
+    if (!e) return fail(GX_ERR_ARG, "null engine");
+    DeviceGuard guard(e->device);
+    GX_HIP(hipDeviceSynchronize());
+    const Params& p = e->p;
+    const size_t Np = p.Npad;
+    std::vector<float4> dyn(3 * Np), obj((size_t)p.P * Np), hs(Np);
+    GX_HIP(hipMemcpy(dyn.data(), e->b.dyn, sizeof(float4) * dyn.size(), hipMemcpyDeviceToHost));
+    GX_HIP(hipMemcpy(obj.data(), e->b.obj, sizeof(float4) * obj.size(), hipMemcpyDeviceToHost));
+    GX_HIP(hipMemcpy(hs.data(), e->b.hist, sizeof(float4) * hs.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < p.N; ++i) {
+        const float4 d0 = dyn[i], d1 = dyn[Np + i], d2 = dyn[2 * Np + i];
+        if (qpos) { qpos[3 * i] = d0.x; qpos[3 * i + 1] = d0.y; qpos[3 * i + 2] = d0.z; }
+        if (qvel) { qvel[3 * i] = d0.w; qvel[3 * i + 1] = d1.x; qvel[3 * i + 2] = d1.y; }
+        if (pose0) { pose0[4 * i] = d1.z; pose0[4 * i + 1] = d1.w; pose0[4 * i + 2] = d2.x; pose0[4 * i + 3] = d2.y; }
+        if (pose1) { pose1[2 * i] = hs[i].x; pose1[2 * i + 1] = hs[i].y; }
+        if (done0) done0[i] = d2.z;
+        if (done1) done1[i] = hs[i].z;
+        if (steps) steps[i] = d2.w;
+        if (objs)
+            for (int o = 0; o < p.nobj; ++o) {
+                const float4 v = obj[(size_t)(o / 2) * Np + i];
+                objs[((size_t)i * p.nobj + o) * 2] = (o & 1) ? v.z : v.x;
+                objs[((size_t)i * p.nobj + o) * 2 + 1] = (o & 1) ? v.w : v.y;
+            }
+    }
+    if (key) { key[0] = e->key[0]; key[1] = e->key[1]; }
+    if (hist) *hist = e->hist;
+    return GX_OK;
+}
+
+extern "C" gx_status gx_set_state(gx_engine* e, const float* qpos, const float* qvel, const float* pose0,
+                                  const float* pose1, const float* objs, const float* done0,
+                                  const float* done1, const float* steps, const uint32_t* key,
+                                  const int32_t* hist)
+{
+    if (!e) return fail(GX_ERR_ARG, "null engine");
+    DeviceGuard guard(e->device);
+    GX_HIP(hipDeviceSynchronize());
+    const Params& p = e->p;
+    const size_t Np = p.Npad;
+    std::vector<float4> dyn(3 * Np), obj((size_t)p.P * Np), hs(Np);
+    GX_HIP(hipMemcpy(dyn.data(), e->b.dyn, sizeof(float4) * dyn.size(), hipMemcpyDeviceToHost));
+    GX_HIP(hipMemcpy(obj.data(), e->b.obj, sizeof(float4) * obj.size(), hipMemcpyDeviceToHost));
+    GX_HIP(hipMemcpy(hs.data(), e->b.hist, sizeof(float4) * hs.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < p.N; ++i) {
+        float4 &d0 = dyn[i], &d1 = dyn[Np + i], &d2 = dyn[2 * Np + i];
+        if (qpos) { d0.x = qpos[3 * i]; d0.y = qpos[3 * i + 1]; d0.z = qpos[3 * i + 2]; }
+        if (qvel) { d0.w = qvel[3 * i]; d1.x = qvel[3 * i + 1]; d1.y = qvel[3 * i + 2]; }
+        if (pose0) { d1.z = pose0[4 * i]; d1.w = pose0[4 * i + 1]; d2.x = pose0[4 * i + 2]; d2.y = pose0[4 * i + 3]; }
+        if (pose1) { hs[i].x = pose1[2 * i]; hs[i].y = pose1[2 * i + 1]; }
+        if (done0) d2.z = done0[i];
+        if (done1) hs[i].z = done1[i];
+        if (steps) d2.w = steps[i];
+        if (objs)
+            for (int o = 0; o < p.nobj; ++o) {
+                float4& v = obj[(size_t)(o / 2) * Np + i];
+                const float ox = objs[((size_t)i * p.nobj + o) * 2], oy = objs[((size_t)i * p.nobj + o) * 2 + 1];
+                if (o & 1) { v.z = ox; v.w = oy; } else { v.x = ox; v.y = oy; }
+            }
+    }
+    GX_HIP(hipMemcpy(e->b.dyn, dyn.data(), sizeof(float4) * dyn.size(), hipMemcpyHostToDevice));
+    GX_HIP(hipMemcpy(e->b.obj, obj.data(), sizeof(float4) * obj.size(), hipMemcpyHostToDevice));
+    GX_HIP(hipMemcpy(e->b.hist, hs.data(), sizeof(float4) * hs.size(), hipMemcpyHostToDevice));
+    if (key) { e->key[0] = key[0]; e->key[1] = key[1]; }
+    if (hist) e->hist = *hist;
+    e->have_reset = true;
+    return GX_OK;
+}
+
+extern "C" gx_status gx_get_pool(gx_engine* e, float* pool, int32_t max_rows, int32_t* got)
+{
+    if (!e || !pool || !got) return fail(GX_ERR_ARG, "null argument");
+    if (!e->have_reset) return fail(GX_ERR_STATE, "gx_get_pool before gx_reset");
+    DeviceGuard guard(e->device);
+    GX_HIP(hipDeviceSynchronize());
+    int L = 0;
+    GX_HIP(hipMemcpy(&L, e->b.layout_size, sizeof(int), hipMemcpyDeviceToHost));
+    const int n = L < max_rows ? L : max_rows;
+    std::vector<int> idx(n > 0 ? n : 1);
+    if (n > 0) GX_HIP(hipMemcpy(idx.data(), e->b.cand_of, sizeof(int) * n, hipMemcpyDeviceToHost));
+    const size_t row = (size_t)e->nobj_total * 2;
+    for (int r = 0; r < n; ++r)
+        GX_HIP(hipMemcpy(pool + r * row, e->b.cand_xy + (size_t)idx[r] * e->nobj_total, sizeof(float) * row,
+                         hipMemcpyDeviceToHost));
+    *got = n;
+    return GX_OK;
+}
+
+extern "C" gx_status gx_math_probe(int32_t n, const float* d_x, const float* d_y, float* d_s, float* d_c,
+                                   float* d_at2, float* d_ex, void* stream)
+{
+    if (n < 1 || !d_x || !d_y || !d_s || !d_c || !d_at2 || !d_ex) return fail(GX_ERR_ARG, "bad argument");
+    launch_math_probe(n, d_x, d_y, d_s, d_c, d_at2, d_ex, (hipStream_t)stream);
+    GX_HIP(hipGetLastError());
+    return GX_OK;
+}
+
+extern "C" gx_status gx_split_probe(const uint32_t* key, int32_t n, uint32_t* d_out, void* stream)
+{
+    if (!key || n < 1 || !d_out) return fail(GX_ERR_ARG, "bad argument");
+    launch_split_probe(key[0], key[1], n, d_out, (hipStream_t)stream);
+    GX_HIP(hipGetLastError());
+    return GX_OK;
+}

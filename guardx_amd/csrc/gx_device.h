@@ -1,0 +1,288 @@
+// gx_device.h -- device-side building blocks of the GUARD step path (gfx950).
+//
+// Everything here is fp32 with one IEEE operation per written operator (the
+// library is compiled with -ffp-contract=off; fused operations are spelled
+// fmaf()).  Division and sqrt rely on hipcc's default correctly-rounded
+// lowering.  The polynomial coefficients come from tools/fit_math.py.
+//
+// Reference lines: /root/reference/safe_rl_envs/safe_rl_envs/envs/engine.py.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GX_HD __host__ __device__ __forceinline__
+#define GX_D __device__ __forceinline__
+
+namespace gx {
+
+// ---------------------------------------------------------------------------
+// parameters shared by all kernels (passed by value -> SGPRs)
+// ---------------------------------------------------------------------------
+struct Params {
+    int N;        // local envs
+    int Npad;     // N rounded up to 256: stride of every SoA array
+    int H;        // hazards
+    int nobj;     // 1 + H   (goal, hazards)
+    int P;        // float4 object-pair arrays = ceil(nobj / 2)
+    int bins;     // lidar bins
+    int D;        // flat obs width
+    int off_acc, off_ctrl, off_comp, off_gl, off_hl, off_qpos, off_qvel, off_vel;
+    int lidar_alias, lidar_max_dist_set;
+    float lidar_max_dist, neg_gain, bin_size;
+    float goal_size, hazards_size, reward_distance, num_steps_f, dt;
+    int physics_steps;
+    int env_total, env_offset;
+    int have_last, have_last_last; // None-ness of _last_done / _last_last_done
+    int hist_on;                   // observe_vel || observe_acc
+};
+
+// ---------------------------------------------------------------------------
+// bit casts / NaN-propagating max (jnp.maximum)
+// ---------------------------------------------------------------------------
+GX_HD float u2f(uint32_t u) { union { uint32_t u; float f; } v; v.u = u; return v.f; }
+GX_HD uint32_t f2u(float f) { union { uint32_t u; float f; } v; v.f = f; return v.u; }
+GX_D float nmax(float a, float b) { return (a > b || a != a) ? a : b; }
+GX_D bool notfinite(float v) { return !(fabsf(v) <= 3.4028234663852886e38f); }
+
+// ---------------------------------------------------------------------------
+// sin/cos: 3-term Cody-Waite to [-pi/4, pi/4], minimax polynomials
+// ---------------------------------------------------------------------------
+GX_D void sincos_f(float x, float& s, float& c)
+{
+    const float x0 = x;
+    if (!(fabsf(x) <= 16777216.0f)) x = x * 0.0f;
+    const float k = rintf(x * 0.6366197466850281f);
+    float r = fmaf(-k, 1.5707963705062866f, x);
+    r = fmaf(-k, -4.371138828673793e-08f, r);
+    r = fmaf(-k, -1.7151245100058819e-15f, r);
+    const float z = r * r;
+    float ps = fmaf(z, -0.00019488747f, 0.008331924f);
+    ps = fmaf(z, ps, -0.1666665f);
+    const float S = fmaf(r * z, ps, r);
+    float pc = fmaf(z, 2.4431205e-05f, -0.0013887306f);
+    pc = fmaf(z, pc, 0.041666646f);
+    const float C = fmaf(z * z, pc, fmaf(z, -0.5f, 1.0f));
+    const int q = ((int)k) & 3;
+    float ss = (q & 1) ? C : S;
+    float cc = (q & 1) ? S : C;
+    if (q == 1 || q == 2) cc = -cc;
+    if (q >= 2) ss = -ss;
+    if (x0 != x0) { ss = x0; cc = x0; }
+    s = ss;
+    c = cc;
+}
+
+// ---------------------------------------------------------------------------
+// atan2: one division + degree-7 polynomial in a^2, a = min/max in [0,1]
+// ---------------------------------------------------------------------------
+GX_D float atan2_f(float y, float x)
+{
+    if (x != x || y != y) return x + y;
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = ax > ay ? ax : ay;
+    const float mn = ax > ay ? ay : ax;
+    float a;
+    if (mx == 0.0f) a = 0.0f;
+    else if (mx == __builtin_inff()) a = (mn == __builtin_inff()) ? 1.0f : 0.0f;
+    else a = mn / mx;
+    const float z = a * a;
+    float p = fmaf(z, 0.0026222442f, -0.015132535f);
+    p = fmaf(z, p, 0.04112186f);
+    p = fmaf(z, p, -0.07366706f);
+    p = fmaf(z, p, 0.10573932f);
+    p = fmaf(z, p, -0.14185975f);
+    p = fmaf(z, p, 0.19990396f);
+    p = fmaf(z, p, -0.33332986f);
+    float t = fmaf(a * z, p, a);
+    if (ay > ax) t = 1.5707963705062866f - t;
+    if (f2u(x) >> 31) t = 3.1415927410125732f - t;
+    return (f2u(y) >> 31) ? -t : t;
+}
+
+// ---------------------------------------------------------------------------
+// exp (lidar closeness).  Below exp(-87) the result is flushed to zero.
+// ---------------------------------------------------------------------------
+GX_D float exp_f(float x)
+{
+    if (x != x) return x;
+    if (x < -87.0f) return 0.0f;
+    if (x > 88.0f) return __builtin_inff();
+    const float k = rintf(x * 1.4426950216293335f);
+    float r = fmaf(-k, 0.6931471824645996f, x);
+    r = fmaf(-k, -1.9046542121259336e-09f, r);
+    float q = fmaf(r, 0.001395172f, 0.008369599f);
+    q = fmaf(r, q, 0.041666187f);
+    q = fmaf(r, q, 0.16666512f);
+    q = fmaf(r, q, 0.5f);
+    const float t = fmaf(r * r, q, r);
+    const float e = 1.0f + t;
+    const int ki = (int)k;
+    return u2f(f2u(e) + ((uint32_t)ki << 23));
+}
+
+// ---------------------------------------------------------------------------
+// jax.random on threefry2x32 (published algorithm: Salmon et al. 2011 /
+// jax/_src/prng.py).  Used on host for the per-step key chain and on device
+// for layout sampling and layout index draws.
+// ---------------------------------------------------------------------------
+GX_HD uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+GX_HD void threefry2x32(uint32_t k0, uint32_t k1, uint32_t x0, uint32_t x1,
+                        uint32_t& o0, uint32_t& o1)
+{
+    const uint32_t k2 = k0 ^ k1 ^ 0x1BD11BDAu;
+#define GX_R4(a, b, c, d)                                   \
+    x0 += x1; x1 = rotl32(x1, a); x1 ^= x0;                 \
+    x0 += x1; x1 = rotl32(x1, b); x1 ^= x0;                 \
+    x0 += x1; x1 = rotl32(x1, c); x1 ^= x0;                 \
+    x0 += x1; x1 = rotl32(x1, d); x1 ^= x0;
+    x0 += k0; x1 += k1;
+    GX_R4(13, 15, 26, 6)  x0 += k1; x1 += k2 + 1u;
+    GX_R4(17, 29, 16, 24) x0 += k2; x1 += k0 + 2u;
+    GX_R4(13, 15, 26, 6)  x0 += k0; x1 += k1 + 3u;
+    GX_R4(17, 29, 16, 24) x0 += k1; x1 += k2 + 4u;
+    GX_R4(13, 15, 26, 6)  x0 += k2; x1 += k0 + 5u;
+#undef GX_R4
+    o0 = x0;
+    o1 = x1;
+}
+
+// element i of random_bits(key, (n,)): counts are padded to even length and cut
+// into halves feeding the two block inputs.
+GX_HD uint32_t tf_bits_at(uint32_t k0, uint32_t k1, uint32_t n, uint32_t i)
+{
+    const uint32_t half = (n + 1u) >> 1;
+    uint32_t o0, o1;
+    if (i < half) {
+        const uint32_t hi = i + half;
+        threefry2x32(k0, k1, i, hi < n ? hi : 0u, o0, o1);
+        return o0;
+    }
+    threefry2x32(k0, k1, i - half, i, o0, o1);
+    return o1;
+}
+
+// jax.random.split(key, 2): both children from two blocks.
+GX_HD void split2(uint32_t k0, uint32_t k1, uint32_t& a0, uint32_t& a1, uint32_t& b0, uint32_t& b1)
+{
+    // flat = bits over iota(4): [B(0,2).0, B(1,3).0, B(0,2).1, B(1,3).1]
+    threefry2x32(k0, k1, 0u, 2u, a0, b0);
+    threefry2x32(k0, k1, 1u, 3u, a1, b1);
+}
+
+// jax.random.split(key, n)[j]
+GX_HD void split_at(uint32_t k0, uint32_t k1, uint32_t n, uint32_t j, uint32_t& o0, uint32_t& o1)
+{
+    o0 = tf_bits_at(k0, k1, 2u * n, 2u * j);
+    o1 = tf_bits_at(k0, k1, 2u * n, 2u * j + 1u);
+}
+
+// jax.random.uniform(key, (), f32, lo, hi)
+GX_HD float uniform_f(uint32_t k0, uint32_t k1, float lo, float hi)
+{
+    uint32_t o0, o1;
+    threefry2x32(k0, k1, 0u, 0u, o0, o1);
+    const float f = u2f((o0 >> 9) | 0x3F800000u) - 1.0f;
+    const float v = f * (hi - lo) + lo;
+    return v > lo ? v : lo;
+}
+
+// jax.random.randint(key, (n,), 0, span)[i] given (k1,k2) = split(key)
+GX_HD uint32_t randint_at(uint32_t k10, uint32_t k11, uint32_t k20, uint32_t k21,
+                          uint32_t n, uint32_t span, uint32_t i)
+{
+    const uint32_t hi = tf_bits_at(k10, k11, n, i), lo = tf_bits_at(k20, k21, n, i);
+    uint32_t mult = 65536u % span;
+    mult = (mult * mult) % span;
+    const uint32_t off = (hi % span) * mult + (lo % span);
+    return off % span;
+}
+
+// ---------------------------------------------------------------------------
+// Point robot: one mjx.step (forward dynamics + Euler with implicit damping)
+// constants from xmls/point.xml:3,5,16-20,37-39 (sphere r=.1 + box .05 at x=.1,
+// density 1; slide damping .01, hinge .005; gear .3; h=.02)
+// ---------------------------------------------------------------------------
+struct PtState { float x, y, th, vx, vy, om; };
+
+template <bool kQacc>
+GX_D void point_substep(PtState& s, float cx, float cy, float ct, float (&pose)[4], float (&qacc)[3])
+{
+    constexpr float kH = 0.02f, kMxc = 0.0001f, kDxy = 0.01f, kDt = 0.005f, kGear = 0.3f;
+    constexpr float kIo = 2.842182748581224e-05f;
+    constexpr float kInvM = (float)(1.0 / 0.005188790204786391);
+    constexpr float kInvA = (float)(1.0 / (0.005188790204786391 + 0.02 * 0.01));
+    constexpr float kEi = (float)(2.842182748581224e-05 + 0.02 * 0.005);
+    float sh, ch;
+    sincos_f(0.5f * s.th, sh, ch);
+    const float c = ch * ch - sh * sh;
+    const float sn = 2.0f * (ch * sh);
+    pose[0] = s.x; pose[1] = s.y; pose[2] = c; pose[3] = sn;
+    const float b = -(kMxc * sn), d = kMxc * c;
+    const float w2 = s.om * s.om;
+    const float fx = (-(kDxy * s.vx) - (-(d * w2))) + kGear * cx;
+    const float fy = (-(kDxy * s.vy) - (b * w2)) + kGear * cy;
+    const float ft = (-(kDt * s.om) - 0.0f) + kGear * ct;
+    const float t = b * fx + d * fy;
+    const float s2 = b * b + d * d;
+    if (kQacc) {
+        const float y3 = ft - t * kInvM;
+        const float d3 = kIo - s2 * kInvM;
+        const float q3 = y3 / d3;
+        qacc[0] = (fx - b * q3) * kInvM;
+        qacc[1] = (fy - d * q3) * kInvM;
+        qacc[2] = q3;
+    }
+    const float y3 = ft - t * kInvA;
+    const float d3 = kEi - s2 * kInvA;
+    const float q3 = y3 / d3;
+    const float q1 = (fx - b * q3) * kInvA;
+    const float q2 = (fy - d * q3) * kInvA;
+    s.vx = s.vx + kH * q1;
+    s.vy = s.vy + kH * q2;
+    s.om = s.om + kH * q3;
+    s.x = s.x + kH * s.vx;
+    s.y = s.y + kH * s.vy;
+    s.th = s.th + kH * s.om;
+}
+
+// ---------------------------------------------------------------------------
+// pseudo-lidar (engine.py:846-900): scatter one object into a bin row that
+// lives in LDS (row[b], stride 1).  Returns true if a non-finite value landed.
+// ---------------------------------------------------------------------------
+GX_D bool lidar_one(const Params& p, float* row, float ox, float oy, const float (&pose)[4])
+{
+    const float dx = ox - pose[0], dy = oy - pose[1];
+    const float zx = dx * pose[2] + dy * pose[3];
+    const float zy = dx * (-pose[3]) + dy * pose[2];
+    const float dist = sqrtf(zx * zx + zy * zy);
+    float ang = atan2_f(zy, zx);
+    if (ang < 0.0f) ang = ang + 6.2831854820251465f;
+    const float q = ang / p.bin_size;
+    const int B = p.bins;
+    int bin;
+    if (!(q >= 0.0f)) bin = 0;
+    else if (q >= (float)B) bin = B;
+    else bin = (int)q;
+    const float bin_angle = p.bin_size * (float)bin;
+    float sensor;
+    if (!p.lidar_max_dist_set) sensor = exp_f(p.neg_gain * dist);
+    else sensor = nmax(0.0f, p.lidar_max_dist - dist) / p.lidar_max_dist;
+    bool bad = false;
+    if (bin < B) {
+        row[bin] = nmax(row[bin], sensor);
+        bad = notfinite(sensor);
+    }
+    if (p.lidar_alias) {
+        const float alias = (ang - bin_angle) / p.bin_size;
+        const int bp = (bin + 1 >= B) ? bin + 1 - B : bin + 1;
+        const int bm = (bin == 0) ? B - 1 : bin - 1;
+        const float a1 = alias * sensor, a2 = (1.0f - alias) * sensor;
+        row[bp] = nmax(row[bp], a1);
+        row[bm] = nmax(row[bm], a2);
+        bad = bad || notfinite(a1) || notfinite(a2);
+    }
+    return bad;
+}
+
+} // namespace gx

@@ -1,0 +1,46 @@
+// gx_kernels.h -- host-callable launchers of the HIP kernels (gx_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gx_device.h"
+
+namespace gx {
+
+// layout-sampler parameters (engine.py:546-621); object types: 0 goal, 1 hazard, 2 robot
+struct SampleParams {
+    int M;          // candidates (engine.py:263)
+    int nobj_total; // goal + hazards + robot
+    float lo_x[3], hi_x[3], lo_y[3], hi_y[3];
+    float thr[3][3]; // thr[placed type][new type] = f32(keepout_p + margin + keepout_new)
+    float min_rg;    // engine.py:571
+    uint32_t k0, k1; // engine key at reset time
+};
+
+struct DevBuffers {
+    float4* dyn;   // [3][Npad]: (x,y,th,vx) (vy,om,px,py) (pc,ps,done0,steps)
+    float4* obj;   // [P][Npad]: object pairs (goal,h0) (h1,h2) ...
+    float4* hist;  // [Npad]: (p1x,p1y,done1,0)   (only when hist_on)
+    // layout pool of the last reset
+    uint8_t* cand_ok;  // [M]
+    float2* cand_xy;   // [M][nobj_total]  (rows written only for valid candidates)
+    int* wave_cnt;     // [ceil(M/64)]
+    int* wave_off;     // [ceil(M/64)]
+    int* cand_of;      // [M] compacted candidate indices
+    int* layout_size;  // [1]
+};
+
+void launch_step(const Params& p, const DevBuffers& b, const float* act, float* obs, float* rew,
+                 float* cost, float* done, float* qacc, hipStream_t s);
+void launch_sample(const SampleParams& sp, const DevBuffers& b, hipStream_t s);
+void launch_reset_apply(const Params& p, const DevBuffers& b, int nobj_total, uint32_t k10,
+                        uint32_t k11, uint32_t k20, uint32_t k21, float* obs, hipStream_t s);
+void launch_reset_done(const Params& p, const DevBuffers& b, int nobj_total, uint32_t k10,
+                       uint32_t k11, uint32_t k20, uint32_t k21, const float* obs_in,
+                       float* obs_out, hipStream_t s);
+void launch_math_probe(int n, const float* x, const float* y, float* s_, float* c, float* at2,
+                       float* ex, hipStream_t s);
+void launch_split_probe(uint32_t k0, uint32_t k1, int n, uint32_t* out, hipStream_t s);
+size_t step_lds_bytes(const Params& p, int block);
+int pick_block(const Params& p);
+
+} // namespace gx

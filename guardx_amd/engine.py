@@ -1,0 +1,414 @@
+"""Batched GUARD environment on MI355X behind the reference `Engine` interface.
+
+Mirrors `safe_rl_envs.envs.engine.Engine` of intelligent-control-lab/guardX
+(reference safe_rl_envs/safe_rl_envs/envs/engine.py): same constructor config
+dict, `reset() / step(action) / reset_done()`, `observation_space`,
+`action_space`, and the `(obs, reward, done, info{'cost','obs'})` float32 torch
+tensor surface (engine.py:454-505), so the safe_rl_libX learners drive it
+unchanged (safe_rl_libX/trpo/trpo.py:449-547).
+
+All arithmetic runs in hand-written HIP kernels through the C ABI of
+`libguardx_hip.so` (include/guardx.h).  PyTorch only provides device memory and
+the current stream.  There is no CPU fallback.
+"""
+from collections import OrderedDict
+from copy import deepcopy
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native
+from .spaces import Box
+
+__all__ = ["Engine", "ResamplingError"]
+
+
+class ResamplingError(AssertionError):
+    """Raised when no valid object layout could be sampled (engine.py:79-81)."""
+
+
+# robot_base -> (native robot id, nq, nv, nu, z_height, act_dim)   (world.py:422-438)
+_ROBOTS = {
+    'xmls/point.xml': (0, 3, 3, 3, 0.1, 2),
+}
+
+
+class Engine:
+    """GUARD `Engine`: `env_num` independent Goal-task arenas stepped in lock-step.
+
+    Extra keyword arguments (not part of the reference config dict):
+      n_candidates  number of layout candidates drawn per reset (engine.py:263: 1e6)
+      shard         (rank, world): this instance owns the `rank`-th contiguous slice
+                    of a global batch of `env_num * world` envs and reproduces exactly
+                    the rows an unsharded Engine(env_num*world) would produce
+      emit_qacc     fill info['obs']['qacc'] (engine.py:763-764); costs one more output array
+    """
+
+    # Interface restatement of Engine.DEFAULT (engine.py:98-204): the key set is
+    # the constructor contract -- unknown keys assert "Bad key" (engine.py:327).
+    DEFAULT = {
+        'num_steps': 1000, 'device_id': 0, 'env_num': 1,
+        'placements_extents': [-2, -2, 2, 2], 'placements_margin': 0.0,
+        'floor_display_mode': False,
+        'robot_placements': None, 'robot_locations': [], 'robot_keepout': 0.4,
+        'robot_base': 'xmls/point.xml', 'robot_rot': None,
+        'observation_flatten': True, 'observe_goal_lidar': True, 'observe_goal_comp': True,
+        'observe_hazards': True, 'observe_qpos': True, 'observe_qvel': True,
+        'observe_qacc': True, 'observe_vel': False, 'observe_acc': False,
+        'observe_ctrl': True, 'observe_vision': False,
+        'render_labels': False, 'render_lidar_markers': True, 'render_lidar_radius': 0.15,
+        'render_lidar_size': 0.025, 'render_lidar_offset_init': 0.5,
+        'render_lidar_offset_delta': 0.06,
+        'sensors_obs': ['accelerometer', 'velocimeter', 'gyro', 'magnetometer'],
+        'sensors_hinge_joints': True, 'sensors_ball_joints': True,
+        'sensors_angle_components': True,
+        'lidar_num_bins': 16, 'lidar_num_bins3D': 1, 'lidar_max_dist': None,
+        'lidar_exp_gain': 1.0, 'lidar_type': 'pseudo', 'lidar_alias': True,
+        'lidar_body': ['robot'],
+        'task': 'goal', 'push_object': 'box', 'goal_mode': 'random', 'goal_travel': 3.0,
+        'goal_velocity': 0.5,
+        'goal_placements': None, 'goal_locations': [], 'goal_keepout': 0.5, 'goal_size': 0.5,
+        'goal_3D': False, 'goal_z_range': [1.0, 1.0],
+        'reward_distance': 1.0, 'reward_goal': 1.0, 'reward_box_dist': 1.0,
+        'reward_box_goal': 1.0, 'reward_orientation': False, 'reward_orientation_scale': 0.002,
+        'reward_orientation_body': 'robot', 'reward_exception': -10.0, 'reward_x': 1.0,
+        'reward_z': 1.0, 'reward_circle': 1e-1, 'reward_clip': 10, 'reward_defense': 1.0,
+        'reward_chase': 1.0,
+        'constrain_hazards': False, 'constrain_indicator': True,
+        'hazards_num': 8, 'hazards_placements': None, 'hazards_locations': [],
+        'hazards_keepout': 0.4, 'hazards_size': 0.3, 'hazards_cost': 1.0,
+        'physics_steps_per_control_step': 1,
+        '_seed': 0,
+    }
+
+    def __init__(self, config={}, *, n_candidates=1_000_000, shard=None, emit_qacc=True):
+        self._ctor_config = deepcopy(config)
+        self._ctor_kwargs = dict(n_candidates=n_candidates, shard=shard, emit_qacc=emit_qacc)
+        self.parse(config)
+        self._h = None
+        self._lib = _native.load()
+
+        if self.task != 'goal':
+            # reference: build_placements_dict only places a goal for task 'goal'
+            # (engine.py:538) and sample_layout then fails on layout['goal'] (:570)
+            raise KeyError('goal')
+        if not self.hazards_num:
+            # reference: build_world_config returns None (engine.py:370-384) -> World(None) fails
+            raise TypeError("hazards_num == 0: build_world_config() returns None in the reference")
+        if self.robot_base not in _ROBOTS:
+            raise NotImplementedError(f"robot_base {self.robot_base!r}: only {sorted(_ROBOTS)} "
+                                      "have HIP dynamics in this build")
+        if not self.observation_flatten:
+            raise NotImplementedError("observation_flatten=False: Engine.obs leaves flat_obs "
+                                      "undefined in the reference (engine.py:773-778)")
+        if self.observe_vision:
+            raise NotImplementedError("observe_vision is not part of the batched path")
+        if self.robot_rot not in (None, 0, 0.0):
+            raise NotImplementedError("robot_rot other than None/0")
+        robot_id, nq, nv, nu, z_height, act_dim = _ROBOTS[self.robot_base]
+        self.robot = type('Robot', (), dict(nq=nq, nv=nv, nu=nu, z_height=z_height))()
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("guardx_amd.Engine needs a HIP device (no CPU fallback)")
+        self.device = torch.device('cuda', int(self.device_id))
+        self.emit_qacc = bool(emit_qacc)
+
+        rank, world = (0, 1) if shard is None else (int(shard[0]), int(shard[1]))
+        assert 0 <= rank < world
+        self.shard = (rank, world)
+
+        self.build_placements_dict()
+        cfg = self._native_config(robot_id, int(n_candidates), rank, world)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _native.check(self._lib.gx_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self._cfg = cfg
+
+        self.dt = 0.02 * self.physics_steps_per_control_step  # engine.py:235 (point.xml:3)
+        self.action_space = Box(np.full(act_dim, -np.inf, np.float32),
+                                np.full(act_dim, np.inf, np.float32), dtype=np.float32)  # :291-297
+        self.build_observation_space()
+        assert self.obs_flat_size == self._lib.gx_obs_dim(self._h)
+
+        self._obs = None
+        self._reward = None
+        self._done = None
+        self._info = None
+        self.layout_size = None
+        self.viewer = None
+
+    # ------------------------------------------------------------------
+    # configuration
+    # ------------------------------------------------------------------
+    def parse(self, config):
+        """engine.py:322-328"""
+        self.config = deepcopy(self.DEFAULT)
+        self.config.update(deepcopy(config))
+        for key, value in self.config.items():
+            assert key in self.DEFAULT, f'Bad key {key}'
+            setattr(self, key, value)
+
+    def placements_dict_from_object(self, object_name):
+        """engine.py:507-531"""
+        placements_dict = {}
+        if hasattr(self, object_name + 's_num'):
+            plural = object_name + 's'
+            fmt = object_name + '{i}'
+            num = getattr(self, plural + '_num', None)
+            locations = getattr(self, plural + '_locations', [])
+            placements = getattr(self, plural + '_placements', None)
+            keepout = getattr(self, plural + '_keepout')
+        else:
+            fmt = object_name
+            num = 1
+            locations = getattr(self, object_name + '_locations', [])
+            placements = getattr(self, object_name + '_placements', None)
+            keepout = getattr(self, object_name + '_keepout')
+        for i in range(num):
+            if i < len(locations):
+                x, y = locations[i]
+                k = keepout + 1e-9
+                rects = [(x - k, y - k, x + k, y + k)]
+            else:
+                rects = placements
+            placements_dict[fmt.format(i=i)] = (rects, keepout)
+        return placements_dict
+
+    def build_placements_dict(self):
+        """engine.py:533-544: order goal, hazard0.., robot"""
+        placements = OrderedDict()
+        placements.update(self.placements_dict_from_object('goal'))
+        placements.update(self.placements_dict_from_object('hazard'))
+        placements.update(self.placements_dict_from_object('robot'))
+        self.placements = placements
+
+    def _native_config(self, robot_id, n_candidates, rank, world):
+        c = _native.GxConfig()
+        c.struct_size = C.sizeof(_native.GxConfig)
+        c.robot = robot_id
+        c.env_num = int(self.env_num)
+        c.env_total = int(self.env_num) * world
+        c.env_offset = int(self.env_num) * rank
+        c.seed = int(self._seed) & 0xFFFFFFFF
+        c.num_steps = int(self.num_steps)
+        c.hazards_num = int(self.hazards_num)
+        c.lidar_num_bins = int(self.lidar_num_bins)
+        c.lidar_alias = int(bool(self.lidar_alias))
+        c.lidar_max_dist_set = int(self.lidar_max_dist is not None)
+        c.lidar_max_dist = float(self.lidar_max_dist or 0.0)
+        c.lidar_exp_gain = float(self.lidar_exp_gain)
+        c.goal_size = float(self.goal_size)
+        c.hazards_size = float(self.hazards_size)
+        c.reward_distance = float(self.reward_distance)
+        c.goal_keepout = float(self.goal_keepout)
+        c.hazards_keepout = float(self.hazards_keepout)
+        c.robot_keepout = float(self.robot_keepout)
+        c.placements_margin = float(self.placements_margin)
+        for i in range(4):
+            c.extents[i] = float(self.placements_extents[i])
+        for name, (rects, _) in self.placements.items():
+            if rects is not None:
+                raise NotImplementedError(
+                    f"explicit placements/locations for {name!r} (draw_placement's multi-rectangle "
+                    "branch uses the undefined self.rs in the reference, engine.py:616)")
+        c.observe_goal_lidar = int(bool(self.observe_goal_lidar))
+        c.observe_goal_comp = int(bool(self.observe_goal_comp))
+        c.observe_hazards = int(bool(self.observe_hazards))
+        c.observe_qpos = int(bool(self.observe_qpos))
+        c.observe_qvel = int(bool(self.observe_qvel))
+        c.observe_ctrl = int(bool(self.observe_ctrl))
+        c.observe_vel = int(bool(self.observe_vel))
+        c.observe_acc = int(bool(self.observe_acc))
+        c.n_candidates = n_candidates
+        c.physics_steps = int(self.physics_steps_per_control_step)
+        c.robot_goal_min_dist = 3.0  # engine.py:571
+        c.device = int(self.device_id)
+        return c
+
+    def build_observation_space(self):
+        """engine.py:386-418"""
+        d = OrderedDict()
+        inf = np.inf
+        if self.observe_goal_lidar:
+            d['goal_lidar'] = Box(0.0, 1.0, (self.lidar_num_bins,), dtype=np.float32)
+        if self.observe_goal_comp:
+            d['goal_compass'] = Box(-inf, inf, (2,), dtype=np.float32)
+        if self.observe_hazards:
+            d['hazards_lidar'] = Box(0.0, 1.0, (self.lidar_num_bins,), dtype=np.float32)
+        if self.observe_qpos:
+            d['qpos'] = Box(-inf, inf, (self.robot.nq,), dtype=np.float32)
+        if self.observe_qvel:
+            d['qvel'] = Box(-inf, inf, (self.robot.nv,), dtype=np.float32)
+        if self.observe_ctrl:
+            d['ctrl'] = Box(-inf, inf, (self.robot.nu,), dtype=np.float32)
+        if self.observe_vel:
+            d['vel'] = Box(-inf, inf, (2,), dtype=np.float32)
+        if self.observe_acc:
+            d['acc'] = Box(-inf, inf, (2,), dtype=np.float32)
+        self.obs_space_dict = d
+        self.obs_flat_size = int(sum(np.prod(v.shape) for v in d.values()))
+        self.observation_space = Box(-inf, inf, (self.obs_flat_size,), dtype=np.float32)
+        # column slices of the flat obs, sorted-key order (engine.py:773-777)
+        self._obs_slices = OrderedDict()
+        o = 0
+        for k in sorted(d.keys()):
+            n = int(np.prod(d[k].shape))
+            self._obs_slices[k] = slice(o, o + n)
+            o += n
+
+    # ------------------------------------------------------------------
+    # gym-style interface
+    # ------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _new(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.device)
+
+    def reset(self):
+        """Resample every layout and return the (env_num, obs_dim) observation (engine.py:454-467)."""
+        obs = self._new(self.env_num, self.obs_flat_size)
+        _native.check(self._lib.gx_reset(self._h, obs.data_ptr(), self._stream()))
+        n = C.c_int32()
+        st = self._lib.gx_layout_size(self._h, C.byref(n))
+        self.layout_size = int(n.value)
+        if st == _native.GX_ERR_LAYOUT:
+            # engine.py:444  assert self.layout_size > self.env_num
+            raise ResamplingError(f"number of valid layout is {self.layout_size} "
+                                  f"<= env_num {self._cfg.env_total}")
+        _native.check(st)
+        self._obs = obs
+        return obs
+
+    def step(self, action):
+        """One control step for every env (engine.py:469-495).  No auto-reset."""
+        a = self._as_action(action)
+        N = self.env_num
+        obs = self._new(N, self.obs_flat_size)
+        reward, cost, done = self._new(N), self._new(N), self._new(N)
+        qacc = self._new(N, self.robot.nv) if self.emit_qacc else None
+        _native.check(self._lib.gx_step(self._h, a.data_ptr(), obs.data_ptr(), reward.data_ptr(),
+                                        cost.data_ptr(), done.data_ptr(),
+                                        qacc.data_ptr() if qacc is not None else None,
+                                        self._stream()))
+        info_obs = {k: obs[:, s] for k, s in self._obs_slices.items()}
+        if qacc is not None and self.observe_qacc:
+            info_obs['qacc'] = qacc
+        info = {'cost': cost, 'obs': info_obs}
+        self._obs, self._reward, self._done, self._info = obs, reward, done, info
+        return obs, reward, done, info
+
+    def reset_done(self):
+        """Re-initialise the envs whose last `done` was set; other rows keep the last
+        step's observation (engine.py:497-505)."""
+        if self._obs is None:
+            raise RuntimeError("reset_done() before reset()")
+        out = self._new(self.env_num, self.obs_flat_size)
+        _native.check(self._lib.gx_reset_done(self._h, self._obs.data_ptr(), out.data_ptr(),
+                                              self._stream()))
+        return out
+
+    def rollout(self, actions):
+        """Open-loop rollout: T x (step -> reset_done) driven by `actions` (T, env_num, act_dim).
+
+        Returns time-major tensors obs (T, N, D) [post-reset_done, i.e. what the learner stores
+        as the next observation], reward, cost, done (T, N).  Equivalent to the learner loop of
+        safe_rl_libX/trpo/trpo.py:466-547 with a fixed action tape."""
+        a = actions
+        if a.dtype != torch.float32 or not a.is_contiguous() or a.device != self.device:
+            a = a.to(device=self.device, dtype=torch.float32).contiguous()
+        T = int(a.shape[0])
+        assert tuple(a.shape[1:]) == (self.env_num, self.action_space.shape[0])
+        N, D = self.env_num, self.obs_flat_size
+        obs = self._new(T, N, D)
+        reward, cost, done = self._new(T, N), self._new(T, N), self._new(T, N)
+        _native.check(self._lib.gx_rollout(self._h, T, a.data_ptr(), obs.data_ptr(),
+                                           reward.data_ptr(), cost.data_ptr(), done.data_ptr(),
+                                           self._stream()))
+        self._obs, self._reward, self._done = obs[-1], reward[-1], done[-1]
+        self._info = {'cost': cost[-1]}
+        return obs, reward, cost, done
+
+    def _as_action(self, action):
+        a = action if torch.is_tensor(action) else torch.as_tensor(action)
+        if a.device != self.device or a.dtype != torch.float32:
+            a = a.to(device=self.device, dtype=torch.float32)
+        a = a.detach()
+        if not a.is_contiguous():
+            a = a.contiguous()
+        if tuple(a.shape) != (self.env_num, self.action_space.shape[0]):
+            raise ValueError(f"action shape {tuple(a.shape)} != "
+                             f"{(self.env_num, self.action_space.shape[0])}")
+        return a
+
+    # ------------------------------------------------------------------
+    # state exchange (tests, checkpoints)
+    # ------------------------------------------------------------------
+    _STATE_FIELDS = (('qpos', 3), ('qvel', 3), ('pose0', 4), ('pose1', 2), ('objs', None),
+                     ('done0', 1), ('done1', 1), ('steps', 1))
+
+    def get_state(self):
+        N, H = self.env_num, int(self.hazards_num)
+        s = OrderedDict()
+        for name, w in self._STATE_FIELDS:
+            shape = (N, 1 + H, 2) if name == 'objs' else ((N,) if w == 1 else (N, w))
+            s[name] = np.empty(shape, np.float32)
+        key = (C.c_uint32 * 2)()
+        hist = C.c_int32()
+        fp = C.POINTER(C.c_float)
+        _native.check(self._lib.gx_get_state(self._h, *[s[n].ctypes.data_as(fp) for n, _ in self._STATE_FIELDS],
+                                             key, C.byref(hist)))
+        s['key'] = np.array([key[0], key[1]], np.uint32)
+        s['hist'] = int(hist.value)
+        return s
+
+    def set_state(self, s):
+        fp = C.POINTER(C.c_float)
+        keep, ptrs = [], []
+        for name, _ in self._STATE_FIELDS:
+            v = s.get(name)
+            if v is None:
+                ptrs.append(None)
+            else:
+                v = np.ascontiguousarray(v, np.float32)
+                keep.append(v)
+                ptrs.append(v.ctypes.data_as(fp))
+        key = None
+        if s.get('key') is not None:
+            key = (C.c_uint32 * 2)(int(s['key'][0]), int(s['key'][1]))
+        hist = C.byref(C.c_int32(int(s['hist']))) if s.get('hist') is not None else None
+        _native.check(self._lib.gx_set_state(self._h, *ptrs, key, hist))
+
+    def get_pool(self, max_rows=4096):
+        H = int(self.hazards_num)
+        pool = np.empty((max_rows, H + 2, 2), np.float32)
+        got = C.c_int32()
+        _native.check(self._lib.gx_get_pool(self._h, pool.ctypes.data_as(C.POINTER(C.c_float)),
+                                            max_rows, C.byref(got)))
+        return pool[:got.value]
+
+    # ------------------------------------------------------------------
+    def render(self):
+        raise NotImplementedError("render() needs the MuJoCo viewer (engine.py:1036-1070); "
+                                  "out of scope for the batched step path")
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.gx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def __reduce__(self):
+        # EzPickle(config=config) in the reference (engine.py:214): the pickle is the config
+        return (_rebuild, (self._ctor_config, self._ctor_kwargs))
+
+
+def _rebuild(config, kwargs):
+    return Engine(config, **kwargs)

@@ -1,0 +1,134 @@
+/*
+ * guardx.h -- C ABI of libguardx_hip.so, the MI355X (gfx950) implementation of
+ * the guardX `safe_rl_envs` batched environment step.
+ *
+ * The reference has NO native boundary for this path (it is pure Python on
+ * jax/mjx); the entry points below are what a Python
+ * binding of `Engine` (reference safe_rl_envs/safe_rl_envs/envs/engine.py) needs
+ * to replace its four jitted callables:
+ *
+ *   gx_reset       <- Engine.reset        engine.py:454-467 (+ reset_layout/get_layout :433-452)
+ *   gx_step        <- Engine.step         engine.py:469-495 (update_data :426-431, mjx_step :659-700)
+ *   gx_reset_done  <- Engine.reset_done   engine.py:497-505 (mjx_reset_done :702-731)
+ *   gx_rollout     <- the learner's inner loop over step()/reset_done()
+ *                     (safe_rl_libX/trpo/trpo.py:466-547) for an open-loop action tape
+ *
+ * All pointers named `d_*` are DEVICE addresses (hipMalloc / torch tensors on
+ * the handle's device), fp32, dense, 16-byte aligned.  `stream` is a
+ * hipStream_t passed as void* (NULL = default stream).  Nothing here throws;
+ * every call returns a gx_status and gx_last_error() describes the last failure
+ * on the calling thread.  No call synchronises the device unless documented.
+ */
+#ifndef GUARDX_H
+#define GUARDX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gx_status {
+    GX_OK = 0,
+    GX_ERR_ARG = 1,         /* bad argument / struct size / alignment */
+    GX_ERR_UNSUPPORTED = 2, /* robot or option not implemented */
+    GX_ERR_LAYOUT = 3,      /* layout_size <= env_num (engine.py:444 assert) */
+    GX_ERR_HIP = 4,         /* a HIP runtime call failed */
+    GX_ERR_STATE = 5        /* call order (e.g. step before reset) */
+} gx_status;
+
+/* Subset of Engine.DEFAULT (engine.py:98-204) that the hot path reads. */
+typedef struct gx_config {
+    int32_t struct_size;        /* sizeof(gx_config) */
+    int32_t robot;              /* 0 = xmls/point.xml */
+    int32_t env_num;            /* envs owned by this handle (local shard) */
+    int32_t env_total;          /* env_num of the whole batch (== env_num unsharded) */
+    int32_t env_offset;         /* global index of local env 0 */
+    uint32_t seed;              /* '_seed'  engine.py:203,216 */
+    int32_t num_steps;          /* engine.py:99 */
+    int32_t hazards_num;        /* engine.py:195 */
+    int32_t lidar_num_bins;     /* engine.py:148 */
+    int32_t lidar_alias;        /* engine.py:153 */
+    int32_t lidar_max_dist_set; /* engine.py:150, 0 == None */
+    float lidar_max_dist;
+    float lidar_exp_gain;       /* engine.py:151 */
+    float goal_size;            /* engine.py:167 */
+    float hazards_size;         /* engine.py:199 */
+    float reward_distance;      /* engine.py:174 */
+    double goal_keepout;        /* engine.py:166 */
+    double hazards_keepout;     /* engine.py:198 */
+    double robot_keepout;       /* engine.py:112 */
+    double placements_margin;   /* engine.py:104 */
+    double extents[4];          /* engine.py:103 */
+    int32_t observe_goal_lidar; /* engine.py:119 */
+    int32_t observe_goal_comp;  /* engine.py:120 */
+    int32_t observe_hazards;    /* engine.py:121 */
+    int32_t observe_qpos;       /* engine.py:123 */
+    int32_t observe_qvel;       /* engine.py:124 */
+    int32_t observe_ctrl;       /* engine.py:128 */
+    int32_t observe_vel;        /* engine.py:126 */
+    int32_t observe_acc;        /* engine.py:127 */
+    int32_t n_candidates;       /* engine.py:263, int(1e6) */
+    int32_t physics_steps;      /* engine.py:202 */
+    float robot_goal_min_dist;  /* engine.py:571, 3.0 */
+    int32_t device;             /* HIP device ordinal ('device_id' engine.py:100) */
+} gx_config;
+
+typedef struct gx_engine gx_engine;
+
+const char* gx_last_error(void);
+int32_t gx_abi_version(void);
+
+gx_status gx_create(const gx_config* cfg, gx_engine** out);
+gx_status gx_destroy(gx_engine* e);
+int32_t gx_obs_dim(const gx_engine* e);
+int32_t gx_act_dim(const gx_engine* e);
+
+/* Engine.reset: resample the layout pool from the current key, re-initialise
+ * every env, write d_obs (env_num x obs_dim).  Asynchronous on `stream`. */
+gx_status gx_reset(gx_engine* e, float* d_obs, void* stream);
+
+/* Size of the valid-layout pool of the last gx_reset.  SYNCHRONISES `stream`
+ * of that reset.  Returns GX_ERR_LAYOUT if *out <= env_total (engine.py:444). */
+gx_status gx_layout_size(gx_engine* e, int32_t* out);
+
+/* Engine.step.  d_action (env_num x act_dim) -> d_obs (env_num x obs_dim),
+ * d_reward, d_cost, d_done (env_num each; done is 0.f/1.f), d_qacc
+ * (env_num x 3, may be NULL).  No auto-reset. */
+gx_status gx_step(gx_engine* e, const float* d_action, float* d_obs, float* d_reward,
+                  float* d_cost, float* d_done, float* d_qacc, void* stream);
+
+/* Engine.reset_done: rows of envs whose last done was > 0 are re-initialised
+ * and their obs rows replaced; other rows are copied from d_obs_in (which may
+ * alias d_obs_out). */
+gx_status gx_reset_done(gx_engine* e, const float* d_obs_in, float* d_obs_out, void* stream);
+
+/* T fused step()+reset_done() iterations driven by an action tape
+ * d_actions[T][env_num][act_dim].  Outputs are time-major: d_obs[T][env_num][obs_dim]
+ * is the observation the learner sees AFTER reset_done (trpo.py:547), d_reward /
+ * d_cost / d_done [T][env_num].  d_obs_final may be NULL. */
+gx_status gx_rollout(gx_engine* e, int32_t T, const float* d_actions, float* d_obs,
+                     float* d_reward, float* d_cost, float* d_done, void* stream);
+
+/* Test / checkpoint support: env-major HOST arrays (any may be NULL).
+ *  qpos[N*3] qvel[N*3] pose0[N*4] pose1[N*2] objs[N*(1+H)*2] done0[N] done1[N]
+ *  steps[N] key[2] hist[1].  Synchronous. */
+gx_status gx_get_state(gx_engine* e, float* qpos, float* qvel, float* pose0, float* pose1,
+                       float* objs, float* done0, float* done1, float* steps,
+                       uint32_t* key, int32_t* hist);
+gx_status gx_set_state(gx_engine* e, const float* qpos, const float* qvel, const float* pose0,
+                       const float* pose1, const float* objs, const float* done0,
+                       const float* done1, const float* steps, const uint32_t* key,
+                       const int32_t* hist);
+/* rows of the valid-layout pool ((H+2)*2 floats each: goal, hazards.., robot) */
+gx_status gx_get_pool(gx_engine* e, float* pool, int32_t max_rows, int32_t* got);
+
+/* Device-math probe (tests): s,c = sincos(x); at2 = atan2(y,x); ex = exp(x). */
+gx_status gx_math_probe(int32_t n, const float* d_x, const float* d_y, float* d_s,
+                        float* d_c, float* d_at2, float* d_ex, void* stream);
+/* Device PRNG probe (tests): out[2n] = jax.random.split(key, n) computed on device. */
+gx_status gx_split_probe(const uint32_t* key, int32_t n, uint32_t* d_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,52 @@
+"""Shared helpers for the parity tests."""
+import numpy as np
+
+GOAL_POINT_8HAZARDS = {   # safe_rl_libX/guard_utils/safe_rl_env_config.py:59-81
+    'robot_base': 'xmls/point.xml', 'task': 'goal', 'goal_size': 0.5,
+    'observe_goal_comp': True, 'observe_hazards': True,
+    'constrain_hazards': True, 'constrain_indicator': False,
+    'lidar_num_bins': 16, 'hazards_num': 8, 'hazards_size': 0.3,
+}
+
+
+def task_config(env_num, seed=0, num_steps=200, **over):
+    cfg = dict(GOAL_POINT_8HAZARDS)
+    cfg.update(env_num=env_num, _seed=seed, num_steps=num_steps)
+    cfg.update(over)
+    return cfg
+
+
+def random_state(N, H, rng, spread=2.5, done_frac=0.1, near_frac=0.3):
+    """A random but plausible engine state (env-major arrays, see gx_get_state)."""
+    f = np.float32
+    qpos = np.empty((N, 3), f)
+    qpos[:, :2] = rng.uniform(-spread, spread, (N, 2))
+    qpos[:, 2] = rng.uniform(-40, 40, N)
+    qvel = np.empty((N, 3), f)
+    qvel[:, :2] = rng.uniform(-3, 3, (N, 2))
+    qvel[:, 2] = rng.uniform(-30, 30, N)
+    th_prev = rng.uniform(-np.pi, np.pi, N)
+    pose0 = np.empty((N, 4), f)
+    pose0[:, :2] = qpos[:, :2] - rng.uniform(-0.05, 0.05, (N, 2)).astype(f)
+    pose0[:, 2] = np.cos(th_prev)
+    pose0[:, 3] = np.sin(th_prev)
+    pose1 = (pose0[:, :2] - rng.uniform(-0.05, 0.05, (N, 2))).astype(f)
+    objs = rng.uniform(-2, 2, (N, 1 + H, 2)).astype(f)
+    # put some goals / hazards right next to the robot so done / cost fire
+    near = rng.random(N) < near_frac
+    objs[near, 0] = qpos[near, :2] + rng.uniform(-0.6, 0.6, (near.sum(), 2)).astype(f)
+    nearh = rng.random(N) < near_frac
+    objs[nearh, 1] = qpos[nearh, :2] + rng.uniform(-0.35, 0.35, (nearh.sum(), 2)).astype(f)
+    done0 = (rng.random(N) < done_frac).astype(f)
+    done1 = (rng.random(N) < done_frac).astype(f)
+    steps = rng.integers(0, 250, N).astype(f)
+    return dict(qpos=qpos, qvel=qvel, pose0=pose0, pose1=pose1, objs=objs,
+                done0=done0, done1=done1, steps=steps,
+                key=np.array([rng.integers(0, 2**32), rng.integers(0, 2**32)], np.uint32), hist=2)
+
+
+def assert_state_equal(a, b, fields=('qpos', 'qvel', 'pose0', 'objs', 'done0', 'steps')):
+    for k in fields:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    np.testing.assert_array_equal(a['key'], b['key'])
+    assert a['hist'] == b['hist']

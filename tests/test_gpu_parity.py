@@ -1,0 +1,229 @@
+"""HIP path vs the CPU restatement (oracle/) on identical inputs -- through the C ABI.
+
+Bar: bit-exact done / cost>0 masks, fp32 obs / reward within 1e-5.
+Because kernel and checker evaluate the same fp32 operation sequence, these
+tests actually demand exact equality of every output and of the state.
+"""
+import numpy as np
+import pytest
+
+from helpers import task_config, random_state, assert_state_equal
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # the north_star tolerance for obs / reward
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return torch
+
+
+def _engines(cfg, oracle, n_candidates=20000, **kw):
+    from guardx_amd import Engine
+    E = Engine(cfg, n_candidates=n_candidates, **kw)
+    O = oracle.OracleEngine(cfg, n_candidates=n_candidates,
+                            env_total=E._cfg.env_total, env_offset=E._cfg.env_offset)
+    return E, O
+
+
+def _cmp_step(out_g, out_o):
+    obs_g, r_g, d_g, info_g = out_g
+    obs_o, r_o, d_o, info_o = out_o
+    obs_g, r_g, d_g = obs_g.cpu().numpy(), r_g.cpu().numpy(), d_g.cpu().numpy()
+    c_g = info_g['cost'].cpu().numpy()
+    # masks: bit exact
+    np.testing.assert_array_equal(d_g, d_o)
+    np.testing.assert_array_equal(c_g > 0, info_o['cost'] > 0)
+    # values: stated tolerance ...
+    np.testing.assert_allclose(obs_g, obs_o, rtol=0, atol=TOL, equal_nan=True)
+    np.testing.assert_allclose(r_g, r_o, rtol=0, atol=TOL)
+    np.testing.assert_allclose(c_g, info_o['cost'], rtol=0, atol=TOL, equal_nan=True)
+    # ... and in fact exact, by construction
+    np.testing.assert_array_equal(obs_g, obs_o)
+    np.testing.assert_array_equal(r_g, r_o)
+    np.testing.assert_array_equal(c_g, info_o['cost'])
+    if 'qacc' in info_g['obs']:
+        np.testing.assert_array_equal(info_g['obs']['qacc'].cpu().numpy(), info_o['qacc'])
+
+
+def test_device_math_bitexact(torch_cuda, oracle):
+    torch = torch_cuda
+    import ctypes as C
+    from guardx_amd import _native
+    lib = _native.load()
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(-300, 300, 1 << 20), rng.uniform(-8, 8, 1 << 20),
+                        rng.uniform(-100, 1, 1 << 18), rng.normal(0, 1e-3, 1 << 18),
+                        [0.0, -0.0, np.inf, -np.inf, np.nan, 1e9, -1e9, 1e-45, -87.5, -86.9, 88.5]]
+                       ).astype(np.float32)
+    y = rng.uniform(-5, 5, x.size).astype(np.float32)
+    y[::97] = 0.0
+    y[1::197] = -0.0
+    x[5::211] = 0.0
+    so, co, ao, eo = oracle.math_probe(x, y)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    outs = [torch.empty_like(xd) for _ in range(4)]
+    _native.check(lib.gx_math_probe(x.size, xd.data_ptr(), yd.data_ptr(), *[o.data_ptr() for o in outs],
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    for name, g, o in zip(("sin", "cos", "atan2", "exp"), outs, (so, co, ao, eo)):
+        np.testing.assert_array_equal(g.cpu().numpy().view(np.uint32) & 0x7FFFFFFF if False else g.cpu().numpy(),
+                                      o, err_msg=name)
+
+
+def test_device_split_matches_oracle(torch_cuda, oracle):
+    torch = torch_cuda
+    import ctypes as C
+    from guardx_amd import _native
+    lib = _native.load()
+    for n, key in ((2, (0, 0)), (7, (1, 2)), (1000, (123, 456)), (100001, (0xdeadbeef, 42))):
+        out = torch.empty(2 * n, dtype=torch.int32, device='cuda')
+        k = (C.c_uint32 * 2)(*key)
+        _native.check(lib.gx_split_probe(k, n, out.data_ptr(),
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        got = out.cpu().numpy().view(np.uint32).reshape(n, 2)
+        np.testing.assert_array_equal(got, oracle.split(key, n))
+
+
+@pytest.mark.parametrize("N", [1, 4, 63, 64, 65, 2000, 5000])
+def test_step_parity_random_states(torch_cuda, oracle, N):
+    torch = torch_cuda
+    E, O = _engines(task_config(N, seed=3), oracle)
+    rng = np.random.default_rng(N)
+    for trial in range(3):
+        s = random_state(N, 8, rng)
+        s['hist'] = [2, 1, 0][trial]
+        E.set_state(s)
+        O.set_state(s)
+        act = rng.uniform(-1, 1, (N, 2)).astype(np.float32)
+        out_g = E.step(torch.from_numpy(act).cuda())
+        out_o = O.step(act)
+        _cmp_step(out_g, out_o)
+        assert_state_equal(E.get_state(), O.get_state())
+
+
+def test_step_parity_nan_inf_actions(torch_cuda, oracle):
+    torch = torch_cuda
+    N = 256
+    E, O = _engines(task_config(N, seed=5), oracle)
+    rng = np.random.default_rng(0)
+    s = random_state(N, 8, rng, done_frac=0.0)
+    E.set_state(s); O.set_state(s)
+    act = rng.uniform(-1, 1, (N, 2)).astype(np.float32)
+    act[::7, 0] = np.nan
+    act[3::11, 1] = np.inf
+    act[5::13, 0] = -np.inf
+    out_g = E.step(torch.from_numpy(act).cuda())
+    out_o = O.step(act)
+    d = out_g[2].cpu().numpy()
+    np.testing.assert_array_equal(d, out_o[2])
+    np.testing.assert_array_equal(out_g[1].cpu().numpy(), out_o[1])
+    np.testing.assert_array_equal(out_g[0].cpu().numpy(), out_o[0])   # NaNs compare equal here
+    assert d[::7].all() and (out_g[1].cpu().numpy()[::7] == 0).all()  # guard engine.py:696-699
+
+
+@pytest.mark.parametrize("N,cand", [(4, 20000), (2000, 200000)])
+def test_reset_parity(torch_cuda, oracle, N, cand):
+    E, O = _engines(task_config(N, seed=0), oracle, n_candidates=cand)
+    obs_g = E.reset().cpu().numpy()
+    obs_o = O.reset()
+    assert E.layout_size == O.layout_size
+    np.testing.assert_array_equal(E.get_pool(512), O.get_pool(512))
+    np.testing.assert_array_equal(obs_g, obs_o)
+    assert_state_equal(E.get_state(), O.get_state())
+
+
+def test_rollout_parity_with_reset_done(torch_cuda, oracle):
+    """200-step random-policy episode with reset_done() whenever any env is done."""
+    torch = torch_cuda
+    N, T = 500, 200
+    E, O = _engines(task_config(N, seed=11, num_steps=T), oracle, n_candidates=60000)
+    og, oo = E.reset(), O.reset()
+    np.testing.assert_array_equal(og.cpu().numpy(), oo)
+    rng = np.random.RandomState(0)
+    n_done = 0
+    for t in range(T):
+        act = rng.uniform(-1, 1, (N, 2)).astype(np.float32)   # myTest.py:28-31 style
+        out_g = E.step(torch.from_numpy(act).cuda())
+        out_o = O.step(act)
+        _cmp_step(out_g, out_o)
+        if out_o[2].any():
+            n_done += int(out_o[2].sum())
+            rg, ro = E.reset_done().cpu().numpy(), O.reset_done()
+            np.testing.assert_array_equal(rg, ro)
+    assert n_done > 0, "the episode never exercised reset_done"
+    assert_state_equal(E.get_state(), O.get_state())
+    # second epoch: reset() with the advanced key, stale _done carried over (SURVEY 3.2 note)
+    np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
+    act = rng.uniform(-1, 1, (N, 2)).astype(np.float32)
+    _cmp_step(E.step(torch.from_numpy(act).cuda()), O.step(act))
+
+
+def test_fused_rollout_equals_stepwise(torch_cuda, oracle):
+    torch = torch_cuda
+    N, T = 300, 64
+    cfg = task_config(N, seed=2, num_steps=T)
+    E, O = _engines(cfg, oracle, n_candidates=40000)
+    E.reset(); O.reset()
+    rng = np.random.default_rng(5)
+    acts = rng.uniform(-1, 1, (T, N, 2)).astype(np.float32)
+    obs, rew, cost, done = E.rollout(torch.from_numpy(acts).cuda())
+    for t in range(T):
+        o, r, d, info = O.step(acts[t])
+        o = O.reset_done()
+        np.testing.assert_array_equal(obs[t].cpu().numpy(), o)
+        np.testing.assert_array_equal(rew[t].cpu().numpy(), r)
+        np.testing.assert_array_equal(done[t].cpu().numpy(), d)
+        np.testing.assert_array_equal(cost[t].cpu().numpy(), info['cost'])
+    assert_state_equal(E.get_state(), O.get_state())
+
+
+def test_variant_configs(torch_cuda, oracle):
+    torch = torch_cuda
+    variants = [
+        dict(hazards_num=3, lidar_num_bins=8),
+        dict(hazards_num=12, lidar_num_bins=24, lidar_alias=False),
+        dict(observe_vel=True, observe_acc=True),
+        dict(observe_qpos=False, observe_ctrl=False, observe_goal_lidar=False),
+        dict(lidar_max_dist=3.0, physics_steps_per_control_step=2, lidar_exp_gain=0.5),
+        dict(hazards_num=20, goal_size=0.3, hazards_size=0.2, reward_distance=2.0,
+             hazards_keepout=0.18, placements_extents=[-3, -3, 3, 3]),
+    ]
+    for v in variants:
+        N = 130
+        cfg = task_config(N, seed=9, num_steps=50, **v)
+        E, O = _engines(cfg, oracle, n_candidates=30000)
+        assert E.obs_flat_size == O.D
+        np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset(check=False))
+        rng = np.random.default_rng(3)
+        for t in range(60):   # crosses the num_steps timeout (engine.py:492)
+            act = rng.uniform(-1, 1, (N, 2)).astype(np.float32)
+            out_g, out_o = E.step(torch.from_numpy(act).cuda()), O.step(act)
+            _cmp_step(out_g, out_o)
+            if t % 7 == 6:
+                np.testing.assert_array_equal(E.reset_done().cpu().numpy(), O.reset_done())
+        assert_state_equal(E.get_state(), O.get_state(),
+                           fields=('qpos', 'qvel', 'pose0', 'pose1', 'objs', 'done0', 'done1', 'steps')
+                           if v.get('observe_vel') else ('qpos', 'qvel', 'pose0', 'objs', 'done0', 'steps'))
+
+
+def test_sharded_equals_unsharded(torch_cuda, oracle):
+    """rank r of a world-of-4 engine reproduces rows [r*N, (r+1)*N) of one 4N-env engine."""
+    torch = torch_cuda
+    from guardx_amd import Engine
+    N, W = 96, 4
+    full = Engine(task_config(N * W, seed=4), n_candidates=50000)
+    obs_full = full.reset().cpu().numpy()
+    rng = np.random.default_rng(0)
+    act = rng.uniform(-1, 1, (N * W, 2)).astype(np.float32)
+    o_full, r_full, d_full, _ = full.step(torch.from_numpy(act).cuda())
+    full_rd = full.reset_done().cpu().numpy()
+    for r in range(W):
+        sh = Engine(task_config(N, seed=4), n_candidates=50000, shard=(r, W))
+        np.testing.assert_array_equal(sh.reset().cpu().numpy(), obs_full[r * N:(r + 1) * N])
+        o, rew, d, _ = sh.step(torch.from_numpy(act[r * N:(r + 1) * N]).cuda())
+        np.testing.assert_array_equal(o.cpu().numpy(), o_full[r * N:(r + 1) * N].cpu().numpy())
+        np.testing.assert_array_equal(sh.reset_done().cpu().numpy(), full_rd[r * N:(r + 1) * N])
