@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec of the GUARD batched environment step,
+Goal_Point_8Hazards, env_num=2000 per GPU, random-policy rollout (BASELINE.json).
+
+A "step" is one pass of the hot path over the batch: Engine.step for all envs plus
+reset_done for the envs that finished (device-side done test; identical results to
+the learner's `if done.any(): reset_done()`), with reset() every `max_ep_len`=200
+steps.  Inputs (the action tape) are resident in HBM before the
+timed region.  Prints ONE JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+TASK = {   # Goal_Point_8Hazards, safe_rl_libX/guard_utils/safe_rl_env_config.py:59-81
+    'robot_base': 'xmls/point.xml', 'task': 'goal', 'goal_size': 0.5,
+    'observe_goal_comp': True, 'observe_hazards': True,
+    'constrain_hazards': True, 'constrain_indicator': False,
+    'lidar_num_bins': 16, 'hazards_num': 8, 'hazards_size': 0.3,
+}
+ENV_NUM = 2000
+EP_LEN = 200
+ALGO_BYTES_PER_ENV_STEP = 372     # 124 B read + 248 B written
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def make_engine(env_num, rank, world, seed=0, n_candidates=1_000_000):
+    from guardx_amd import Engine
+    cfg = dict(TASK)
+    cfg.update(env_num=env_num, _seed=seed, num_steps=EP_LEN, device_id=torch.cuda.current_device())
+    return Engine(cfg, shard=(rank, world) if world > 1 else None, n_candidates=n_candidates)
+
+
+def action_tape(T, N, seed, device):
+    g = torch.Generator(device=device).manual_seed(seed)
+    return torch.rand(T, N, 2, device=device, generator=g) * 2 - 1   # a ~ U(-1,1), myTest.py:28-31
+
+
+def run_epochs(env, tapes, steps, gather):
+    """`steps` hot-path passes = steps/EP_LEN epochs of reset() + fused rollout (+ hand-off)."""
+    from guardx_amd import dist as gxd
+    done_steps = 0
+    ep = 0
+    while done_steps < steps:
+        T = min(EP_LEN, steps - done_steps)
+        env.reset()
+        acts = tapes[ep % len(tapes)][:T]
+        obs, rew, cost, done = env.rollout(acts)
+        if gather:
+            gxd.all_gather_rollout(gxd.pack_rollout(obs, acts, rew, cost, done))
+        done_steps += T
+        ep += 1
+
+
+def time_step_kernel(env_num, nlaunch, device):
+    """Average duration of one step-kernel launch, HIP events on the launch stream."""
+    env = make_engine(env_num, 0, 1, n_candidates=200_000)
+    env.reset()
+    act = action_tape(1, env_num, 7, device)[0]
+    N, D = env_num, env.obs_flat_size
+    obs = torch.empty(N, D, device=device)
+    r, c, d = (torch.empty(N, device=device) for _ in range(3))
+    qacc = torch.empty(N, 3, device=device)
+    from guardx_amd import _native
+    import ctypes as C
+    lib = _native.load()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def launch():
+        _native.check(lib.gx_step(env._h, act.data_ptr(), obs.data_ptr(), r.data_ptr(), c.data_ptr(),
+                                  d.data_ptr(), qacc.data_ptr(), stream))
+    for _ in range(20):
+        launch()
+    torch.cuda.synchronize()
+    # (a) one event pair per launch: kernel duration (+ event overhead)
+    pairs = []
+    for _ in range(nlaunch):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); launch(); e1.record()
+        pairs.append((e0, e1))
+    torch.cuda.synchronize()
+    per = np.array([a.elapsed_time(b) for a, b in pairs]) * 1e-3
+    # (b) back-to-back launches between two events: launch cadence
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(nlaunch):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    cadence = e0.elapsed_time(e1) * 1e-3 / nlaunch
+    env.close()
+    return float(np.median(per)), float(cadence)
+
+
+def roofline(env_num, nlaunch, device):
+    per, cadence = time_step_kernel(env_num, nlaunch, device)
+    t = min(per, cadence)
+    ach = ALGO_BYTES_PER_ENV_STEP * env_num / t / 1e9
+    return {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+            "kernel": "gx::step_kernel", "env_num": env_num,
+            "avg_launch_us": round(t * 1e6, 3), "event_pair_us": round(per * 1e6, 3),
+            "back_to_back_us": round(cadence * 1e6, 3),
+            "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP}
+
+
+def cpu_baseline(epochs=2):
+    """The CPU restatement (oracle/, 'port') timed on the host cores on a bounded sample."""
+    from oracle import gxo
+    cfg = dict(TASK)
+    cfg.update(env_num=ENV_NUM, _seed=0, num_steps=EP_LEN)
+    ref = gxo.OracleEngine(cfg, n_candidates=1_000_000)
+    rng = np.random.RandomState(0)
+    acts = rng.uniform(-1, 1, (EP_LEN, ENV_NUM, 2)).astype(np.float32)
+    t0 = time.perf_counter()
+    n = 0
+    for _ in range(epochs):
+        ref.reset()
+        for t in range(EP_LEN):
+            _, _, d, _ = ref.step(acts[t])
+            if d.any():
+                ref.reset_done()
+            n += ENV_NUM
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 1), "unit": "env-steps/s", "cores": int(gxo.lib().gxo_get_threads()),
+            "kind": "port",
+            "sample": f"{epochs} epochs x {EP_LEN} steps x {ENV_NUM} envs incl. reset() over 1e6 layout "
+                      f"candidates (OpenMP) and reset_done(); {dt:.1f} s wall",
+            "note": "CPU restatement (oracle/), not the reference's XLA:CPU program"}
+
+
+def api_loop_rate(env, tape, steps):
+    """Python-driven Engine.step()/reset_done() loop (what an unmodified learner drives)."""
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s = 0
+    while s < steps:
+        env.reset()
+        for t in range(min(EP_LEN, steps - s)):
+            env.step(tape[t])
+            env.reset_done()
+            s += 1
+    torch.cuda.synchronize()
+    return env.env_num * steps / (time.perf_counter() - t0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10000)    # 50 epochs of 200 steps
+    ap.add_argument("--warmup", type=int, default=1000)    # 5 epochs
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    from guardx_amd import dist as gxd
+    rank, local, world = gxd.init_from_env()
+    assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    env = make_engine(ENV_NUM, rank, world)
+    tapes = [action_tape(EP_LEN, ENV_NUM, 1000 * rank + k, device) for k in range(4)]
+    gather = world > 1
+
+    run_epochs(env, tapes, args.warmup, gather)
+    gxd.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_epochs(env, tapes, args.steps, gather)
+    torch.cuda.synchronize()
+    gxd.barrier()
+    dt = gxd.max_over_ranks(time.perf_counter() - t0, device)
+
+    value = ENV_NUM * world * args.steps / dt
+    line = {
+        "metric": "env-steps/sec", "value": round(value, 1), "unit": "env-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 6), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "Goal_Point_8Hazards env_num=2000/GPU, random-policy rollout "
+                               "(U(-1,1) action tape), 200-step epochs: reset() + 200 x (step + reset_done)"
+                               + (", RCCL all-gather of the packed rollout shard per epoch" if gather else ""),
+                   "env_num_per_gpu": ENV_NUM, "max_ep_len": EP_LEN, "obs_dim": env.obs_flat_size,
+                   "driver": "gx_rollout (C loop of step+reset_done launches per epoch)",
+                   "layout_candidates_per_reset": 1_000_000},
+    }
+    if rank == 0:
+        line["roofline"] = roofline(ENV_NUM, 400, device)
+        if not args.no_extras:
+            # bandwidth regime: the same kernel at 2^22 envs (N=2000 is launch-latency bound)
+            line["roofline_large_batch"] = roofline(1 << 22, 30, device)
+            line["api_step_loop_env_steps_per_s"] = round(api_loop_rate(env, tapes[0], 1000), 1)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    gxd.barrier()
+    env.close()
+
+
+if __name__ == "__main__":
+    main()
