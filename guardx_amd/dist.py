@@ -45,9 +45,11 @@ def all_gather_rollout(packed, out=None):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return packed.unsqueeze(0)
     world = dist.get_world_size()
+    shape = tuple(packed.shape)
     if out is None:
-        out = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
-    dist.all_gather_into_tensor(out, packed.contiguous())
+        out = torch.empty((world,) + shape, dtype=packed.dtype, device=packed.device)
+    # concatenated-along-dim-0 form: accepted by both RCCL and gloo
+    dist.all_gather_into_tensor(out.view((world * shape[0],) + shape[1:]), packed.contiguous())
     return out
 
 

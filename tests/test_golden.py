@@ -1,0 +1,65 @@
+"""Committed self-consistency vectors (tools/gen_golden.py): the CPU restatement must
+reproduce them bit for bit on any host, and the HIP path must reproduce them on the GPU
+without the oracle in the loop.  They are NOT reference outputs (parity unpinned)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from helpers import task_config
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = {
+    "goal_point_8hazards_n4_seed0": (task_config(4, seed=0, num_steps=200), 20000),
+    "goal_point_8hazards_n24_seed5": (task_config(24, seed=5, num_steps=40, goal_size=1.2), 30000),
+}
+
+
+def _replay(E, g, to_np, to_dev):
+    np.testing.assert_array_equal(to_np(E.reset()), g['reset_obs'])
+    assert E.layout_size == int(g['layout_size'])
+    np.testing.assert_array_equal(E.get_pool(8), g['pool_head'])
+    T = g['actions'].shape[0]
+    for t in range(T):
+        o, r, d, info = E.step(to_dev(g['actions'][t]))
+        np.testing.assert_array_equal(to_np(o), g['obs'][t])
+        np.testing.assert_array_equal(to_np(r), g['reward'][t])
+        np.testing.assert_array_equal(to_np(d), g['done'][t])
+        np.testing.assert_array_equal(to_np(info['cost']), g['cost'][t])
+        np.testing.assert_array_equal(to_np(E.reset_done()), g['reset_done_obs'][t])
+    st = E.get_state()
+    for k in ('qpos', 'qvel', 'pose0', 'objs', 'done0', 'steps', 'key'):
+        np.testing.assert_array_equal(st[k], g['final_' + k])
+
+
+def test_fixture_files_present():
+    assert sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz"))) == sorted(CASES)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_reproduces_golden(oracle, name):
+    cfg, cand = CASES[name]
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    assert g['done'].sum() > 0 or name.endswith("seed0")
+    E = oracle.OracleEngine(cfg, n_candidates=cand)
+
+    class Wrap:
+        layout_size = property(lambda s: E.layout_size)
+        def reset(s): return E.reset(check=False)
+        def step(s, a): return E.step(a)
+        def reset_done(s): return E.reset_done()
+        def get_pool(s, n): return E.get_pool(n)
+        def get_state(s): return E.get_state()
+    _replay(Wrap(), g, lambda x: x, lambda a: a)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_hip_reproduces_golden(name):
+    import torch
+    from guardx_amd import Engine, ResamplingError
+    cfg, cand = CASES[name]
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    E = Engine(cfg, n_candidates=cand)
+    _replay(E, g, lambda x: x.cpu().numpy(), lambda a: torch.from_numpy(a).cuda())

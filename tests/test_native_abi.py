@@ -1,0 +1,64 @@
+"""The C-ABI library loads on a CPU-only host and exports every symbol that
+include/guardx.h declares (no compute calls without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "guardx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gx_[a-z_0-9]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def native():
+    from guardx_amd import build, _native
+    build.build()
+    return _native
+
+
+def test_every_declared_symbol_is_exported_and_bound(native):
+    lib = native.load()
+    names = _declared()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in guardx.h but not exported"
+        assert n in native.SYMBOLS, f"{n} has no ctypes prototype"
+    assert sorted(native.SYMBOLS) == names
+
+
+def test_abi_version_and_struct_size(native):
+    lib = native.load()
+    assert lib.gx_abi_version() == 1
+    cfg = native.GxConfig()
+    h = C.c_void_p()
+    cfg.struct_size = 4                       # wrong size is rejected before any HIP call
+    assert lib.gx_create(C.byref(cfg), C.byref(h)) == native.GX_ERR_ARG
+    assert b"struct_size" in lib.gx_last_error()
+    # the right size passes the ABI check (and then fails on the arguments / missing device)
+    cfg.struct_size = C.sizeof(native.GxConfig)
+    rc = lib.gx_create(C.byref(cfg), C.byref(h))
+    assert rc != native.GX_OK and b"struct_size" not in lib.gx_last_error()
+
+
+def test_oracle_and_product_config_structs_have_the_same_layout(native):
+    from oracle import gxo
+    a = [(n, t) for n, t in native.GxConfig._fields_]
+    b = [(n, t) for n, t in gxo.Config._fields_]
+    assert [t for _, t in a] == [t for _, t in b]
+    assert C.sizeof(native.GxConfig) == C.sizeof(gxo.Config)
+
+
+def test_null_arguments_are_errors_not_crashes(native):
+    lib = native.load()
+    assert lib.gx_create(None, None) == native.GX_ERR_ARG
+    assert lib.gx_reset(None, None, None) == native.GX_ERR_ARG
+    assert lib.gx_step(None, None, None, None, None, None, None, None) == native.GX_ERR_ARG
+    assert lib.gx_reset_done(None, None, None, None) == native.GX_ERR_ARG
+    assert lib.gx_obs_dim(None) == -1
+    assert lib.gx_destroy(None) == native.GX_OK

@@ -1,0 +1,295 @@
+"""Closed-form checks of the CPU restatement against the formulas of the reference
+(engine.py line numbers in each test)."""
+import numpy as np
+import pytest
+
+from helpers import task_config, random_state
+
+f32 = np.float32
+
+
+def _engine(oracle, N=4, cand=6000, **kw):
+    E = oracle.OracleEngine(task_config(N, **kw), n_candidates=cand)
+    E.reset(check=False)
+    return E
+
+
+def _still_state(N, H=8, theta=0.0, robot=(0.0, 0.0)):
+    """robot at rest at `robot`, heading theta, objects far away"""
+    s = dict(
+        qpos=np.tile(np.array([robot[0], robot[1], theta], f32), (N, 1)),
+        qvel=np.zeros((N, 3), f32),
+        pose0=np.tile(np.array([robot[0], robot[1], np.cos(theta), np.sin(theta)], f32), (N, 1)),
+        pose1=np.tile(np.array(robot, f32), (N, 1)),
+        objs=np.full((N, 1 + H, 2), 50.0, f32),
+        done0=np.zeros(N, f32), done1=np.zeros(N, f32), steps=np.zeros(N, f32),
+        key=np.array([0, 1], np.uint32), hist=2)
+    return s
+
+
+def test_obs_layout_and_dims(oracle):
+    """flat obs = sorted keys: ctrl[0:3] goal_compass[3:5] goal_lidar[5:21] hazards_lidar[21:37]
+    qpos[37:40] qvel[40:43]  (engine.py:386-409, 773-777)"""
+    E = _engine(oracle)
+    assert E.D == 43
+    s = _still_state(4)
+    s['qpos'][:, :] = [0.3, -0.2, 0.0]
+    s['pose0'][:, :2] = [0.3, -0.2]
+    s['objs'][:, 0] = [1.3, -0.2]      # goal 1 m straight ahead
+    E.set_state(s)
+    obs, r, d, info = E.step(np.tile(np.array([0.5, -0.25], f32), (4, 1)))
+    np.testing.assert_allclose(obs[0, 0:3], [0.5, 0.0, -0.25], atol=1e-7)      # ctrl = (a0*c, a0*s, a1)
+    np.testing.assert_allclose(obs[0, 3:5], [1.0, 0.0], atol=1e-6)             # compass, not normalised
+    assert obs[0, 5] == pytest.approx(np.exp(-1.0), abs=2e-7)                  # goal lidar bin 0
+    assert obs[0, 37] != 0.3 and abs(obs[0, 37] - 0.3) < 0.05                  # qpos is POST-integration
+    assert obs[0, 40] > 0                                                      # qvel x after the push
+
+
+@pytest.mark.parametrize("k", range(16))
+def test_lidar_bin_centre_and_alias(oracle, k):
+    """object in the middle of bin k: bin k = exp(-d), neighbours = 0.5*exp(-d) (engine.py:879-899)"""
+    E = _engine(oracle)
+    s = _still_state(4)
+    ang = (k + 0.5) * 2 * np.pi / 16
+    dist = 1.5
+    s['objs'][:, 0] = [dist * np.cos(ang), dist * np.sin(ang)]
+    E.set_state(s)
+    obs, *_ = E.step(np.zeros((4, 2), f32))
+    gl = obs[0, 5:21]
+    want = np.zeros(16)
+    want[k] = np.exp(-dist)
+    want[(k + 1) % 16] = 0.5 * np.exp(-dist)
+    want[(k - 1) % 16] = 0.5 * np.exp(-dist)
+    np.testing.assert_allclose(gl, want, atol=2e-6)
+    assert (obs[0, 21:37] < 1e-20).all()         # hazards 70 m away
+
+
+def test_lidar_is_egocentric_and_max_over_objects(oracle):
+    E = _engine(oracle)
+    th = np.pi / 2
+    s = _still_state(4, theta=th)
+    # world +y is straight ahead for heading pi/2 -> ego angle ~0+ -> bin 0 (+ alias into 15)
+    s['objs'][:, 1] = [-0.01, 1.0]
+    s['objs'][:, 2] = [-0.02, 2.0]        # farther object in the same direction: occluded by max
+    E.set_state(s)
+    obs, *_ = E.step(np.zeros((4, 2), f32))
+    hl = obs[0, 21:37]
+    d = np.hypot(0.01, 1.0)
+    assert hl[0] == pytest.approx(np.exp(-d), abs=1e-6)
+    assert hl[2:15].max() < 1e-6
+    alias = 0.01 / (2 * np.pi / 16)
+    assert hl[15] == pytest.approx((1 - alias) * np.exp(-d), abs=2e-5)
+    assert hl[1] == pytest.approx(max(alias * np.exp(-d), 2 * alias * np.exp(-np.hypot(0.02, 2.0))), abs=2e-5)
+
+
+def test_lidar_angle_rounding_to_2pi_edge(oracle):
+    """angle % 2pi can round to exactly f32(2pi): bin == 16, the scatter into obs[16] is dropped
+    and the reading survives only through the (1-alias) write into bin 15."""
+    E = _engine(oracle)
+    s = _still_state(4, theta=np.pi / 2)   # cos(f32(pi/2)) = -4.4e-8 -> ego angle = -4.4e-8
+    s['objs'][:, 1] = [0.0, 1.0]
+    E.set_state(s)
+    obs, *_ = E.step(np.zeros((4, 2), f32))
+    hl = obs[0, 21:37]
+    assert hl[0] == 0 and hl[1] == 0
+    assert hl[15] == pytest.approx(np.exp(-1.0), abs=1e-6)
+
+
+def test_lidar_uses_stale_pose_not_new_qpos(oracle):
+    """lidar/compass/reward/cost read xpos/xmat of the forward() at the START of the step
+    (SURVEY fact 8), i.e. the qpos passed in, not the integrated one."""
+    E = _engine(oracle)
+    s = _still_state(4)
+    s['qvel'][:, 0] = 5.0                 # moving fast along +x
+    s['objs'][:, 0] = [1.0, 0.0]
+    E.set_state(s)
+    obs, *_ = E.step(np.zeros((4, 2), f32))
+    assert obs[0, 37] > 0.05                                   # qpos moved ...
+    np.testing.assert_allclose(obs[0, 3:5], [1.0, 0.0], atol=1e-6)   # ... compass still from x=0
+
+
+def test_action_rotated_by_prestep_heading(oracle):
+    """convert_action uses data.xmat BEFORE the step (engine.py:672-685): heading of pose0,
+    not the current qpos angle."""
+    E = _engine(oracle)
+    s = _still_state(4, theta=0.0)
+    s['pose0'][:, 2:] = [0.0, 1.0]        # stale heading = +y while theta = 0
+    E.set_state(s)
+    obs, *_ = E.step(np.tile(np.array([1.0, 0.0], f32), (4, 1)))
+    np.testing.assert_allclose(obs[0, 0:3], [0.0, 1.0, 0.0], atol=1e-7)
+    assert abs(obs[0, 40]) < 1e-3 and obs[0, 41] > 0.5        # pushed along world y
+
+
+def test_cost_dense_sum(oracle):
+    """cost = sum_h (size - min(dist_h, size)), size = 0.3 (engine.py:804-811)"""
+    E = _engine(oracle)
+    s = _still_state(4)
+    s['objs'][:, 1] = [0.1, 0.0]
+    s['objs'][:, 2] = [0.0, -0.25]
+    s['objs'][:, 3] = [0.3, 0.0]          # exactly on the rim: contributes 0
+    s['objs'][:, 4] = [0.31, 0.0]
+    E.set_state(s)
+    _, _, _, info = E.step(np.zeros((4, 2), f32))
+    assert info['cost'][0] == pytest.approx(0.2 + 0.05, abs=1e-6)
+    s['objs'][:, 1:3] = 50.0
+    E.set_state(s)
+    _, _, _, info = E.step(np.zeros((4, 2), f32))
+    assert info['cost'][0] < 1e-7 and info['cost'][0] >= 0
+
+
+def test_reward_and_done(oracle):
+    """reward = (last_dist - dist)*reward_distance; done = dist < goal_size;
+    |delta|>1 -> done, reward 0 (engine.py:787-802)"""
+    E = _engine(oracle)
+    s = _still_state(4)
+    s['objs'][:, 0] = [2.0, 0.0]
+    s['pose0'][:, :2] = [-0.25, 0.0]      # last_data.xpos: robot was 0.25 further away
+    E.set_state(s)
+    _, r, d, _ = E.step(np.zeros((4, 2), f32))
+    assert r[0] == pytest.approx(0.25, abs=1e-6) and d[0] == 0
+    # inside the goal radius -> done
+    s['objs'][:, 0] = [0.49, 0.0]
+    s['pose0'][:, :2] = [0.0, 0.0]
+    E.set_state(s)
+    _, r, d, _ = E.step(np.zeros((4, 2), f32))
+    assert d[0] == 1 and abs(r[0]) < 1e-6
+    s['objs'][:, 0] = [0.5, 0.0]          # exactly goal_size: strict '<'
+    E.set_state(s)
+    assert E.step(np.zeros((4, 2), f32))[2][0] == 0
+    # teleport guard
+    s['objs'][:, 0] = [3.0, 0.0]
+    s['pose0'][:, :2] = [-1.5, 0.0]
+    E.set_state(s)
+    _, r, d, _ = E.step(np.zeros((4, 2), f32))
+    assert d[0] == 1 and r[0] == 0
+
+
+def test_reward_zero_after_done_and_on_first_step(oracle):
+    E = _engine(oracle)
+    s = _still_state(4)
+    s['objs'][:, 0] = [2.0, 0.0]
+    s['pose0'][:, :2] = [-0.25, 0.0]
+    s['done0'][:] = [1, 0, 1, 0]          # becomes _last_done in update_data
+    E.set_state(s)
+    _, r, _, _ = E.step(np.zeros((4, 2), f32))
+    np.testing.assert_allclose(r, [0, 0.25, 0, 0.25], atol=1e-6)
+    s['hist'] = 0                          # _last_done is None on the very first step (engine.py:793-796)
+    s['done0'][:] = 0
+    E.set_state(s)
+    assert (E.step(np.zeros((4, 2), f32))[1] == 0).all()
+
+
+def test_timeout_and_step_counter(oracle):
+    """done |= steps > num_steps (strict); steps = done ? 0 : steps+1 (engine.py:492-493)"""
+    E = _engine(oracle, num_steps=10)
+    s = _still_state(4)
+    s['steps'][:] = [9, 10, 11, 3]
+    E.set_state(s)
+    _, _, d, _ = E.step(np.zeros((4, 2), f32))
+    np.testing.assert_array_equal(d, [0, 0, 1, 0])
+    np.testing.assert_array_equal(E.get_state()['steps'], [10, 11, 0, 4])
+
+
+def test_nan_guard(oracle):
+    E = _engine(oracle)
+    s = _still_state(4)
+    s['objs'][:, 0] = [2.0, 0.0]
+    s['pose0'][:, :2] = [-0.25, 0.0]
+    E.set_state(s)
+    a = np.zeros((4, 2), f32)
+    a[1, 0] = np.nan
+    a[2, 1] = np.inf
+    obs, r, d, _ = E.step(a)
+    np.testing.assert_array_equal(d, [0, 1, 1, 0])
+    assert r[1] == 0 and r[2] == 0 and r[0] > 0
+    assert np.isnan(obs[1]).any() and not np.isfinite(obs[2]).all()
+
+
+def test_point_dynamics_limits(oracle):
+    """terminal velocity = gear*ctrl/damping = 0.3/0.01 = 30 m/s; per-step decay m/(m+h d)."""
+    E = _engine(oracle)
+    s = _still_state(4)
+    E.set_state(s)
+    for _ in range(400):
+        obs, *_ = E.step(np.tile(np.array([1.0, 0.0], f32), (4, 1)))
+    assert obs[0, 40] == pytest.approx(30.0, rel=2e-3)
+    s = _still_state(4)
+    s['qvel'][:, 0] = 1.0
+    E.set_state(s)
+    obs, *_ = E.step(np.zeros((4, 2), f32))
+    m = 0.005188790204786391
+    assert obs[0, 40] == pytest.approx(m / (m + 0.02 * 0.01), rel=1e-5)
+    # first-step angular acceleration: qacc_z = 0.3 / Izz' (data.qacc has no implicit damping)
+    s = _still_state(4)
+    E.set_state(s)
+    _, _, _, info = E.step(np.tile(np.array([0.0, 1.0], f32), (4, 1)))
+    I_c = 2.842182748581224e-05 - 1e-4 ** 2 / m
+    assert info['qacc'][0, 2] == pytest.approx(0.3 / I_c, rel=1e-5)
+
+
+def test_reset_layout_constraints_and_key_use(oracle):
+    E = oracle.OracleEngine(task_config(64, seed=3), n_candidates=30000)
+    o1 = E.reset()
+    st = E.get_state()
+    objs, robot = st['objs'], st['qpos'][:, :2]
+    assert (np.abs(objs[:, 0]) <= 1.5 + 1e-6).all() and (np.abs(objs[:, 1:]) <= 1.6 + 1e-6).all()
+    assert (np.abs(robot) <= 1.6 + 1e-6).all()
+    assert (np.linalg.norm(robot - objs[:, 0], axis=1) >= 3.0).all()          # engine.py:570-571
+    d_gh = np.linalg.norm(objs[:, 1:] - objs[:, :1], axis=2)
+    assert (d_gh >= 0.9 - 1e-6).all()                                          # 0.5 + 0.4
+    for i in range(1, 9):
+        for j in range(i + 1, 9):
+            assert (np.linalg.norm(objs[:, i] - objs[:, j], axis=1) >= 0.8 - 1e-6).all()
+    assert (np.linalg.norm(objs[:, 1:] - robot[:, None], axis=2) >= 0.8 - 1e-6).all()
+    assert (st['qvel'] == 0).all() and (st['qpos'][:, 2] == 0).all() and (st['steps'] == 0).all()
+    np.testing.assert_array_equal(st['pose0'], np.c_[robot, np.ones(64), np.zeros(64)].astype(f32))
+    assert (o1[:, 0:3] == 0).all() and (o1[:, 40:43] == 0).all()
+    np.testing.assert_array_equal(o1[:, 37:39], robot)
+    # reset() does not advance the key: same layouts again; a step() does
+    np.testing.assert_array_equal(E.reset(), o1)
+    E.step(np.zeros((64, 2), f32))
+    assert not np.array_equal(E.reset(), o1)
+
+
+def test_reset_done_semantics(oracle):
+    """only done rows change; stale pose kept; next reward of a reset env is 0"""
+    N = 32
+    E = oracle.OracleEngine(task_config(N, seed=1), n_candidates=30000)
+    E.reset()
+    rng = np.random.default_rng(0)
+    s = random_state(N, 8, rng, done_frac=0.0)
+    s['done0'][::4] = 1
+    s['steps'][::4] = 0
+    E.set_state(s)
+    # _obs of the engine is whatever the last step wrote; make one by stepping from a copy
+    before = E.get_state()
+    obs = E.reset_done()
+    after = E.get_state()
+    dn = before['done0'] > 0
+    assert dn.sum() == 8
+    np.testing.assert_array_equal(after['qpos'][~dn], before['qpos'][~dn])
+    np.testing.assert_array_equal(after['objs'][~dn], before['objs'][~dn])
+    np.testing.assert_array_equal(after['pose0'], before['pose0'])            # stale xpos/xmat (:731)
+    assert (after['qvel'][dn] == 0).all() and (after['qpos'][dn, 2] == 0).all()
+    assert (np.linalg.norm(after['qpos'][dn, :2] - after['objs'][dn, 0], axis=1) >= 3.0).all()
+    assert (obs[dn, 0:3] == 0).all() and (obs[dn, 40:43] == 0).all()
+    np.testing.assert_array_equal(obs[dn, 37:39], after['qpos'][dn, :2])
+    # idempotent: the key did not move, _done did not change
+    np.testing.assert_array_equal(E.reset_done(), obs)
+    _, r, _, _ = E.step(rng.uniform(-1, 1, (N, 2)).astype(f32))
+    assert (r[dn] == 0).all()
+
+
+def test_sharded_oracle_equals_unsharded(oracle):
+    N, W = 24, 3
+    full = oracle.OracleEngine(task_config(N * W, seed=2), n_candidates=40000)
+    of = full.reset()
+    for r in range(W):
+        sh = oracle.OracleEngine(task_config(N, seed=2), n_candidates=40000, env_total=N * W, env_offset=r * N)
+        np.testing.assert_array_equal(sh.reset(), of[r * N:(r + 1) * N])
+
+
+def test_layout_assert(oracle):
+    E = oracle.OracleEngine(task_config(500, seed=0), n_candidates=2000)
+    with pytest.raises(AssertionError):
+        E.reset()
