@@ -43,7 +43,22 @@ struct gx_engine {
     hipEvent_t layout_ev;
     bool layout_pending;
     int device;
+    int path_mode;       // 0 auto, 1 thread-per-env kernels, 2 lane-group kernels
+    // per-step layout keys for the fused rollout: ring of pinned staging + device buffers
+    static const int kKeyRing = 4;
+    uint4* h_keys[kKeyRing];
+    uint4* d_keys[kKeyRing];
+    int keys_cap[kKeyRing];
+    hipEvent_t keys_ev[kKeyRing];
+    int keys_next;
 };
+
+static bool use_group_path(const gx_engine* e)
+{
+    if (e->path_mode == 1) return false;
+    if (e->path_mode == 2) return true;
+    return e->p.N <= 16384; // <= 4096 single-wave workgroups: latency regime
+}
 
 struct DeviceGuard {
     int prev = -1;
@@ -64,8 +79,6 @@ extern "C" const char* gx_last_error(void) { return g_err.c_str(); }
 extern "C" int32_t gx_abi_version(void) { return 1; }
 extern "C" int32_t gx_obs_dim(const gx_engine* e) { return e ? e->p.D : -1; }
 extern "C" int32_t gx_act_dim(const gx_engine* e) { return e ? 2 : -1; }
-
-static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
 {
@@ -150,6 +163,9 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     e->have_reset = false;
     e->layout_pending = false;
     e->h_layout_size = nullptr;
+    e->path_mode = 0;
+    e->keys_next = 0;
+    for (int i = 0; i < gx_engine::kKeyRing; ++i) { e->h_keys[i] = nullptr; e->d_keys[i] = nullptr; e->keys_cap[i] = 0; e->keys_ev[i] = nullptr; }
     memset(&e->b, 0, sizeof(e->b));
 
     const size_t M = (size_t)sp.M, W = (M + 63) / 64;
@@ -193,6 +209,11 @@ extern "C" gx_status gx_destroy(gx_engine* e)
                     e->b.wave_off, e->b.cand_of, e->b.layout_size};
     for (void* q : bufs)
         if (q) (void)hipFree(q);
+    for (int i = 0; i < gx_engine::kKeyRing; ++i) {
+        if (e->h_keys[i]) (void)hipHostFree(e->h_keys[i]);
+        if (e->d_keys[i]) (void)hipFree(e->d_keys[i]);
+        if (e->keys_ev[i]) (void)hipEventDestroy(e->keys_ev[i]);
+    }
     if (e->h_layout_size) (void)hipHostFree(e->h_layout_size);
     if (e->layout_ev) (void)hipEventDestroy(e->layout_ev);
     delete e;
@@ -208,7 +229,6 @@ static void layout_keys(const gx_engine* e, uint32_t (&k)[4])
 extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
 {
     if (!e || !d_obs) return fail(GX_ERR_ARG, "null argument");
-    if (!aligned16(d_obs)) return fail(GX_ERR_ARG, "d_obs must be 16-byte aligned");
     DeviceGuard guard(e->device);
     hipStream_t s = (hipStream_t)stream;
     e->sp.k0 = e->key[0];
@@ -248,8 +268,8 @@ extern "C" gx_status gx_step(gx_engine* e, const float* d_action, float* d_obs, 
 {
     if (!e || !d_action || !d_obs || !d_reward || !d_cost || !d_done) return fail(GX_ERR_ARG, "null argument");
     if (!e->have_reset) return fail(GX_ERR_STATE, "gx_step before gx_reset (engine.py: _data is None)");
-    if (!aligned16(d_obs) || (reinterpret_cast<uintptr_t>(d_action) & 7u))
-        return fail(GX_ERR_ARG, "d_obs must be 16-byte and d_action 8-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(d_action) & 7u) || (reinterpret_cast<uintptr_t>(d_obs) & 3u))
+        return fail(GX_ERR_ARG, "d_action must be 8-byte aligned (float2 rows), d_obs 4-byte");
     DeviceGuard guard(e->device);
     // update_data: key, _ = split(key, 2)  engine.py:431
     uint32_t a0, a1, b0, b1;
@@ -258,7 +278,16 @@ extern "C" gx_status gx_step(gx_engine* e, const float* d_action, float* d_obs, 
     e->key[1] = a1;
     e->p.have_last = e->hist >= 1;
     e->p.have_last_last = e->hist >= 2;
-    launch_step(e->p, e->b, d_action, d_obs, d_reward, d_cost, d_done, d_qacc, (hipStream_t)stream);
+    if (use_group_path(e)) {
+        RolloutArgs r;
+        memset(&r, 0, sizeof r);
+        r.T = 1; r.do_reset = 0; r.nobj_total = e->nobj_total; r.hist0 = e->hist;
+        r.act = reinterpret_cast<const float2*>(d_action);
+        r.obs = d_obs; r.rew = d_reward; r.cost = d_cost; r.done = d_done; r.qacc = d_qacc;
+        launch_group_rollout(e->p, r, e->b, (hipStream_t)stream);
+    } else {
+        launch_step(e->p, e->b, d_action, d_obs, d_reward, d_cost, d_done, d_qacc, (hipStream_t)stream);
+    }
     if (e->hist < 2) e->hist++;
     GX_HIP(hipGetLastError());
     return GX_OK;
@@ -268,7 +297,6 @@ extern "C" gx_status gx_reset_done(gx_engine* e, const float* d_obs_in, float* d
 {
     if (!e || !d_obs_in || !d_obs_out) return fail(GX_ERR_ARG, "null argument");
     if (!e->have_reset) return fail(GX_ERR_STATE, "gx_reset_done before gx_reset");
-    if (!aligned16(d_obs_in) || !aligned16(d_obs_out)) return fail(GX_ERR_ARG, "obs buffers must be 16-byte aligned");
     DeviceGuard guard(e->device);
     hipStream_t s = (hipStream_t)stream;
     if (e->hist == 0) { // self._done is None: mjx_reset_done falls through (engine.py:713)
@@ -291,8 +319,52 @@ extern "C" gx_status gx_rollout(gx_engine* e, int32_t T, const float* d_actions,
         return fail(GX_ERR_ARG, "bad argument");
     if (!e->have_reset) return fail(GX_ERR_STATE, "gx_rollout before gx_reset");
     const size_t N = (size_t)e->p.N, D = (size_t)e->p.D;
-    if ((N * D * sizeof(float)) % 16 != 0 || (N * 2 * sizeof(float)) % 8 != 0)
-        return fail(GX_ERR_ARG, "env_num*obs_dim*4 must be a multiple of 16 for time-major outputs");
+    if (use_group_path(e)) {
+        DeviceGuard guard(e->device);
+        hipStream_t s = (hipStream_t)stream;
+        // key chain on the host: step t advances the key (engine.py:431), the reset_done that
+        // follows draws randint with that key (engine.py:447,500)
+        const int slot = e->keys_next;
+        e->keys_next = (slot + 1) % gx_engine::kKeyRing;
+        if (e->keys_cap[slot] < T) {
+            if (e->keys_ev[slot]) GX_HIP(hipEventSynchronize(e->keys_ev[slot]));
+            if (e->h_keys[slot]) (void)hipHostFree(e->h_keys[slot]);
+            if (e->d_keys[slot]) (void)hipFree(e->d_keys[slot]);
+            e->h_keys[slot] = nullptr; e->d_keys[slot] = nullptr;
+            const int cap = T > 256 ? T : 256;
+            GX_HIP(hipHostMalloc((void**)&e->h_keys[slot], sizeof(uint4) * cap, hipHostMallocDefault));
+            GX_HIP(hipMalloc((void**)&e->d_keys[slot], sizeof(uint4) * cap));
+            e->keys_cap[slot] = cap;
+            if (!e->keys_ev[slot]) GX_HIP(hipEventCreateWithFlags(&e->keys_ev[slot], hipEventDisableTiming));
+        } else {
+            GX_HIP(hipEventSynchronize(e->keys_ev[slot])); // staging free again?
+        }
+        uint32_t k0 = e->key[0], k1 = e->key[1];
+        for (int32_t t = 0; t < T; ++t) {
+            uint32_t a0, a1, b0, b1;
+            split2(k0, k1, a0, a1, b0, b1);
+            k0 = a0; k1 = a1;
+            uint4 kk;
+            split2(k0, k1, kk.x, kk.y, kk.z, kk.w);
+            e->h_keys[slot][t] = kk;
+        }
+        GX_HIP(hipMemcpyAsync(e->d_keys[slot], e->h_keys[slot], sizeof(uint4) * T, hipMemcpyHostToDevice, s));
+        GX_HIP(hipEventRecord(e->keys_ev[slot], s));
+        RolloutArgs r;
+        memset(&r, 0, sizeof r);
+        r.T = T; r.do_reset = 1; r.nobj_total = e->nobj_total; r.hist0 = e->hist;
+        r.act = reinterpret_cast<const float2*>(d_actions);
+        r.obs = d_obs; r.rew = d_reward; r.cost = d_cost; r.done = d_done; r.qacc = nullptr;
+        r.keys = e->d_keys[slot];
+        r.layout_size = e->b.layout_size; r.cand_of = e->b.cand_of; r.cand_xy = e->b.cand_xy;
+        e->p.have_last = e->hist >= 1;
+        e->p.have_last_last = e->hist >= 2;
+        launch_group_rollout(e->p, r, e->b, s);
+        GX_HIP(hipGetLastError());
+        e->key[0] = k0; e->key[1] = k1;
+        e->hist = (e->hist + T) >= 2 ? 2 : e->hist + T;
+        return GX_OK;
+    }
     for (int32_t t = 0; t < T; ++t) {
         float* obs_t = d_obs + (size_t)t * N * D;
         gx_status st = gx_step(e, d_actions + (size_t)t * N * 2, obs_t, d_reward + (size_t)t * N,
@@ -396,6 +468,13 @@ extern "C" gx_status gx_get_pool(gx_engine* e, float* pool, int32_t max_rows, in
         GX_HIP(hipMemcpy(pool + r * row, e->b.cand_xy + (size_t)idx[r] * e->nobj_total, sizeof(float) * row,
                          hipMemcpyDeviceToHost));
     *got = n;
+    return GX_OK;
+}
+
+extern "C" gx_status gx_set_path(gx_engine* e, int32_t mode)
+{
+    if (!e || mode < 0 || mode > 2) return fail(GX_ERR_ARG, "gx_set_path: mode must be 0 (auto), 1 (thread-per-env) or 2 (lane-group)");
+    e->path_mode = mode;
     return GX_OK;
 }
 

@@ -247,10 +247,13 @@ GX_D void point_substep(PtState& s, float cx, float cy, float ct, float (&pose)[
 }
 
 // ---------------------------------------------------------------------------
-// pseudo-lidar (engine.py:846-900): scatter one object into a bin row that
-// lives in LDS (row[b], stride 1).  Returns true if a non-finite value landed.
+// pseudo-lidar (engine.py:846-900).  lidar_terms() evaluates one object:
+// bin index (0..B; B = "angle rounded to 2*pi", whose own scatter is dropped),
+// closeness `sensor` and the two aliased values a1 -> bin+1, a2 -> bin-1.
 // ---------------------------------------------------------------------------
-GX_D bool lidar_one(const Params& p, float* row, float ox, float oy, const float (&pose)[4])
+struct LidarTerms { int bin; float sensor, a1, a2; };
+
+GX_D LidarTerms lidar_terms(const Params& p, float ox, float oy, const float (&pose)[4])
 {
     const float dx = ox - pose[0], dy = oy - pose[1];
     const float zx = dx * pose[2] + dy * pose[3];
@@ -260,29 +263,55 @@ GX_D bool lidar_one(const Params& p, float* row, float ox, float oy, const float
     if (ang < 0.0f) ang = ang + 6.2831854820251465f;
     const float q = ang / p.bin_size;
     const int B = p.bins;
-    int bin;
-    if (!(q >= 0.0f)) bin = 0;
-    else if (q >= (float)B) bin = B;
-    else bin = (int)q;
-    const float bin_angle = p.bin_size * (float)bin;
-    float sensor;
-    if (!p.lidar_max_dist_set) sensor = exp_f(p.neg_gain * dist);
-    else sensor = nmax(0.0f, p.lidar_max_dist - dist) / p.lidar_max_dist;
-    bool bad = false;
-    if (bin < B) {
-        row[bin] = nmax(row[bin], sensor);
-        bad = notfinite(sensor);
-    }
-    if (p.lidar_alias) {
-        const float alias = (ang - bin_angle) / p.bin_size;
-        const int bp = (bin + 1 >= B) ? bin + 1 - B : bin + 1;
-        const int bm = (bin == 0) ? B - 1 : bin - 1;
-        const float a1 = alias * sensor, a2 = (1.0f - alias) * sensor;
-        row[bp] = nmax(row[bp], a1);
-        row[bm] = nmax(row[bm], a2);
-        bad = bad || notfinite(a1) || notfinite(a2);
-    }
+    LidarTerms t;
+    if (!(q >= 0.0f)) t.bin = 0;
+    else if (q >= (float)B) t.bin = B;
+    else t.bin = (int)q;
+    const float bin_angle = p.bin_size * (float)t.bin;
+    if (!p.lidar_max_dist_set) t.sensor = exp_f(p.neg_gain * dist);
+    else t.sensor = nmax(0.0f, p.lidar_max_dist - dist) / p.lidar_max_dist;
+    const float alias = (ang - bin_angle) / p.bin_size;
+    t.a1 = alias * t.sensor;
+    t.a2 = (1.0f - alias) * t.sensor;
+    return t;
+}
+
+GX_D int bin_plus(int bin, int B) { return (bin + 1 >= B) ? bin + 1 - B : bin + 1; }
+GX_D int bin_minus(int bin, int B) { return (bin == 0) ? B - 1 : bin - 1; }
+
+// values of `t` that would land in the observation are non-finite?
+GX_D bool lidar_bad(const Params& p, const LidarTerms& t)
+{
+    bool bad = (t.bin < p.bins) && notfinite(t.sensor);
+    if (p.lidar_alias) bad = bad || notfinite(t.a1) || notfinite(t.a2);
     return bad;
+}
+
+// thread-per-env form: scatter-max one object into a bin row that lives in LDS.
+GX_D bool lidar_one(const Params& p, float* row, float ox, float oy, const float (&pose)[4])
+{
+    const LidarTerms t = lidar_terms(p, ox, oy, pose);
+    const int B = p.bins;
+    if (t.bin < B) row[t.bin] = nmax(row[t.bin], t.sensor);
+    if (p.lidar_alias) {
+        const int bp = bin_plus(t.bin, B), bm = bin_minus(t.bin, B);
+        row[bp] = nmax(row[bp], t.a1);
+        row[bm] = nmax(row[bm], t.a2);
+    }
+    return lidar_bad(p, t);
+}
+
+// lane-per-bin form: what object `t` contributes to bin b (0 when nothing).
+GX_D float lidar_contrib(const Params& p, const LidarTerms& t, int b)
+{
+    const int B = p.bins;
+    float c = 0.0f;
+    if (t.bin == b) c = t.sensor; // t.bin == B never equals a valid b: dropped scatter
+    if (p.lidar_alias) {
+        if (bin_plus(t.bin, B) == b) c = t.a1;
+        if (bin_minus(t.bin, B) == b) c = t.a2;
+    }
+    return c;
 }
 
 } // namespace gx

@@ -37,6 +37,22 @@ void launch_reset_apply(const Params& p, const DevBuffers& b, int nobj_total, ui
 void launch_reset_done(const Params& p, const DevBuffers& b, int nobj_total, uint32_t k10,
                        uint32_t k11, uint32_t k20, uint32_t k21, const float* obs_in,
                        float* obs_out, hipStream_t s);
+// lane-group persistent rollout (small batches); RolloutArgs is defined in gx_kernels.hip's
+// public mirror below
+struct RolloutArgs {
+    int T, do_reset, nobj_total, hist0;
+    const float2* act;
+    float* obs;
+    float* rew;
+    float* cost;
+    float* done;
+    float* qacc;
+    const uint4* keys;
+    const int* layout_size;
+    const int* cand_of;
+    const float2* cand_xy;
+};
+void launch_group_rollout(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s);
 void launch_math_probe(int n, const float* x, const float* y, float* s_, float* c, float* at2,
                        float* ex, hipStream_t s);
 void launch_split_probe(uint32_t k0, uint32_t k1, int n, uint32_t* out, hipStream_t s);

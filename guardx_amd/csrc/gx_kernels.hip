@@ -67,15 +67,35 @@ GX_D bool build_obs_row(const Params& p, float* row, const float (&pose)[4],
     return bad;
 }
 
-// stream the block's LDS tile (nenv rows of D floats, env-major) to global
+// stream the block's LDS tile (nenv rows of D floats, env-major) to global.
+// float4 stores when the destination is 16-byte aligned (always true for an
+// (N, D) tensor; a time-major slice with odd N*D may not be), dwords otherwise.
 template <int BLOCK>
 GX_D void flush_tile(const float* tile, float* gbase, int total)
 {
-    const int nvec = total >> 2;
-    const float4* t4 = reinterpret_cast<const float4*>(tile);
-    float4* g4 = reinterpret_cast<float4*>(gbase);
-    for (int v = threadIdx.x; v < nvec; v += BLOCK) g4[v] = t4[v];
-    for (int k = (nvec << 2) + threadIdx.x; k < total; k += BLOCK) gbase[k] = tile[k];
+    if ((reinterpret_cast<uintptr_t>(gbase) & 15u) == 0) {
+        const int nvec = total >> 2;
+        const float4* t4 = reinterpret_cast<const float4*>(tile);
+        float4* g4 = reinterpret_cast<float4*>(gbase);
+        for (int v = threadIdx.x; v < nvec; v += BLOCK) g4[v] = t4[v];
+        for (int k = (nvec << 2) + threadIdx.x; k < total; k += BLOCK) gbase[k] = tile[k];
+    } else {
+        for (int k = threadIdx.x; k < total; k += BLOCK) gbase[k] = tile[k];
+    }
+}
+
+template <int BLOCK>
+GX_D void stage_tile(float* tile, const float* gbase, int total)
+{
+    if ((reinterpret_cast<uintptr_t>(gbase) & 15u) == 0) {
+        const int nvec = total >> 2;
+        float4* t4 = reinterpret_cast<float4*>(tile);
+        const float4* g4 = reinterpret_cast<const float4*>(gbase);
+        for (int v = threadIdx.x; v < nvec; v += BLOCK) t4[v] = g4[v];
+        for (int k = (nvec << 2) + threadIdx.x; k < total; k += BLOCK) tile[k] = gbase[k];
+    } else {
+        for (int k = threadIdx.x; k < total; k += BLOCK) tile[k] = gbase[k];
+    }
 }
 
 GX_D float dist2(float ax, float ay, float bx, float by)
@@ -388,13 +408,7 @@ __global__ __launch_bounds__(BLOCK) void reset_done_kernel(Params p, int nobj_to
     const int total = nenv * p.D;
     if (!any && obs_in == obs_out) return; // nothing to do for this tile
     // stage the old rows (self._obs) in LDS
-    {
-        const int nvec = total >> 2;
-        const float4* g4 = reinterpret_cast<const float4*>(obs_in + (size_t)env0 * p.D);
-        for (int v = tid; v < nvec; v += BLOCK) tile4[v] = g4[v];
-        const float* g = obs_in + (size_t)env0 * p.D;
-        for (int k = (nvec << 2) + tid; k < total; k += BLOCK) tile[k] = g[k];
-    }
+    stage_tile<BLOCK>(tile, obs_in + (size_t)env0 * p.D, total);
     __syncthreads();
     if (dn) {
         const uint32_t gi = (uint32_t)(p.env_offset + i);
@@ -417,6 +431,273 @@ __global__ __launch_bounds__(BLOCK) void reset_done_kernel(Params p, int nobj_to
     }
     __syncthreads();
     flush_tile<BLOCK>(tile, obs_out + (size_t)env0 * p.D, total);
+}
+
+// ---------------------------------------------------------------------------
+// Lane-group kernel for SMALL batches (latency regime, env_num ~ 10^3..10^4).
+//
+// 16 lanes cooperate on one environment, 4 environments per wave64, one wave per
+// workgroup: env_num=2000 becomes 500 single-wave workgroups spread over the
+// chip instead of 32 waves each grinding through 9 objects serially.
+//   * every lane carries the env's dynamic state and integrates it (redundantly:
+//     identical operations, identical bits) -- no broadcast on the critical path;
+//   * lane o evaluates object o (goal, hazard0..): ego vector, sqrt, atan2, exp,
+//     alias, hazard cost term -- the 9 transcendental chains run side by side;
+//   * the per-object (bin, sensor, a1, a2) records are exchanged through 1 KiB of
+//     LDS and lane b folds them into lidar bin b (the scatter-max becomes a
+//     gather-max with the same operand order, so results are bit-identical to the
+//     thread-per-env kernel);
+//   * the kernel is persistent over T steps: state and layout stay in registers,
+//     per step it reads 8 B of action and writes the obs row + 3 scalars;
+//   * reset_done (engine.py:497-505) is folded in: a wave-uniform ballot of the done
+//     flags gates the re-draw of the layout index and the rebuild of the obs row.
+// ---------------------------------------------------------------------------
+
+constexpr int kGL = 16; // lanes per environment
+
+template <int OPL, int BPL>
+struct GroupObs { float gl[BPL], hl[BPL], comp0, comp1, cost; bool bad; };
+
+// object phase + LDS exchange + bin phase for one pose
+template <int OPL, int BPL>
+GX_D GroupObs<OPL, BPL> group_observe(const Params& p, float4 (*rec)[64], float (*term)[64], int lane,
+                                      const float (&pose)[4], float gx, float gy,
+                                      const float (&ox)[OPL], const float (&oy)[OPL])
+{
+    const int l = lane & (kGL - 1), gbase = lane & ~(kGL - 1);
+    GroupObs<OPL, BPL> out;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < OPL; ++j) {
+        const int o = l + kGL * j;
+        const bool valid = o < p.nobj;
+        LidarTerms t = lidar_terms(p, ox[j], oy[j], pose);
+        const bool enabled = (o == 0) ? (p.off_gl >= 0) : (p.off_hl >= 0);
+        if (valid && enabled) bad = bad || lidar_bad(p, t);
+        float tc = 0.0f;
+        if (valid && o >= 1) { // cost term :804-811
+            const float dh = dist2(ox[j], oy[j], pose[0], pose[1]);
+            float below = dh < p.hazards_size ? dh : p.hazards_size;
+            if (dh != dh) below = dh;
+            tc = p.hazards_size - below;
+        }
+        if (!valid) { t.bin = -1000; t.sensor = 0.f; t.a1 = 0.f; t.a2 = 0.f; }
+        rec[j][lane] = make_float4(__int_as_float(t.bin), t.sensor, t.a1, t.a2);
+        term[j][lane] = tc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int jb = 0; jb < BPL; ++jb) {
+        const int b = l + kGL * jb;
+        float gl = 0.0f, hl = 0.0f;
+        for (int o = 0; o < p.nobj; ++o) {
+            const float4 rc = rec[o >> 4][gbase + (o & 15)];
+            LidarTerms t;
+            t.bin = __float_as_int(rc.x); t.sensor = rc.y; t.a1 = rc.z; t.a2 = rc.w;
+            const float c = lidar_contrib(p, t, b);
+            if (o == 0) gl = nmax(gl, c);
+            else hl = nmax(hl, c);
+        }
+        out.gl[jb] = gl;
+        out.hl[jb] = hl;
+    }
+    float cs = 0.0f;
+    for (int o = 1; o < p.nobj; ++o) cs = cs + term[o >> 4][gbase + (o & 15)];
+    out.cost = cs;
+    { // obs_compass :834-844 (same expression as ego_xy of the goal)
+        const float dx = gx - pose[0], dy = gy - pose[1];
+        out.comp0 = dx * pose[2] + dy * pose[3];
+        out.comp1 = dx * (-pose[3]) + dy * pose[2];
+        if (p.off_comp >= 0) bad = bad || notfinite(out.comp0) || notfinite(out.comp1);
+    }
+    // any lane of this env's group
+    const unsigned long long m = __ballot(bad);
+    out.bad = ((m >> gbase) & 0xFFFFull) != 0ull;
+    __syncthreads();
+    return out;
+}
+
+template <int OPL, int BPL, bool kQacc>
+__global__ __launch_bounds__(64) void group_rollout_kernel(Params p, RolloutArgs r,
+                                                          float4* __restrict__ dyn,
+                                                          float4* __restrict__ obj,
+                                                          float4* __restrict__ hist)
+{
+    __shared__ float4 rec[OPL][64];
+    __shared__ float term[OPL][64];
+    const int lane = threadIdx.x;
+    const int l = lane & (kGL - 1);
+    const int env = blockIdx.x * (64 / kGL) + (lane >> 4);
+    const bool live = env < p.N;
+    const int e = live ? env : 0;
+
+    // ---- state (every lane of the group holds a copy)
+    const float4 d0 = dyn[e], d1 = dyn[p.Npad + e], d2 = dyn[2 * p.Npad + e];
+    PtState st = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y};
+    float P0x = d1.z, P0y = d1.w, pc = d2.x, ps = d2.y, done0 = d2.z, steps = d2.w;
+    float P1x = 0.f, P1y = 0.f, done1 = 0.f;
+    if (p.hist_on) { const float4 h = hist[e]; P1x = h.x; P1y = h.y; done1 = h.z; }
+    const float2* obj2 = reinterpret_cast<const float2*>(obj);
+    float ox[OPL], oy[OPL];
+#pragma unroll
+    for (int j = 0; j < OPL; ++j) {
+        const int o = l + kGL * j;
+        float2 v = make_float2(0.f, 0.f);
+        if (o < p.nobj) v = obj2[((size_t)(o >> 1) * p.Npad + e) * 2 + (o & 1)];
+        ox[j] = v.x; oy[j] = v.y;
+    }
+    float gx, gy;
+    { const float2 g = obj2[(size_t)e * 2]; gx = g.x; gy = g.y; }
+    bool touched_layout = false;
+
+    float2 a_next = r.act[(size_t)e];
+    for (int t = 0; t < r.T; ++t) {
+        const float2 a = a_next;
+        if (t + 1 < r.T) a_next = r.act[(size_t)(t + 1) * p.N + e];
+        const bool have_last = (r.hist0 + t) >= 1, have_last_last = (r.hist0 + t) >= 2;
+
+        // update_data :426-431 (history shift)
+        const float done2 = done1;
+        const float last_done = done0;
+        const float P2x = P1x, P2y = P1y;
+        const float L1x = P0x, L1y = P0y; // last_data.xpos
+
+        // convert_action :672-685, mjx.step :689
+        const float cx = pc * a.x, cy = ps * a.x, ct = a.y;
+        float pose[4], qacc[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < p.physics_steps; ++k) point_substep<kQacc>(st, cx, cy, ct, pose, qacc);
+
+        // ego_vel_acc :902-929
+        float vel0 = 0.f, vel1 = 0.f, acc0 = 0.f, acc1 = 0.f;
+        if (p.hist_on) {
+            float plx = pose[0], ply = pose[1], pllx = pose[0], plly = pose[1];
+            if (have_last) {
+                if (!(last_done > 0.0f)) { plx = L1x; ply = L1y; }
+                if (have_last_last) {
+                    if (done2 + last_done > 0.0f) { pllx = plx; plly = ply; }
+                    else { pllx = P2x; plly = P2y; }
+                }
+            }
+            const float vwx = (pose[0] - plx) / p.dt, vwy = (pose[1] - ply) / p.dt;
+            const float lvx = (plx - pllx) / p.dt, lvy = (ply - plly) / p.dt;
+            const float awx = (vwx - lvx) / p.dt, awy = (vwy - lvy) / p.dt;
+            vel0 = vwx * pose[2] + vwy * pose[3];
+            vel1 = vwx * (-pose[3]) + vwy * pose[2];
+            acc0 = awx * pose[2] + awy * pose[3];
+            acc1 = awx * (-pose[3]) + awy * pose[2];
+        }
+
+        GroupObs<OPL, BPL> ob = group_observe<OPL, BPL>(p, rec, term, lane, pose, gx, gy, ox, oy);
+        bool bad = ob.bad;
+        if (p.off_acc >= 0) bad = bad || notfinite(acc0) || notfinite(acc1);
+        if (p.off_ctrl >= 0) bad = bad || notfinite(cx) || notfinite(cy) || notfinite(ct);
+        if (p.off_qpos >= 0) bad = bad || notfinite(st.x) || notfinite(st.y) || notfinite(st.th);
+        if (p.off_qvel >= 0) bad = bad || notfinite(st.vx) || notfinite(st.vy) || notfinite(st.om);
+        if (p.off_vel >= 0) bad = bad || notfinite(vel0) || notfinite(vel1);
+
+        // reward_done :787-802
+        const float dg = dist2(gx, gy, pose[0], pose[1]);
+        float last = dg;
+        if (have_last && !(last_done > 0.0f)) last = dist2(gx, gy, L1x, L1y);
+        const float dd = last - dg;
+        float rw = dd * p.reward_distance;
+        float dn = dg < p.goal_size ? 1.0f : 0.0f;
+        if (fabsf(dd) > 1.0f) { dn = 1.0f; rw = 0.0f; }
+        if (bad) { rw = 0.0f; dn = 1.0f; }          // :696-699
+        if (steps > p.num_steps_f) dn = 1.0f;        // :492
+        steps = dn > 0.0f ? 0.0f : steps + 1.0f;     // :493
+
+        // commit the history
+        P1x = L1x; P1y = L1y; done1 = last_done;
+        P0x = pose[0]; P0y = pose[1]; pc = pose[2]; ps = pose[3];
+        done0 = dn;
+
+        // values of this env's obs row
+        float o_cx = cx, o_cy = cy, o_ct = ct;
+        float o_qx = st.x, o_qy = st.y, o_qt = st.th, o_vx = st.vx, o_vy = st.vy, o_vt = st.om;
+        float o_v0 = vel0, o_v1 = vel1, o_a0 = acc0, o_a1 = acc1;
+
+        // reset_done :497-505 folded in (wave-uniform gate)
+        if (r.do_reset) {
+            const int L = *r.layout_size;
+            const bool rs = live && dn > 0.0f && L > 0;
+            if (__ballot(rs) != 0ull) {
+                float nox[OPL], noy[OPL], ngx = gx, ngy = gy, rx = st.x, ry = st.y;
+#pragma unroll
+                for (int j = 0; j < OPL; ++j) { nox[j] = ox[j]; noy[j] = oy[j]; }
+                if (rs) {
+                    const uint4 k = r.keys[t];
+                    const uint32_t idx = randint_at(k.x, k.y, k.z, k.w, (uint32_t)p.env_total, (uint32_t)L,
+                                                    (uint32_t)(p.env_offset + env));
+                    const float2* rowp = r.cand_xy + (size_t)r.cand_of[idx] * r.nobj_total;
+#pragma unroll
+                    for (int j = 0; j < OPL; ++j) {
+                        const int o = l + kGL * j;
+                        if (o < p.nobj) { const float2 v = rowp[o]; nox[j] = v.x; noy[j] = v.y; }
+                    }
+                    const float2 g = rowp[0], rb = rowp[r.nobj_total - 1];
+                    ngx = g.x; ngy = g.y; rx = rb.x; ry = rb.y;
+                }
+                const float rpose[4] = {rx, ry, 1.0f, 0.0f};
+                const GroupObs<OPL, BPL> rob = group_observe<OPL, BPL>(p, rec, term, lane, rpose, ngx, ngy, nox, noy);
+                if (rs) {
+#pragma unroll
+                    for (int j = 0; j < OPL; ++j) { ox[j] = nox[j]; oy[j] = noy[j]; }
+                    gx = ngx; gy = ngy;
+                    st.x = rx; st.y = ry; st.th = 0.f; st.vx = 0.f; st.vy = 0.f; st.om = 0.f;
+#pragma unroll
+                    for (int jb = 0; jb < BPL; ++jb) { ob.gl[jb] = rob.gl[jb]; ob.hl[jb] = rob.hl[jb]; }
+                    ob.comp0 = rob.comp0; ob.comp1 = rob.comp1;
+                    o_cx = o_cy = o_ct = 0.f;
+                    o_qx = rx; o_qy = ry; o_qt = 0.f; o_vx = o_vy = o_vt = 0.f;
+                    o_v0 = o_v1 = o_a0 = o_a1 = 0.f;
+                    touched_layout = true;
+                }
+            }
+        }
+
+        if (live) {
+            const size_t te = (size_t)t * p.N + env;
+            float* row = r.obs + te * p.D;
+#pragma unroll
+            for (int jb = 0; jb < BPL; ++jb) {
+                const int b = l + kGL * jb;
+                if (b < p.bins) {
+                    if (p.off_gl >= 0) row[p.off_gl + b] = ob.gl[jb];
+                    if (p.off_hl >= 0) row[p.off_hl + b] = ob.hl[jb];
+                }
+            }
+            if (l < 3) {
+                if (p.off_ctrl >= 0) row[p.off_ctrl + l] = (l == 0) ? o_cx : (l == 1 ? o_cy : o_ct);
+                if (p.off_qpos >= 0) row[p.off_qpos + l] = (l == 0) ? o_qx : (l == 1 ? o_qy : o_qt);
+                if (p.off_qvel >= 0) row[p.off_qvel + l] = (l == 0) ? o_vx : (l == 1 ? o_vy : o_vt);
+                if (kQacc) r.qacc[te * 3 + l] = qacc[l == 0 ? 0 : (l == 1 ? 1 : 2)];
+            }
+            if (l < 2) {
+                if (p.off_comp >= 0) row[p.off_comp + l] = (l == 0) ? ob.comp0 : ob.comp1;
+                if (p.off_vel >= 0) row[p.off_vel + l] = (l == 0) ? o_v0 : o_v1;
+                if (p.off_acc >= 0) row[p.off_acc + l] = (l == 0) ? o_a0 : o_a1;
+            }
+            if (l == 0) { r.rew[te] = rw; r.cost[te] = ob.cost; r.done[te] = dn; }
+        }
+    }
+
+    if (live) {
+        if (l == 0) {
+            dyn[env] = make_float4(st.x, st.y, st.th, st.vx);
+            dyn[p.Npad + env] = make_float4(st.vy, st.om, P0x, P0y);
+            dyn[2 * p.Npad + env] = make_float4(pc, ps, done0, steps);
+            if (p.hist_on) hist[env] = make_float4(P1x, P1y, done1, 0.f);
+        }
+        if (touched_layout) {
+            float2* objw = reinterpret_cast<float2*>(obj);
+#pragma unroll
+            for (int j = 0; j < OPL; ++j) {
+                const int o = l + kGL * j;
+                if (o < p.nobj) objw[((size_t)(o >> 1) * p.Npad + env) * 2 + (o & 1)] = make_float2(ox[j], oy[j]);
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -538,6 +819,22 @@ void launch_reset_done(const Params& p, const DevBuffers& b, int nobj_total, uin
                        hipStream_t s)
 {
     GX_DISPATCH_BP(launch_reset_done_bp, p, b, nobj_total, k10, k11, k20, k21, obs_in, obs_out, s);
+}
+
+template <int OPL, int BPL>
+static void launch_group_ob(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s)
+{
+    const dim3 grid((p.N + 3) / 4), blk(64);
+    if (r.qacc)
+        hipLaunchKernelGGL((group_rollout_kernel<OPL, BPL, true>), grid, blk, 0, s, p, r, b.dyn, b.obj, b.hist);
+    else
+        hipLaunchKernelGGL((group_rollout_kernel<OPL, BPL, false>), grid, blk, 0, s, p, r, b.dyn, b.obj, b.hist);
+}
+
+void launch_group_rollout(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s)
+{
+    if (p.nobj <= 16 && p.bins <= 16) launch_group_ob<1, 1>(p, r, b, s);
+    else launch_group_ob<5, 4>(p, r, b, s);
 }
 
 void launch_math_probe(int n, const float* x, const float* y, float* s_, float* c, float* at2,

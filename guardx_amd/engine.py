@@ -331,6 +331,10 @@ class Engine:
         self._info = {'cost': cost[-1]}
         return obs, reward, cost, done
 
+    def set_path(self, mode):
+        """0 auto, 1 thread-per-env kernels, 2 lane-group kernels (bit-identical results)."""
+        _native.check(self._lib.gx_set_path(self._h, int(mode)))
+
     def _as_action(self, action):
         a = action if torch.is_tensor(action) else torch.as_tensor(action)
         if a.device != self.device or a.dtype != torch.float32:

@@ -14,7 +14,8 @@
  *                     (safe_rl_libX/trpo/trpo.py:466-547) for an open-loop action tape
  *
  * All pointers named `d_*` are DEVICE addresses (hipMalloc / torch tensors on
- * the handle's device), fp32, dense, 16-byte aligned.  `stream` is a
+ * the handle's device), fp32, dense; 16-byte aligned observation buffers take the
+ * vector-store path, action rows must be 8-byte aligned.  `stream` is a
  * hipStream_t passed as void* (NULL = default stream).  Nothing here throws;
  * every call returns a gx_status and gx_last_error() describes the last failure
  * on the calling thread.  No call synchronises the device unless documented.
@@ -105,7 +106,7 @@ gx_status gx_reset_done(gx_engine* e, const float* d_obs_in, float* d_obs_out, v
 /* T fused step()+reset_done() iterations driven by an action tape
  * d_actions[T][env_num][act_dim].  Outputs are time-major: d_obs[T][env_num][obs_dim]
  * is the observation the learner sees AFTER reset_done (trpo.py:547), d_reward /
- * d_cost / d_done [T][env_num].  d_obs_final may be NULL. */
+ * d_cost / d_done [T][env_num]. */
 gx_status gx_rollout(gx_engine* e, int32_t T, const float* d_actions, float* d_obs,
                      float* d_reward, float* d_cost, float* d_done, void* stream);
 
@@ -121,6 +122,11 @@ gx_status gx_set_state(gx_engine* e, const float* qpos, const float* qvel, const
                        const int32_t* hist);
 /* rows of the valid-layout pool ((H+2)*2 floats each: goal, hazards.., robot) */
 gx_status gx_get_pool(gx_engine* e, float* pool, int32_t max_rows, int32_t* got);
+
+/* Kernel family used by step / rollout: 0 = auto (lane-group kernels up to 16384 envs,
+ * thread-per-env kernels above), 1 = force thread-per-env, 2 = force lane-group.
+ * Results are bit-identical either way (tests/test_gpu_parity.py). */
+gx_status gx_set_path(gx_engine* e, int32_t mode);
 
 /* Device-math probe (tests): s,c = sincos(x); at2 = atan2(y,x); ex = exp(x). */
 gx_status gx_math_probe(int32_t n, const float* d_x, const float* d_y, float* d_s,

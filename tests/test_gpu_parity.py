@@ -21,9 +21,14 @@ def torch_cuda():
     return torch
 
 
-def _engines(cfg, oracle, n_candidates=20000, **kw):
+PATHS = {"thread": 1, "group": 2}
+
+
+def _engines(cfg, oracle, n_candidates=20000, path=None, **kw):
     from guardx_amd import Engine
     E = Engine(cfg, n_candidates=n_candidates, **kw)
+    if path is not None:
+        E.set_path(PATHS[path])
     O = oracle.OracleEngine(cfg, n_candidates=n_candidates,
                             env_total=E._cfg.env_total, env_offset=E._cfg.env_offset)
     return E, O
@@ -87,10 +92,11 @@ def test_device_split_matches_oracle(torch_cuda, oracle):
         np.testing.assert_array_equal(got, oracle.split(key, n))
 
 
+@pytest.mark.parametrize("path", ["thread", "group"])
 @pytest.mark.parametrize("N", [1, 4, 63, 64, 65, 2000, 5000])
-def test_step_parity_random_states(torch_cuda, oracle, N):
+def test_step_parity_random_states(torch_cuda, oracle, N, path):
     torch = torch_cuda
-    E, O = _engines(task_config(N, seed=3), oracle)
+    E, O = _engines(task_config(N, seed=3), oracle, path=path)
     rng = np.random.default_rng(N)
     for trial in range(3):
         s = random_state(N, 8, rng)
@@ -104,10 +110,11 @@ def test_step_parity_random_states(torch_cuda, oracle, N):
         assert_state_equal(E.get_state(), O.get_state())
 
 
-def test_step_parity_nan_inf_actions(torch_cuda, oracle):
+@pytest.mark.parametrize("path", ["thread", "group"])
+def test_step_parity_nan_inf_actions(torch_cuda, oracle, path):
     torch = torch_cuda
     N = 256
-    E, O = _engines(task_config(N, seed=5), oracle)
+    E, O = _engines(task_config(N, seed=5), oracle, path=path)
     rng = np.random.default_rng(0)
     s = random_state(N, 8, rng, done_frac=0.0)
     E.set_state(s); O.set_state(s)
@@ -135,11 +142,12 @@ def test_reset_parity(torch_cuda, oracle, N, cand):
     assert_state_equal(E.get_state(), O.get_state())
 
 
-def test_rollout_parity_with_reset_done(torch_cuda, oracle):
+@pytest.mark.parametrize("path", ["thread", "group"])
+def test_rollout_parity_with_reset_done(torch_cuda, oracle, path):
     """200-step random-policy episode with reset_done() whenever any env is done."""
     torch = torch_cuda
     N, T = 500, 200
-    E, O = _engines(task_config(N, seed=11, num_steps=T), oracle, n_candidates=60000)
+    E, O = _engines(task_config(N, seed=11, num_steps=T), oracle, n_candidates=60000, path=path)
     og, oo = E.reset(), O.reset()
     np.testing.assert_array_equal(og.cpu().numpy(), oo)
     rng = np.random.RandomState(0)
@@ -161,15 +169,17 @@ def test_rollout_parity_with_reset_done(torch_cuda, oracle):
     _cmp_step(E.step(torch.from_numpy(act).cuda()), O.step(act))
 
 
-def test_fused_rollout_equals_stepwise(torch_cuda, oracle):
+@pytest.mark.parametrize("path", ["thread", "group"])
+def test_fused_rollout_equals_stepwise(torch_cuda, oracle, path):
     torch = torch_cuda
-    N, T = 300, 64
-    cfg = task_config(N, seed=2, num_steps=T)
-    E, O = _engines(cfg, oracle, n_candidates=40000)
+    N, T = 301, 64
+    cfg = task_config(N, seed=2, num_steps=40, goal_size=0.9)
+    E, O = _engines(cfg, oracle, n_candidates=40000, path=path)
     E.reset(); O.reset()
     rng = np.random.default_rng(5)
     acts = rng.uniform(-1, 1, (T, N, 2)).astype(np.float32)
     obs, rew, cost, done = E.rollout(torch.from_numpy(acts).cuda())
+    assert done.sum().item() > 0
     for t in range(T):
         o, r, d, info = O.step(acts[t])
         o = O.reset_done()
@@ -180,7 +190,8 @@ def test_fused_rollout_equals_stepwise(torch_cuda, oracle):
     assert_state_equal(E.get_state(), O.get_state())
 
 
-def test_variant_configs(torch_cuda, oracle):
+@pytest.mark.parametrize("path", ["thread", "group"])
+def test_variant_configs(torch_cuda, oracle, path):
     torch = torch_cuda
     variants = [
         dict(hazards_num=3, lidar_num_bins=8),
@@ -194,7 +205,7 @@ def test_variant_configs(torch_cuda, oracle):
     for v in variants:
         N = 130
         cfg = task_config(N, seed=9, num_steps=50, **v)
-        E, O = _engines(cfg, oracle, n_candidates=30000)
+        E, O = _engines(cfg, oracle, n_candidates=30000, path=path)
         assert E.obs_flat_size == O.D
         np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset(check=False))
         rng = np.random.default_rng(3)
@@ -204,6 +215,15 @@ def test_variant_configs(torch_cuda, oracle):
             _cmp_step(out_g, out_o)
             if t % 7 == 6:
                 np.testing.assert_array_equal(E.reset_done().cpu().numpy(), O.reset_done())
+        # and a fused stretch on top (group path: persistent kernel with in-kernel reset_done)
+        acts = rng.uniform(-1, 1, (9, N, 2)).astype(np.float32)
+        obs, rew, cost, done = E.rollout(torch.from_numpy(acts).cuda())
+        for t in range(9):
+            o, r, d, info = O.step(acts[t])
+            np.testing.assert_array_equal(obs[t].cpu().numpy(), O.reset_done())
+            np.testing.assert_array_equal(rew[t].cpu().numpy(), r)
+            np.testing.assert_array_equal(done[t].cpu().numpy(), d)
+            np.testing.assert_array_equal(cost[t].cpu().numpy(), info['cost'])
         assert_state_equal(E.get_state(), O.get_state(),
                            fields=('qpos', 'qvel', 'pose0', 'pose1', 'objs', 'done0', 'done1', 'steps')
                            if v.get('observe_vel') else ('qpos', 'qvel', 'pose0', 'objs', 'done0', 'steps'))
