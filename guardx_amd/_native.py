@@ -53,6 +53,7 @@ SYMBOLS = {
     "gx_get_state": (C.c_int, [C.c_void_p] + [_HFP] * 8 + [_U32P, _I32P]),
     "gx_set_state": (C.c_int, [C.c_void_p] + [_HFP] * 8 + [_U32P, _I32P]),
     "gx_get_pool": (C.c_int, [C.c_void_p, _HFP, C.c_int32, _I32P]),
+    "gx_set_prefetch": (C.c_int, [C.c_void_p, C.c_int32]),
     "gx_set_path": (C.c_int, [C.c_void_p, C.c_int32]),
     "gx_math_probe": (C.c_int, [C.c_int32, _FP, _FP, _FP, _FP, _FP, _FP, C.c_void_p]),
     "gx_split_probe": (C.c_int, [_U32P, C.c_int32, _FP, C.c_void_p]),

@@ -44,6 +44,16 @@ struct gx_engine {
     bool layout_pending;
     int device;
     int path_mode;       // 0 auto, 1 thread-per-env kernels, 2 lane-group kernels
+    // double-buffered layout pools + side stream: the pool of the NEXT reset() is sampled
+    // while the current epoch is being stepped (the key chain is data-independent)
+    Pool pools[2];
+    int cur;                 // pool the envs are drawn from
+    hipStream_t side;
+    hipEvent_t pool_ready[2]; // recorded on the sampling stream when pool i is complete
+    hipEvent_t pool_free[2];  // recorded on the caller's stream when pool i is no longer read
+    bool pf_valid;            // pools[1-cur] holds (or will hold) the pool for key pf_key
+    uint32_t pf_key[2];
+    int prefetch_steps;       // predicted step() calls between resets; < 0 disables prefetch
     // per-step layout keys for the fused rollout: ring of pinned staging + device buffers
     static const int kKeyRing = 4;
     uint4* h_keys[kKeyRing];
@@ -164,6 +174,11 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     e->layout_pending = false;
     e->h_layout_size = nullptr;
     e->path_mode = 0;
+    e->pf_valid = false;
+    e->prefetch_steps = cfg->num_steps;
+    e->side = nullptr;
+    memset(e->pools, 0, sizeof(e->pools));
+    for (int i = 0; i < 2; ++i) { e->pool_ready[i] = nullptr; e->pool_free[i] = nullptr; }
     e->keys_next = 0;
     for (int i = 0; i < gx_engine::kKeyRing; ++i) { e->h_keys[i] = nullptr; e->d_keys[i] = nullptr; e->keys_cap[i] = 0; e->keys_ev[i] = nullptr; }
     memset(&e->b, 0, sizeof(e->b));
@@ -177,12 +192,26 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     alloc((void**)&e->b.dyn, sizeof(float4) * 3 * p.Npad);
     alloc((void**)&e->b.obj, sizeof(float4) * (size_t)p.P * p.Npad);
     alloc((void**)&e->b.hist, sizeof(float4) * p.Npad);
-    alloc((void**)&e->b.cand_ok, M);
-    alloc((void**)&e->b.cand_xy, sizeof(float2) * M * e->nobj_total);
-    alloc((void**)&e->b.wave_cnt, sizeof(int) * W);
-    alloc((void**)&e->b.wave_off, sizeof(int) * W);
-    alloc((void**)&e->b.cand_of, sizeof(int) * M);
-    alloc((void**)&e->b.layout_size, sizeof(int));
+    for (int i = 0; i < 2; ++i) {
+        Pool& pl = e->pools[i];
+        alloc((void**)&pl.cand_ok, M);
+        alloc((void**)&pl.cand_xy, sizeof(float2) * M * e->nobj_total);
+        alloc((void**)&pl.wave_cnt, sizeof(int) * W);
+        alloc((void**)&pl.wave_off, sizeof(int) * W);
+        alloc((void**)&pl.cand_of, sizeof(int) * M);
+        alloc((void**)&pl.layout_size, sizeof(int));
+        alloc((void**)&pl.n_surv, sizeof(int));
+        alloc((void**)&pl.surv, sizeof(uint32_t) * 32 * M);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&e->pool_ready[i], hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&e->pool_free[i], hipEventDisableTiming);
+    }
+    if (err == hipSuccess) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi); // lo = least urgent
+        err = hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, lo);
+    }
+    e->cur = 0;
+    e->b.pool = e->pools[0];
     if (err == hipSuccess) err = hipHostMalloc((void**)&e->h_layout_size, sizeof(int), hipHostMallocDefault);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&e->layout_ev, hipEventDisableTiming);
     if (err == hipSuccess) {
@@ -205,10 +234,18 @@ extern "C" gx_status gx_destroy(gx_engine* e)
     if (!e) return GX_OK;
     DeviceGuard guard(e->device);
     (void)hipDeviceSynchronize();
-    void* bufs[] = {e->b.dyn, e->b.obj, e->b.hist, e->b.cand_ok, e->b.cand_xy, e->b.wave_cnt,
-                    e->b.wave_off, e->b.cand_of, e->b.layout_size};
+    void* bufs[] = {e->b.dyn, e->b.obj, e->b.hist};
     for (void* q : bufs)
         if (q) (void)hipFree(q);
+    for (int i = 0; i < 2; ++i) {
+        Pool& pl = e->pools[i];
+        void* pb[] = {pl.cand_ok, pl.cand_xy, pl.wave_cnt, pl.wave_off, pl.cand_of, pl.layout_size, pl.n_surv, pl.surv};
+        for (void* q : pb)
+            if (q) (void)hipFree(q);
+        if (e->pool_ready[i]) (void)hipEventDestroy(e->pool_ready[i]);
+        if (e->pool_free[i]) (void)hipEventDestroy(e->pool_free[i]);
+    }
+    if (e->side) (void)hipStreamDestroy(e->side);
     for (int i = 0; i < gx_engine::kKeyRing; ++i) {
         if (e->h_keys[i]) (void)hipHostFree(e->h_keys[i]);
         if (e->d_keys[i]) (void)hipFree(e->d_keys[i]);
@@ -231,17 +268,58 @@ extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
     if (!e || !d_obs) return fail(GX_ERR_ARG, "null argument");
     DeviceGuard guard(e->device);
     hipStream_t s = (hipStream_t)stream;
-    e->sp.k0 = e->key[0];
-    e->sp.k1 = e->key[1];
-    launch_sample(e->sp, e->b, s); // reset_layout  engine.py:433-444
+    const int other = 1 - e->cur;
+    const bool hit = e->pf_valid && e->pf_key[0] == e->key[0] && e->pf_key[1] == e->key[1];
+    if (e->pf_valid) // whatever the side stream is doing to pools[other] finishes first
+        GX_HIP(hipStreamWaitEvent(s, e->pool_ready[other], 0));
+    if (hit || e->have_reset) {
+        // switch pools; the old one is free once everything already queued on `s` has run
+        GX_HIP(hipEventRecord(e->pool_free[e->cur], s));
+        e->cur = other;
+    }
+    if (!hit) { // reset_layout on the caller's stream  engine.py:433-444
+        e->sp.k0 = e->key[0];
+        e->sp.k1 = e->key[1];
+        launch_sample(e->sp, e->pools[e->cur], s);
+    }
+    e->pf_valid = false;
+    e->b.pool = e->pools[e->cur];
     uint32_t k[4];
     layout_keys(e, k);
     launch_reset_apply(e->p, e->b, e->nobj_total, k[0], k[1], k[2], k[3], d_obs, s);
-    GX_HIP(hipMemcpyAsync(e->h_layout_size, e->b.layout_size, sizeof(int), hipMemcpyDeviceToHost, s));
+    GX_HIP(hipMemcpyAsync(e->h_layout_size, e->b.pool.layout_size, sizeof(int), hipMemcpyDeviceToHost, s));
     GX_HIP(hipEventRecord(e->layout_ev, s));
     GX_HIP(hipGetLastError());
     e->layout_pending = true;
+    const bool first = !e->have_reset;
     e->have_reset = true;
+
+    // prefetch the pool of the next reset(): the key then is this key advanced by one split per
+    // step() (engine.py:431) -- independent of the data, so it can be computed now
+    if (e->prefetch_steps >= 0) {
+        uint32_t k0 = e->key[0], k1 = e->key[1];
+        for (int t = 0; t < e->prefetch_steps; ++t) {
+            uint32_t a0, a1, b0, b1;
+            split2(k0, k1, a0, a1, b0, b1);
+            k0 = a0; k1 = a1;
+        }
+        const int tgt = 1 - e->cur;
+        if (!first) GX_HIP(hipStreamWaitEvent(e->side, e->pool_free[tgt], 0));
+        SampleParams sp = e->sp;
+        sp.k0 = k0; sp.k1 = k1;
+        launch_sample(sp, e->pools[tgt], e->side);
+        GX_HIP(hipEventRecord(e->pool_ready[tgt], e->side));
+        GX_HIP(hipGetLastError());
+        e->pf_valid = true;
+        e->pf_key[0] = k0; e->pf_key[1] = k1;
+    }
+    return GX_OK;
+}
+
+extern "C" gx_status gx_set_prefetch(gx_engine* e, int32_t steps)
+{
+    if (!e) return fail(GX_ERR_ARG, "null engine");
+    e->prefetch_steps = steps;
     return GX_OK;
 }
 
@@ -356,7 +434,7 @@ extern "C" gx_status gx_rollout(gx_engine* e, int32_t T, const float* d_actions,
         r.act = reinterpret_cast<const float2*>(d_actions);
         r.obs = d_obs; r.rew = d_reward; r.cost = d_cost; r.done = d_done; r.qacc = nullptr;
         r.keys = e->d_keys[slot];
-        r.layout_size = e->b.layout_size; r.cand_of = e->b.cand_of; r.cand_xy = e->b.cand_xy;
+        r.layout_size = e->b.pool.layout_size; r.cand_of = e->b.pool.cand_of; r.cand_xy = e->b.pool.cand_xy;
         e->p.have_last = e->hist >= 1;
         e->p.have_last_last = e->hist >= 2;
         launch_group_rollout(e->p, r, e->b, s);
@@ -459,13 +537,13 @@ extern "C" gx_status gx_get_pool(gx_engine* e, float* pool, int32_t max_rows, in
     DeviceGuard guard(e->device);
     GX_HIP(hipDeviceSynchronize());
     int L = 0;
-    GX_HIP(hipMemcpy(&L, e->b.layout_size, sizeof(int), hipMemcpyDeviceToHost));
+    GX_HIP(hipMemcpy(&L, e->b.pool.layout_size, sizeof(int), hipMemcpyDeviceToHost));
     const int n = L < max_rows ? L : max_rows;
     std::vector<int> idx(n > 0 ? n : 1);
-    if (n > 0) GX_HIP(hipMemcpy(idx.data(), e->b.cand_of, sizeof(int) * n, hipMemcpyDeviceToHost));
+    if (n > 0) GX_HIP(hipMemcpy(idx.data(), e->b.pool.cand_of, sizeof(int) * n, hipMemcpyDeviceToHost));
     const size_t row = (size_t)e->nobj_total * 2;
     for (int r = 0; r < n; ++r)
-        GX_HIP(hipMemcpy(pool + r * row, e->b.cand_xy + (size_t)idx[r] * e->nobj_total, sizeof(float) * row,
+        GX_HIP(hipMemcpy(pool + r * row, e->b.pool.cand_xy + (size_t)idx[r] * e->nobj_total, sizeof(float) * row,
                          hipMemcpyDeviceToHost));
     *got = n;
     return GX_OK;

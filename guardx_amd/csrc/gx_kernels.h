@@ -16,22 +16,29 @@ struct SampleParams {
     uint32_t k0, k1; // engine key at reset time
 };
 
-struct DevBuffers {
-    float4* dyn;   // [3][Npad]: (x,y,th,vx) (vy,om,px,py) (pc,ps,done0,steps)
-    float4* obj;   // [P][Npad]: object pairs (goal,h0) (h1,h2) ...
-    float4* hist;  // [Npad]: (p1x,p1y,done1,0)   (only when hist_on)
-    // layout pool of the last reset
+// valid-layout pool of one reset_layout() (engine.py:433-444); two of them are kept so the
+// next epoch's pool can be sampled on a side stream while the current one is in use
+struct Pool {
     uint8_t* cand_ok;  // [M]
     float2* cand_xy;   // [M][nobj_total]  (rows written only for valid candidates)
     int* wave_cnt;     // [ceil(M/64)]
     int* wave_off;     // [ceil(M/64)]
-    int* cand_of;      // [M] compacted candidate indices
+    int* cand_of;      // [M] compacted candidate indices (ascending)
     int* layout_size;  // [1]
+    int* n_surv;       // [1] phase-1 survivors
+    uint32_t* surv;    // [M][32] survivor records
+};
+
+struct DevBuffers {
+    float4* dyn;   // [3][Npad]: (x,y,th,vx) (vy,om,px,py) (pc,ps,done0,steps)
+    float4* obj;   // [P][Npad]: object pairs (goal,h0) (h1,h2) ...
+    float4* hist;  // [Npad]: (p1x,p1y,done1,0)   (only when hist_on)
+    Pool pool;     // the pool the envs are currently drawn from
 };
 
 void launch_step(const Params& p, const DevBuffers& b, const float* act, float* obs, float* rew,
                  float* cost, float* done, float* qacc, hipStream_t s);
-void launch_sample(const SampleParams& sp, const DevBuffers& b, hipStream_t s);
+void launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s);
 void launch_reset_apply(const Params& p, const DevBuffers& b, int nobj_total, uint32_t k10,
                         uint32_t k11, uint32_t k20, uint32_t k21, float* obs, hipStream_t s);
 void launch_reset_done(const Params& p, const DevBuffers& b, int nobj_total, uint32_t k10,

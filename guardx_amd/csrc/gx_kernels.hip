@@ -226,59 +226,142 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p, const float2* __r
 
 // ---------------------------------------------------------------------------
 // layout rejection sampler: sample_layout (engine.py:546-572) for candidate j,
-// key_j = split(key, M)[j] (:263).  Placed objects live in LDS, object-major.
+// key_j = split(key, M)[j] (:263).  Two phases with a global compaction between:
+//
+//  phase 1 (every candidate, 244 of the 600 Threefry blocks): walk the 10*(H+2)
+//    links of the `rng, rng1 = split(rng)` chain, draw only the goal (its 10 tries
+//    are all valid because nothing is placed yet, so the 10th wins) and the 10
+//    robot tries.  A layout can only succeed if its final robot position is >= 3.0
+//    from the goal (:570-571), and the final position is one of the 10 tries, so a
+//    candidate none of whose tries is that far is rejected here -- exactly, not
+//    heuristically (~75 % of all candidates for the default arena).
+//  phase 2 (survivors only): place the hazards (chain restarted from the saved
+//    key after the goal), validate the saved robot tries, decide success.
 // ---------------------------------------------------------------------------
 constexpr int kSampleBlock = 256;
+constexpr int kSurvWords = 32; // j, rng(2), goal(2), robot tries(20), pad
 
-__global__ __launch_bounds__(kSampleBlock) void sample_kernel(SampleParams sp,
-                                                              uint8_t* __restrict__ ok,
-                                                              float2* __restrict__ cand_xy,
-                                                              int* __restrict__ wave_cnt)
+GX_D void draw_xy(uint32_t g0, uint32_t g1, float lox, float hix, float loy, float hiy, float& x, float& y)
 {
-    extern __shared__ float4 smem4[];
-    float2* placed = reinterpret_cast<float2*>(smem4); // [nobj_total][kSampleBlock]
+    uint32_t u0, u1, v0, v1;
+    split2(g0, g1, u0, u1, v0, v1); // draw_placement :618
+    x = uniform_f(u0, u1, lox, hix);
+    y = uniform_f(v0, v1, loy, hiy);
+}
+
+__global__ __launch_bounds__(kSampleBlock) void sample_phase1_kernel(SampleParams sp,
+                                                                     uint8_t* __restrict__ ok,
+                                                                     int* __restrict__ n_surv,
+                                                                     uint32_t* __restrict__ surv)
+{
     const int tid = threadIdx.x;
     const int j = blockIdx.x * kSampleBlock + tid;
     const bool live = j < sp.M;
     uint32_t r0, r1;
     split_at(sp.k0, sp.k1, (uint32_t)sp.M, (uint32_t)(live ? j : 0), r0, r1);
-    bool success = true;
-    const int nobj = sp.nobj_total;
-    for (int o = 0; o < nobj; ++o) {
-        const int ty = (o == 0) ? 0 : (o == nobj - 1 ? 2 : 1);
-        const float lox = sp.lo_x[ty], hix = sp.hi_x[ty], loy = sp.lo_y[ty], hiy = sp.hi_y[ty];
-        bool conflicted = true;
-        float px = -__builtin_inff(), py = -__builtin_inff();
-        for (int t = 0; t < 10; ++t) {
-            uint32_t n0, n1, g0, g1, u0, u1, v0, v1;
-            split2(r0, r1, n0, n1, g0, g1); // rng, rng1 = split(rng)
-            r0 = n0; r1 = n1;
-            split2(g0, g1, u0, u1, v0, v1); // draw_placement :618
-            const float cx = uniform_f(u0, u1, lox, hix);
-            const float cy = uniform_f(v0, v1, loy, hiy);
-            bool flag = true;
-            for (int q = 0; q < o; ++q) {
-                const float2 pq = placed[q * kSampleBlock + tid];
-                const float dist = dist2(cx, cy, pq.x, pq.y);
-                const int tq = (q == 0) ? 0 : 1;
-                if (dist < sp.thr[tq][ty]) flag = false;
-            }
-            if (flag) { px = cx; py = cy; conflicted = false; }
+    uint32_t n0, n1, g0 = 0, g1 = 0;
+    // goal: 10 links, the draw of the last try is the goal
+    for (int t = 0; t < 10; ++t) { split2(r0, r1, n0, n1, g0, g1); r0 = n0; r1 = n1; }
+    float gx, gy;
+    draw_xy(g0, g1, sp.lo_x[0], sp.hi_x[0], sp.lo_y[0], sp.hi_y[0], gx, gy);
+    const uint32_t s0 = r0, s1 = r1; // chain state after the goal
+    // hazards: links only
+    const int nh = 10 * (sp.nobj_total - 2);
+    for (int t = 0; t < nh; ++t) { split2(r0, r1, n0, n1, g0, g1); r0 = n0; r1 = n1; }
+    // robot tries
+    float rx[10], ry[10];
+    bool any_far = false;
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+        split2(r0, r1, n0, n1, g0, g1); r0 = n0; r1 = n1;
+        draw_xy(g0, g1, sp.lo_x[2], sp.hi_x[2], sp.lo_y[2], sp.hi_y[2], rx[t], ry[t]);
+        if (!(dist2(rx[t], ry[t], gx, gy) < sp.min_rg)) any_far = true;
+    }
+    const bool surv_me = live && any_far;
+    if (live) ok[j] = 0;
+    const unsigned long long m = __ballot(surv_me);
+    if (m != 0ull) {
+        const int lane = tid & 63;
+        const int leader = __ffsll((long long)m) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(n_surv, __popcll(m));
+        base = __shfl(base, leader);
+        if (surv_me) {
+            uint32_t* rec = surv + (size_t)(base + __popcll(m & ((1ull << lane) - 1ull))) * kSurvWords;
+            rec[0] = (uint32_t)j; rec[1] = s0; rec[2] = s1; rec[3] = f2u(gx); rec[4] = f2u(gy);
+#pragma unroll
+            for (int t = 0; t < 10; ++t) { rec[5 + 2 * t] = f2u(rx[t]); rec[6 + 2 * t] = f2u(ry[t]); }
         }
-        placed[o * kSampleBlock + tid] = make_float2(px, py);
-        if (conflicted) success = false;
     }
-    {
-        const float2 g = placed[tid], rb = placed[(nobj - 1) * kSampleBlock + tid];
-        const float d = dist2(rb.x, rb.y, g.x, g.y);
-        if (d < sp.min_rg) success = false;
+}
+
+__global__ __launch_bounds__(kSampleBlock) void sample_phase2_kernel(SampleParams sp,
+                                                                     const int* __restrict__ n_surv,
+                                                                     const uint32_t* __restrict__ surv,
+                                                                     uint8_t* __restrict__ ok,
+                                                                     float2* __restrict__ cand_xy)
+{
+    extern __shared__ float4 smem4[];
+    float2* placed = reinterpret_cast<float2*>(smem4); // [nobj_total][kSampleBlock]
+    const int tid = threadIdx.x;
+    const int S = *n_surv;
+    const int nobj = sp.nobj_total;
+    for (int i = blockIdx.x * kSampleBlock + tid; i < S; i += gridDim.x * kSampleBlock) {
+        const uint32_t* rec = surv + (size_t)i * kSurvWords;
+        const int j = (int)rec[0];
+        uint32_t r0 = rec[1], r1 = rec[2];
+        const float gx = u2f(rec[3]), gy = u2f(rec[4]);
+        placed[tid] = make_float2(gx, gy);
+        bool success = true;
+        for (int o = 1; o < nobj - 1; ++o) { // hazards
+            bool conflicted = true;
+            float px = -__builtin_inff(), py = -__builtin_inff();
+            for (int t = 0; t < 10; ++t) {
+                uint32_t n0, n1, g0, g1;
+                split2(r0, r1, n0, n1, g0, g1); r0 = n0; r1 = n1;
+                float cx, cy;
+                draw_xy(g0, g1, sp.lo_x[1], sp.hi_x[1], sp.lo_y[1], sp.hi_y[1], cx, cy);
+                bool flag = true;
+                for (int q = 0; q < o; ++q) { // placement_is_valid :549-555
+                    const float2 pq = placed[q * kSampleBlock + tid];
+                    if (dist2(cx, cy, pq.x, pq.y) < sp.thr[q == 0 ? 0 : 1][1]) flag = false;
+                }
+                if (flag) { px = cx; py = cy; conflicted = false; }
+            }
+            placed[o * kSampleBlock + tid] = make_float2(px, py);
+            if (conflicted) success = false;
+        }
+        { // robot: tries were drawn in phase 1
+            bool conflicted = true;
+            float px = -__builtin_inff(), py = -__builtin_inff();
+            for (int t = 0; t < 10; ++t) {
+                const float cx = u2f(rec[5 + 2 * t]), cy = u2f(rec[6 + 2 * t]);
+                bool flag = true;
+                for (int q = 0; q < nobj - 1; ++q) {
+                    const float2 pq = placed[q * kSampleBlock + tid];
+                    if (dist2(cx, cy, pq.x, pq.y) < sp.thr[q == 0 ? 0 : 1][2]) flag = false;
+                }
+                if (flag) { px = cx; py = cy; conflicted = false; }
+            }
+            placed[(nobj - 1) * kSampleBlock + tid] = make_float2(px, py);
+            if (conflicted) success = false;
+            if (dist2(px, py, gx, gy) < sp.min_rg) success = false; // :570-571
+        }
+        if (success) {
+            ok[j] = 1;
+            for (int o = 0; o < nobj; ++o) cand_xy[(size_t)j * nobj + o] = placed[o * kSampleBlock + tid];
+        }
     }
-    success = success && live;
-    if (live) ok[j] = success ? 1 : 0;
-    if (success)
-        for (int o = 0; o < nobj; ++o) cand_xy[(size_t)j * nobj + o] = placed[o * kSampleBlock + tid];
-    const unsigned long long m = __ballot(success);
-    if ((tid & 63) == 0 && live) wave_cnt[j >> 6] = __popcll(m);
+}
+
+// per-wave count of valid candidates (in candidate order)
+__global__ __launch_bounds__(kSampleBlock) void count_kernel(int M, const uint8_t* __restrict__ ok,
+                                                             int* __restrict__ wave_cnt)
+{
+    const int j = blockIdx.x * kSampleBlock + threadIdx.x;
+    const bool live = j < M;
+    const unsigned long long m = __ballot(live && ok[live ? j : 0]);
+    if ((threadIdx.x & 63) == 0 && live) wave_cnt[j >> 6] = __popcll(m);
 }
 
 // exclusive scan of the per-wave valid counts (one block)
@@ -774,17 +857,22 @@ void launch_step(const Params& p, const DevBuffers& b, const float* act, float* 
     GX_DISPATCH_BP(launch_step_bp, p, b, act, obs, rew, cost, done, qacc, s);
 }
 
-void launch_sample(const SampleParams& sp, const DevBuffers& b, hipStream_t s)
+void launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s)
 {
     const int M = sp.M, W = (M + 63) / 64;
     const int grid = (M + kSampleBlock - 1) / kSampleBlock;
     const size_t lds = (size_t)sp.nobj_total * kSampleBlock * sizeof(float2);
-    hipLaunchKernelGGL(sample_kernel, dim3(grid), dim3(kSampleBlock), lds, s, sp, b.cand_ok, b.cand_xy,
-                       b.wave_cnt);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kScanBlock), 0, s, b.wave_cnt, b.wave_off, W,
-                       b.layout_size);
-    hipLaunchKernelGGL(compact_kernel, dim3(grid), dim3(kSampleBlock), 0, s, M, b.cand_ok, b.wave_off,
-                       b.cand_of);
+    (void)hipMemsetAsync(pl.n_surv, 0, sizeof(int), s);
+    hipLaunchKernelGGL(sample_phase1_kernel, dim3(grid), dim3(kSampleBlock), 0, s, sp, pl.cand_ok, pl.n_surv,
+                       pl.surv);
+    const int grid2 = grid < 1024 ? grid : 1024;
+    hipLaunchKernelGGL(sample_phase2_kernel, dim3(grid2), dim3(kSampleBlock), lds, s, sp, pl.n_surv, pl.surv,
+                       pl.cand_ok, pl.cand_xy);
+    hipLaunchKernelGGL(count_kernel, dim3(grid), dim3(kSampleBlock), 0, s, M, pl.cand_ok, pl.wave_cnt);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kScanBlock), 0, s, pl.wave_cnt, pl.wave_off, W,
+                       pl.layout_size);
+    hipLaunchKernelGGL(compact_kernel, dim3(grid), dim3(kSampleBlock), 0, s, M, pl.cand_ok, pl.wave_off,
+                       pl.cand_of);
 }
 
 template <int BLOCK, int PMAX>
@@ -793,7 +881,7 @@ static void launch_reset_apply_bp(const Params& p, const DevBuffers& b, int nobj
 {
     const dim3 grid((p.N + BLOCK - 1) / BLOCK), blk(BLOCK);
     hipLaunchKernelGGL((reset_apply_kernel<BLOCK, PMAX>), grid, blk, step_lds_bytes(p, BLOCK), s, p,
-                       nobj_total, k10, k11, k20, k21, b.layout_size, b.cand_of, b.cand_xy, b.dyn, b.obj,
+                       nobj_total, k10, k11, k20, k21, b.pool.layout_size, b.pool.cand_of, b.pool.cand_xy, b.dyn, b.obj,
                        obs);
 }
 
@@ -810,7 +898,7 @@ static void launch_reset_done_bp(const Params& p, const DevBuffers& b, int nobj_
 {
     const dim3 grid((p.N + BLOCK - 1) / BLOCK), blk(BLOCK);
     hipLaunchKernelGGL((reset_done_kernel<BLOCK, PMAX>), grid, blk, step_lds_bytes(p, BLOCK), s, p,
-                       nobj_total, k10, k11, k20, k21, b.layout_size, b.cand_of, b.cand_xy, b.dyn, b.obj,
+                       nobj_total, k10, k11, k20, k21, b.pool.layout_size, b.pool.cand_of, b.pool.cand_xy, b.dyn, b.obj,
                        obs_in, obs_out);
 }
 

@@ -331,6 +331,11 @@ class Engine:
         self._info = {'cost': cost[-1]}
         return obs, reward, cost, done
 
+    def set_prefetch(self, steps):
+        """Predicted number of step() calls between reset()s for the layout-pool prefetch
+        (default num_steps); negative disables.  Never changes results."""
+        _native.check(self._lib.gx_set_prefetch(self._h, int(steps)))
+
     def set_path(self, mode):
         """0 auto, 1 thread-per-env kernels, 2 lane-group kernels (bit-identical results)."""
         _native.check(self._lib.gx_set_path(self._h, int(mode)))

@@ -123,6 +123,12 @@ gx_status gx_set_state(gx_engine* e, const float* qpos, const float* qvel, const
 /* rows of the valid-layout pool ((H+2)*2 floats each: goal, hazards.., robot) */
 gx_status gx_get_pool(gx_engine* e, float* pool, int32_t max_rows, int32_t* got);
 
+/* Layout-pool prefetch: after each gx_reset the pool for the NEXT reset (the key advanced
+ * by `steps` step() calls, engine.py:431) is sampled on a low-priority side stream while the
+ * epoch runs; a reset whose key matches uses it, otherwise it samples inline.  Results are
+ * identical either way.  steps < 0 disables; the default is cfg.num_steps. */
+gx_status gx_set_prefetch(gx_engine* e, int32_t steps);
+
 /* Kernel family used by step / rollout: 0 = auto (lane-group kernels up to 16384 envs,
  * thread-per-env kernels above), 1 = force thread-per-env, 2 = force lane-group.
  * Results are bit-identical either way (tests/test_gpu_parity.py). */
