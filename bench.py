@@ -63,10 +63,10 @@ def run_epochs(env, tapes, steps, gather):
         ep += 1
 
 
-def time_step_kernel(env_num, nlaunch, device):
-    """Average duration of one step-kernel launch, HIP events on the launch stream."""
+def _fresh_engine(env_num):
     from guardx_amd import ResamplingError
     env = make_engine(env_num, 0, 1, n_candidates=200_000)
+    env.set_prefetch(-1)
     try:
         env.reset()
     except ResamplingError:
@@ -74,20 +74,13 @@ def time_step_kernel(env_num, nlaunch, device):
         # the envs are initialised from the pool anyway (drawn with replacement), which is all
         # the kernel timing needs
         assert env_num > ENV_NUM
-    act = action_tape(1, env_num, 7, device)[0]
-    N, D = env_num, env.obs_flat_size
-    obs = torch.empty(N, D, device=device)
-    r, c, d = (torch.empty(N, device=device) for _ in range(3))
-    qacc = torch.empty(N, 3, device=device)
-    from guardx_amd import _native
-    import ctypes as C
-    lib = _native.load()
-    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return env
 
-    def launch():
-        _native.check(lib.gx_step(env._h, act.data_ptr(), obs.data_ptr(), r.data_ptr(), c.data_ptr(),
-                                  d.data_ptr(), qacc.data_ptr(), stream))
-    for _ in range(20):
+
+def time_launches(launch, nlaunch):
+    """Average duration of one kernel launch measured with HIP events on the launch stream
+    (torch's current stream is the stream every gx_* call is given)."""
+    for _ in range(3):
         launch()
     torch.cuda.synchronize()
     # (a) one event pair per launch: kernel duration (+ event overhead)
@@ -106,17 +99,65 @@ def time_step_kernel(env_num, nlaunch, device):
     e1.record()
     torch.cuda.synchronize()
     cadence = e0.elapsed_time(e1) * 1e-3 / nlaunch
-    env.close()
     return float(np.median(per)), float(cadence)
 
 
-def roofline(env_num, nlaunch, device):
-    per, cadence = time_step_kernel(env_num, nlaunch, device)
+def roofline_rollout(env_num, T, nlaunch, device):
+    """The dominant kernel of the headline workload: the persistent lane-group rollout kernel
+    (one launch = T fused step+reset_done passes over env_num envs)."""
+    env = _fresh_engine(env_num)
+    tape = action_tape(T, env_num, 7, device)
+    N, D = env_num, env.obs_flat_size
+    obs = torch.empty(T, N, D, device=device)
+    r, c, d = (torch.empty(T, N, device=device) for _ in range(3))
+    from guardx_amd import _native
+    import ctypes as C
+    lib = _native.load()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def launch():
+        _native.check(lib.gx_rollout(env._h, T, tape.data_ptr(), obs.data_ptr(), r.data_ptr(), c.data_ptr(),
+                                     d.data_ptr(), stream))
+    per, cadence = time_launches(launch, nlaunch)
+    env.close()
+    t = min(per, cadence)
+    ach = ALGO_BYTES_PER_ENV_STEP * env_num * T / t / 1e9
+    return {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+            "kernel": "gx::group_rollout_kernel<1,1,false>", "env_num": env_num, "steps_per_launch": T,
+            "avg_launch_us": round(t * 1e6, 3), "event_pair_us": round(per * 1e6, 3),
+            "back_to_back_us": round(cadence * 1e6, 3),
+            "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
+            "note": "latency-bound at env_num=2000: 500 single-wave workgroups, 0.74 MB of algorithmic "
+                    "traffic per step; see roofline_large_batch for the bandwidth regime"}
+
+
+def roofline_step(env_num, nlaunch, device):
+    """The thread-per-env step kernel (one launch = one step over env_num envs)."""
+    env = _fresh_engine(env_num)
+    act = action_tape(1, env_num, 7, device)[0]
+    N, D = env_num, env.obs_flat_size
+    obs = torch.empty(N, D, device=device)
+    r, c, d = (torch.empty(N, device=device) for _ in range(3))
+    qacc = torch.empty(N, 3, device=device)
+    from guardx_amd import _native
+    import ctypes as C
+    lib = _native.load()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def launch():
+        _native.check(lib.gx_step(env._h, act.data_ptr(), obs.data_ptr(), r.data_ptr(), c.data_ptr(),
+                                  d.data_ptr(), qacc.data_ptr(), stream))
+    per, cadence = time_launches(launch, nlaunch)
+    env.close()
     t = min(per, cadence)
     ach = ALGO_BYTES_PER_ENV_STEP * env_num / t / 1e9
     return {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
-            "kernel": "gx::step_kernel", "env_num": env_num,
+            "frac": round(ach / HBM_PEAK_GBS, 6),
+            "traffic": round(380 * env_num / 1e9, 4),
+            "traffic_note": "GB per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE = 380 B/env, "
+                            "profiles/r01_step_N4194304_pmc_*.csv)",
+            "kernel": "gx::step_kernel<256,5,true>", "env_num": env_num,
             "avg_launch_us": round(t * 1e6, 3), "event_pair_us": round(per * 1e6, 3),
             "back_to_back_us": round(cadence * 1e6, 3),
             "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP}
@@ -200,14 +241,14 @@ def main():
                                "(U(-1,1) action tape), 200-step epochs: reset() + 200 x (step + reset_done)"
                                + (", RCCL all-gather of the packed rollout shard per epoch" if gather else ""),
                    "env_num_per_gpu": ENV_NUM, "max_ep_len": EP_LEN, "obs_dim": env.obs_flat_size,
-                   "driver": "gx_rollout (C loop of step+reset_done launches per epoch)",
+                   "driver": "gx_rollout: one persistent lane-group kernel launch per 200-step epoch, layout pool of the next epoch prefetched on a side stream",
                    "layout_candidates_per_reset": 1_000_000},
     }
     if rank == 0:
-        line["roofline"] = roofline(ENV_NUM, 400, device)
+        line["roofline"] = roofline_rollout(ENV_NUM, EP_LEN, 30, device)
         if not args.no_extras:
-            # bandwidth regime: the same kernel at 2^22 envs (N=2000 is launch-latency bound)
-            line["roofline_large_batch"] = roofline(1 << 22, 30, device)
+            # bandwidth regime: the thread-per-env step kernel at 2^22 envs
+            line["roofline_large_batch"] = roofline_step(1 << 22, 30, device)
             line["api_step_loop_env_steps_per_s"] = round(api_loop_rate(env, tapes[0], 1000), 1)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

@@ -7,6 +7,7 @@
 #include "../../include/guardx.h"
 #include "gx_kernels.h"
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -84,6 +85,18 @@ struct DeviceGuard {
         if (changed) (void)hipSetDevice(prev);
     }
 };
+
+// smallest float x with fl(sqrtf(x)) >= thr, so that  sqrtf(d2) < thr  <=>  d2 < x  exactly
+// (sqrtf is correctly rounded and monotone).  thr <= 0 or NaN: nothing is ever "< thr".
+static float sqrt_cutoff(float thr)
+{
+    if (!(thr > 0.0f)) return 0.0f;
+    if (std::isinf(thr)) return thr;
+    float c = thr * thr;
+    while (c > 0.0f && sqrtf(std::nextafterf(c, 0.0f)) >= thr) c = std::nextafterf(c, 0.0f);
+    while (sqrtf(c) < thr) c = std::nextafterf(c, INFINITY);
+    return c;
+}
 
 extern "C" const char* gx_last_error(void) { return g_err.c_str(); }
 extern "C" int32_t gx_abi_version(void) { return 1; }
@@ -165,6 +178,9 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
         for (int q = 0; q < 3; ++q) sp.thr[q][t] = (float)(ko[q] + cfg->placements_margin + ko[t]);
     }
     sp.min_rg = cfg->robot_goal_min_dist;
+    for (int q = 0; q < 3; ++q)
+        for (int t = 0; t < 3; ++t) sp.thr_sq[q][t] = sqrt_cutoff(sp.thr[q][t]);
+    sp.min_rg_sq = sqrt_cutoff(sp.min_rg);
 
     // PRNGKey(seed)  engine.py:216
     e->key[0] = 0u;

@@ -13,6 +13,8 @@ struct SampleParams {
     float lo_x[3], hi_x[3], lo_y[3], hi_y[3];
     float thr[3][3]; // thr[placed type][new type] = f32(keepout_p + margin + keepout_new)
     float min_rg;    // engine.py:571
+    float thr_sq[3][3]; // exact cutoffs: sqrtf(d2) < thr  <=>  d2 < thr_sq
+    float min_rg_sq;
     uint32_t k0, k1; // engine key at reset time
 };
 

@@ -241,6 +241,15 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p, const float2* __r
 constexpr int kSampleBlock = 256;
 constexpr int kSurvWords = 32; // j, rng(2), goal(2), robot tries(20), pad
 
+// squared distance with the operation order of sqrt(sum(square(a - b))) (engine.py:553);
+// `sqrtf(d2) < thr` is evaluated as `d2 < thr_sq` where thr_sq is the exact cutoff
+// min{x : fl(sqrt(x)) >= thr} computed on the host (SampleParams), so no sqrt is needed
+GX_D float dsq(float ax, float ay, float bx, float by)
+{
+    const float dx = ax - bx, dy = ay - by;
+    return dx * dx + dy * dy;
+}
+
 GX_D void draw_xy(uint32_t g0, uint32_t g1, float lox, float hix, float loy, float hiy, float& x, float& y)
 {
     uint32_t u0, u1, v0, v1;
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(kSampleBlock) void sample_phase1_kernel(SampleParam
     for (int t = 0; t < 10; ++t) {
         split2(r0, r1, n0, n1, g0, g1); r0 = n0; r1 = n1;
         draw_xy(g0, g1, sp.lo_x[2], sp.hi_x[2], sp.lo_y[2], sp.hi_y[2], rx[t], ry[t]);
-        if (!(dist2(rx[t], ry[t], gx, gy) < sp.min_rg)) any_far = true;
+        if (!(dsq(rx[t], ry[t], gx, gy) < sp.min_rg_sq)) any_far = true;
     }
     const bool surv_me = live && any_far;
     if (live) ok[j] = 0;
@@ -324,7 +333,7 @@ __global__ __launch_bounds__(kSampleBlock) void sample_phase2_kernel(SampleParam
                 bool flag = true;
                 for (int q = 0; q < o; ++q) { // placement_is_valid :549-555
                     const float2 pq = placed[q * kSampleBlock + tid];
-                    if (dist2(cx, cy, pq.x, pq.y) < sp.thr[q == 0 ? 0 : 1][1]) flag = false;
+                    if (dsq(cx, cy, pq.x, pq.y) < sp.thr_sq[q == 0 ? 0 : 1][1]) flag = false;
                 }
                 if (flag) { px = cx; py = cy; conflicted = false; }
             }
@@ -339,13 +348,13 @@ __global__ __launch_bounds__(kSampleBlock) void sample_phase2_kernel(SampleParam
                 bool flag = true;
                 for (int q = 0; q < nobj - 1; ++q) {
                     const float2 pq = placed[q * kSampleBlock + tid];
-                    if (dist2(cx, cy, pq.x, pq.y) < sp.thr[q == 0 ? 0 : 1][2]) flag = false;
+                    if (dsq(cx, cy, pq.x, pq.y) < sp.thr_sq[q == 0 ? 0 : 1][2]) flag = false;
                 }
                 if (flag) { px = cx; py = cy; conflicted = false; }
             }
             placed[(nobj - 1) * kSampleBlock + tid] = make_float2(px, py);
             if (conflicted) success = false;
-            if (dist2(px, py, gx, gy) < sp.min_rg) success = false; // :570-571
+            if (dsq(px, py, gx, gy) < sp.min_rg_sq) success = false; // :570-571
         }
         if (success) {
             ok[j] = 1;
@@ -573,6 +582,7 @@ GX_D GroupObs<OPL, BPL> group_observe(const Params& p, float4 (*rec)[64], float 
     for (int jb = 0; jb < BPL; ++jb) {
         const int b = l + kGL * jb;
         float gl = 0.0f, hl = 0.0f;
+#pragma unroll 9
         for (int o = 0; o < p.nobj; ++o) {
             const float4 rc = rec[o >> 4][gbase + (o & 15)];
             LidarTerms t;
@@ -585,6 +595,7 @@ GX_D GroupObs<OPL, BPL> group_observe(const Params& p, float4 (*rec)[64], float 
         out.hl[jb] = hl;
     }
     float cs = 0.0f;
+#pragma unroll 8
     for (int o = 1; o < p.nobj; ++o) cs = cs + term[o >> 4][gbase + (o & 15)];
     out.cost = cs;
     { // obs_compass :834-844 (same expression as ego_xy of the goal)
@@ -600,12 +611,36 @@ GX_D GroupObs<OPL, BPL> group_observe(const Params& p, float4 (*rec)[64], float 
     return out;
 }
 
-template <int OPL, int BPL, bool kQacc>
-__global__ __launch_bounds__(64) void group_rollout_kernel(Params p, RolloutArgs r,
+// Fold the integer layout of the default Goal_*_8Hazards observation (8 hazards, 16 bins,
+// every observe_* flag at its default, aliasing on, exponential lidar, 1 physics step) into
+// compile-time constants: loops unroll, flag tests and their scalar bookkeeping disappear.
+GX_HD bool is_default_layout(const Params& p)
+{
+    return p.nobj == 9 && p.bins == 16 && p.D == 43 && p.off_acc == -1 && p.off_ctrl == 0 &&
+           p.off_comp == 3 && p.off_gl == 5 && p.off_hl == 21 && p.off_qpos == 37 && p.off_qvel == 40 &&
+           p.off_vel == -1 && p.lidar_alias == 1 && p.lidar_max_dist_set == 0 && p.physics_steps == 1 &&
+           p.hist_on == 0;
+}
+
+template <bool kDef>
+GX_D Params fold_params(Params p)
+{
+    if (kDef) {
+        p.H = 8; p.nobj = 9; p.P = 5; p.bins = 16; p.D = 43;
+        p.off_acc = -1; p.off_ctrl = 0; p.off_comp = 3; p.off_gl = 5; p.off_hl = 21;
+        p.off_qpos = 37; p.off_qvel = 40; p.off_vel = -1;
+        p.lidar_alias = 1; p.lidar_max_dist_set = 0; p.physics_steps = 1; p.hist_on = 0;
+    }
+    return p;
+}
+
+template <int OPL, int BPL, bool kQacc, bool kDef>
+__global__ __launch_bounds__(64) void group_rollout_kernel(Params p_in, RolloutArgs r,
                                                           float4* __restrict__ dyn,
                                                           float4* __restrict__ obj,
                                                           float4* __restrict__ hist)
 {
+    const Params p = fold_params<kDef>(p_in);
     __shared__ float4 rec[OPL][64];
     __shared__ float term[OPL][64];
     const int lane = threadIdx.x;
@@ -914,14 +949,20 @@ static void launch_group_ob(const Params& p, const RolloutArgs& r, const DevBuff
 {
     const dim3 grid((p.N + 3) / 4), blk(64);
     if (r.qacc)
-        hipLaunchKernelGGL((group_rollout_kernel<OPL, BPL, true>), grid, blk, 0, s, p, r, b.dyn, b.obj, b.hist);
+        hipLaunchKernelGGL((group_rollout_kernel<OPL, BPL, true, false>), grid, blk, 0, s, p, r, b.dyn, b.obj, b.hist);
     else
-        hipLaunchKernelGGL((group_rollout_kernel<OPL, BPL, false>), grid, blk, 0, s, p, r, b.dyn, b.obj, b.hist);
+        hipLaunchKernelGGL((group_rollout_kernel<OPL, BPL, false, false>), grid, blk, 0, s, p, r, b.dyn, b.obj, b.hist);
 }
 
 void launch_group_rollout(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s)
 {
-    if (p.nobj <= 16 && p.bins <= 16) launch_group_ob<1, 1>(p, r, b, s);
+    if (is_default_layout(p)) {
+        const dim3 grid((p.N + 3) / 4), blk(64);
+        if (r.qacc)
+            hipLaunchKernelGGL((group_rollout_kernel<1, 1, true, true>), grid, blk, 0, s, p, r, b.dyn, b.obj, b.hist);
+        else
+            hipLaunchKernelGGL((group_rollout_kernel<1, 1, false, true>), grid, blk, 0, s, p, r, b.dyn, b.obj, b.hist);
+    } else if (p.nobj <= 16 && p.bins <= 16) launch_group_ob<1, 1>(p, r, b, s);
     else launch_group_ob<5, 4>(p, r, b, s);
 }
 

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of the pieces of one epoch (MI355X): fused rollout alone, reset alone
+(sampler inline vs prefetched), and the overlap of the two."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
+
+def timeit(fn, n):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    env = bench.make_engine(N, 0, 1)
+    tape = bench.action_tape(200, N, 0, dev)
+    env.set_prefetch(-1)
+    env.reset()
+    t_roll = timeit(lambda: env.rollout(tape), 20)
+    t_reset = timeit(lambda: env.reset(), 10)
+    print(f"N={N} rollout(200) alone: {t_roll*1e3:.3f} ms = {t_roll/200*1e6:.2f} us/step ; reset (inline sampler): {t_reset*1e3:.3f} ms")
+
+    def epoch():
+        env.reset()
+        env.rollout(tape)
+    t_seq = timeit(epoch, 10)
+    env.set_prefetch(200)
+    epoch()
+    t_ovl = timeit(epoch, 20)
+    print(f"epoch sequential {t_seq*1e3:.3f} ms ; with side-stream prefetch {t_ovl*1e3:.3f} ms "
+          f"-> {N*200/t_ovl/1e6:.1f} M env-steps/s")
+    for T in (1, 10, 50):
+        tp = tape[:T].contiguous()
+        t = timeit(lambda: env.rollout(tp), 50)
+        print(f"rollout(T={T}): {t*1e6:.1f} us total, {t/T*1e6:.2f} us/step")
+    act = tape[0]
+    t = timeit(lambda: env.step(act), 200)
+    print(f"Engine.step python loop: {t*1e6:.2f} us/step")
+
+
+if __name__ == "__main__":
+    main()
