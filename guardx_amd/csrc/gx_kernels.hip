@@ -104,11 +104,34 @@ GX_D float dist2(float ax, float ay, float bx, float by)
     return sqrtf(dx * dx + dy * dy);
 }
 
+// Fold the integer layout of the default Goal_*_8Hazards observation (8 hazards, 16 bins,
+// every observe_* flag at its default, aliasing on, exponential lidar, 1 physics step) into
+// compile-time constants: loops unroll, flag tests and their scalar bookkeeping disappear.
+GX_HD bool is_default_layout(const Params& p)
+{
+    return p.nobj == 9 && p.bins == 16 && p.D == 43 && p.off_acc == -1 && p.off_ctrl == 0 &&
+           p.off_comp == 3 && p.off_gl == 5 && p.off_hl == 21 && p.off_qpos == 37 && p.off_qvel == 40 &&
+           p.off_vel == -1 && p.lidar_alias == 1 && p.lidar_max_dist_set == 0 && p.physics_steps == 1 &&
+           p.hist_on == 0;
+}
+
+template <bool kDef>
+GX_D Params fold_params(Params p)
+{
+    if (kDef) {
+        p.H = 8; p.nobj = 9; p.P = 5; p.bins = 16; p.D = 43;
+        p.off_acc = -1; p.off_ctrl = 0; p.off_comp = 3; p.off_gl = 5; p.off_hl = 21;
+        p.off_qpos = 37; p.off_qvel = 40; p.off_vel = -1;
+        p.lidar_alias = 1; p.lidar_max_dist_set = 0; p.physics_steps = 1; p.hist_on = 0;
+    }
+    return p;
+}
+
 // ---------------------------------------------------------------------------
 // Engine.step (engine.py:469-495 + mjx_step :659-700), Point robot.
 // ---------------------------------------------------------------------------
-template <int BLOCK, int PMAX, bool kQacc>
-__global__ __launch_bounds__(BLOCK) void step_kernel(Params p, const float2* __restrict__ act,
+template <int BLOCK, int PMAX, bool kQacc, bool kDef>
+__global__ __launch_bounds__(BLOCK) void step_kernel(Params p_in, const float2* __restrict__ act,
                                                      float4* __restrict__ dyn,
                                                      const float4* __restrict__ obj,
                                                      float4* __restrict__ hist,
@@ -118,6 +141,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p, const float2* __r
                                                      float* __restrict__ done,
                                                      float* __restrict__ qacc_out)
 {
+    const Params p = fold_params<kDef>(p_in);
     extern __shared__ float4 tile4[];
     float* tile = reinterpret_cast<float*>(tile4);
     const int tid = threadIdx.x;
@@ -611,29 +635,6 @@ GX_D GroupObs<OPL, BPL> group_observe(const Params& p, float4 (*rec)[64], float 
     return out;
 }
 
-// Fold the integer layout of the default Goal_*_8Hazards observation (8 hazards, 16 bins,
-// every observe_* flag at its default, aliasing on, exponential lidar, 1 physics step) into
-// compile-time constants: loops unroll, flag tests and their scalar bookkeeping disappear.
-GX_HD bool is_default_layout(const Params& p)
-{
-    return p.nobj == 9 && p.bins == 16 && p.D == 43 && p.off_acc == -1 && p.off_ctrl == 0 &&
-           p.off_comp == 3 && p.off_gl == 5 && p.off_hl == 21 && p.off_qpos == 37 && p.off_qvel == 40 &&
-           p.off_vel == -1 && p.lidar_alias == 1 && p.lidar_max_dist_set == 0 && p.physics_steps == 1 &&
-           p.hist_on == 0;
-}
-
-template <bool kDef>
-GX_D Params fold_params(Params p)
-{
-    if (kDef) {
-        p.H = 8; p.nobj = 9; p.P = 5; p.bins = 16; p.D = 43;
-        p.off_acc = -1; p.off_ctrl = 0; p.off_comp = 3; p.off_gl = 5; p.off_hl = 21;
-        p.off_qpos = 37; p.off_qvel = 40; p.off_vel = -1;
-        p.lidar_alias = 1; p.lidar_max_dist_set = 0; p.physics_steps = 1; p.hist_on = 0;
-    }
-    return p;
-}
-
 template <int OPL, int BPL, bool kQacc, bool kDef>
 __global__ __launch_bounds__(64) void group_rollout_kernel(Params p_in, RolloutArgs r,
                                                           float4* __restrict__ dyn,
@@ -861,14 +862,20 @@ static void launch_step_bp(const Params& p, const DevBuffers& b, const float* ac
 {
     const dim3 grid((p.N + BLOCK - 1) / BLOCK), blk(BLOCK);
     const size_t lds = step_lds_bytes(p, BLOCK);
-    if (qacc)
-        hipLaunchKernelGGL((step_kernel<BLOCK, PMAX, true>), grid, blk, lds, s, p,
-                           reinterpret_cast<const float2*>(act), b.dyn, b.obj, b.hist, obs, rew, cost,
-                           done, qacc);
+    const float2* a2 = reinterpret_cast<const float2*>(act);
+    if (PMAX == 5 && is_default_layout(p)) {
+        if (qacc)
+            hipLaunchKernelGGL((step_kernel<BLOCK, 5, true, true>), grid, blk, lds, s, p, a2, b.dyn, b.obj, b.hist,
+                               obs, rew, cost, done, qacc);
+        else
+            hipLaunchKernelGGL((step_kernel<BLOCK, 5, false, true>), grid, blk, lds, s, p, a2, b.dyn, b.obj, b.hist,
+                               obs, rew, cost, done, qacc);
+    } else if (qacc)
+        hipLaunchKernelGGL((step_kernel<BLOCK, PMAX, true, false>), grid, blk, lds, s, p, a2, b.dyn, b.obj, b.hist,
+                           obs, rew, cost, done, qacc);
     else
-        hipLaunchKernelGGL((step_kernel<BLOCK, PMAX, false>), grid, blk, lds, s, p,
-                           reinterpret_cast<const float2*>(act), b.dyn, b.obj, b.hist, obs, rew, cost,
-                           done, qacc);
+        hipLaunchKernelGGL((step_kernel<BLOCK, PMAX, false, false>), grid, blk, lds, s, p, a2, b.dyn, b.obj, b.hist,
+                           obs, rew, cost, done, qacc);
 }
 
 #define GX_DISPATCH_BP(FN, ...)                                        \

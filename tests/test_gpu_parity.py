@@ -246,3 +246,92 @@ def test_sharded_equals_unsharded(torch_cuda, oracle):
         o, rew, d, _ = sh.step(torch.from_numpy(act[r * N:(r + 1) * N]).cuda())
         np.testing.assert_array_equal(o.cpu().numpy(), o_full[r * N:(r + 1) * N].cpu().numpy())
         np.testing.assert_array_equal(sh.reset_done().cpu().numpy(), full_rd[r * N:(r + 1) * N])
+
+
+@pytest.mark.parametrize("prefetch", [None, -1, 7])
+def test_layout_prefetch_hit_and_miss_give_identical_resets(torch_cuda, oracle, prefetch):
+    """The pool of the next reset() is sampled ahead on a side stream for a PREDICTED key; a
+    mispredicted number of steps must fall back to inline sampling with identical results."""
+    torch = torch_cuda
+    N = 64
+    E, O = _engines(task_config(N, seed=21, num_steps=10), oracle, n_candidates=30000)
+    if prefetch is not None:
+        E.set_prefetch(prefetch)
+    rng = np.random.default_rng(1)
+    for nsteps in (0, 3, 10, 10, 7, 1, 10):      # default prediction is num_steps = 10
+        np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
+        assert E.layout_size == O.layout_size
+        np.testing.assert_array_equal(E.get_pool(64), O.get_pool(64))
+        for _ in range(nsteps):
+            act = rng.uniform(-1, 1, (N, 2)).astype(np.float32)
+            _cmp_step(E.step(torch.from_numpy(act).cuda()), O.step(act))
+            np.testing.assert_array_equal(E.reset_done().cpu().numpy(), O.reset_done())
+    assert_state_equal(E.get_state(), O.get_state())
+
+
+def test_engine_api_contract(torch_cuda):
+    """Shapes / dtypes / devices the unmodified learners rely on (trpo.py:449-547)."""
+    torch = torch_cuda
+    from guardx_amd import Engine
+    import pickle
+    N = 100
+    env = Engine(task_config(N, seed=0, num_steps=20), n_candidates=30000)
+    assert env.observation_space.shape == (43,) and env.action_space.shape == (2,)
+    o = env.reset()
+    assert o.shape == (N, 43) and o.dtype == torch.float32 and o.device.type == 'cuda'
+    act = torch.randn(N, 2, device='cuda')
+    o2, r, d, info = env.step(act)
+    assert o2.data_ptr() != o.data_ptr()                      # fresh buffers every call
+    assert r.shape == d.shape == info['cost'].shape == (N,)
+    assert all(t.dtype == torch.float32 for t in (o2, r, d, info['cost']))
+    assert set(torch.unique(d).tolist()) <= {0.0, 1.0}
+    assert set(info['obs']) == {'ctrl', 'goal_compass', 'goal_lidar', 'hazards_lidar', 'qpos', 'qvel', 'qacc'}
+    torch.testing.assert_close(info['obs']['goal_lidar'], o2[:, 5:21], rtol=0, atol=0)
+    torch.testing.assert_close(info['obs']['qvel'], o2[:, 40:43], rtol=0, atol=0)
+    keep = o2.clone()
+    o3 = env.reset_done()
+    torch.testing.assert_close(o2, keep, rtol=0, atol=0)      # self._obs is not modified (engine.py:501)
+    nd = d == 0
+    torch.testing.assert_close(o3[nd], o2[nd], rtol=0, atol=0)
+    # learner-style in-place edit of a returned tensor must not corrupt the env (trpo.py:529)
+    o3[o3.isnan()] = 0
+    env.step(act)
+    # the pickle is the config (EzPickle, engine.py:214)
+    env2 = pickle.loads(pickle.dumps(env))
+    assert env2.env_num == N and env2.num_steps == 20
+    torch.testing.assert_close(env2.reset(), Engine(task_config(N, seed=0, num_steps=20), n_candidates=30000).reset(),
+                               rtol=0, atol=0)
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(N, 3, device='cuda'))
+
+
+def test_learner_loop_contract(torch_cuda, oracle):
+    """The TRPO collection loop (trpo.py:466-547) driven verbatim against the Engine, with the
+    oracle in lock-step: host-side bookkeeping (ep_ret / ep_cost / done handling) matches."""
+    torch = torch_cuda
+    N, T = 200, 60
+    E, O = _engines(task_config(N, seed=8, num_steps=T, goal_size=0.8), oracle, n_candidates=40000)
+    o, oo = E.reset(), O.reset()
+    gen = torch.Generator(device='cuda').manual_seed(0)
+    ep_ret = np.zeros(N); ep_cost = np.zeros(N); ep_ret_o = np.zeros(N); ep_cost_o = np.zeros(N)
+    finished = 0
+    for t in range(T):
+        act = torch.rand(N, 2, device='cuda', generator=gen) * 2 - 1          # stand-in for ac.step(o)
+        next_o, r, d, info = E.step(act)
+        no_o, r_o, d_o, info_o = O.step(act.cpu().numpy())
+        assert 'cost' in info.keys()
+        ep_ret += r.cpu().numpy().squeeze(); ep_cost += info['cost'].cpu().numpy().squeeze()
+        ep_ret_o += r_o; ep_cost_o += info_o['cost']
+        o = next_o
+        timeout = (t + 1) == T
+        terminal = d.cpu().numpy().any() > 0 or timeout
+        if terminal and not timeout:
+            done = d.cpu().numpy()
+            np.testing.assert_array_equal(done, d_o)
+            finished += int(done.sum())
+            ep_ret[np.where(done == 1)] = 0; ep_ret_o[np.where(d_o == 1)] = 0
+            o = E.reset_done()
+            np.testing.assert_array_equal(o.cpu().numpy(), O.reset_done())
+    assert finished > 0
+    np.testing.assert_array_equal(ep_ret, ep_ret_o)
+    np.testing.assert_array_equal(ep_cost, ep_cost_o)
