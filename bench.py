@@ -159,8 +159,12 @@ def roofline_rollout(env_num, T, nlaunch, device):
     t = min(per, cadence)
     ach = ALGO_BYTES_PER_ENV_STEP * env_num * T / t / 1e9
     return {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
-            "kernel": "gx::group_rollout_kernel<1,1,false>", "env_num": env_num, "steps_per_launch": T,
+            "frac": round(ach / HBM_PEAK_GBS, 6),
+            "traffic": round((2 * 6612.375 + 78236.094) * 1024 / 1e9 * (env_num * T) / (2000 * 200), 4),
+            "traffic_note": "GB per launch from rocprofv3 PMC at env_num=2000, T=200: 2*FETCH_SIZE + WRITE_SIZE = "
+                            "13.5 MB + 80.1 MB (profiles/r01_rollout_N2000_T200_pmc_*.csv); below the 148.8 MB "
+                            "algorithmic figure because state and layout stay in registers across the 200 steps",
+            "kernel": "gx::group_rollout_kernel<1,1,false,true>", "env_num": env_num, "steps_per_launch": T,
             "avg_launch_us": round(t * 1e6, 3), "event_pair_us": round(per * 1e6, 3),
             "back_to_back_us": round(cadence * 1e6, 3),
             "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,

@@ -228,7 +228,7 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     }
     e->cur = 0;
     e->b.pool = e->pools[0];
-    if (err == hipSuccess) err = hipHostMalloc((void**)&e->h_layout_size, sizeof(int), hipHostMallocDefault);
+    if (err == hipSuccess) err = hipHostMalloc((void**)&e->h_layout_size, sizeof(int), hipHostMallocMapped);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&e->layout_ev, hipEventDisableTiming);
     if (err == hipSuccess) {
         // xmat of the zero pose: cos = 1 (engine.py:229 MjData default)
@@ -302,8 +302,7 @@ extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
     e->b.pool = e->pools[e->cur];
     uint32_t k[4];
     layout_keys(e, k);
-    launch_reset_apply(e->p, e->b, e->nobj_total, k[0], k[1], k[2], k[3], d_obs, s);
-    GX_HIP(hipMemcpyAsync(e->h_layout_size, e->b.pool.layout_size, sizeof(int), hipMemcpyDeviceToHost, s));
+    launch_reset_apply(e->p, e->b, e->nobj_total, k[0], k[1], k[2], k[3], d_obs, e->h_layout_size, s);
     GX_HIP(hipEventRecord(e->layout_ev, s));
     GX_HIP(hipGetLastError());
     e->layout_pending = true;
@@ -426,8 +425,7 @@ extern "C" gx_status gx_rollout(gx_engine* e, int32_t T, const float* d_actions,
             if (e->d_keys[slot]) (void)hipFree(e->d_keys[slot]);
             e->h_keys[slot] = nullptr; e->d_keys[slot] = nullptr;
             const int cap = T > 256 ? T : 256;
-            GX_HIP(hipHostMalloc((void**)&e->h_keys[slot], sizeof(uint4) * cap, hipHostMallocDefault));
-            GX_HIP(hipMalloc((void**)&e->d_keys[slot], sizeof(uint4) * cap));
+            GX_HIP(hipHostMalloc((void**)&e->h_keys[slot], sizeof(uint4) * cap, hipHostMallocMapped));
             e->keys_cap[slot] = cap;
             if (!e->keys_ev[slot]) GX_HIP(hipEventCreateWithFlags(&e->keys_ev[slot], hipEventDisableTiming));
         } else {
@@ -442,18 +440,17 @@ extern "C" gx_status gx_rollout(gx_engine* e, int32_t T, const float* d_actions,
             split2(k0, k1, kk.x, kk.y, kk.z, kk.w);
             e->h_keys[slot][t] = kk;
         }
-        GX_HIP(hipMemcpyAsync(e->d_keys[slot], e->h_keys[slot], sizeof(uint4) * T, hipMemcpyHostToDevice, s));
-        GX_HIP(hipEventRecord(e->keys_ev[slot], s));
         RolloutArgs r;
         memset(&r, 0, sizeof r);
         r.T = T; r.do_reset = 1; r.nobj_total = e->nobj_total; r.hist0 = e->hist;
         r.act = reinterpret_cast<const float2*>(d_actions);
         r.obs = d_obs; r.rew = d_reward; r.cost = d_cost; r.done = d_done; r.qacc = nullptr;
-        r.keys = e->d_keys[slot];
+        r.keys = e->h_keys[slot]; // pinned + device-visible: read over the host link only on a reset
         r.layout_size = e->b.pool.layout_size; r.cand_of = e->b.pool.cand_of; r.cand_xy = e->b.pool.cand_xy;
         e->p.have_last = e->hist >= 1;
         e->p.have_last_last = e->hist >= 2;
         launch_group_rollout(e->p, r, e->b, s);
+        GX_HIP(hipEventRecord(e->keys_ev[slot], s)); // staging reusable once this launch is done
         GX_HIP(hipGetLastError());
         e->key[0] = k0; e->key[1] = k1;
         e->hist = (e->hist + T) >= 2 ? 2 : e->hist + T;

@@ -42,7 +42,8 @@ void launch_step(const Params& p, const DevBuffers& b, const float* act, float* 
                  float* cost, float* done, float* qacc, hipStream_t s);
 void launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s);
 void launch_reset_apply(const Params& p, const DevBuffers& b, int nobj_total, uint32_t k10,
-                        uint32_t k11, uint32_t k20, uint32_t k21, float* obs, hipStream_t s);
+                        uint32_t k11, uint32_t k20, uint32_t k21, float* obs, int* host_layout_size,
+                        hipStream_t s);
 void launch_reset_done(const Params& p, const DevBuffers& b, int nobj_total, uint32_t k10,
                        uint32_t k11, uint32_t k20, uint32_t k21, const float* obs_in,
                        float* obs_out, hipStream_t s);

@@ -462,11 +462,15 @@ __global__ __launch_bounds__(BLOCK) void reset_apply_kernel(Params p, int nobj_t
                                                             const float2* __restrict__ cand_xy,
                                                             float4* __restrict__ dyn,
                                                             float4* __restrict__ obj,
-                                                            float* __restrict__ obs)
+                                                            float* __restrict__ obs,
+                                                            int* __restrict__ host_layout_size)
 {
     extern __shared__ float4 tile4[];
     float* tile = reinterpret_cast<float*>(tile4);
     const int L = *layout_size;
+    // len(idx) for the host-side assert (engine.py:442-444): written straight into mapped pinned
+    // host memory, no copy kernel on the stream
+    if (blockIdx.x == 0 && threadIdx.x == 0) *host_layout_size = L;
     if (L <= 0) return; // host raises GX_ERR_LAYOUT (engine.py:444)
     const int tid = threadIdx.x;
     const int env0 = blockIdx.x * BLOCK;
@@ -919,18 +923,19 @@ void launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s)
 
 template <int BLOCK, int PMAX>
 static void launch_reset_apply_bp(const Params& p, const DevBuffers& b, int nobj_total, uint32_t k10,
-                                  uint32_t k11, uint32_t k20, uint32_t k21, float* obs, hipStream_t s)
+                                  uint32_t k11, uint32_t k20, uint32_t k21, float* obs, int* host_ls,
+                                  hipStream_t s)
 {
     const dim3 grid((p.N + BLOCK - 1) / BLOCK), blk(BLOCK);
     hipLaunchKernelGGL((reset_apply_kernel<BLOCK, PMAX>), grid, blk, step_lds_bytes(p, BLOCK), s, p,
                        nobj_total, k10, k11, k20, k21, b.pool.layout_size, b.pool.cand_of, b.pool.cand_xy, b.dyn, b.obj,
-                       obs);
+                       obs, host_ls);
 }
 
 void launch_reset_apply(const Params& p, const DevBuffers& b, int nobj_total, uint32_t k10,
-                        uint32_t k11, uint32_t k20, uint32_t k21, float* obs, hipStream_t s)
+                        uint32_t k11, uint32_t k20, uint32_t k21, float* obs, int* host_ls, hipStream_t s)
 {
-    GX_DISPATCH_BP(launch_reset_apply_bp, p, b, nobj_total, k10, k11, k20, k21, obs, s);
+    GX_DISPATCH_BP(launch_reset_apply_bp, p, b, nobj_total, k10, k11, k20, k21, obs, host_ls, s);
 }
 
 template <int BLOCK, int PMAX>
