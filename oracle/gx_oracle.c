@@ -227,6 +227,8 @@ void gxo_randint(const uint32_t* key, int32_t n, uint32_t span, int32_t* out_n)
 struct gxo_env {
     gxo_config cfg;
     int N, H, NOBJ, D, bins;
+    int nq, nv, nu, na; /* robot.nq/nv/nu (world.py:435-438) and action width */
+    float h;            /* opt.timestep */
     int off_acc, off_ctrl, off_comp, off_glidar, off_hlidar, off_qpos, off_qvel, off_vel;
     float *qpos, *qvel, *pose0, *pose1, *objs; /* env-major */
     float *done0, *done1, *done2, *steps, *obs;
@@ -248,12 +250,16 @@ int gxo_get_threads(void)
 }
 
 int gxo_obs_dim(const gxo_env* e) { return e->D; }
+void gxo_dims(const gxo_env* e, int32_t* nq, int32_t* nv, int32_t* nu, int32_t* na)
+{
+    *nq = e->nq; *nv = e->nv; *nu = e->nu; *na = e->na;
+}
 int gxo_layout_size(const gxo_env* e) { return e->layout_size; }
 
 int gxo_create(const gxo_config* cfg, gxo_env** out)
 {
     if (!cfg || !out || cfg->struct_size != (int32_t)sizeof(gxo_config)) return GXO_ERR_ARG;
-    if (cfg->robot != 0) return GXO_ERR_UNSUPPORTED;
+    if (cfg->robot != 0 && cfg->robot != 1) return GXO_ERR_UNSUPPORTED;
     if (cfg->env_num < 1 || cfg->hazards_num < 1 || cfg->hazards_num > 64) return GXO_ERR_ARG;
     if (cfg->lidar_num_bins < 3 || cfg->lidar_num_bins > 64) return GXO_ERR_ARG;
     if (cfg->env_offset < 0 || cfg->env_offset + cfg->env_num > cfg->env_total) return GXO_ERR_ARG;
@@ -263,22 +269,24 @@ int gxo_create(const gxo_config* cfg, gxo_env** out)
     e->H = cfg->hazards_num;
     e->NOBJ = 1 + e->H;
     e->bins = cfg->lidar_num_bins;
+    if (cfg->robot == 0) { e->nq = 3; e->nv = 3; e->nu = 3; e->na = 2; e->h = PT_H; }   /* point.xml */
+    else { e->nq = 5; e->nv = 5; e->nu = 2; e->na = 2; e->h = 0.03f; }                 /* swimmer.xml */
     /* flat obs = concat over sorted(obs_space_dict keys)  engine.py:386-409,773-777 */
     int o = 0;
     e->off_acc = e->off_ctrl = e->off_comp = e->off_glidar = e->off_hlidar = -1;
     e->off_qpos = e->off_qvel = e->off_vel = -1;
     if (cfg->observe_acc) { e->off_acc = o; o += 2; }
-    if (cfg->observe_ctrl) { e->off_ctrl = o; o += 3; }
+    if (cfg->observe_ctrl) { e->off_ctrl = o; o += e->nu; }
     if (cfg->observe_goal_comp) { e->off_comp = o; o += 2; }
     if (cfg->observe_goal_lidar) { e->off_glidar = o; o += e->bins; }
     if (cfg->observe_hazards) { e->off_hlidar = o; o += e->bins; }
-    if (cfg->observe_qpos) { e->off_qpos = o; o += 3; }
-    if (cfg->observe_qvel) { e->off_qvel = o; o += 3; }
+    if (cfg->observe_qpos) { e->off_qpos = o; o += e->nq; }
+    if (cfg->observe_qvel) { e->off_qvel = o; o += e->nv; }
     if (cfg->observe_vel) { e->off_vel = o; o += 2; }
     e->D = o;
     int N = e->N;
-    e->qpos = (float*)calloc((size_t)N * 3, 4);
-    e->qvel = (float*)calloc((size_t)N * 3, 4);
+    e->qpos = (float*)calloc((size_t)N * e->nq, 4);
+    e->qvel = (float*)calloc((size_t)N * e->nv, 4);
     e->pose0 = (float*)calloc((size_t)N * 4, 4);
     e->pose1 = (float*)calloc((size_t)N * 2, 4);
     e->objs = (float*)calloc((size_t)N * e->NOBJ * 2, 4);
@@ -392,7 +400,7 @@ typedef struct {
 
 /* One mjx.step for the Point robot [derived, SURVEY Appendix B]:
  * forward(qpos,qvel,ctrl) -> pose, qacc ; Euler with implicit joint damping. */
-static void point_substep(ptstate* s, const float ctrl[3], float pose[4], float qacc[3])
+static void point_substep_s(ptstate* s, const float ctrl[3], float pose[4], float qacc[3])
 {
     /* kinematics: hinge quaternion (cos th/2, 0,0, sin th/2) -> xmat */
     float sh, ch;
@@ -435,6 +443,208 @@ static void point_substep(ptstate* s, const float ctrl[3], float pose[4], float 
     s->th = s->th + PT_H * s->om;
 }
 
+static void point_substep(float q[3], float v[3], const float ctrl[3], float pose[4], float qacc[3])
+{
+    ptstate s = {q[0], q[1], q[2], v[0], v[1], v[2]};
+    point_substep_s(&s, ctrl, pose, qacc);
+    q[0] = s.x; q[1] = s.y; q[2] = s.th; v[0] = s.vx; v[1] = s.vy; v[2] = s.om;
+}
+
+/* ------------------------------------------------------------------ */
+/* Swimmer (xmls/swimmer.xml) [derived]: planar 3-link chain, qpos =      */
+/* (x, y, th1, phi2, phi3); constants from tools/model_constants.py.      */
+/* ------------------------------------------------------------------ */
+#define SW_H 0.03f                         /* swimmer.xml:3 */
+#define SW_M 0.22200588085367876f          /* capsule r=.02 l=.15 density 1000 (:18,23,27) */
+#define SW_IC 0.00060383505197098225f      /* capsule inertia about a perpendicular axis */
+#define SW_ARM 0.1f                        /* :6 joint armature */
+#define SW_GEAR 20.0f                      /* :58-59 */
+#define SW_LIM 1.7453292519943295f         /* :24,28 range +-100 deg */
+#define SW_INVW2 9.3234461878793518f       /* dof_invweight0[motor1_rot] */
+#define SW_INVW3 9.8671592198756102f       /* dof_invweight0[motor2_rot] */
+#define SW_K 307.78701138811942f           /* 1/(dmax^2 tc^2), tc = max(.02, 2h) */
+#define SW_B 35.087719298245617f           /* 2/(dmax tc) */
+#define SW_A11 0.225f
+#define SW_A21 0.15f
+#define SW_A22 (-0.075f)
+#define SW_A31 0.15f
+#define SW_A32 (-0.15f)
+#define SW_A33 (-0.075f)
+
+typedef struct { float rd0, rd1, rd2, l10, l20, l21; } ldl3;
+
+static void ldl3_factor(const float S[3][3], ldl3* f)
+{
+    f->rd0 = 1.0f / S[0][0];
+    f->l10 = S[1][0] * f->rd0;
+    f->l20 = S[2][0] * f->rd0;
+    const float d1 = S[1][1] - f->l10 * S[1][0];
+    f->rd1 = 1.0f / d1;
+    const float t21 = S[2][1] - f->l20 * S[1][0];
+    f->l21 = t21 * f->rd1;
+    const float d2 = (S[2][2] - f->l20 * S[2][0]) - f->l21 * t21;
+    f->rd2 = 1.0f / d2;
+}
+
+static void ldl3_solve(const ldl3* f, const float b[3], float x[3])
+{
+    const float y0 = b[0];
+    const float y1 = b[1] - f->l10 * y0;
+    const float y2 = (b[2] - f->l20 * y0) - f->l21 * y1;
+    const float z2 = y2 * f->rd2;
+    const float z1 = y1 * f->rd1 - f->l21 * z2;
+    const float z0 = (y0 * f->rd0 - f->l10 * z1) - f->l20 * z2;
+    x[0] = z0; x[1] = z1; x[2] = z2;
+}
+
+/* joint-limit row (MJX constraint._instantiate_limit_slide_hinge + _kbi):
+ * present if violated; returns sign, aref and R = 1/D. */
+static int limit_row(float q, float vel, float invw, float* sign, float* aref, float* R)
+{
+    const float dmin = q - (-SW_LIM), dmax_ = SW_LIM - q;
+    const float pos = dmin < dmax_ ? dmin : dmax_;
+    const float sg = dmin < dmax_ ? 1.0f : -1.0f;
+    if (!(pos < 0.0f)) return 0;
+    /* impedance: solimp = (.9, .95, .001, .5, 2) */
+    const float ix = fabsf(pos) / 0.001f;
+    float iy;
+    if (ix < 0.5f) iy = 2.0f * (ix * ix);
+    else iy = 1.0f - 2.0f * ((1.0f - ix) * (1.0f - ix));
+    float imp = 0.9f + iy * (0.95f - 0.9f);
+    if (imp < 0.9f) imp = 0.9f;
+    if (imp > 0.95f) imp = 0.95f;
+    if (ix > 1.0f) imp = 0.95f;
+    *sign = sg;
+    *aref = -(SW_B * (sg * vel)) - (SW_K * imp) * pos;
+    float r = ((1.0f - imp) * invw) / imp;
+    if (r < 1e-15f) r = 1e-15f;
+    *R = r;
+    return 1;
+}
+
+static void swimmer_substep(float q[5], float v[5], const float ctrl[2], float pose[4], float qacc[5])
+{
+    /* kinematics: hinge quaternions (cos, sin of half angles) composed down the chain */
+    float sh1, ch1, sh2, ch2, sh3, ch3;
+    gx_sincos(0.5f * q[2], &sh1, &ch1);
+    gx_sincos(0.5f * q[3], &sh2, &ch2);
+    gx_sincos(0.5f * q[4], &sh3, &ch3);
+    const float w1 = ch1, z1 = sh1;
+    const float w2 = w1 * ch2 - z1 * sh2, z2 = w1 * sh2 + z1 * ch2;
+    const float w3 = w2 * ch3 - z2 * sh3, z3 = w2 * sh3 + z2 * ch3;
+    const float c1 = w1 * w1 - z1 * z1, s1 = 2.0f * (w1 * z1);
+    const float c2 = w2 * w2 - z2 * z2, s2 = 2.0f * (w2 * z2);
+    const float c3 = w3 * w3 - z3 * z3, s3 = 2.0f * (w3 * z3);
+    pose[0] = q[0]; pose[1] = q[1]; pose[2] = c1; pose[3] = s1;
+    /* absolute angular rates */
+    const float W1 = v[2], W2 = W1 + v[3], W3 = W2 + v[4];
+    /* COM Jacobian columns g_ij = sum_{k>=j} a_ik n_k, n_k = (-s_k, c_k) */
+    const float g11x = SW_A11 * -s1, g11y = SW_A11 * c1;
+    const float g22x = SW_A22 * -s2, g22y = SW_A22 * c2;
+    const float g21x = SW_A21 * -s1 + g22x, g21y = SW_A21 * c1 + g22y;
+    const float g33x = SW_A33 * -s3, g33y = SW_A33 * c3;
+    const float g32x = SW_A32 * -s2 + g33x, g32y = SW_A32 * c2 + g33y;
+    const float g31x = SW_A31 * -s1 + g32x, g31y = SW_A31 * c1 + g32y;
+    /* velocity-product acceleration of the COMs: -sum_k a_ik u_k W_k^2 */
+    const float e1 = W1 * W1, e2 = W2 * W2, e3 = W3 * W3;
+    const float q1x = -((SW_A11 * e1) * c1), q1y = -((SW_A11 * e1) * s1);
+    const float q2x = -((SW_A21 * e1) * c1 + (SW_A22 * e2) * c2), q2y = -((SW_A21 * e1) * s1 + (SW_A22 * e2) * s2);
+    const float q3x = -(((SW_A31 * e1) * c1 + (SW_A32 * e2) * c2) + (SW_A33 * e3) * c3);
+    const float q3y = -(((SW_A31 * e1) * s1 + (SW_A32 * e2) * s2) + (SW_A33 * e3) * s3);
+    /* mass matrix blocks */
+    const float Mx[3] = {SW_M * ((g11x + g21x) + g31x), SW_M * (g22x + g32x), SW_M * g33x};
+    const float My[3] = {SW_M * ((g11y + g21y) + g31y), SW_M * (g22y + g32y), SW_M * g33y};
+    float T[3][3];
+    T[0][0] = (SW_M * (((g11x * g11x + g11y * g11y) + (g21x * g21x + g21y * g21y)) + (g31x * g31x + g31y * g31y)) + 3.0f * SW_IC) + SW_ARM;
+    T[1][0] = SW_M * ((g21x * g22x + g21y * g22y) + (g31x * g32x + g31y * g32y)) + 2.0f * SW_IC;
+    T[2][0] = SW_M * (g31x * g33x + g31y * g33y) + SW_IC;
+    T[1][1] = (SW_M * ((g22x * g22x + g22y * g22y) + (g32x * g32x + g32y * g32y)) + 2.0f * SW_IC) + SW_ARM;
+    T[2][1] = SW_M * (g32x * g33x + g32y * g33y) + SW_IC;
+    T[2][2] = (SW_M * (g33x * g33x + g33y * g33y) + SW_IC) + SW_ARM;
+    T[0][1] = T[1][0]; T[0][2] = T[2][0]; T[1][2] = T[2][1];
+    /* bias and smooth force: qfrc_smooth = (passive - bias) + actuator */
+    const float bx = SW_M * ((q1x + q2x) + q3x), by = SW_M * ((q1y + q2y) + q3y);
+    const float b1 = SW_M * (((g11x * q1x + g11y * q1y) + (g21x * q2x + g21y * q2y)) + (g31x * q3x + g31y * q3y));
+    const float b2 = SW_M * ((g22x * q2x + g22y * q2y) + (g32x * q3x + g32y * q3y));
+    const float b3 = SW_M * (g33x * q3x + g33y * q3y);
+    float u0 = ctrl[0], u1 = ctrl[1]; /* ctrl clamped to ctrlrange for the force only */
+    u0 = u0 < -1.0f ? -1.0f : (u0 > 1.0f ? 1.0f : u0);
+    u1 = u1 < -1.0f ? -1.0f : (u1 > 1.0f ? 1.0f : u1);
+    const float fx = 0.0f - bx, fy = 0.0f - by;
+    const float ft[3] = {0.0f - b1, (0.0f - b2) + SW_GEAR * u0, (0.0f - b3) + SW_GEAR * u1};
+    /* eliminate the (diagonal) translation block, factor the 3x3 Schur complement */
+    const float imu = (float)(1.0 / (3.0 * 0.22200588085367876 + 0.1));
+    float S[3][3], r[3];
+    for (int j = 0; j < 3; ++j) {
+        for (int k = 0; k <= j; ++k) S[j][k] = T[j][k] - (Mx[j] * Mx[k] + My[j] * My[k]) * imu;
+        r[j] = ft[j] - (Mx[j] * fx + My[j] * fy) * imu;
+    }
+    S[0][1] = S[1][0]; S[0][2] = S[2][0]; S[1][2] = S[2][1];
+    ldl3 F;
+    ldl3_factor(S, &F);
+    float a[3];
+    ldl3_solve(&F, r, a); /* unconstrained qacc (angles) */
+    /* joint limits on phi2, phi3 */
+    float sg2 = 0, ar2 = 0, R2 = 0, sg3 = 0, ar3 = 0, R3 = 0;
+    const int p2 = limit_row(q[3], v[3], SW_INVW2, &sg2, &ar2, &R2);
+    const int p3 = limit_row(q[4], v[4], SW_INVW3, &sg3, &ar3, &R3);
+    if (p2 || p3) {
+        const float e2v[3] = {0.0f, 1.0f, 0.0f}, e3v[3] = {0.0f, 0.0f, 1.0f};
+        float zc2[3], zc3[3];
+        ldl3_solve(&F, e2v, zc2);
+        ldl3_solve(&F, e3v, zc3);
+        const float A22 = zc2[1], A33 = zc3[2], A23 = zc3[1] * (sg2 * sg3);
+        const float E2 = sg2 * a[1] - ar2, E3 = sg3 * a[2] - ar3; /* J a0 - aref */
+        float f2 = 0.0f, f3 = 0.0f;
+        int done = 0;
+        if (p2 && p3) {
+            const float m22 = R2 + A22, m33 = R3 + A33;
+            const float det = m22 * m33 - A23 * A23;
+            const float g2 = ((-E2) * m33 - A23 * (-E3)) / det;
+            const float g3 = (m22 * (-E3) - A23 * (-E2)) / det;
+            if (g2 > 0.0f && g3 > 0.0f) { f2 = g2; f3 = g3; done = 1; }
+        }
+        if (!done && p2) {
+            const float g2 = (-E2) / (R2 + A22);
+            if (g2 > 0.0f && (!p3 || !(E3 + A23 * g2 < 0.0f))) { f2 = g2; f3 = 0.0f; done = 1; }
+        }
+        if (!done && p3) {
+            const float g3 = (-E3) / (R3 + A33);
+            if (g3 > 0.0f && (!p2 || !(E2 + A23 * g3 < 0.0f))) { f3 = g3; f2 = 0.0f; done = 1; }
+        }
+        const float rc[3] = {r[0], r[1] + sg2 * f2, r[2] + sg3 * f3};
+        ldl3_solve(&F, rc, a);
+    }
+    const float ax = (fx - ((Mx[0] * a[0] + Mx[1] * a[1]) + Mx[2] * a[2])) * imu;
+    const float ay = (fy - ((My[0] * a[0] + My[1] * a[1]) + My[2] * a[2])) * imu;
+    qacc[0] = ax; qacc[1] = ay; qacc[2] = a[0]; qacc[3] = a[1]; qacc[4] = a[2];
+    for (int k = 0; k < 5; ++k) v[k] = v[k] + SW_H * qacc[k];
+    for (int k = 0; k < 5; ++k) q[k] = q[k] + SW_H * v[k];
+}
+
+#define GX_MAXQ 5
+/* one mjx.step of the configured robot */
+static void robot_substep(const gxo_env* e, float* q, float* v, const float* ctrl, float pose[4], float* qacc)
+{
+    if (e->cfg.robot == 0) point_substep(q, v, ctrl, pose, qacc);
+    else swimmer_substep(q, v, ctrl, pose, qacc);
+}
+
+/* convert_action engine.py:672-685: Point rotates (a0,0,0) by the PRE-step xmat; others pass through */
+static void convert_action(const gxo_env* e, const float pose0[4], const float* a, float* ctrl)
+{
+    if (e->cfg.robot == 0) { ctrl[0] = pose0[2] * a[0]; ctrl[1] = pose0[3] * a[0]; ctrl[2] = a[1]; }
+    else { for (int k = 0; k < e->nu; ++k) ctrl[k] = a[k]; }
+}
+
+/* pose of the robot body from qpos (mjx.forward kinematics), qpos with zero angles */
+static void pose_of_rest(const float* q, float pose[4])
+{
+    float sh, ch;
+    gx_sincos(0.5f * q[2], &sh, &ch);
+    pose[0] = q[0]; pose[1] = q[1]; pose[2] = ch * ch - sh * sh; pose[3] = 2.0f * (ch * sh);
+}
+
 /* obs_lidar engine.py:846-900 over `n` objects (xy pairs), pose=(x,y,c,s). */
 static void obs_lidar(const gxo_env* e, const float pose[4], const float* objs, int n, float* out)
 {
@@ -473,11 +683,11 @@ static void obs_lidar(const gxo_env* e, const float pose[4], const float* objs, 
 
 /* Engine.obs engine.py:738-778 -> flat row.  vel/acc passed in. */
 static void build_obs(const gxo_env* e, const float pose[4], const float* objs,
-                      const float ctrl[3], const ptstate* s, const float vel[2],
+                      const float* ctrl, const float* q, const float* v, const float vel[2],
                       const float acc[2], float* row)
 {
     if (e->off_acc >= 0) { row[e->off_acc] = acc[0]; row[e->off_acc + 1] = acc[1]; }
-    if (e->off_ctrl >= 0) { for (int i = 0; i < 3; ++i) row[e->off_ctrl + i] = ctrl[i]; }
+    if (e->off_ctrl >= 0) { for (int i = 0; i < e->nu; ++i) row[e->off_ctrl + i] = ctrl[i]; }
     if (e->off_comp >= 0) { /* obs_compass :834-844 */
         float dx = objs[0] - pose[0], dy = objs[1] - pose[1];
         row[e->off_comp] = dx * pose[2] + dy * pose[3];
@@ -485,8 +695,8 @@ static void build_obs(const gxo_env* e, const float pose[4], const float* objs,
     }
     if (e->off_glidar >= 0) obs_lidar(e, pose, objs, 1, &row[e->off_glidar]);
     if (e->off_hlidar >= 0) obs_lidar(e, pose, objs + 2, e->H, &row[e->off_hlidar]);
-    if (e->off_qpos >= 0) { row[e->off_qpos] = s->x; row[e->off_qpos + 1] = s->y; row[e->off_qpos + 2] = s->th; }
-    if (e->off_qvel >= 0) { row[e->off_qvel] = s->vx; row[e->off_qvel + 1] = s->vy; row[e->off_qvel + 2] = s->om; }
+    if (e->off_qpos >= 0) { for (int i = 0; i < e->nq; ++i) row[e->off_qpos + i] = q[i]; }
+    if (e->off_qvel >= 0) { for (int i = 0; i < e->nv; ++i) row[e->off_qvel + i] = v[i]; }
     if (e->off_vel >= 0) { row[e->off_vel] = vel[0]; row[e->off_vel + 1] = vel[1]; }
 }
 
@@ -500,10 +710,12 @@ static void load_layout(gxo_env* e, int i, const float* lay)
 {
     /* layout2qpos engine.py:623-639: goal, hazards -> their slide joints; robot -> qpos[0:2] */
     memcpy(&e->objs[(size_t)i * e->NOBJ * 2], lay, (size_t)e->NOBJ * 2 * 4);
-    e->qpos[3 * i] = lay[2 * e->NOBJ];
-    e->qpos[3 * i + 1] = lay[2 * e->NOBJ + 1];
-    e->qpos[3 * i + 2] = 0.0f;
-    e->qvel[3 * i] = e->qvel[3 * i + 1] = e->qvel[3 * i + 2] = 0.0f;
+    float* q = &e->qpos[(size_t)i * e->nq];
+    float* v = &e->qvel[(size_t)i * e->nv];
+    for (int k = 0; k < e->nq; ++k) q[k] = 0.0f;
+    for (int k = 0; k < e->nv; ++k) v[k] = 0.0f;
+    q[0] = lay[2 * e->NOBJ];
+    q[1] = lay[2 * e->NOBJ + 1];
 }
 
 /* get_layout engine.py:446-452: idx = randint(key, (env_num,), 0, layout_size) */
@@ -525,17 +737,14 @@ int gxo_reset(gxo_env* e, float* obs)
     uint32_t* idx = (uint32_t*)malloc((size_t)e->N * 4);
     layout_indices(e, idx); /* :458 */
     const int row = (e->H + 2) * 2;
-    const float zero3[3] = {0, 0, 0}, zero2[2] = {0, 0};
+    const float zero5[GX_MAXQ] = {0, 0, 0, 0, 0}, zero2[2] = {0, 0};
     for (int i = 0; i < e->N; ++i) {
         load_layout(e, i, &e->pool[(size_t)idx[i] * row]);
         /* mjx_reset :644-657: ctrl=0, mjx.forward -> pose(qpos), obs without history */
-        ptstate s = {e->qpos[3 * i], e->qpos[3 * i + 1], 0.0f, 0.0f, 0.0f, 0.0f};
-        float sh, ch;
-        gx_sincos(0.5f * s.th, &sh, &ch);
         float* p0 = &e->pose0[4 * i];
-        p0[0] = s.x; p0[1] = s.y; p0[2] = ch * ch - sh * sh; p0[3] = 2.0f * (ch * sh);
-        build_obs(e, p0, &e->objs[(size_t)i * e->NOBJ * 2], zero3, &s, zero2, zero2,
-                  &e->obs[(size_t)i * e->D]);
+        pose_of_rest(&e->qpos[(size_t)i * e->nq], p0);
+        build_obs(e, p0, &e->objs[(size_t)i * e->NOBJ * 2], zero5, &e->qpos[(size_t)i * e->nq],
+                  &e->qvel[(size_t)i * e->nv], zero2, zero2, &e->obs[(size_t)i * e->D]);
         e->steps[i] = 0.0f; /* :463 */
     }
     free(idx);
@@ -556,7 +765,8 @@ int gxo_step(gxo_env* e, const float* action, float* obs, float* reward, float* 
         e->key[0] = nk[0]; e->key[1] = nk[1];
     }
     const int have_last = e->hist >= 1, have_last_last = e->hist >= 2;
-    const float dt = PT_H * (float)e->cfg.physics_steps; /* :235 */
+    const float dt = e->h * (float)e->cfg.physics_steps; /* :235 */
+    const int nq = e->nq, nv = e->nv, na = e->na;
 #pragma omp parallel for schedule(static) num_threads(gxo_get_threads()) if (N >= 4096)
     for (int i = 0; i < N; ++i) {
         float* p0 = &e->pose0[4 * i];
@@ -565,12 +775,13 @@ int gxo_step(gxo_env* e, const float* action, float* obs, float* reward, float* 
         float P1[2] = {p0[0], p0[1]};   /* last_data.xpos */
         float P2[2] = {p1[0], p1[1]};   /* last_last_data.xpos */
         /* convert_action :672-685 with the PRE-step xmat */
-        float a0 = action[2 * i], a1 = action[2 * i + 1];
-        float ctrl[3] = {p0[2] * a0, p0[3] * a0, a1};
-        ptstate s = {e->qpos[3 * i], e->qpos[3 * i + 1], e->qpos[3 * i + 2],
-                     e->qvel[3 * i], e->qvel[3 * i + 1], e->qvel[3 * i + 2]};
-        float pose[4], qacc[3];
-        for (int k = 0; k < e->cfg.physics_steps; ++k) point_substep(&s, ctrl, pose, qacc); /* :689 */
+        float ctrl[GX_MAXQ] = {0, 0, 0, 0, 0};
+        convert_action(e, p0, &action[(size_t)na * i], ctrl);
+        float q[GX_MAXQ], v[GX_MAXQ];
+        for (int k = 0; k < nq; ++k) q[k] = e->qpos[(size_t)i * nq + k];
+        for (int k = 0; k < nv; ++k) v[k] = e->qvel[(size_t)i * nv + k];
+        float pose[4], qacc[GX_MAXQ] = {0, 0, 0, 0, 0};
+        for (int k = 0; k < e->cfg.physics_steps; ++k) robot_substep(e, q, v, ctrl, pose, qacc); /* :689 */
         /* ego_vel_acc :902-929 */
         float vel[2] = {0, 0}, acc[2] = {0, 0};
         if (e->off_vel >= 0 || e->off_acc >= 0) {
@@ -595,7 +806,7 @@ int gxo_step(gxo_env* e, const float* action, float* obs, float* reward, float* 
             acc[1] = aw[0] * (-pose[3]) + aw[1] * pose[2];
         }
         float* row = &e->obs[(size_t)i * D];
-        build_obs(e, pose, objs, ctrl, &s, vel, acc, row); /* :690 */
+        build_obs(e, pose, objs, ctrl, q, v, vel, acc, row); /* :690 */
         /* reward_done :787-802 */
         float dg = dist_goal(objs, pose);
         float last = dg;
@@ -621,13 +832,13 @@ int gxo_step(gxo_env* e, const float* action, float* obs, float* reward, float* 
         if (e->steps[i] > (float)e->cfg.num_steps) dn = 1.0f;
         e->steps[i] = dn > 0.0f ? 0.0f : e->steps[i] + 1.0f;
         /* commit */
-        e->qpos[3 * i] = s.x; e->qpos[3 * i + 1] = s.y; e->qpos[3 * i + 2] = s.th;
-        e->qvel[3 * i] = s.vx; e->qvel[3 * i + 1] = s.vy; e->qvel[3 * i + 2] = s.om;
+        for (int k = 0; k < nq; ++k) e->qpos[(size_t)i * nq + k] = q[k];
+        for (int k = 0; k < nv; ++k) e->qvel[(size_t)i * nv + k] = v[k];
         p1[0] = P1[0]; p1[1] = P1[1];
         p0[0] = pose[0]; p0[1] = pose[1]; p0[2] = pose[2]; p0[3] = pose[3];
         e->done0[i] = dn;
         reward[i] = r; cost[i] = cs; done[i] = dn;
-        if (qacc_out) { qacc_out[3 * i] = qacc[0]; qacc_out[3 * i + 1] = qacc[1]; qacc_out[3 * i + 2] = qacc[2]; }
+        if (qacc_out) { for (int k = 0; k < nv; ++k) qacc_out[(size_t)i * nv + k] = qacc[k]; }
     }
     if (e->hist < 2) e->hist++;
     memcpy(obs, e->obs, (size_t)N * D * 4);
@@ -645,16 +856,17 @@ int gxo_reset_done(gxo_env* e, float* obs)
     uint32_t* idx = (uint32_t*)malloc((size_t)N * 4);
     layout_indices(e, idx); /* :500 */
     memcpy(obs, e->obs, (size_t)N * D * 4); /* self._obs is NOT updated by reset_done (:501) */
-    const float zero3[3] = {0, 0, 0}, zero2[2] = {0, 0};
+    const float zero5[GX_MAXQ] = {0, 0, 0, 0, 0}, zero2[2] = {0, 0};
     for (int i = 0; i < N; ++i) {
         if (!(e->done0[i] > 0.0f)) continue; /* :715-717 */
         load_layout(e, i, &e->pool[(size_t)idx[i] * row]);
         /* fake step (:719-724) on a scratch copy: its pose/qpos/qvel feed the obs only;
          * the returned data keeps the stale xpos/xmat (:731). */
-        ptstate s = {e->qpos[3 * i], e->qpos[3 * i + 1], e->qpos[3 * i + 2], 0.0f, 0.0f, 0.0f};
-        float pose[4], qacc[3];
-        for (int k = 0; k < e->cfg.physics_steps; ++k) point_substep(&s, zero3, pose, qacc);
-        build_obs(e, pose, &e->objs[(size_t)i * e->NOBJ * 2], zero3, &s, zero2, zero2,
+        float q[GX_MAXQ], v[GX_MAXQ], pose[4], qacc[GX_MAXQ];
+        for (int k = 0; k < e->nq; ++k) q[k] = e->qpos[(size_t)i * e->nq + k];
+        for (int k = 0; k < e->nv; ++k) v[k] = 0.0f;
+        for (int k = 0; k < e->cfg.physics_steps; ++k) robot_substep(e, q, v, zero5, pose, qacc);
+        build_obs(e, pose, &e->objs[(size_t)i * e->NOBJ * 2], zero5, q, v, zero2, zero2,
                   &obs[(size_t)i * D]); /* :726-729 */
     }
     free(idx);
@@ -666,8 +878,8 @@ int gxo_get_state(const gxo_env* e, float* qpos, float* qvel, float* pose0, floa
                   int32_t* hist)
 {
     const size_t N = (size_t)e->N;
-    if (qpos) memcpy(qpos, e->qpos, N * 12);
-    if (qvel) memcpy(qvel, e->qvel, N * 12);
+    if (qpos) memcpy(qpos, e->qpos, N * e->nq * 4);
+    if (qvel) memcpy(qvel, e->qvel, N * e->nv * 4);
     if (pose0) memcpy(pose0, e->pose0, N * 16);
     if (pose1) memcpy(pose1, e->pose1, N * 8);
     if (objs) memcpy(objs, e->objs, N * e->NOBJ * 8);
@@ -685,8 +897,8 @@ int gxo_set_state(gxo_env* e, const float* qpos, const float* qvel, const float*
                   const int32_t* hist)
 {
     const size_t N = (size_t)e->N;
-    if (qpos) memcpy(e->qpos, qpos, N * 12);
-    if (qvel) memcpy(e->qvel, qvel, N * 12);
+    if (qpos) memcpy(e->qpos, qpos, N * e->nq * 4);
+    if (qvel) memcpy(e->qvel, qvel, N * e->nv * 4);
     if (pose0) memcpy(e->pose0, pose0, N * 16);
     if (pose1) memcpy(e->pose1, pose1, N * 8);
     if (objs) memcpy(e->objs, objs, N * e->NOBJ * 8);

@@ -27,7 +27,7 @@ extern "C" {
  * checker does not include product headers). */
 typedef struct gxo_config {
     int32_t struct_size;        /* sizeof(gxo_config), ABI check */
-    int32_t robot;              /* 0 = xmls/point.xml */
+    int32_t robot;              /* 0 = xmls/point.xml, 1 = xmls/swimmer.xml */
     int32_t env_num;            /* envs owned by this instance */
     int32_t env_total;          /* env_num of the whole (possibly sharded) batch */
     int32_t env_offset;         /* global index of local env 0 */
@@ -68,9 +68,11 @@ enum { GXO_OK = 0, GXO_ERR_ARG = 1, GXO_ERR_UNSUPPORTED = 2, GXO_ERR_LAYOUT = 3 
 int  gxo_create(const gxo_config* cfg, gxo_env** out);
 void gxo_destroy(gxo_env* e);
 int  gxo_obs_dim(const gxo_env* e);
+/* robot.nq / nv / nu (world.py:435-438) and the action width */
+void gxo_dims(const gxo_env* e, int32_t* nq, int32_t* nv, int32_t* nu, int32_t* na);
 /* Engine.reset  engine.py:454-467 */
 int  gxo_reset(gxo_env* e, float* obs);
-/* Engine.step   engine.py:469-495 ; qacc may be NULL */
+/* Engine.step   engine.py:469-495 ; action[N*na]; qacc[N*nv] may be NULL */
 int  gxo_step(gxo_env* e, const float* action, float* obs, float* reward,
               float* cost, float* done, float* qacc);
 /* Engine.reset_done engine.py:497-505 */
@@ -78,7 +80,7 @@ int  gxo_reset_done(gxo_env* e, float* obs);
 int  gxo_layout_size(const gxo_env* e);
 
 /* Flat env-major state exchange used by the parity tests.
- *  qpos[N*3] qvel[N*3] pose0[N*4]=(x,y,cos,sin of _data.xpos/xmat) pose1[N*2]
+ *  qpos[N*nq] qvel[N*nv] pose0[N*4]=(x,y,cos,sin of _data.xpos/xmat) pose1[N*2]
  *  objs[N*(1+H)*2]=(goal, hazard0..) done0[N] done1[N] steps[N] key[2] hist[1] */
 int  gxo_get_state(const gxo_env* e, float* qpos, float* qvel, float* pose0,
                    float* pose1, float* objs, float* done0, float* done1,

@@ -200,3 +200,122 @@ def step(state, action, cfg):
     new = dict(state, qpos=q, qvel=v, pose0=pose, done0=done, done1=last_done.copy(), steps=nsteps,
                hist=min(2, state['hist'] + 1))
     return obs, rew, done, cost, new, (pos_g, pos_h), qacc
+
+
+# --------------------------------------------------------------------------
+# Swimmer (xmls/swimmer.xml): independent float64 restatement of one mjx.step
+# [derived].  Generic formulation on purpose (complex-number kinematics, Jacobians
+# of COM positions, velocity-product term by differentiating J numerically, limit
+# rows solved by an active-set loop) -- nothing shared with gx_oracle.c's closed form.
+# --------------------------------------------------------------------------
+SW = dict(h=0.03, r=0.02, length=0.15, rho=1000.0, arm=0.1, gear=20.0, lim=100 * np.pi / 180,
+          solref=(0.02, 1.0), solimp=(0.9, 0.95, 0.001, 0.5, 2.0))
+
+
+def _sw_capsule():
+    r, L, rho = SW['r'], SW['length'], SW['rho']
+    vc, vs = np.pi * r * r * L, 4 / 3 * np.pi * r ** 3
+    mc, ms = rho * vc, rho * vs
+    I = mc * (3 * r * r + L * L) / 12 + 2 * ms * r * r / 5 + ms * L * (3 * r + 2 * L) / 8
+    return mc + ms, I
+
+
+def _sw_coms(q):
+    """COM of the three links as complex numbers; bodies per swimmer.xml:14-31"""
+    p = q[0] + 1j * q[1]
+    a1 = q[2]; a2 = a1 + q[3]; a3 = a2 + q[4]
+    u1, u2, u3 = np.exp(1j * a1), np.exp(1j * a2), np.exp(1j * a3)
+    b2 = p + 0.15 * u1            # body "mid" origin
+    b3 = b2 - 0.15 * u2           # body "back" origin
+    return np.array([p + 0.225 * u1, b2 - 0.075 * u2, b3 - 0.075 * u3])
+
+
+def _sw_jac(q):
+    """J[i] (2x5) of COM_i, analytic via the complex derivative"""
+    a1 = q[2]; a2 = a1 + q[3]; a3 = a2 + q[4]
+    d1, d2, d3 = 1j * np.exp(1j * a1), 1j * np.exp(1j * a2), 1j * np.exp(1j * a3)
+    cols = np.zeros((3, 5), complex)
+    cols[:, 0] = 1.0
+    cols[:, 1] = 1j
+    # link1
+    cols[0, 2] = 0.225 * d1
+    # link2: p + .15 u1 - .075 u2
+    cols[1, 2] = 0.15 * d1 - 0.075 * d2
+    cols[1, 3] = -0.075 * d2
+    # link3: p + .15 u1 - .15 u2 - .075 u3
+    cols[2, 2] = 0.15 * d1 - 0.15 * d2 - 0.075 * d3
+    cols[2, 3] = -0.15 * d2 - 0.075 * d3
+    cols[2, 4] = -0.075 * d3
+    J = np.zeros((3, 2, 5))
+    J[:, 0, :] = cols.real
+    J[:, 1, :] = cols.imag
+    return J
+
+
+def swimmer_mass_bias(q, v):
+    m, I = _sw_capsule()
+    J = _sw_jac(q)
+    Jw = np.array([[0, 0, 1, 0, 0], [0, 0, 1, 1, 0], [0, 0, 1, 1, 1]], float)   # link angular rates
+    M = sum(m * J[i].T @ J[i] + I * np.outer(Jw[i], Jw[i]) for i in range(3)) + SW['arm'] * np.eye(5)
+    # velocity-product force  c = sum_i m J_i^T (dJ_i/dt v): differentiate J along v numerically
+    eps = 1e-6
+    Jp, Jm = _sw_jac(q + eps * v), _sw_jac(q - eps * v)
+    Jdot = (Jp - Jm) / (2 * eps)
+    c = sum(m * J[i].T @ (Jdot[i] @ v) for i in range(3))
+    return M, c
+
+
+def _sw_limit_rows(q, v, M):
+    rows = []
+    m0, _ = swimmer_mass_bias(np.zeros(5), np.zeros(5))
+    A0 = np.linalg.inv(m0)
+    tc = max(SW['solref'][0], 2 * SW['h'])
+    dmin, dmax, width, mid, power = SW['solimp']
+    b = 2 / (dmax * tc)
+    k = 1 / (dmax * dmax * tc * tc * SW['solref'][1] ** 2)
+    for j in (3, 4):
+        dlo, dhi = q[j] + SW['lim'], SW['lim'] - q[j]
+        pos = min(dlo, dhi)
+        if pos >= 0:
+            continue
+        sg = 1.0 if dlo < dhi else -1.0
+        x = abs(pos) / width
+        y = (x ** power) / mid ** (power - 1) if x < mid else 1 - ((1 - x) ** power) / (1 - mid) ** (power - 1)
+        imp = min(max(dmin + y * (dmax - dmin), dmin), dmax)
+        if x > 1:
+            imp = dmax
+        Jr = np.zeros(5); Jr[j] = sg
+        aref = -b * (Jr @ v) - k * imp * pos
+        R = max(1e-15, (1 - imp) / imp * A0[j, j])
+        rows.append((Jr, aref, 1 / R))
+    return rows
+
+
+def swimmer_step(q, v, ctrl):
+    """one mjx.step: returns (pose of the robot body at the START state, qacc, q', v')"""
+    q = np.asarray(q, float); v = np.asarray(v, float)
+    M, c = swimmer_mass_bias(q, v)
+    tau = np.zeros(5)
+    tau[3:] = SW['gear'] * np.clip(ctrl, -1, 1)
+    f = -c + tau
+    a0 = np.linalg.solve(M, f)
+    rows = _sw_limit_rows(q, v, M)
+    qacc = a0
+    if rows:
+        # minimise 1/2 (a-a0)' M (a-a0) + sum_i 1/2 D_i min(0, J_i a - aref_i)^2 : active-set iteration
+        active = [True] * len(rows)
+        for _ in range(20):
+            H = M.copy(); g = M @ a0
+            for on, (Jr, aref, D) in zip(active, rows):
+                if on:
+                    H += D * np.outer(Jr, Jr); g += D * Jr * aref
+            a = np.linalg.solve(H, g)
+            new = [(Jr @ a - aref) < 0 for (Jr, aref, D) in rows]
+            if new == active:
+                break
+            active = new
+        qacc = a
+    v2 = v + SW['h'] * qacc
+    q2 = q + SW['h'] * v2
+    pose = np.array([q[0], q[1], np.cos(q[2]), np.sin(q[2])])
+    return pose, qacc, q2, v2

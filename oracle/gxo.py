@@ -71,6 +71,8 @@ def lib():
         L.gxo_destroy.argtypes = [C.c_void_p]
         L.gxo_destroy.restype = None
         L.gxo_obs_dim.argtypes = [C.c_void_p]
+        L.gxo_dims.argtypes = [C.c_void_p] + [C.POINTER(C.c_int32)] * 4
+        L.gxo_dims.restype = None
         L.gxo_reset.argtypes = [C.c_void_p, fp]
         L.gxo_step.argtypes = [C.c_void_p, fp, fp, fp, fp, fp, fp]
         L.gxo_reset_done.argtypes = [C.c_void_p, fp]
@@ -149,6 +151,9 @@ class OracleEngine:
         self.N = self.cfg.env_num
         self.H = self.cfg.hazards_num
         self.D = self.L.gxo_obs_dim(self.h)
+        d = [C.c_int32() for _ in range(4)]
+        self.L.gxo_dims(self.h, *[C.byref(x) for x in d])
+        self.nq, self.nv, self.nu, self.na = (int(x.value) for x in d)
 
     def __del__(self):
         if getattr(self, 'h', None):
@@ -164,12 +169,12 @@ class OracleEngine:
 
     def step(self, action):
         a = np.ascontiguousarray(action, np.float32)
-        assert a.shape == (self.N, 2)
+        assert a.shape == (self.N, self.na)
         obs = np.empty((self.N, self.D), np.float32)
         rew = np.empty(self.N, np.float32)
         cost = np.empty(self.N, np.float32)
         done = np.empty(self.N, np.float32)
-        qacc = np.empty((self.N, 3), np.float32)
+        qacc = np.empty((self.N, self.nv), np.float32)
         rc = self.L.gxo_step(self.h, _fp(a), _fp(obs), _fp(rew), _fp(cost), _fp(done), _fp(qacc))
         assert rc == 0
         return obs, rew, done, {'cost': cost, 'qacc': qacc}
@@ -187,7 +192,7 @@ class OracleEngine:
     def get_state(self):
         N, H = self.N, self.H
         s = {
-            'qpos': np.empty((N, 3), np.float32), 'qvel': np.empty((N, 3), np.float32),
+            'qpos': np.empty((N, self.nq), np.float32), 'qvel': np.empty((N, self.nv), np.float32),
             'pose0': np.empty((N, 4), np.float32), 'pose1': np.empty((N, 2), np.float32),
             'objs': np.empty((N, 1 + H, 2), np.float32), 'done0': np.empty(N, np.float32),
             'done1': np.empty(N, np.float32), 'steps': np.empty(N, np.float32),
