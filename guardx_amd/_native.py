@@ -45,6 +45,7 @@ SYMBOLS = {
     "gx_destroy": (C.c_int, [C.c_void_p]),
     "gx_obs_dim": (C.c_int32, [C.c_void_p]),
     "gx_act_dim": (C.c_int32, [C.c_void_p]),
+    "gx_dims": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int32)] * 4),
     "gx_reset": (C.c_int, [C.c_void_p, _FP, C.c_void_p]),
     "gx_layout_size": (C.c_int, [C.c_void_p, _I32P]),
     "gx_step": (C.c_int, [C.c_void_p, _FP, _FP, _FP, _FP, _FP, _FP, C.c_void_p]),

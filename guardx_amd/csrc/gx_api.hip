@@ -6,6 +6,7 @@
 // (/root/reference/safe_rl_envs/safe_rl_envs/envs/engine.py).
 #include "../../include/guardx.h"
 #include "gx_kernels.h"
+#include "gx_robot.h"
 
 #include <cmath>
 #include <cstdio>
@@ -44,6 +45,7 @@ struct gx_engine {
     hipEvent_t layout_ev;
     bool layout_pending;
     int device;
+    int nq, nv, nu, na, ndyn; // robot.nq/nv/nu (world.py:435-438), action width, float4s of state
     int path_mode;       // 0 auto, 1 thread-per-env kernels, 2 lane-group kernels
     // double-buffered layout pools + side stream: the pool of the NEXT reset() is sampled
     // while the current epoch is being stepped (the key chain is data-independent)
@@ -101,15 +103,21 @@ static float sqrt_cutoff(float thr)
 extern "C" const char* gx_last_error(void) { return g_err.c_str(); }
 extern "C" int32_t gx_abi_version(void) { return 1; }
 extern "C" int32_t gx_obs_dim(const gx_engine* e) { return e ? e->p.D : -1; }
-extern "C" int32_t gx_act_dim(const gx_engine* e) { return e ? 2 : -1; }
+extern "C" int32_t gx_act_dim(const gx_engine* e) { return e ? e->na : -1; }
+extern "C" gx_status gx_dims(const gx_engine* e, int32_t* nq, int32_t* nv, int32_t* nu, int32_t* na)
+{
+    if (!e || !nq || !nv || !nu || !na) return fail(GX_ERR_ARG, "null argument");
+    *nq = e->nq; *nv = e->nv; *nu = e->nu; *na = e->na;
+    return GX_OK;
+}
 
 extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
 {
     if (!cfg || !out) return fail(GX_ERR_ARG, "null argument");
     if (cfg->struct_size != (int32_t)sizeof(gx_config))
         return fail(GX_ERR_ARG, "gx_config.struct_size mismatch");
-    if (cfg->robot != 0)
-        return fail(GX_ERR_UNSUPPORTED, "only xmls/point.xml is implemented by the HIP path");
+    if (cfg->robot != PointRobot::kId && cfg->robot != SwimmerRobot::kId)
+        return fail(GX_ERR_UNSUPPORTED, "robots with HIP dynamics: 0 = xmls/point.xml, 1 = xmls/swimmer.xml");
     if (cfg->env_num < 1 || cfg->env_total < cfg->env_num || cfg->env_offset < 0 ||
         cfg->env_offset + cfg->env_num > cfg->env_total)
         return fail(GX_ERR_ARG, "bad env_num/env_total/env_offset");
@@ -129,6 +137,14 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     e->cfg = *cfg;
     e->device = cfg->device;
     Params& p = e->p;
+    p.robot = cfg->robot;
+    if (cfg->robot == SwimmerRobot::kId) {
+        e->nq = SwimmerRobot::NQ; e->nv = SwimmerRobot::NV; e->nu = SwimmerRobot::NU;
+        e->na = SwimmerRobot::NA; e->ndyn = SwimmerRobot::NDYN;
+    } else {
+        e->nq = PointRobot::NQ; e->nv = PointRobot::NV; e->nu = PointRobot::NU;
+        e->na = PointRobot::NA; e->ndyn = PointRobot::NDYN;
+    }
     p.N = cfg->env_num;
     p.Npad = (p.N + 255) / 256 * 256;
     p.H = cfg->hazards_num;
@@ -139,12 +155,12 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     int o = 0;
     p.off_acc = p.off_ctrl = p.off_comp = p.off_gl = p.off_hl = p.off_qpos = p.off_qvel = p.off_vel = -1;
     if (cfg->observe_acc) { p.off_acc = o; o += 2; }
-    if (cfg->observe_ctrl) { p.off_ctrl = o; o += 3; }
+    if (cfg->observe_ctrl) { p.off_ctrl = o; o += e->nu; }
     if (cfg->observe_goal_comp) { p.off_comp = o; o += 2; }
     if (cfg->observe_goal_lidar) { p.off_gl = o; o += p.bins; }
     if (cfg->observe_hazards) { p.off_hl = o; o += p.bins; }
-    if (cfg->observe_qpos) { p.off_qpos = o; o += 3; }
-    if (cfg->observe_qvel) { p.off_qvel = o; o += 3; }
+    if (cfg->observe_qpos) { p.off_qpos = o; o += e->nq; }
+    if (cfg->observe_qvel) { p.off_qvel = o; o += e->nv; }
     if (cfg->observe_vel) { p.off_vel = o; o += 2; }
     p.D = o;
     if (p.D < 1) { delete e; return fail(GX_ERR_ARG, "empty observation"); }
@@ -158,7 +174,7 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     p.reward_distance = cfg->reward_distance;
     p.num_steps_f = (float)cfg->num_steps;
     p.physics_steps = cfg->physics_steps;
-    p.dt = 0.02f * (float)cfg->physics_steps; // engine.py:235
+    p.dt = (cfg->robot == SwimmerRobot::kId ? SwimmerRobot::kH : PointRobot::kH) * (float)cfg->physics_steps; // engine.py:235
     p.env_total = cfg->env_total;
     p.env_offset = cfg->env_offset;
     p.have_last = p.have_last_last = 0;
@@ -205,7 +221,7 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
         if (err == hipSuccess) err = hipMalloc(ptr, bytes);
         if (err == hipSuccess) err = hipMemset(*ptr, 0, bytes);
     };
-    alloc((void**)&e->b.dyn, sizeof(float4) * 3 * p.Npad);
+    alloc((void**)&e->b.dyn, sizeof(float4) * e->ndyn * p.Npad);
     alloc((void**)&e->b.obj, sizeof(float4) * (size_t)p.P * p.Npad);
     alloc((void**)&e->b.hist, sizeof(float4) * p.Npad);
     for (int i = 0; i < 2; ++i) {
@@ -231,9 +247,11 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     if (err == hipSuccess) err = hipHostMalloc((void**)&e->h_layout_size, sizeof(int), hipHostMallocMapped);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&e->layout_ev, hipEventDisableTiming);
     if (err == hipSuccess) {
-        // xmat of the zero pose: cos = 1 (engine.py:229 MjData default)
-        std::vector<float4> d2(p.Npad, make_float4(1.f, 0.f, 0.f, 0.f));
-        err = hipMemcpy(e->b.dyn + 2 * (size_t)p.Npad, d2.data(), sizeof(float4) * p.Npad, hipMemcpyHostToDevice);
+        // xmat of the zero pose: cos = 1 (engine.py:229 MjData default); it sits in .x of the last
+        // float4 of the dynamic state for every robot
+        std::vector<float4> dl(p.Npad, make_float4(1.f, 0.f, 0.f, 0.f));
+        err = hipMemcpy(e->b.dyn + (size_t)(e->ndyn - 1) * p.Npad, dl.data(), sizeof(float4) * p.Npad,
+                        hipMemcpyHostToDevice);
     }
     if (err != hipSuccess) {
         std::string m = std::string("device allocation failed: ") + hipGetErrorString(err);
@@ -458,7 +476,7 @@ extern "C" gx_status gx_rollout(gx_engine* e, int32_t T, const float* d_actions,
     }
     for (int32_t t = 0; t < T; ++t) {
         float* obs_t = d_obs + (size_t)t * N * D;
-        gx_status st = gx_step(e, d_actions + (size_t)t * N * 2, obs_t, d_reward + (size_t)t * N,
+        gx_status st = gx_step(e, d_actions + (size_t)t * N * e->na, obs_t, d_reward + (size_t)t * N,
                                d_cost + (size_t)t * N, d_done + (size_t)t * N, nullptr, stream);
         if (st != GX_OK) return st;
         st = gx_reset_done(e, obs_t, obs_t, stream);
@@ -468,8 +486,15 @@ extern "C" gx_status gx_rollout(gx_engine* e, int32_t T, const float* d_actions,
 }
 
 // ---------------------------------------------------------------------------
-// state exchange (tests / checkpoints); synchronous
+// state exchange (tests / checkpoints); synchronous.  The dynamic state of env i is the
+// flat sequence  q[nq] v[nv] pose0[4] done0 steps  spread over ndyn float4 arrays.
 // ---------------------------------------------------------------------------
+static inline float& dyn_at(std::vector<float4>& dyn, size_t Np, int i, int k)
+{
+    float4& f = dyn[(size_t)(k >> 2) * Np + i];
+    return (k & 3) == 0 ? f.x : ((k & 3) == 1 ? f.y : ((k & 3) == 2 ? f.z : f.w));
+}
+
 extern "C" gx_status gx_get_state(gx_engine* e, float* qpos, float* qvel, float* pose0, float* pose1,
                                   float* objs, float* done0, float* done1, float* steps,
                                   uint32_t* key, int32_t* hist)
@@ -479,19 +504,19 @@ extern "C" gx_status gx_get_state(gx_engine* e, float* qpos, float* qvel, float*
     GX_HIP(hipDeviceSynchronize());
     const Params& p = e->p;
     const size_t Np = p.Npad;
-    std::vector<float4> dyn(3 * Np), obj((size_t)p.P * Np), hs(Np);
+    const int nq = e->nq, nv = e->nv;
+    std::vector<float4> dyn((size_t)e->ndyn * Np), obj((size_t)p.P * Np), hs(Np);
     GX_HIP(hipMemcpy(dyn.data(), e->b.dyn, sizeof(float4) * dyn.size(), hipMemcpyDeviceToHost));
     GX_HIP(hipMemcpy(obj.data(), e->b.obj, sizeof(float4) * obj.size(), hipMemcpyDeviceToHost));
     GX_HIP(hipMemcpy(hs.data(), e->b.hist, sizeof(float4) * hs.size(), hipMemcpyDeviceToHost));
     for (int i = 0; i < p.N; ++i) {
-        const float4 d0 = dyn[i], d1 = dyn[Np + i], d2 = dyn[2 * Np + i];
-        if (qpos) { qpos[3 * i] = d0.x; qpos[3 * i + 1] = d0.y; qpos[3 * i + 2] = d0.z; }
-        if (qvel) { qvel[3 * i] = d0.w; qvel[3 * i + 1] = d1.x; qvel[3 * i + 2] = d1.y; }
-        if (pose0) { pose0[4 * i] = d1.z; pose0[4 * i + 1] = d1.w; pose0[4 * i + 2] = d2.x; pose0[4 * i + 3] = d2.y; }
+        if (qpos) for (int k = 0; k < nq; ++k) qpos[(size_t)i * nq + k] = dyn_at(dyn, Np, i, k);
+        if (qvel) for (int k = 0; k < nv; ++k) qvel[(size_t)i * nv + k] = dyn_at(dyn, Np, i, nq + k);
+        if (pose0) for (int k = 0; k < 4; ++k) pose0[4 * i + k] = dyn_at(dyn, Np, i, nq + nv + k);
         if (pose1) { pose1[2 * i] = hs[i].x; pose1[2 * i + 1] = hs[i].y; }
-        if (done0) done0[i] = d2.z;
+        if (done0) done0[i] = dyn_at(dyn, Np, i, nq + nv + 4);
         if (done1) done1[i] = hs[i].z;
-        if (steps) steps[i] = d2.w;
+        if (steps) steps[i] = dyn_at(dyn, Np, i, nq + nv + 5);
         if (objs)
             for (int o = 0; o < p.nobj; ++o) {
                 const float4 v = obj[(size_t)(o / 2) * Np + i];
@@ -514,19 +539,19 @@ extern "C" gx_status gx_set_state(gx_engine* e, const float* qpos, const float* 
     GX_HIP(hipDeviceSynchronize());
     const Params& p = e->p;
     const size_t Np = p.Npad;
-    std::vector<float4> dyn(3 * Np), obj((size_t)p.P * Np), hs(Np);
+    const int nq = e->nq, nv = e->nv;
+    std::vector<float4> dyn((size_t)e->ndyn * Np), obj((size_t)p.P * Np), hs(Np);
     GX_HIP(hipMemcpy(dyn.data(), e->b.dyn, sizeof(float4) * dyn.size(), hipMemcpyDeviceToHost));
     GX_HIP(hipMemcpy(obj.data(), e->b.obj, sizeof(float4) * obj.size(), hipMemcpyDeviceToHost));
     GX_HIP(hipMemcpy(hs.data(), e->b.hist, sizeof(float4) * hs.size(), hipMemcpyDeviceToHost));
     for (int i = 0; i < p.N; ++i) {
-        float4 &d0 = dyn[i], &d1 = dyn[Np + i], &d2 = dyn[2 * Np + i];
-        if (qpos) { d0.x = qpos[3 * i]; d0.y = qpos[3 * i + 1]; d0.z = qpos[3 * i + 2]; }
-        if (qvel) { d0.w = qvel[3 * i]; d1.x = qvel[3 * i + 1]; d1.y = qvel[3 * i + 2]; }
-        if (pose0) { d1.z = pose0[4 * i]; d1.w = pose0[4 * i + 1]; d2.x = pose0[4 * i + 2]; d2.y = pose0[4 * i + 3]; }
+        if (qpos) for (int k = 0; k < nq; ++k) dyn_at(dyn, Np, i, k) = qpos[(size_t)i * nq + k];
+        if (qvel) for (int k = 0; k < nv; ++k) dyn_at(dyn, Np, i, nq + k) = qvel[(size_t)i * nv + k];
+        if (pose0) for (int k = 0; k < 4; ++k) dyn_at(dyn, Np, i, nq + nv + k) = pose0[4 * i + k];
         if (pose1) { hs[i].x = pose1[2 * i]; hs[i].y = pose1[2 * i + 1]; }
-        if (done0) d2.z = done0[i];
+        if (done0) dyn_at(dyn, Np, i, nq + nv + 4) = done0[i];
         if (done1) hs[i].z = done1[i];
-        if (steps) d2.w = steps[i];
+        if (steps) dyn_at(dyn, Np, i, nq + nv + 5) = steps[i];
         if (objs)
             for (int o = 0; o < p.nobj; ++o) {
                 float4& v = obj[(size_t)(o / 2) * Np + i];

@@ -34,6 +34,7 @@ struct Params {
     int env_total, env_offset;
     int have_last, have_last_last; // None-ness of _last_done / _last_last_done
     int hist_on;                   // observe_vel || observe_acc
+    int robot;                     // 0 point, 1 swimmer
 };
 
 // ---------------------------------------------------------------------------
@@ -196,54 +197,6 @@ GX_HD uint32_t randint_at(uint32_t k10, uint32_t k11, uint32_t k20, uint32_t k21
     mult = (mult * mult) % span;
     const uint32_t off = (hi % span) * mult + (lo % span);
     return off % span;
-}
-
-// ---------------------------------------------------------------------------
-// Point robot: one mjx.step (forward dynamics + Euler with implicit damping)
-// constants from xmls/point.xml:3,5,16-20,37-39 (sphere r=.1 + box .05 at x=.1,
-// density 1; slide damping .01, hinge .005; gear .3; h=.02)
-// ---------------------------------------------------------------------------
-struct PtState { float x, y, th, vx, vy, om; };
-
-template <bool kQacc>
-GX_D void point_substep(PtState& s, float cx, float cy, float ct, float (&pose)[4], float (&qacc)[3])
-{
-    constexpr float kH = 0.02f, kMxc = 0.0001f, kDxy = 0.01f, kDt = 0.005f, kGear = 0.3f;
-    constexpr float kIo = 2.842182748581224e-05f;
-    constexpr float kInvM = (float)(1.0 / 0.005188790204786391);
-    constexpr float kInvA = (float)(1.0 / (0.005188790204786391 + 0.02 * 0.01));
-    constexpr float kEi = (float)(2.842182748581224e-05 + 0.02 * 0.005);
-    float sh, ch;
-    sincos_f(0.5f * s.th, sh, ch);
-    const float c = ch * ch - sh * sh;
-    const float sn = 2.0f * (ch * sh);
-    pose[0] = s.x; pose[1] = s.y; pose[2] = c; pose[3] = sn;
-    const float b = -(kMxc * sn), d = kMxc * c;
-    const float w2 = s.om * s.om;
-    const float fx = (-(kDxy * s.vx) - (-(d * w2))) + kGear * cx;
-    const float fy = (-(kDxy * s.vy) - (b * w2)) + kGear * cy;
-    const float ft = (-(kDt * s.om) - 0.0f) + kGear * ct;
-    const float t = b * fx + d * fy;
-    const float s2 = b * b + d * d;
-    if (kQacc) {
-        const float y3 = ft - t * kInvM;
-        const float d3 = kIo - s2 * kInvM;
-        const float q3 = y3 / d3;
-        qacc[0] = (fx - b * q3) * kInvM;
-        qacc[1] = (fy - d * q3) * kInvM;
-        qacc[2] = q3;
-    }
-    const float y3 = ft - t * kInvA;
-    const float d3 = kEi - s2 * kInvA;
-    const float q3 = y3 / d3;
-    const float q1 = (fx - b * q3) * kInvA;
-    const float q2 = (fy - d * q3) * kInvA;
-    s.vx = s.vx + kH * q1;
-    s.vy = s.vy + kH * q2;
-    s.om = s.om + kH * q3;
-    s.x = s.x + kH * s.vx;
-    s.y = s.y + kH * s.vy;
-    s.th = s.th + kH * s.om;
 }
 
 // ---------------------------------------------------------------------------

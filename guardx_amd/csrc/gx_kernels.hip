@@ -9,6 +9,7 @@
 //
 // Reference lines: /root/reference/safe_rl_envs/safe_rl_envs/envs/engine.py.
 #include "gx_kernels.h"
+#include "gx_robot.h"
 
 namespace gx {
 
@@ -16,10 +17,10 @@ namespace gx {
 // observation row (engine.py:738-778) built in this thread's LDS row.
 // `ob` holds the object pairs: ob[k] = (obj 2k xy, obj 2k+1 xy); obj 0 = goal.
 // ---------------------------------------------------------------------------
-template <int PMAX>
+template <class R, int PMAX>
 GX_D bool build_obs_row(const Params& p, float* row, const float (&pose)[4],
-                        const float4 (&ob)[PMAX], float cx, float cy, float ct,
-                        const PtState& st, float vel0, float vel1, float acc0, float acc1)
+                        const float4 (&ob)[PMAX], const float (&ctrl)[R::NU], const float (&q)[R::NQ],
+                        const float (&v)[R::NV], float vel0, float vel1, float acc0, float acc1)
 {
     bool bad = false;
     if (p.off_acc >= 0) {
@@ -27,8 +28,8 @@ GX_D bool build_obs_row(const Params& p, float* row, const float (&pose)[4],
         bad = bad || notfinite(acc0) || notfinite(acc1);
     }
     if (p.off_ctrl >= 0) {
-        row[p.off_ctrl] = cx; row[p.off_ctrl + 1] = cy; row[p.off_ctrl + 2] = ct;
-        bad = bad || notfinite(cx) || notfinite(cy) || notfinite(ct);
+#pragma unroll
+        for (int k = 0; k < R::NU; ++k) { row[p.off_ctrl + k] = ctrl[k]; bad = bad || notfinite(ctrl[k]); }
     }
     if (p.off_comp >= 0) { // obs_compass :834-844
         const float dx = ob[0].x - pose[0], dy = ob[0].y - pose[1];
@@ -53,12 +54,12 @@ GX_D bool build_obs_row(const Params& p, float* row, const float (&pose)[4],
         }
     }
     if (p.off_qpos >= 0) {
-        row[p.off_qpos] = st.x; row[p.off_qpos + 1] = st.y; row[p.off_qpos + 2] = st.th;
-        bad = bad || notfinite(st.x) || notfinite(st.y) || notfinite(st.th);
+#pragma unroll
+        for (int k = 0; k < R::NQ; ++k) { row[p.off_qpos + k] = q[k]; bad = bad || notfinite(q[k]); }
     }
     if (p.off_qvel >= 0) {
-        row[p.off_qvel] = st.vx; row[p.off_qvel + 1] = st.vy; row[p.off_qvel + 2] = st.om;
-        bad = bad || notfinite(st.vx) || notfinite(st.vy) || notfinite(st.om);
+#pragma unroll
+        for (int k = 0; k < R::NV; ++k) { row[p.off_qvel + k] = v[k]; bad = bad || notfinite(v[k]); }
     }
     if (p.off_vel >= 0) {
         row[p.off_vel] = vel0; row[p.off_vel + 1] = vel1;
@@ -104,33 +105,56 @@ GX_D float dist2(float ax, float ay, float bx, float by)
     return sqrtf(dx * dx + dy * dy);
 }
 
-// Fold the integer layout of the default Goal_*_8Hazards observation (8 hazards, 16 bins,
-// every observe_* flag at its default, aliasing on, exponential lidar, 1 physics step) into
-// compile-time constants: loops unroll, flag tests and their scalar bookkeeping disappear.
-GX_HD bool is_default_layout(const Params& p)
+// Fold the integer layout of the default Goal_<Robot>_8Hazards observation (8 hazards, 16
+// bins, every observe_* flag at its default, aliasing on, exponential lidar, 1 physics step)
+// into compile-time constants: loops unroll, flag tests and their scalar bookkeeping disappear.
+template <class R>
+static bool is_default_layout(const Params& p)
 {
-    return p.nobj == 9 && p.bins == 16 && p.D == 43 && p.off_acc == -1 && p.off_ctrl == 0 &&
-           p.off_comp == 3 && p.off_gl == 5 && p.off_hl == 21 && p.off_qpos == 37 && p.off_qvel == 40 &&
-           p.off_vel == -1 && p.lidar_alias == 1 && p.lidar_max_dist_set == 0 && p.physics_steps == 1 &&
-           p.hist_on == 0;
+    return p.nobj == 9 && p.bins == 16 && p.D == R::kD && p.off_acc == -1 && p.off_ctrl == R::kOffCtrl &&
+           p.off_comp == R::kOffComp && p.off_gl == R::kOffGl && p.off_hl == R::kOffHl &&
+           p.off_qpos == R::kOffQpos && p.off_qvel == R::kOffQvel && p.off_vel == -1 && p.lidar_alias == 1 &&
+           p.lidar_max_dist_set == 0 && p.physics_steps == 1 && p.hist_on == 0;
 }
 
-template <bool kDef>
+template <class R, bool kDef>
 GX_D Params fold_params(Params p)
 {
     if (kDef) {
-        p.H = 8; p.nobj = 9; p.P = 5; p.bins = 16; p.D = 43;
-        p.off_acc = -1; p.off_ctrl = 0; p.off_comp = 3; p.off_gl = 5; p.off_hl = 21;
-        p.off_qpos = 37; p.off_qvel = 40; p.off_vel = -1;
+        p.H = 8; p.nobj = 9; p.P = 5; p.bins = 16; p.D = R::kD;
+        p.off_acc = -1; p.off_ctrl = R::kOffCtrl; p.off_comp = R::kOffComp; p.off_gl = R::kOffGl;
+        p.off_hl = R::kOffHl; p.off_qpos = R::kOffQpos; p.off_qvel = R::kOffQvel; p.off_vel = -1;
         p.lidar_alias = 1; p.lidar_max_dist_set = 0; p.physics_steps = 1; p.hist_on = 0;
     }
     return p;
 }
 
+// ego_vel_acc (engine.py:902-929)
+GX_D void ego_vel_acc(const Params& p, const float (&pose)[4], float L1x, float L1y, float P2x, float P2y,
+                      float last_done, float done2, bool have_last, bool have_last_last, float& vel0,
+                      float& vel1, float& acc0, float& acc1)
+{
+    float plx = pose[0], ply = pose[1], pllx = pose[0], plly = pose[1];
+    if (have_last) {
+        if (!(last_done > 0.0f)) { plx = L1x; ply = L1y; }
+        if (have_last_last) {
+            if (done2 + last_done > 0.0f) { pllx = plx; plly = ply; }
+            else { pllx = P2x; plly = P2y; }
+        }
+    }
+    const float vwx = (pose[0] - plx) / p.dt, vwy = (pose[1] - ply) / p.dt;
+    const float lvx = (plx - pllx) / p.dt, lvy = (ply - plly) / p.dt;
+    const float awx = (vwx - lvx) / p.dt, awy = (vwy - lvy) / p.dt;
+    vel0 = vwx * pose[2] + vwy * pose[3];
+    vel1 = vwx * (-pose[3]) + vwy * pose[2];
+    acc0 = awx * pose[2] + awy * pose[3];
+    acc1 = awx * (-pose[3]) + awy * pose[2];
+}
+
 // ---------------------------------------------------------------------------
-// Engine.step (engine.py:469-495 + mjx_step :659-700), Point robot.
+// Engine.step (engine.py:469-495 + mjx_step :659-700), thread-per-env form.
 // ---------------------------------------------------------------------------
-template <int BLOCK, int PMAX, bool kQacc, bool kDef>
+template <class R, int BLOCK, int PMAX, bool kQacc, bool kDef>
 __global__ __launch_bounds__(BLOCK) void step_kernel(Params p_in, const float2* __restrict__ act,
                                                      float4* __restrict__ dyn,
                                                      const float4* __restrict__ obj,
@@ -141,7 +165,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p_in, const float2* 
                                                      float* __restrict__ done,
                                                      float* __restrict__ qacc_out)
 {
-    const Params p = fold_params<kDef>(p_in);
+    const Params p = fold_params<R, kDef>(p_in);
     extern __shared__ float4 tile4[];
     float* tile = reinterpret_cast<float*>(tile4);
     const int tid = threadIdx.x;
@@ -151,50 +175,30 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p_in, const float2* 
 
     // ---- coalesced loads (arrays are padded to Npad, every lane may load)
     const float2 a = live ? act[i] : make_float2(0.f, 0.f);
-    const float4 d0 = dyn[i];
-    const float4 d1 = dyn[p.Npad + i];
-    const float4 d2 = dyn[2 * p.Npad + i];
+    float q[R::NQ], v[R::NV], pose0[4], last_done, steps;
+    R::load(dyn, p.Npad, i, q, v, pose0, last_done, steps);
     float4 ob[PMAX];
 #pragma unroll
     for (int k = 0; k < PMAX; ++k)
         ob[k] = (k < p.P) ? obj[(size_t)k * p.Npad + i] : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 hs = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.hist_on) hs = hist[i];
+    const float P1x = pose0[0], P1y = pose0[1]; // last_data.xpos
 
-    PtState st = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y};
-    const float P1x = d1.z, P1y = d1.w; // last_data.xpos
-    const float pc = d2.x, ps = d2.y;   // pre-step xmat (heading)
-    const float last_done = d2.z;       // _last_done after update_data
-    const float steps = d2.w;
+    float ctrl[R::NU];
+    R::convert_action(pose0, a.x, a.y, ctrl); // :672-685, PRE-step xmat
+    float pose[4], qacc[R::NV];
+#pragma unroll
+    for (int k = 0; k < R::NV; ++k) qacc[k] = 0.f;
+    for (int k = 0; k < p.physics_steps; ++k) R::template substep<kQacc>(q, v, ctrl, pose, qacc);
 
-    // convert_action :672-685
-    const float cx = pc * a.x, cy = ps * a.x, ct = a.y;
-
-    float pose[4], qacc[3] = {0.f, 0.f, 0.f};
-    for (int k = 0; k < p.physics_steps; ++k) point_substep<kQacc>(st, cx, cy, ct, pose, qacc);
-
-    // ego_vel_acc :902-929
     float vel0 = 0.f, vel1 = 0.f, acc0 = 0.f, acc1 = 0.f;
-    if (p.hist_on) {
-        float plx = pose[0], ply = pose[1], pllx = pose[0], plly = pose[1];
-        if (p.have_last) {
-            if (!(last_done > 0.0f)) { plx = P1x; ply = P1y; }
-            if (p.have_last_last) {
-                if (hs.z + last_done > 0.0f) { pllx = plx; plly = ply; }
-                else { pllx = hs.x; plly = hs.y; }
-            }
-        }
-        const float vwx = (pose[0] - plx) / p.dt, vwy = (pose[1] - ply) / p.dt;
-        const float lvx = (plx - pllx) / p.dt, lvy = (ply - plly) / p.dt;
-        const float awx = (vwx - lvx) / p.dt, awy = (vwy - lvy) / p.dt;
-        vel0 = vwx * pose[2] + vwy * pose[3];
-        vel1 = vwx * (-pose[3]) + vwy * pose[2];
-        acc0 = awx * pose[2] + awy * pose[3];
-        acc1 = awx * (-pose[3]) + awy * pose[2];
-    }
+    if (p.hist_on)
+        ego_vel_acc(p, pose, P1x, P1y, hs.x, hs.y, last_done, hs.z, p.have_last != 0, p.have_last_last != 0,
+                    vel0, vel1, acc0, acc1);
 
     float* row = tile + tid * p.D;
-    const bool bad = build_obs_row<PMAX>(p, row, pose, ob, cx, cy, ct, st, vel0, vel1, acc0, acc1);
+    const bool bad = build_obs_row<R, PMAX>(p, row, pose, ob, ctrl, q, v, vel0, vel1, acc0, acc1);
 
     // reward_done :787-802
     const float dg = dist2(ob[0].x, ob[0].y, pose[0], pose[1]);
@@ -229,17 +233,14 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p_in, const float2* 
     const float nsteps = dn > 0.0f ? 0.0f : steps + 1.0f;
 
     if (live) {
-        dyn[i] = make_float4(st.x, st.y, st.th, st.vx);
-        dyn[p.Npad + i] = make_float4(st.vy, st.om, pose[0], pose[1]);
-        dyn[2 * p.Npad + i] = make_float4(pose[2], pose[3], dn, nsteps);
+        R::store(dyn, p.Npad, i, q, v, pose, dn, nsteps);
         if (p.hist_on) hist[i] = make_float4(P1x, P1y, last_done, 0.f);
         rew[i] = r;
         cost[i] = cs;
         done[i] = dn;
         if (kQacc) {
-            qacc_out[3 * i] = qacc[0];
-            qacc_out[3 * i + 1] = qacc[1];
-            qacc_out[3 * i + 2] = qacc[2];
+#pragma unroll
+            for (int k = 0; k < R::NV; ++k) qacc_out[R::NV * i + k] = qacc[k];
         }
     }
 
@@ -454,7 +455,7 @@ GX_D void load_layout(const Params& p, const float2* __restrict__ cand_xy, int n
     rx = rb.x; ry = rb.y;
 }
 
-template <int BLOCK, int PMAX>
+template <class R, int BLOCK, int PMAX>
 __global__ __launch_bounds__(BLOCK) void reset_apply_kernel(Params p, int nobj_total, uint32_t k10,
                                                             uint32_t k11, uint32_t k20, uint32_t k21,
                                                             const int* __restrict__ layout_size,
@@ -483,15 +484,21 @@ __global__ __launch_bounds__(BLOCK) void reset_apply_kernel(Params p, int nobj_t
     float rx, ry;
     load_layout<PMAX>(p, cand_xy, nobj_total, j, ob, rx, ry);
     // mjx_reset :644-657: qpos from layout, qvel = ctrl = 0, forward -> pose
-    const PtState st = {rx, ry, 0.f, 0.f, 0.f, 0.f};
+    float q[R::NQ], v[R::NV], ctrl[R::NU];
+#pragma unroll
+    for (int k = 0; k < R::NQ; ++k) q[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < R::NV; ++k) v[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < R::NU; ++k) ctrl[k] = 0.f;
+    q[0] = rx; q[1] = ry;
     const float pose[4] = {rx, ry, 1.0f, 0.0f};
     float* row = tile + tid * p.D;
-    build_obs_row<PMAX>(p, row, pose, ob, 0.f, 0.f, 0.f, st, 0.f, 0.f, 0.f, 0.f);
+    build_obs_row<R, PMAX>(p, row, pose, ob, ctrl, q, v, 0.f, 0.f, 0.f, 0.f);
     if (live) {
-        const float4 d2 = dyn[2 * p.Npad + i];
-        dyn[i] = make_float4(rx, ry, 0.f, 0.f);
-        dyn[p.Npad + i] = make_float4(0.f, 0.f, rx, ry);
-        dyn[2 * p.Npad + i] = make_float4(1.0f, 0.0f, d2.z, 0.0f); // _done kept, _steps = 0 (:463)
+        float oq[R::NQ], ov[R::NV], opose[4], odone, osteps;
+        R::load(dyn, p.Npad, i, oq, ov, opose, odone, osteps);
+        R::store(dyn, p.Npad, i, q, v, pose, odone, 0.0f); // _done kept, _steps = 0 (:463)
 #pragma unroll
         for (int k = 0; k < PMAX; ++k)
             if (k < p.P) obj[(size_t)k * p.Npad + i] = ob[k];
@@ -504,7 +511,7 @@ __global__ __launch_bounds__(BLOCK) void reset_apply_kernel(Params p, int nobj_t
 // ---------------------------------------------------------------------------
 // Engine.reset_done (engine.py:497-505, mjx_reset_done :702-731)
 // ---------------------------------------------------------------------------
-template <int BLOCK, int PMAX>
+template <class R, int BLOCK, int PMAX>
 __global__ __launch_bounds__(BLOCK) void reset_done_kernel(Params p, int nobj_total, uint32_t k10,
                                                            uint32_t k11, uint32_t k20, uint32_t k21,
                                                            const int* __restrict__ layout_size,
@@ -521,8 +528,9 @@ __global__ __launch_bounds__(BLOCK) void reset_done_kernel(Params p, int nobj_to
     const int i = env0 + tid;
     const bool live = i < p.N;
     const int L = *layout_size;
-    const float4 d2 = dyn[2 * p.Npad + i];
-    const bool dn = live && (d2.z > 0.0f) && (L > 0);
+    float oq[R::NQ], ov[R::NV], opose[4], odone, osteps;
+    R::load(dyn, p.Npad, i, oq, ov, opose, odone, osteps);
+    const bool dn = live && (odone > 0.0f) && (L > 0);
     const int any = __syncthreads_or(dn ? 1 : 0);
     const int nenv = min(BLOCK, p.N - env0);
     const int total = nenv * p.D;
@@ -539,12 +547,17 @@ __global__ __launch_bounds__(BLOCK) void reset_done_kernel(Params p, int nobj_to
         load_layout<PMAX>(p, cand_xy, nobj_total, j, ob, rx, ry);
         // "fake step" (:719-724) from rest with zero ctrl leaves qpos/qvel unchanged;
         // its forward() gives pose(qpos_reset) for the obs; data keeps the STALE xpos/xmat (:731)
-        const PtState st = {rx, ry, 0.f, 0.f, 0.f, 0.f};
+        float q[R::NQ], v[R::NV], ctrl[R::NU];
+#pragma unroll
+        for (int k = 0; k < R::NQ; ++k) q[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < R::NV; ++k) v[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < R::NU; ++k) ctrl[k] = 0.f;
+        q[0] = rx; q[1] = ry;
         const float pose[4] = {rx, ry, 1.0f, 0.0f};
-        build_obs_row<PMAX>(p, tile + tid * p.D, pose, ob, 0.f, 0.f, 0.f, st, 0.f, 0.f, 0.f, 0.f);
-        const float4 d1 = dyn[p.Npad + i];
-        dyn[i] = make_float4(rx, ry, 0.f, 0.f);
-        dyn[p.Npad + i] = make_float4(0.f, 0.f, d1.z, d1.w);
+        build_obs_row<R, PMAX>(p, tile + tid * p.D, pose, ob, ctrl, q, v, 0.f, 0.f, 0.f, 0.f);
+        R::store(dyn, p.Npad, i, q, v, opose, odone, osteps);
 #pragma unroll
         for (int k = 0; k < PMAX; ++k)
             if (k < p.P) obj[(size_t)k * p.Npad + i] = ob[k];
@@ -639,13 +652,23 @@ GX_D GroupObs<OPL, BPL> group_observe(const Params& p, float4 (*rec)[64], float 
     return out;
 }
 
-template <int OPL, int BPL, bool kQacc, bool kDef>
+// value k of a small register array selected by a per-lane index (compare-select chain)
+template <int N>
+GX_D float pick(const float (&a)[N], int k)
+{
+    float r = a[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) r = (k == i) ? a[i] : r;
+    return r;
+}
+
+template <class R, int OPL, int BPL, bool kQacc, bool kDef>
 __global__ __launch_bounds__(64) void group_rollout_kernel(Params p_in, RolloutArgs r,
                                                           float4* __restrict__ dyn,
                                                           float4* __restrict__ obj,
                                                           float4* __restrict__ hist)
 {
-    const Params p = fold_params<kDef>(p_in);
+    const Params p = fold_params<R, kDef>(p_in);
     __shared__ float4 rec[OPL][64];
     __shared__ float term[OPL][64];
     const int lane = threadIdx.x;
@@ -655,9 +678,8 @@ __global__ __launch_bounds__(64) void group_rollout_kernel(Params p_in, RolloutA
     const int e = live ? env : 0;
 
     // ---- state (every lane of the group holds a copy)
-    const float4 d0 = dyn[e], d1 = dyn[p.Npad + e], d2 = dyn[2 * p.Npad + e];
-    PtState st = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y};
-    float P0x = d1.z, P0y = d1.w, pc = d2.x, ps = d2.y, done0 = d2.z, steps = d2.w;
+    float q[R::NQ], v[R::NV], pose0[4], done0, steps;
+    R::load(dyn, p.Npad, e, q, v, pose0, done0, steps);
     float P1x = 0.f, P1y = 0.f, done1 = 0.f;
     if (p.hist_on) { const float4 h = hist[e]; P1x = h.x; P1y = h.y; done1 = h.z; }
     const float2* obj2 = reinterpret_cast<const float2*>(obj);
@@ -665,9 +687,9 @@ __global__ __launch_bounds__(64) void group_rollout_kernel(Params p_in, RolloutA
 #pragma unroll
     for (int j = 0; j < OPL; ++j) {
         const int o = l + kGL * j;
-        float2 v = make_float2(0.f, 0.f);
-        if (o < p.nobj) v = obj2[((size_t)(o >> 1) * p.Npad + e) * 2 + (o & 1)];
-        ox[j] = v.x; oy[j] = v.y;
+        float2 t = make_float2(0.f, 0.f);
+        if (o < p.nobj) t = obj2[((size_t)(o >> 1) * p.Npad + e) * 2 + (o & 1)];
+        ox[j] = t.x; oy[j] = t.y;
     }
     float gx, gy;
     { const float2 g = obj2[(size_t)e * 2]; gx = g.x; gy = g.y; }
@@ -683,39 +705,36 @@ __global__ __launch_bounds__(64) void group_rollout_kernel(Params p_in, RolloutA
         const float done2 = done1;
         const float last_done = done0;
         const float P2x = P1x, P2y = P1y;
-        const float L1x = P0x, L1y = P0y; // last_data.xpos
+        const float L1x = pose0[0], L1y = pose0[1]; // last_data.xpos
 
         // convert_action :672-685, mjx.step :689
-        const float cx = pc * a.x, cy = ps * a.x, ct = a.y;
-        float pose[4], qacc[3] = {0.f, 0.f, 0.f};
-        for (int k = 0; k < p.physics_steps; ++k) point_substep<kQacc>(st, cx, cy, ct, pose, qacc);
+        float ctrl[R::NU];
+        R::convert_action(pose0, a.x, a.y, ctrl);
+        float pose[4], qacc[R::NV];
+#pragma unroll
+        for (int k = 0; k < R::NV; ++k) qacc[k] = 0.f;
+        for (int k = 0; k < p.physics_steps; ++k) R::template substep<kQacc>(q, v, ctrl, pose, qacc);
 
-        // ego_vel_acc :902-929
         float vel0 = 0.f, vel1 = 0.f, acc0 = 0.f, acc1 = 0.f;
-        if (p.hist_on) {
-            float plx = pose[0], ply = pose[1], pllx = pose[0], plly = pose[1];
-            if (have_last) {
-                if (!(last_done > 0.0f)) { plx = L1x; ply = L1y; }
-                if (have_last_last) {
-                    if (done2 + last_done > 0.0f) { pllx = plx; plly = ply; }
-                    else { pllx = P2x; plly = P2y; }
-                }
-            }
-            const float vwx = (pose[0] - plx) / p.dt, vwy = (pose[1] - ply) / p.dt;
-            const float lvx = (plx - pllx) / p.dt, lvy = (ply - plly) / p.dt;
-            const float awx = (vwx - lvx) / p.dt, awy = (vwy - lvy) / p.dt;
-            vel0 = vwx * pose[2] + vwy * pose[3];
-            vel1 = vwx * (-pose[3]) + vwy * pose[2];
-            acc0 = awx * pose[2] + awy * pose[3];
-            acc1 = awx * (-pose[3]) + awy * pose[2];
-        }
+        if (p.hist_on)
+            ego_vel_acc(p, pose, L1x, L1y, P2x, P2y, last_done, done2, have_last, have_last_last, vel0, vel1,
+                        acc0, acc1);
 
         GroupObs<OPL, BPL> ob = group_observe<OPL, BPL>(p, rec, term, lane, pose, gx, gy, ox, oy);
         bool bad = ob.bad;
         if (p.off_acc >= 0) bad = bad || notfinite(acc0) || notfinite(acc1);
-        if (p.off_ctrl >= 0) bad = bad || notfinite(cx) || notfinite(cy) || notfinite(ct);
-        if (p.off_qpos >= 0) bad = bad || notfinite(st.x) || notfinite(st.y) || notfinite(st.th);
-        if (p.off_qvel >= 0) bad = bad || notfinite(st.vx) || notfinite(st.vy) || notfinite(st.om);
+        if (p.off_ctrl >= 0) {
+#pragma unroll
+            for (int k = 0; k < R::NU; ++k) bad = bad || notfinite(ctrl[k]);
+        }
+        if (p.off_qpos >= 0) {
+#pragma unroll
+            for (int k = 0; k < R::NQ; ++k) bad = bad || notfinite(q[k]);
+        }
+        if (p.off_qvel >= 0) {
+#pragma unroll
+            for (int k = 0; k < R::NV; ++k) bad = bad || notfinite(v[k]);
+        }
         if (p.off_vel >= 0) bad = bad || notfinite(vel0) || notfinite(vel1);
 
         // reward_done :787-802
@@ -732,12 +751,18 @@ __global__ __launch_bounds__(64) void group_rollout_kernel(Params p_in, RolloutA
 
         // commit the history
         P1x = L1x; P1y = L1y; done1 = last_done;
-        P0x = pose[0]; P0y = pose[1]; pc = pose[2]; ps = pose[3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pose0[k] = pose[k];
         done0 = dn;
 
         // values of this env's obs row
-        float o_cx = cx, o_cy = cy, o_ct = ct;
-        float o_qx = st.x, o_qy = st.y, o_qt = st.th, o_vx = st.vx, o_vy = st.vy, o_vt = st.om;
+        float o_ctrl[R::NU], o_q[R::NQ], o_v[R::NV];
+#pragma unroll
+        for (int k = 0; k < R::NU; ++k) o_ctrl[k] = ctrl[k];
+#pragma unroll
+        for (int k = 0; k < R::NQ; ++k) o_q[k] = q[k];
+#pragma unroll
+        for (int k = 0; k < R::NV; ++k) o_v[k] = v[k];
         float o_v0 = vel0, o_v1 = vel1, o_a0 = acc0, o_a1 = acc1;
 
         // reset_done :497-505 folded in (wave-uniform gate)
@@ -745,18 +770,18 @@ __global__ __launch_bounds__(64) void group_rollout_kernel(Params p_in, RolloutA
             const int L = *r.layout_size;
             const bool rs = live && dn > 0.0f && L > 0;
             if (__ballot(rs) != 0ull) {
-                float nox[OPL], noy[OPL], ngx = gx, ngy = gy, rx = st.x, ry = st.y;
+                float nox[OPL], noy[OPL], ngx = gx, ngy = gy, rx = q[0], ry = q[1];
 #pragma unroll
                 for (int j = 0; j < OPL; ++j) { nox[j] = ox[j]; noy[j] = oy[j]; }
                 if (rs) {
-                    const uint4 k = r.keys[t];
-                    const uint32_t idx = randint_at(k.x, k.y, k.z, k.w, (uint32_t)p.env_total, (uint32_t)L,
+                    const uint4 kk = r.keys[t];
+                    const uint32_t idx = randint_at(kk.x, kk.y, kk.z, kk.w, (uint32_t)p.env_total, (uint32_t)L,
                                                     (uint32_t)(p.env_offset + env));
                     const float2* rowp = r.cand_xy + (size_t)r.cand_of[idx] * r.nobj_total;
 #pragma unroll
                     for (int j = 0; j < OPL; ++j) {
                         const int o = l + kGL * j;
-                        if (o < p.nobj) { const float2 v = rowp[o]; nox[j] = v.x; noy[j] = v.y; }
+                        if (o < p.nobj) { const float2 t2 = rowp[o]; nox[j] = t2.x; noy[j] = t2.y; }
                     }
                     const float2 g = rowp[0], rb = rowp[r.nobj_total - 1];
                     ngx = g.x; ngy = g.y; rx = rb.x; ry = rb.y;
@@ -767,12 +792,16 @@ __global__ __launch_bounds__(64) void group_rollout_kernel(Params p_in, RolloutA
 #pragma unroll
                     for (int j = 0; j < OPL; ++j) { ox[j] = nox[j]; oy[j] = noy[j]; }
                     gx = ngx; gy = ngy;
-                    st.x = rx; st.y = ry; st.th = 0.f; st.vx = 0.f; st.vy = 0.f; st.om = 0.f;
+#pragma unroll
+                    for (int k = 0; k < R::NQ; ++k) { q[k] = 0.f; o_q[k] = 0.f; }
+#pragma unroll
+                    for (int k = 0; k < R::NV; ++k) { v[k] = 0.f; o_v[k] = 0.f; }
+#pragma unroll
+                    for (int k = 0; k < R::NU; ++k) o_ctrl[k] = 0.f;
+                    q[0] = rx; q[1] = ry; o_q[0] = rx; o_q[1] = ry;
 #pragma unroll
                     for (int jb = 0; jb < BPL; ++jb) { ob.gl[jb] = rob.gl[jb]; ob.hl[jb] = rob.hl[jb]; }
                     ob.comp0 = rob.comp0; ob.comp1 = rob.comp1;
-                    o_cx = o_cy = o_ct = 0.f;
-                    o_qx = rx; o_qy = ry; o_qt = 0.f; o_vx = o_vy = o_vt = 0.f;
                     o_v0 = o_v1 = o_a0 = o_a1 = 0.f;
                     touched_layout = true;
                 }
@@ -790,11 +819,11 @@ __global__ __launch_bounds__(64) void group_rollout_kernel(Params p_in, RolloutA
                     if (p.off_hl >= 0) row[p.off_hl + b] = ob.hl[jb];
                 }
             }
-            if (l < 3) {
-                if (p.off_ctrl >= 0) row[p.off_ctrl + l] = (l == 0) ? o_cx : (l == 1 ? o_cy : o_ct);
-                if (p.off_qpos >= 0) row[p.off_qpos + l] = (l == 0) ? o_qx : (l == 1 ? o_qy : o_qt);
-                if (p.off_qvel >= 0) row[p.off_qvel + l] = (l == 0) ? o_vx : (l == 1 ? o_vy : o_vt);
-                if (kQacc) r.qacc[te * 3 + l] = qacc[l == 0 ? 0 : (l == 1 ? 1 : 2)];
+            if (l < R::NU && p.off_ctrl >= 0) row[p.off_ctrl + l] = pick(o_ctrl, l);
+            if (l < R::NQ && p.off_qpos >= 0) row[p.off_qpos + l] = pick(o_q, l);
+            if (l < R::NV) {
+                if (p.off_qvel >= 0) row[p.off_qvel + l] = pick(o_v, l);
+                if (kQacc) r.qacc[te * R::NV + l] = pick(qacc, l);
             }
             if (l < 2) {
                 if (p.off_comp >= 0) row[p.off_comp + l] = (l == 0) ? ob.comp0 : ob.comp1;
@@ -807,9 +836,7 @@ __global__ __launch_bounds__(64) void group_rollout_kernel(Params p_in, RolloutA
 
     if (live) {
         if (l == 0) {
-            dyn[env] = make_float4(st.x, st.y, st.th, st.vx);
-            dyn[p.Npad + env] = make_float4(st.vy, st.om, P0x, P0y);
-            dyn[2 * p.Npad + env] = make_float4(pc, ps, done0, steps);
+            R::store(dyn, p.Npad, env, q, v, pose0, done0, steps);
             if (p.hist_on) hist[env] = make_float4(P1x, P1y, done1, 0.f);
         }
         if (touched_layout) {
@@ -860,41 +887,47 @@ int pick_block(const Params& p)
     return (step_lds_bytes(p, 256) <= 48 * 1024) ? 256 : 64;
 }
 
-template <int BLOCK, int PMAX>
+template <class R, int BLOCK, int PMAX>
 static void launch_step_bp(const Params& p, const DevBuffers& b, const float* act, float* obs,
                            float* rew, float* cost, float* done, float* qacc, hipStream_t s)
 {
     const dim3 grid((p.N + BLOCK - 1) / BLOCK), blk(BLOCK);
     const size_t lds = step_lds_bytes(p, BLOCK);
     const float2* a2 = reinterpret_cast<const float2*>(act);
-    if (PMAX == 5 && is_default_layout(p)) {
+    if (PMAX == 5 && is_default_layout<R>(p)) {
         if (qacc)
-            hipLaunchKernelGGL((step_kernel<BLOCK, 5, true, true>), grid, blk, lds, s, p, a2, b.dyn, b.obj, b.hist,
+            hipLaunchKernelGGL((step_kernel<R, BLOCK, 5, true, true>), grid, blk, lds, s, p, a2, b.dyn, b.obj, b.hist,
                                obs, rew, cost, done, qacc);
         else
-            hipLaunchKernelGGL((step_kernel<BLOCK, 5, false, true>), grid, blk, lds, s, p, a2, b.dyn, b.obj, b.hist,
+            hipLaunchKernelGGL((step_kernel<R, BLOCK, 5, false, true>), grid, blk, lds, s, p, a2, b.dyn, b.obj, b.hist,
                                obs, rew, cost, done, qacc);
     } else if (qacc)
-        hipLaunchKernelGGL((step_kernel<BLOCK, PMAX, true, false>), grid, blk, lds, s, p, a2, b.dyn, b.obj, b.hist,
+        hipLaunchKernelGGL((step_kernel<R, BLOCK, PMAX, true, false>), grid, blk, lds, s, p, a2, b.dyn, b.obj, b.hist,
                            obs, rew, cost, done, qacc);
     else
-        hipLaunchKernelGGL((step_kernel<BLOCK, PMAX, false, false>), grid, blk, lds, s, p, a2, b.dyn, b.obj, b.hist,
+        hipLaunchKernelGGL((step_kernel<R, BLOCK, PMAX, false, false>), grid, blk, lds, s, p, a2, b.dyn, b.obj, b.hist,
                            obs, rew, cost, done, qacc);
 }
 
-#define GX_DISPATCH_BP(FN, ...)                                        \
+#define GX_DISPATCH_BP_R(R, FN, ...)                                   \
     do {                                                               \
         const int blk_ = pick_block(p);                                \
         if (p.P <= 5) {                                                \
-            if (blk_ == 64) FN<64, 5>(__VA_ARGS__);                    \
-            else FN<256, 5>(__VA_ARGS__);                              \
+            if (blk_ == 64) FN<R, 64, 5>(__VA_ARGS__);                 \
+            else FN<R, 256, 5>(__VA_ARGS__);                           \
         } else if (p.P <= 9) {                                         \
-            if (blk_ == 64) FN<64, 9>(__VA_ARGS__);                    \
-            else FN<256, 9>(__VA_ARGS__);                              \
+            if (blk_ == 64) FN<R, 64, 9>(__VA_ARGS__);                 \
+            else FN<R, 256, 9>(__VA_ARGS__);                           \
         } else {                                                       \
-            if (blk_ == 64) FN<64, 33>(__VA_ARGS__);                   \
-            else FN<256, 33>(__VA_ARGS__);                             \
+            if (blk_ == 64) FN<R, 64, 33>(__VA_ARGS__);                \
+            else FN<R, 256, 33>(__VA_ARGS__);                          \
         }                                                              \
+    } while (0)
+
+#define GX_DISPATCH_BP(FN, ...)                                        \
+    do {                                                               \
+        if (p.robot == SwimmerRobot::kId) GX_DISPATCH_BP_R(SwimmerRobot, FN, __VA_ARGS__); \
+        else GX_DISPATCH_BP_R(PointRobot, FN, __VA_ARGS__);            \
     } while (0)
 
 void launch_step(const Params& p, const DevBuffers& b, const float* act, float* obs, float* rew,
@@ -921,13 +954,13 @@ void launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s)
                        pl.cand_of);
 }
 
-template <int BLOCK, int PMAX>
+template <class R, int BLOCK, int PMAX>
 static void launch_reset_apply_bp(const Params& p, const DevBuffers& b, int nobj_total, uint32_t k10,
                                   uint32_t k11, uint32_t k20, uint32_t k21, float* obs, int* host_ls,
                                   hipStream_t s)
 {
     const dim3 grid((p.N + BLOCK - 1) / BLOCK), blk(BLOCK);
-    hipLaunchKernelGGL((reset_apply_kernel<BLOCK, PMAX>), grid, blk, step_lds_bytes(p, BLOCK), s, p,
+    hipLaunchKernelGGL((reset_apply_kernel<R, BLOCK, PMAX>), grid, blk, step_lds_bytes(p, BLOCK), s, p,
                        nobj_total, k10, k11, k20, k21, b.pool.layout_size, b.pool.cand_of, b.pool.cand_xy, b.dyn, b.obj,
                        obs, host_ls);
 }
@@ -938,13 +971,13 @@ void launch_reset_apply(const Params& p, const DevBuffers& b, int nobj_total, ui
     GX_DISPATCH_BP(launch_reset_apply_bp, p, b, nobj_total, k10, k11, k20, k21, obs, host_ls, s);
 }
 
-template <int BLOCK, int PMAX>
+template <class R, int BLOCK, int PMAX>
 static void launch_reset_done_bp(const Params& p, const DevBuffers& b, int nobj_total, uint32_t k10,
                                  uint32_t k11, uint32_t k20, uint32_t k21, const float* obs_in,
                                  float* obs_out, hipStream_t s)
 {
     const dim3 grid((p.N + BLOCK - 1) / BLOCK), blk(BLOCK);
-    hipLaunchKernelGGL((reset_done_kernel<BLOCK, PMAX>), grid, blk, step_lds_bytes(p, BLOCK), s, p,
+    hipLaunchKernelGGL((reset_done_kernel<R, BLOCK, PMAX>), grid, blk, step_lds_bytes(p, BLOCK), s, p,
                        nobj_total, k10, k11, k20, k21, b.pool.layout_size, b.pool.cand_of, b.pool.cand_xy, b.dyn, b.obj,
                        obs_in, obs_out);
 }
@@ -956,26 +989,27 @@ void launch_reset_done(const Params& p, const DevBuffers& b, int nobj_total, uin
     GX_DISPATCH_BP(launch_reset_done_bp, p, b, nobj_total, k10, k11, k20, k21, obs_in, obs_out, s);
 }
 
-template <int OPL, int BPL>
-static void launch_group_ob(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s)
+template <class R>
+static void launch_group_r(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s)
 {
     const dim3 grid((p.N + 3) / 4), blk(64);
-    if (r.qacc)
-        hipLaunchKernelGGL((group_rollout_kernel<OPL, BPL, true, false>), grid, blk, 0, s, p, r, b.dyn, b.obj, b.hist);
-    else
-        hipLaunchKernelGGL((group_rollout_kernel<OPL, BPL, false, false>), grid, blk, 0, s, p, r, b.dyn, b.obj, b.hist);
+#define GX_GROUP_LAUNCH(OPL, BPL, DEF)                                                                      \
+    do {                                                                                                    \
+        if (r.qacc)                                                                                         \
+            hipLaunchKernelGGL((group_rollout_kernel<R, OPL, BPL, true, DEF>), grid, blk, 0, s, p, r, b.dyn, b.obj, b.hist); \
+        else                                                                                                \
+            hipLaunchKernelGGL((group_rollout_kernel<R, OPL, BPL, false, DEF>), grid, blk, 0, s, p, r, b.dyn, b.obj, b.hist); \
+    } while (0)
+    if (is_default_layout<R>(p)) GX_GROUP_LAUNCH(1, 1, true);
+    else if (p.nobj <= 16 && p.bins <= 16) GX_GROUP_LAUNCH(1, 1, false);
+    else GX_GROUP_LAUNCH(5, 4, false);
+#undef GX_GROUP_LAUNCH
 }
 
 void launch_group_rollout(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s)
 {
-    if (is_default_layout(p)) {
-        const dim3 grid((p.N + 3) / 4), blk(64);
-        if (r.qacc)
-            hipLaunchKernelGGL((group_rollout_kernel<1, 1, true, true>), grid, blk, 0, s, p, r, b.dyn, b.obj, b.hist);
-        else
-            hipLaunchKernelGGL((group_rollout_kernel<1, 1, false, true>), grid, blk, 0, s, p, r, b.dyn, b.obj, b.hist);
-    } else if (p.nobj <= 16 && p.bins <= 16) launch_group_ob<1, 1>(p, r, b, s);
-    else launch_group_ob<5, 4>(p, r, b, s);
+    if (p.robot == SwimmerRobot::kId) launch_group_r<SwimmerRobot>(p, r, b, s);
+    else launch_group_r<PointRobot>(p, r, b, s);
 }
 
 void launch_math_probe(int n, const float* x, const float* y, float* s_, float* c, float* at2,

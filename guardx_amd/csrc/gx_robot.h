@@ -1,0 +1,278 @@
+// gx_robot.h -- per-robot dynamics (one mjx.step each) and state packing.
+//
+// A robot is a trait struct: widths (robot.nq/nv/nu, world.py:435-438), the
+// float4 SoA packing of its dynamic state, convert_action (engine.py:672-685)
+// and `substep` = forward dynamics + semi-implicit Euler [derived: MuJoCo
+// computation chapter; constants from tools/model_constants.py].
+// fp32, one IEEE operation per operator (see gx_device.h).
+#pragma once
+#include "gx_device.h"
+
+namespace gx {
+
+// ===========================================================================
+// Point (xmls/point.xml): slide-x, slide-y, hinge-z; sphere r=.1 + box .05 at
+// x=.1, density 1 (:5,19-20); damping .01 .01 .005 (:16-18); general actuators
+// gear .3 without ctrl limits (:37-39); h=.02 (:3).
+// dyn: (x,y,th,vx) (vy,om,px,py) (pc,ps,done0,steps)
+// ===========================================================================
+struct PointRobot {
+    static constexpr int kId = 0, NQ = 3, NV = 3, NU = 3, NA = 2, NDYN = 3;
+    static constexpr float kH = 0.02f;
+    // default Goal_Point_8Hazards observation: ctrl[0:3] compass[3:5] glidar[5:21] hlidar[21:37] qpos[37:40] qvel[40:43]
+    static constexpr int kD = 43, kOffCtrl = 0, kOffComp = 3, kOffGl = 5, kOffHl = 21, kOffQpos = 37, kOffQvel = 40;
+
+    GX_D static void load(const float4* __restrict__ dyn, int Npad, int i, float (&q)[NQ], float (&v)[NV],
+                          float (&pose0)[4], float& done0, float& steps)
+    {
+        const float4 d0 = dyn[i], d1 = dyn[Npad + i], d2 = dyn[2 * Npad + i];
+        q[0] = d0.x; q[1] = d0.y; q[2] = d0.z; v[0] = d0.w; v[1] = d1.x; v[2] = d1.y;
+        pose0[0] = d1.z; pose0[1] = d1.w; pose0[2] = d2.x; pose0[3] = d2.y;
+        done0 = d2.z; steps = d2.w;
+    }
+    GX_D static void store(float4* __restrict__ dyn, int Npad, int i, const float (&q)[NQ], const float (&v)[NV],
+                           const float (&pose0)[4], float done0, float steps)
+    {
+        dyn[i] = make_float4(q[0], q[1], q[2], v[0]);
+        dyn[Npad + i] = make_float4(v[1], v[2], pose0[0], pose0[1]);
+        dyn[2 * Npad + i] = make_float4(pose0[2], pose0[3], done0, steps);
+    }
+    // convert_action :672-685: (a0,0,0) rotated by the PRE-step xmat, a1 on the hinge
+    GX_D static void convert_action(const float (&pose0)[4], float a0, float a1, float (&ctrl)[NU])
+    {
+        ctrl[0] = pose0[2] * a0; ctrl[1] = pose0[3] * a0; ctrl[2] = a1;
+    }
+
+    template <bool kQacc>
+    GX_D static void substep(float (&q)[NQ], float (&v)[NV], const float (&ctrl)[NU], float (&pose)[4],
+                             float (&qacc)[NV])
+    {
+        constexpr float kMxc = 0.0001f, kDxy = 0.01f, kDt = 0.005f, kGear = 0.3f;
+        constexpr float kIo = 2.842182748581224e-05f;
+        constexpr float kInvM = (float)(1.0 / 0.005188790204786391);
+        constexpr float kInvA = (float)(1.0 / (0.005188790204786391 + 0.02 * 0.01));
+        constexpr float kEi = (float)(2.842182748581224e-05 + 0.02 * 0.005);
+        float sh, ch;
+        sincos_f(0.5f * q[2], sh, ch);
+        const float c = ch * ch - sh * sh;
+        const float sn = 2.0f * (ch * sh);
+        pose[0] = q[0]; pose[1] = q[1]; pose[2] = c; pose[3] = sn;
+        const float b = -(kMxc * sn), d = kMxc * c;
+        const float w2 = v[2] * v[2];
+        const float fx = (-(kDxy * v[0]) - (-(d * w2))) + kGear * ctrl[0];
+        const float fy = (-(kDxy * v[1]) - (b * w2)) + kGear * ctrl[1];
+        const float ft = (-(kDt * v[2]) - 0.0f) + kGear * ctrl[2];
+        const float t = b * fx + d * fy;
+        const float s2 = b * b + d * d;
+        if (kQacc) {
+            const float y3 = ft - t * kInvM;
+            const float d3 = kIo - s2 * kInvM;
+            const float q3 = y3 / d3;
+            qacc[0] = (fx - b * q3) * kInvM;
+            qacc[1] = (fy - d * q3) * kInvM;
+            qacc[2] = q3;
+        }
+        const float y3 = ft - t * kInvA;
+        const float d3 = kEi - s2 * kInvA;
+        const float q3 = y3 / d3;
+        const float q1 = (fx - b * q3) * kInvA;
+        const float q2 = (fy - d * q3) * kInvA;
+        v[0] = v[0] + kH * q1;
+        v[1] = v[1] + kH * q2;
+        v[2] = v[2] + kH * q3;
+        q[0] = q[0] + kH * v[0];
+        q[1] = q[1] + kH * v[1];
+        q[2] = q[2] + kH * v[2];
+    }
+};
+
+// ===========================================================================
+// Swimmer (xmls/swimmer.xml): slide-x, slide-y, hinge-z at the head link, two
+// limited hinges (+-100 deg, :24,28) down a 3-capsule chain (r=.02, l=.15,
+// density 1000, :18,23,27); armature .1 on every DOF (:6); motors gear 20 with
+// ctrlrange +-1 (:58-59); h=.03 (:3); no damping, no contacts (capsules rest at
+// dist == margin).  Joint-limit rows follow MJX (_instantiate_limit_slide_hinge,
+// _kbi: solref (.02,1) with refsafe -> timeconst .06, solimp (.9,.95,.001,.5,2));
+// with at most two scalar rows the constraint QP is solved exactly by enumeration.
+// dyn: (x,y,t1,p2) (p3,vx,vy,w1) (w2,w3,px,py) (pc,ps,done0,steps)
+// ===========================================================================
+struct SwimmerRobot {
+    static constexpr int kId = 1, NQ = 5, NV = 5, NU = 2, NA = 2, NDYN = 4;
+    static constexpr float kH = 0.03f;
+    // default Goal_Swimmer_8Hazards observation: ctrl[0:2] compass[2:4] glidar[4:20] hlidar[20:36] qpos[36:41] qvel[41:46]
+    static constexpr int kD = 46, kOffCtrl = 0, kOffComp = 2, kOffGl = 4, kOffHl = 20, kOffQpos = 36, kOffQvel = 41;
+
+    GX_D static void load(const float4* __restrict__ dyn, int Npad, int i, float (&q)[NQ], float (&v)[NV],
+                          float (&pose0)[4], float& done0, float& steps)
+    {
+        const float4 d0 = dyn[i], d1 = dyn[Npad + i], d2 = dyn[2 * Npad + i], d3 = dyn[3 * Npad + i];
+        q[0] = d0.x; q[1] = d0.y; q[2] = d0.z; q[3] = d0.w; q[4] = d1.x;
+        v[0] = d1.y; v[1] = d1.z; v[2] = d1.w; v[3] = d2.x; v[4] = d2.y;
+        pose0[0] = d2.z; pose0[1] = d2.w; pose0[2] = d3.x; pose0[3] = d3.y;
+        done0 = d3.z; steps = d3.w;
+    }
+    GX_D static void store(float4* __restrict__ dyn, int Npad, int i, const float (&q)[NQ], const float (&v)[NV],
+                           const float (&pose0)[4], float done0, float steps)
+    {
+        dyn[i] = make_float4(q[0], q[1], q[2], q[3]);
+        dyn[Npad + i] = make_float4(q[4], v[0], v[1], v[2]);
+        dyn[2 * Npad + i] = make_float4(v[3], v[4], pose0[0], pose0[1]);
+        dyn[3 * Npad + i] = make_float4(pose0[2], pose0[3], done0, steps);
+    }
+    GX_D static void convert_action(const float (&)[4], float a0, float a1, float (&ctrl)[NU])
+    {
+        ctrl[0] = a0; ctrl[1] = a1; // non-point robots: the action is the ctrl (:673)
+    }
+
+    struct Ldl3 { float rd0, rd1, rd2, l10, l20, l21; };
+    GX_D static void ldl_solve(const Ldl3& f, float b0, float b1, float b2, float (&x)[3])
+    {
+        const float y0 = b0;
+        const float y1 = b1 - f.l10 * y0;
+        const float y2 = (b2 - f.l20 * y0) - f.l21 * y1;
+        const float z2 = y2 * f.rd2;
+        const float z1 = y1 * f.rd1 - f.l21 * z2;
+        const float z0 = (y0 * f.rd0 - f.l10 * z1) - f.l20 * z2;
+        x[0] = z0; x[1] = z1; x[2] = z2;
+    }
+    // joint-limit row: present when violated; sign, aref and R = 1/D
+    GX_D static bool limit_row(float qj, float vel, float invw, float& sign, float& aref, float& R)
+    {
+        constexpr float kLim = 1.7453292519943295f, kK = 307.78701138811942f, kB = 35.087719298245617f;
+        const float dlo = qj - (-kLim), dhi = kLim - qj;
+        const float pos = dlo < dhi ? dlo : dhi;
+        const float sg = dlo < dhi ? 1.0f : -1.0f;
+        sign = sg; aref = 0.0f; R = 1.0f;
+        if (!(pos < 0.0f)) return false;
+        const float ix = fabsf(pos) / 0.001f;
+        float iy;
+        if (ix < 0.5f) iy = 2.0f * (ix * ix);
+        else iy = 1.0f - 2.0f * ((1.0f - ix) * (1.0f - ix));
+        float imp = 0.9f + iy * (0.95f - 0.9f);
+        if (imp < 0.9f) imp = 0.9f;
+        if (imp > 0.95f) imp = 0.95f;
+        if (ix > 1.0f) imp = 0.95f;
+        aref = -(kB * (sg * vel)) - (kK * imp) * pos;
+        float r = ((1.0f - imp) * invw) / imp;
+        if (r < 1e-15f) r = 1e-15f;
+        R = r;
+        return true;
+    }
+
+    template <bool kQacc>
+    GX_D static void substep(float (&q)[NQ], float (&v)[NV], const float (&ctrl)[NU], float (&pose)[4],
+                             float (&qacc)[NV])
+    {
+        constexpr float kM = 0.22200588085367876f, kIc = 0.00060383505197098225f, kArm = 0.1f, kGear = 20.0f;
+        constexpr float kInvW2 = 9.3234461878793518f, kInvW3 = 9.8671592198756102f;
+        constexpr float A11 = 0.225f, A21 = 0.15f, A22 = -0.075f, A31 = 0.15f, A32 = -0.15f, A33 = -0.075f;
+        constexpr float kImu = (float)(1.0 / (3.0 * 0.22200588085367876 + 0.1));
+        // kinematics: hinge quaternions (half angles) composed down the chain
+        float sh1, ch1, sh2, ch2, sh3, ch3;
+        sincos_f(0.5f * q[2], sh1, ch1);
+        sincos_f(0.5f * q[3], sh2, ch2);
+        sincos_f(0.5f * q[4], sh3, ch3);
+        const float w1 = ch1, z1 = sh1;
+        const float w2 = w1 * ch2 - z1 * sh2, z2 = w1 * sh2 + z1 * ch2;
+        const float w3 = w2 * ch3 - z2 * sh3, z3 = w2 * sh3 + z2 * ch3;
+        const float c1 = w1 * w1 - z1 * z1, s1 = 2.0f * (w1 * z1);
+        const float c2 = w2 * w2 - z2 * z2, s2 = 2.0f * (w2 * z2);
+        const float c3 = w3 * w3 - z3 * z3, s3 = 2.0f * (w3 * z3);
+        pose[0] = q[0]; pose[1] = q[1]; pose[2] = c1; pose[3] = s1;
+        const float W1 = v[2], W2 = W1 + v[3], W3 = W2 + v[4];
+        // COM Jacobian columns g_ij = sum_{k>=j} a_ik n_k, n_k = (-s_k, c_k)
+        const float g11x = A11 * -s1, g11y = A11 * c1;
+        const float g22x = A22 * -s2, g22y = A22 * c2;
+        const float g21x = A21 * -s1 + g22x, g21y = A21 * c1 + g22y;
+        const float g33x = A33 * -s3, g33y = A33 * c3;
+        const float g32x = A32 * -s2 + g33x, g32y = A32 * c2 + g33y;
+        const float g31x = A31 * -s1 + g32x, g31y = A31 * c1 + g32y;
+        // velocity-product acceleration of the COMs
+        const float e1 = W1 * W1, e2 = W2 * W2, e3 = W3 * W3;
+        const float q1x = -((A11 * e1) * c1), q1y = -((A11 * e1) * s1);
+        const float q2x = -((A21 * e1) * c1 + (A22 * e2) * c2), q2y = -((A21 * e1) * s1 + (A22 * e2) * s2);
+        const float q3x = -(((A31 * e1) * c1 + (A32 * e2) * c2) + (A33 * e3) * c3);
+        const float q3y = -(((A31 * e1) * s1 + (A32 * e2) * s2) + (A33 * e3) * s3);
+        // mass matrix blocks
+        const float Mx0 = kM * ((g11x + g21x) + g31x), Mx1 = kM * (g22x + g32x), Mx2 = kM * g33x;
+        const float My0 = kM * ((g11y + g21y) + g31y), My1 = kM * (g22y + g32y), My2 = kM * g33y;
+        const float T00 = (kM * (((g11x * g11x + g11y * g11y) + (g21x * g21x + g21y * g21y)) + (g31x * g31x + g31y * g31y)) + 3.0f * kIc) + kArm;
+        const float T10 = kM * ((g21x * g22x + g21y * g22y) + (g31x * g32x + g31y * g32y)) + 2.0f * kIc;
+        const float T20 = kM * (g31x * g33x + g31y * g33y) + kIc;
+        const float T11 = (kM * ((g22x * g22x + g22y * g22y) + (g32x * g32x + g32y * g32y)) + 2.0f * kIc) + kArm;
+        const float T21 = kM * (g32x * g33x + g32y * g33y) + kIc;
+        const float T22 = (kM * (g33x * g33x + g33y * g33y) + kIc) + kArm;
+        // bias, smooth force = (passive - bias) + actuator (ctrl clamped for the force only)
+        const float bx = kM * ((q1x + q2x) + q3x), by = kM * ((q1y + q2y) + q3y);
+        const float b1 = kM * (((g11x * q1x + g11y * q1y) + (g21x * q2x + g21y * q2y)) + (g31x * q3x + g31y * q3y));
+        const float b2 = kM * ((g22x * q2x + g22y * q2y) + (g32x * q3x + g32y * q3y));
+        const float b3 = kM * (g33x * q3x + g33y * q3y);
+        float u0 = ctrl[0], u1 = ctrl[1];
+        u0 = u0 < -1.0f ? -1.0f : (u0 > 1.0f ? 1.0f : u0);
+        u1 = u1 < -1.0f ? -1.0f : (u1 > 1.0f ? 1.0f : u1);
+        const float fx = 0.0f - bx, fy = 0.0f - by;
+        const float ft0 = 0.0f - b1, ft1 = (0.0f - b2) + kGear * u0, ft2 = (0.0f - b3) + kGear * u1;
+        // Schur complement of the diagonal translation block, LDL^T
+        const float S00 = T00 - (Mx0 * Mx0 + My0 * My0) * kImu;
+        const float S10 = T10 - (Mx1 * Mx0 + My1 * My0) * kImu;
+        const float S11 = T11 - (Mx1 * Mx1 + My1 * My1) * kImu;
+        const float S20 = T20 - (Mx2 * Mx0 + My2 * My0) * kImu;
+        const float S21 = T21 - (Mx2 * Mx1 + My2 * My1) * kImu;
+        const float S22 = T22 - (Mx2 * Mx2 + My2 * My2) * kImu;
+        const float r0 = ft0 - (Mx0 * fx + My0 * fy) * kImu;
+        const float r1 = ft1 - (Mx1 * fx + My1 * fy) * kImu;
+        const float r2 = ft2 - (Mx2 * fx + My2 * fy) * kImu;
+        Ldl3 F;
+        F.rd0 = 1.0f / S00;
+        F.l10 = S10 * F.rd0;
+        F.l20 = S20 * F.rd0;
+        const float d1 = S11 - F.l10 * S10;
+        F.rd1 = 1.0f / d1;
+        const float t21 = S21 - F.l20 * S10;
+        F.l21 = t21 * F.rd1;
+        const float d2 = (S22 - F.l20 * S20) - F.l21 * t21;
+        F.rd2 = 1.0f / d2;
+        float a[3];
+        ldl_solve(F, r0, r1, r2, a);
+        // joint limits on phi2, phi3
+        float sg2, ar2, R2, sg3, ar3, R3;
+        const bool p2 = limit_row(q[3], v[3], kInvW2, sg2, ar2, R2);
+        const bool p3 = limit_row(q[4], v[4], kInvW3, sg3, ar3, R3);
+        if (p2 || p3) {
+            if (!p2) sg2 = 0.0f;
+            if (!p3) sg3 = 0.0f;
+            float zc2[3], zc3[3];
+            ldl_solve(F, 0.0f, 1.0f, 0.0f, zc2);
+            ldl_solve(F, 0.0f, 0.0f, 1.0f, zc3);
+            const float A22i = zc2[1], A33i = zc3[2], A23i = zc3[1] * (sg2 * sg3);
+            const float E2 = sg2 * a[1] - ar2, E3 = sg3 * a[2] - ar3;
+            float f2 = 0.0f, f3 = 0.0f;
+            bool done = false;
+            if (p2 && p3) {
+                const float m22 = R2 + A22i, m33 = R3 + A33i;
+                const float det = m22 * m33 - A23i * A23i;
+                const float g2 = ((-E2) * m33 - A23i * (-E3)) / det;
+                const float g3 = (m22 * (-E3) - A23i * (-E2)) / det;
+                if (g2 > 0.0f && g3 > 0.0f) { f2 = g2; f3 = g3; done = true; }
+            }
+            if (!done && p2) {
+                const float g2 = (-E2) / (R2 + A22i);
+                if (g2 > 0.0f && (!p3 || !(E3 + A23i * g2 < 0.0f))) { f2 = g2; f3 = 0.0f; done = true; }
+            }
+            if (!done && p3) {
+                const float g3 = (-E3) / (R3 + A33i);
+                if (g3 > 0.0f && (!p2 || !(E2 + A23i * g3 < 0.0f))) { f3 = g3; f2 = 0.0f; done = true; }
+            }
+            ldl_solve(F, r0, r1 + sg2 * f2, r2 + sg3 * f3, a);
+        }
+        const float ax = (fx - ((Mx0 * a[0] + Mx1 * a[1]) + Mx2 * a[2])) * kImu;
+        const float ay = (fy - ((My0 * a[0] + My1 * a[1]) + My2 * a[2])) * kImu;
+        qacc[0] = ax; qacc[1] = ay; qacc[2] = a[0]; qacc[3] = a[1]; qacc[4] = a[2];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] = v[k] + kH * qacc[k];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) q[k] = q[k] + kH * v[k];
+    }
+};
+
+} // namespace gx

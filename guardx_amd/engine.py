@@ -28,9 +28,12 @@ class ResamplingError(AssertionError):
     """Raised when no valid object layout could be sampled (engine.py:79-81)."""
 
 
-# robot_base -> (native robot id, nq, nv, nu, z_height, act_dim)   (world.py:422-438)
+# robot_base -> (native robot id, nq, nv, nu, z_height, timestep, action low/high)
+#   nq/nv/nu/z_height as world.py:422-438 reads them from the robot-only MJCF; action bounds =
+#   actuator ctrlrange where ctrllimited, else +-inf, Point keeps its first 2 rows (engine.py:291-297)
 _ROBOTS = {
-    'xmls/point.xml': (0, 3, 3, 3, 0.1, 2),
+    'xmls/point.xml': (0, 3, 3, 3, 0.1, 0.02, (-np.inf, np.inf, 2)),      # point.xml:3,16-18,37-39
+    'xmls/swimmer.xml': (1, 5, 5, 2, 0.03, 0.03, (-1.0, 1.0, 2)),         # swimmer.xml:3,14,58-59
 }
 
 
@@ -106,7 +109,7 @@ class Engine:
             raise NotImplementedError("observe_vision is not part of the batched path")
         if self.robot_rot not in (None, 0, 0.0):
             raise NotImplementedError("robot_rot other than None/0")
-        robot_id, nq, nv, nu, z_height, act_dim = _ROBOTS[self.robot_base]
+        robot_id, nq, nv, nu, z_height, timestep, (act_lo, act_hi, act_dim) = _ROBOTS[self.robot_base]
         self.robot = type('Robot', (), dict(nq=nq, nv=nv, nu=nu, z_height=z_height))()
 
         if not torch.cuda.is_available():
@@ -126,9 +129,9 @@ class Engine:
         self._h = h
         self._cfg = cfg
 
-        self.dt = 0.02 * self.physics_steps_per_control_step  # engine.py:235 (point.xml:3)
-        self.action_space = Box(np.full(act_dim, -np.inf, np.float32),
-                                np.full(act_dim, np.inf, np.float32), dtype=np.float32)  # :291-297
+        self.dt = timestep * self.physics_steps_per_control_step  # engine.py:235
+        self.action_space = Box(np.full(act_dim, act_lo, np.float32),
+                                np.full(act_dim, act_hi, np.float32), dtype=np.float32)  # :291-297
         self.build_observation_space()
         assert self.obs_flat_size == self._lib.gx_obs_dim(self._h)
 
@@ -355,8 +358,10 @@ class Engine:
     # ------------------------------------------------------------------
     # state exchange (tests, checkpoints)
     # ------------------------------------------------------------------
-    _STATE_FIELDS = (('qpos', 3), ('qvel', 3), ('pose0', 4), ('pose1', 2), ('objs', None),
-                     ('done0', 1), ('done1', 1), ('steps', 1))
+    @property
+    def _STATE_FIELDS(self):
+        return (('qpos', self.robot.nq), ('qvel', self.robot.nv), ('pose0', 4), ('pose1', 2), ('objs', None),
+                ('done0', 1), ('done1', 1), ('steps', 1))
 
     def get_state(self):
         N, H = self.env_num, int(self.hazards_num)

@@ -40,7 +40,7 @@ typedef enum gx_status {
 /* Subset of Engine.DEFAULT (engine.py:98-204) that the hot path reads. */
 typedef struct gx_config {
     int32_t struct_size;        /* sizeof(gx_config) */
-    int32_t robot;              /* 0 = xmls/point.xml */
+    int32_t robot;              /* 0 = xmls/point.xml, 1 = xmls/swimmer.xml ('robot_base' engine.py:113) */
     int32_t env_num;            /* envs owned by this handle (local shard) */
     int32_t env_total;          /* env_num of the whole batch (== env_num unsharded) */
     int32_t env_offset;         /* global index of local env 0 */
@@ -83,6 +83,8 @@ gx_status gx_create(const gx_config* cfg, gx_engine** out);
 gx_status gx_destroy(gx_engine* e);
 int32_t gx_obs_dim(const gx_engine* e);
 int32_t gx_act_dim(const gx_engine* e);
+/* robot.nq / nv / nu (world.py:435-438) and the action width */
+gx_status gx_dims(const gx_engine* e, int32_t* nq, int32_t* nv, int32_t* nu, int32_t* na);
 
 /* Engine.reset: resample the layout pool from the current key, re-initialise
  * every env, write d_obs (env_num x obs_dim).  Asynchronous on `stream`. */
@@ -94,7 +96,7 @@ gx_status gx_layout_size(gx_engine* e, int32_t* out);
 
 /* Engine.step.  d_action (env_num x act_dim) -> d_obs (env_num x obs_dim),
  * d_reward, d_cost, d_done (env_num each; done is 0.f/1.f), d_qacc
- * (env_num x 3, may be NULL).  No auto-reset. */
+ * (env_num x nv, may be NULL).  No auto-reset. */
 gx_status gx_step(gx_engine* e, const float* d_action, float* d_obs, float* d_reward,
                   float* d_cost, float* d_done, float* d_qacc, void* stream);
 
@@ -111,7 +113,7 @@ gx_status gx_rollout(gx_engine* e, int32_t T, const float* d_actions, float* d_o
                      float* d_reward, float* d_cost, float* d_done, void* stream);
 
 /* Test / checkpoint support: env-major HOST arrays (any may be NULL).
- *  qpos[N*3] qvel[N*3] pose0[N*4] pose1[N*2] objs[N*(1+H)*2] done0[N] done1[N]
+ *  qpos[N*nq] qvel[N*nv] pose0[N*4] pose1[N*2] objs[N*(1+H)*2] done0[N] done1[N]
  *  steps[N] key[2] hist[1].  Synchronous. */
 gx_status gx_get_state(gx_engine* e, float* qpos, float* qvel, float* pose0, float* pose1,
                        float* objs, float* done0, float* done1, float* steps,

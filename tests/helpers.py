@@ -16,15 +16,27 @@ def task_config(env_num, seed=0, num_steps=200, **over):
     return cfg
 
 
-def random_state(N, H, rng, spread=2.5, done_frac=0.1, near_frac=0.3):
+SWIMMER = {'robot_base': 'xmls/swimmer.xml'}
+
+
+def random_state(N, H, rng, spread=2.5, done_frac=0.1, near_frac=0.3, robot='point'):
     """A random but plausible engine state (env-major arrays, see gx_get_state)."""
     f = np.float32
-    qpos = np.empty((N, 3), f)
+    nq = 3 if robot == 'point' else 5
+    qpos = np.empty((N, nq), f)
     qpos[:, :2] = rng.uniform(-spread, spread, (N, 2))
     qpos[:, 2] = rng.uniform(-40, 40, N)
-    qvel = np.empty((N, 3), f)
+    qvel = np.empty((N, nq), f)
     qvel[:, :2] = rng.uniform(-3, 3, (N, 2))
     qvel[:, 2] = rng.uniform(-30, 30, N)
+    if robot == 'swimmer':
+        qpos[:, 2] = rng.uniform(-8, 8, N)
+        qpos[:, 3:] = rng.uniform(-1.7, 1.7, (N, 2))
+        k = N // 3                      # a third of the envs sit beyond a joint limit (one or both)
+        qpos[:k, 3] = rng.choice([-1, 1], k) * (1.7453293 + rng.uniform(1e-6, 0.3, k))
+        qpos[k // 2:k, 4] = rng.choice([-1, 1], k - k // 2) * (1.7453293 + rng.uniform(1e-6, 0.3, k - k // 2))
+        qvel[:, :2] = rng.uniform(-1, 1, (N, 2))
+        qvel[:, 2:] = rng.uniform(-8, 8, (N, 3))
     th_prev = rng.uniform(-np.pi, np.pi, N)
     pose0 = np.empty((N, 4), f)
     pose0[:, :2] = qpos[:, :2] - rng.uniform(-0.05, 0.05, (N, 2)).astype(f)

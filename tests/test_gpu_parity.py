@@ -7,7 +7,7 @@ tests actually demand exact equality of every output and of the state.
 import numpy as np
 import pytest
 
-from helpers import task_config, random_state, assert_state_equal
+from helpers import task_config, random_state, assert_state_equal, SWIMMER
 
 pytestmark = pytest.mark.gpu
 
@@ -335,3 +335,53 @@ def test_learner_loop_contract(torch_cuda, oracle):
     assert finished > 0
     np.testing.assert_array_equal(ep_ret, ep_ret_o)
     np.testing.assert_array_equal(ep_cost, ep_cost_o)
+
+
+# ---------------------------------------------------------------------------
+# Swimmer (BASELINE config 3): articulated dynamics + joint-limit rows
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("path", ["thread", "group"])
+@pytest.mark.parametrize("N", [5, 64, 2000])
+def test_swimmer_step_parity_random_states(torch_cuda, oracle, N, path):
+    torch = torch_cuda
+    E, O = _engines(task_config(N, seed=3, **SWIMMER), oracle, path=path)
+    assert E.obs_flat_size == O.D == 46 and E.action_space.shape == (2,)
+    assert float(E.action_space.low[0]) == -1.0 and float(E.action_space.high[1]) == 1.0
+    rng = np.random.default_rng(N)
+    for trial in range(3):
+        s = random_state(N, 8, rng, robot='swimmer')
+        s['hist'] = [2, 1, 0][trial]
+        E.set_state(s)
+        O.set_state(s)
+        act = rng.uniform(-1.4, 1.4, (N, 2)).astype(np.float32)      # beyond ctrlrange: clipped for the force
+        out_g = E.step(torch.from_numpy(act).cuda())
+        out_o = O.step(act)
+        _cmp_step(out_g, out_o)
+        assert_state_equal(E.get_state(), O.get_state())
+
+
+@pytest.mark.parametrize("path", ["thread", "group"])
+def test_swimmer_rollout_parity(torch_cuda, oracle, path):
+    torch = torch_cuda
+    N, T = 300, 120
+    E, O = _engines(task_config(N, seed=6, num_steps=80, goal_size=1.0, **SWIMMER), oracle,
+                    n_candidates=60000, path=path)
+    np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
+    rng = np.random.RandomState(1)
+    for t in range(40):                       # step()/reset_done() API
+        act = rng.uniform(-1, 1, (N, 2)).astype(np.float32)
+        _cmp_step(E.step(torch.from_numpy(act).cuda()), O.step(act))
+        np.testing.assert_array_equal(E.reset_done().cpu().numpy(), O.reset_done())
+    acts = rng.uniform(-1, 1, (T, N, 2)).astype(np.float32)   # fused rollout
+    obs, rew, cost, done = E.rollout(torch.from_numpy(acts).cuda())
+    hit = 0
+    for t in range(T):
+        o, r, d, info = O.step(acts[t])
+        hit += int((np.abs(O.get_state()['qpos'][:, 3:]) > 1.7453293).sum())
+        np.testing.assert_array_equal(obs[t].cpu().numpy(), O.reset_done())
+        np.testing.assert_array_equal(rew[t].cpu().numpy(), r)
+        np.testing.assert_array_equal(done[t].cpu().numpy(), d)
+        np.testing.assert_array_equal(cost[t].cpu().numpy(), info['cost'])
+    assert hit > 0 and done.sum().item() > 0
+    assert_state_equal(E.get_state(), O.get_state())
+    np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
