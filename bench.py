@@ -35,9 +35,11 @@ ALGO_BYTES_PER_ENV_STEP = 372     # 124 B read + 248 B w
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def make_engine(env_num, rank, world, seed=0, n_candidates=1_000_000):
+def make_engine(env_num, rank, world, seed=0, n_candidates=1_000_000, robot_base=None):
     from guardx_amd import Engine
     cfg = dict(TASK)
+    if robot_base:
+        cfg['robot_base'] = robot_base
     cfg.update(env_num=env_num, _seed=seed, num_steps=EP_LEN, device_id=torch.cuda.current_device())
     return Engine(cfg, shard=(rank, world) if world > 1 else None, n_candidates=n_candidates)
 

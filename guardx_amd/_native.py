@@ -69,9 +69,15 @@ def load():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise ImportError(
-            f"{LIB_PATH} is missing: build it with `python -m guardx_amd.build` "
-            "(guardx_amd has no CPU fallback)")
+        # in-tree build on first use (hipcc cross-compiles gfx950 without a GPU); there is no
+        # CPU fallback: if this fails the import fails
+        try:
+            from . import build as _build
+            _build.build(force=True)
+        except Exception as exc:  # noqa: BLE001
+            raise ImportError(
+                f"{LIB_PATH} is missing and could not be built with hipcc ({exc}); "
+                "run `python -m guardx_amd.build` (guardx_amd has no CPU fallback)") from exc
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the ABI drifted

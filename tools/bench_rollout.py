@@ -22,9 +22,11 @@ def timeit(fn, n):
 
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+    robot = sys.argv[2] if len(sys.argv) > 2 else None      # e.g. xmls/swimmer.xml
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
-    env = bench.make_engine(N, 0, 1)
+    env = bench.make_engine(N, 0, 1, robot_base=robot)
+    print("robot", env.robot_base, "obs", env.obs_flat_size)
     tape = bench.action_tape(200, N, 0, dev)
     env.set_prefetch(-1)
     env.reset()
