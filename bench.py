@@ -290,6 +290,8 @@ def main():
     from guardx_amd import dist as gxd
     rank, local, world = gxd.init_from_env()
     assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    if os.environ.get("GX_BENCH_FORCE_DEVICE"):      # rehearsal: several ranks share one GPU
+        local = int(os.environ["GX_BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
