@@ -25,6 +25,8 @@ static gx_status fail(gx_status st, const std::string& msg)
     return st;
 }
 
+gx_status gx_fail_msg(gx_status st, const char* msg) { return fail(st, msg); } // for gx_gae.hip
+
 #define GX_HIP(call)                                                                       \
     do {                                                                                   \
         hipError_t e_ = (call);                                                            \

@@ -136,6 +136,26 @@ gx_status gx_set_prefetch(gx_engine* e, int32_t steps);
  * Results are bit-identical either way (tests/test_gpu_parity.py). */
 gx_status gx_set_path(gx_engine* e, int32_t mode);
 
+/* ---- learner-side rollout buffer on device -------------------------------
+ * Counterparts of TRPOBufferX (safe_rl_libX/trpo/trpo.py:24-146); buffers are env-major
+ * (env_num, max_ep_len, .) fp32 device arrays owned by the caller.
+ *   gx_buffer_store     <- TRPOBufferX.store        trpo.py:49-64   (7 strided writes -> 1 launch)
+ *   gx_gae_finish_path  <- TRPOBufferX.finish_path  trpo.py:66-119  (GAE-lambda + rewards-to-go for
+ *                          the envs whose d_done == 1, all envs when d_done is NULL; d_path_start is
+ *                          advanced to ptr for them; no host sync, no per-env Python loop)
+ *   gx_adv_normalize    <- the per-env advantage normalisation in TRPOBufferX.get  trpo.py:131-135 */
+gx_status gx_buffer_store(int32_t env_num, int32_t max_ep_len, int32_t ptr, int32_t obs_dim,
+                          int32_t act_dim, const float* d_obs, const float* d_act, const float* d_rew,
+                          const float* d_val, const float* d_logp, const float* d_mu,
+                          const float* d_logstd, float* d_obs_buf, float* d_act_buf, float* d_rew_buf,
+                          float* d_val_buf, float* d_logp_buf, float* d_mu_buf, float* d_logstd_buf,
+                          void* stream);
+gx_status gx_gae_finish_path(int32_t env_num, int32_t max_ep_len, int32_t ptr, const float* d_rew_buf,
+                             const float* d_val_buf, const float* d_last_val, const float* d_done,
+                             int32_t* d_path_start, double gamma, double lam, float* d_adv_buf,
+                             float* d_ret_buf, void* stream);
+gx_status gx_adv_normalize(int32_t env_num, int32_t max_ep_len, float* d_adv_buf, void* stream);
+
 /* Device-math probe (tests): s,c = sincos(x); at2 = atan2(y,x); ex = exp(x). */
 gx_status gx_math_probe(int32_t n, const float* d_x, const float* d_y, float* d_s,
                         float* d_c, float* d_at2, float* d_ex, void* stream);
