@@ -234,8 +234,9 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
         alloc((void**)&pl.wave_off, sizeof(int) * W);
         alloc((void**)&pl.cand_of, sizeof(int) * M);
         alloc((void**)&pl.layout_size, sizeof(int));
-        alloc((void**)&pl.n_surv, sizeof(int));
+        alloc((void**)&pl.n_surv, 2 * sizeof(int));
         alloc((void**)&pl.surv, sizeof(uint32_t) * 32 * M);
+        alloc((void**)&pl.surv0, sizeof(uint32_t) * 8 * M);
         if (err == hipSuccess) err = hipEventCreateWithFlags(&e->pool_ready[i], hipEventDisableTiming);
         if (err == hipSuccess) err = hipEventCreateWithFlags(&e->pool_free[i], hipEventDisableTiming);
     }
@@ -275,7 +276,7 @@ extern "C" gx_status gx_destroy(gx_engine* e)
         if (q) (void)hipFree(q);
     for (int i = 0; i < 2; ++i) {
         Pool& pl = e->pools[i];
-        void* pb[] = {pl.cand_ok, pl.cand_xy, pl.wave_cnt, pl.wave_off, pl.cand_of, pl.layout_size, pl.n_surv, pl.surv};
+        void* pb[] = {pl.cand_ok, pl.cand_xy, pl.wave_cnt, pl.wave_off, pl.cand_of, pl.layout_size, pl.n_surv, pl.surv, pl.surv0};
         for (void* q : pb)
             if (q) (void)hipFree(q);
         if (e->pool_ready[i]) (void)hipEventDestroy(e->pool_ready[i]);

@@ -27,8 +27,9 @@ struct Pool {
     int* wave_off;     // [ceil(M/64)]
     int* cand_of;      // [M] compacted candidate indices (ascending)
     int* layout_size;  // [1]
-    int* n_surv;       // [1] phase-1 survivors
-    uint32_t* surv;    // [M][32] survivor records
+    int* n_surv;       // [2] phase-1 survivors, phase-0 survivors
+    uint32_t* surv;    // [M][32] phase-1 survivor records
+    uint32_t* surv0;   // [M][8] phase-0 survivor records
 };
 
 struct DevBuffers {

@@ -251,9 +251,11 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p_in, const float2* 
 
 // ---------------------------------------------------------------------------
 // layout rejection sampler: sample_layout (engine.py:546-572) for candidate j,
-// key_j = split(key, M)[j] (:263).  Two phases with a global compaction between:
+// key_j = split(key, M)[j] (:263).  Three phases with global compactions between:
 //
-//  phase 1 (every candidate, 244 of the 600 Threefry blocks): walk the 10*(H+2)
+//  phase 0 (every candidate, 24 blocks): the goal; reject when no robot position can be
+//    3.0 away from it.
+//  phase 1 (the rest, 220 more blocks; 244 of 600 so far): walk the 10*(H+2)
 //    links of the `rng, rng1 = split(rng)` chain, draw only the goal (its 10 tries
 //    are all valid because nothing is placed yet, so the 10th wins) and the 10
 //    robot tries.  A layout can only succeed if its final robot position is >= 3.0
@@ -283,10 +285,39 @@ GX_D void draw_xy(uint32_t g0, uint32_t g1, float lox, float hix, float loy, flo
     y = uniform_f(v0, v1, loy, hiy);
 }
 
-__global__ __launch_bounds__(kSampleBlock) void sample_phase1_kernel(SampleParams sp,
+// workgroup-aggregated slot allocation in a compacted list: ONE returning atomic per 256-thread
+// workgroup (a single counter word sustains only ~88 returning atomics/us chip-wide, which at one
+// atomic per wave -- 15,625 of them -- would cost more than phase 0 itself).  Must be reached by
+// every thread of the workgroup.
+GX_D int alloc_slot(bool want, int* __restrict__ counter)
+{
+    __shared__ int wcnt[kSampleBlock / 64];
+    __shared__ int bbase;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(want);
+    if (lane == 0) wcnt[w] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int k = 0; k < kSampleBlock / 64; ++k) tot += wcnt[k];
+        bbase = tot ? atomicAdd(counter, tot) : 0;
+    }
+    __syncthreads();
+    int off = bbase;
+    for (int k = 0; k < w; ++k) off += wcnt[k];
+    const int slot = want ? off + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+    __syncthreads();
+    return slot;
+}
+
+// phase 0 (every candidate, 24 blocks): the goal.  If even the farthest corner of the robot's
+// placement rectangle is closer than 3.0 (with a safety margin for rounding) the candidate
+// cannot succeed, whatever the robot draws are (~22 % of the candidates).
+__global__ __launch_bounds__(kSampleBlock) void sample_phase0_kernel(SampleParams sp,
                                                                      uint8_t* __restrict__ ok,
-                                                                     int* __restrict__ n_surv,
-                                                                     uint32_t* __restrict__ surv)
+                                                                     int* __restrict__ n_surv0,
+                                                                     uint32_t* __restrict__ surv0)
 {
     const int tid = threadIdx.x;
     const int j = blockIdx.x * kSampleBlock + tid;
@@ -294,34 +325,55 @@ __global__ __launch_bounds__(kSampleBlock) void sample_phase1_kernel(SampleParam
     uint32_t r0, r1;
     split_at(sp.k0, sp.k1, (uint32_t)sp.M, (uint32_t)(live ? j : 0), r0, r1);
     uint32_t n0, n1, g0 = 0, g1 = 0;
-    // goal: 10 links, the draw of the last try is the goal
     for (int t = 0; t < 10; ++t) { split2(r0, r1, n0, n1, g0, g1); r0 = n0; r1 = n1; }
     float gx, gy;
     draw_xy(g0, g1, sp.lo_x[0], sp.hi_x[0], sp.lo_y[0], sp.hi_y[0], gx, gy);
-    const uint32_t s0 = r0, s1 = r1; // chain state after the goal
-    // hazards: links only
-    const int nh = 10 * (sp.nobj_total - 2);
-    for (int t = 0; t < nh; ++t) { split2(r0, r1, n0, n1, g0, g1); r0 = n0; r1 = n1; }
-    // robot tries
-    float rx[10], ry[10];
-    bool any_far = false;
-#pragma unroll
-    for (int t = 0; t < 10; ++t) {
-        split2(r0, r1, n0, n1, g0, g1); r0 = n0; r1 = n1;
-        draw_xy(g0, g1, sp.lo_x[2], sp.hi_x[2], sp.lo_y[2], sp.hi_y[2], rx[t], ry[t]);
-        if (!(dsq(rx[t], ry[t], gx, gy) < sp.min_rg_sq)) any_far = true;
-    }
-    const bool surv_me = live && any_far;
+    const float fx = fmaxf(fabsf(sp.lo_x[2] - gx), fabsf(sp.hi_x[2] - gx));
+    const float fy = fmaxf(fabsf(sp.lo_y[2] - gy), fabsf(sp.hi_y[2] - gy));
+    const bool feasible = !((fx * fx + fy * fy) * 1.0001f < sp.min_rg_sq);
     if (live) ok[j] = 0;
-    const unsigned long long m = __ballot(surv_me);
-    if (m != 0ull) {
-        const int lane = tid & 63;
-        const int leader = __ffsll((long long)m) - 1;
-        int base = 0;
-        if (lane == leader) base = atomicAdd(n_surv, __popcll(m));
-        base = __shfl(base, leader);
-        if (surv_me) {
-            uint32_t* rec = surv + (size_t)(base + __popcll(m & ((1ull << lane) - 1ull))) * kSurvWords;
+    const int slot = alloc_slot(live && feasible, n_surv0);
+    if (slot >= 0) {
+        uint4* rec = reinterpret_cast<uint4*>(surv0) + (size_t)slot * 2;
+        rec[0] = make_uint4((uint32_t)j, r0, r1, f2u(gx));
+        rec[1] = make_uint4(f2u(gy), 0u, 0u, 0u);
+    }
+}
+
+// phase 1 (goal-feasible candidates, 220 blocks): hazard links, the 10 robot tries
+__global__ __launch_bounds__(kSampleBlock) void sample_phase1_kernel(SampleParams sp,
+                                                                     const int* __restrict__ n_surv0,
+                                                                     const uint32_t* __restrict__ surv0,
+                                                                     int* __restrict__ n_surv,
+                                                                     uint32_t* __restrict__ surv)
+{
+    const int tid = threadIdx.x;
+    const int S0 = *n_surv0;
+    const int nh = 10 * (sp.nobj_total - 2);
+    // grid-stride with whole waves active until the last one (ballot-based allocation below)
+    for (int base_i = blockIdx.x * kSampleBlock; base_i < S0; base_i += gridDim.x * kSampleBlock) {
+        const int i = base_i + tid;
+        const bool live = i < S0;
+        const uint4* rin = reinterpret_cast<const uint4*>(surv0) + (size_t)(live ? i : 0) * 2;
+        const uint4 h0 = rin[0];
+        const uint4 h1 = rin[1];
+        const int j = (int)h0.x;
+        uint32_t r0 = h0.y, r1 = h0.z;
+        const float gx = u2f(h0.w), gy = u2f(h1.x);
+        const uint32_t s0 = r0, s1 = r1; // chain state after the goal
+        uint32_t n0, n1, g0 = 0, g1 = 0;
+        for (int t = 0; t < nh; ++t) { split2(r0, r1, n0, n1, g0, g1); r0 = n0; r1 = n1; }
+        float rx[10], ry[10];
+        bool any_far = false;
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {
+            split2(r0, r1, n0, n1, g0, g1); r0 = n0; r1 = n1;
+            draw_xy(g0, g1, sp.lo_x[2], sp.hi_x[2], sp.lo_y[2], sp.hi_y[2], rx[t], ry[t]);
+            if (!(dsq(rx[t], ry[t], gx, gy) < sp.min_rg_sq)) any_far = true;
+        }
+        const int slot = alloc_slot(live && any_far, n_surv);
+        if (slot >= 0) {
+            uint32_t* rec = surv + (size_t)slot * kSurvWords;
             rec[0] = (uint32_t)j; rec[1] = s0; rec[2] = s1; rec[3] = f2u(gx); rec[4] = f2u(gy);
 #pragma unroll
             for (int t = 0; t < 10; ++t) { rec[5 + 2 * t] = f2u(rx[t]); rec[6 + 2 * t] = f2u(ry[t]); }
@@ -941,9 +993,12 @@ void launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s)
     const int M = sp.M, W = (M + 63) / 64;
     const int grid = (M + kSampleBlock - 1) / kSampleBlock;
     const size_t lds = (size_t)sp.nobj_total * kSampleBlock * sizeof(float2);
-    (void)hipMemsetAsync(pl.n_surv, 0, sizeof(int), s);
-    hipLaunchKernelGGL(sample_phase1_kernel, dim3(grid), dim3(kSampleBlock), 0, s, sp, pl.cand_ok, pl.n_surv,
-                       pl.surv);
+    (void)hipMemsetAsync(pl.n_surv, 0, 2 * sizeof(int), s); // n_surv, n_surv0
+    hipLaunchKernelGGL(sample_phase0_kernel, dim3(grid), dim3(kSampleBlock), 0, s, sp, pl.cand_ok, pl.n_surv + 1,
+                       pl.surv0);
+    const int grid1 = grid < 3072 ? grid : 3072;
+    hipLaunchKernelGGL(sample_phase1_kernel, dim3(grid1), dim3(kSampleBlock), 0, s, sp, pl.n_surv + 1, pl.surv0,
+                       pl.n_surv, pl.surv);
     const int grid2 = grid < 1024 ? grid : 1024;
     hipLaunchKernelGGL(sample_phase2_kernel, dim3(grid2), dim3(kSampleBlock), lds, s, sp, pl.n_surv, pl.surv,
                        pl.cand_ok, pl.cand_xy);
