@@ -30,6 +30,7 @@ class GxConfig(C.Structure):
         ("observe_vel", C.c_int32), ("observe_acc", C.c_int32),
         ("n_candidates", C.c_int32), ("physics_steps", C.c_int32),
         ("robot_goal_min_dist", C.c_float), ("device", C.c_int32),
+        ("placements", C.POINTER(C.c_double)),
     ]
 
 

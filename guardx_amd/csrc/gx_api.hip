@@ -48,6 +48,7 @@ struct gx_engine {
     bool layout_pending;
     int device;
     int nq, nv, nu, na, ndyn; // robot.nq/nv/nu (world.py:435-438), action width, float4s of state
+    float4* haz_bounds;  // device copy of the per-hazard placement bounds (or null)
     int path_mode;       // 0 auto, 1 thread-per-env kernels, 2 lane-group kernels
     // double-buffered layout pools + side stream: the pool of the NEXT reset() is sampled
     // while the current epoch is being stepped (the key chain is data-independent)
@@ -188,13 +189,25 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     sp.M = cfg->n_candidates;
     sp.nobj_total = e->nobj_total;
     const double ko[3] = {cfg->goal_keepout, cfg->hazards_keepout, cfg->robot_keepout};
+    std::vector<float4> hb; // per-hazard rectangles when explicit placements are given
     for (int t = 0; t < 3; ++t) {
-        sp.lo_x[t] = (float)(cfg->extents[0] + ko[t]);
-        sp.lo_y[t] = (float)(cfg->extents[1] + ko[t]);
-        sp.hi_x[t] = (float)(cfg->extents[2] - ko[t]);
-        sp.hi_y[t] = (float)(cfg->extents[3] - ko[t]);
+        // object of this type whose rectangle seeds the per-type bounds: goal = 0, robot = last
+        const double* rc = cfg->extents;
+        if (cfg->placements && t == 0) rc = &cfg->placements[0];
+        if (cfg->placements && t == 2) rc = &cfg->placements[4 * (p.H + 1)];
+        sp.lo_x[t] = (float)(rc[0] + ko[t]);
+        sp.lo_y[t] = (float)(rc[1] + ko[t]);
+        sp.hi_x[t] = (float)(rc[2] - ko[t]);
+        sp.hi_y[t] = (float)(rc[3] - ko[t]);
         for (int q = 0; q < 3; ++q) sp.thr[q][t] = (float)(ko[q] + cfg->placements_margin + ko[t]);
     }
+    sp.haz_bounds = nullptr;
+    if (cfg->placements)
+        for (int hz = 0; hz < p.H; ++hz) {
+            const double* rc = &cfg->placements[4 * (1 + hz)];
+            hb.push_back(make_float4((float)(rc[0] + ko[1]), (float)(rc[2] - ko[1]), (float)(rc[1] + ko[1]),
+                                     (float)(rc[3] - ko[1])));
+        }
     sp.min_rg = cfg->robot_goal_min_dist;
     for (int q = 0; q < 3; ++q)
         for (int t = 0; t < 3; ++t) sp.thr_sq[q][t] = sqrt_cutoff(sp.thr[q][t]);
@@ -208,6 +221,8 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     e->layout_pending = false;
     e->h_layout_size = nullptr;
     e->path_mode = 0;
+    e->haz_bounds = nullptr;
+    e->cfg.placements = nullptr; // not retained (folded into SampleParams above)
     e->pf_valid = false;
     e->prefetch_steps = cfg->num_steps;
     e->side = nullptr;
@@ -226,6 +241,11 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     alloc((void**)&e->b.dyn, sizeof(float4) * e->ndyn * p.Npad);
     alloc((void**)&e->b.obj, sizeof(float4) * (size_t)p.P * p.Npad);
     alloc((void**)&e->b.hist, sizeof(float4) * p.Npad);
+    if (!hb.empty()) {
+        alloc((void**)&e->haz_bounds, sizeof(float4) * hb.size());
+        if (err == hipSuccess) err = hipMemcpy(e->haz_bounds, hb.data(), sizeof(float4) * hb.size(), hipMemcpyHostToDevice);
+        sp.haz_bounds = e->haz_bounds;
+    }
     for (int i = 0; i < 2; ++i) {
         Pool& pl = e->pools[i];
         alloc((void**)&pl.cand_ok, M);
@@ -271,7 +291,7 @@ extern "C" gx_status gx_destroy(gx_engine* e)
     if (!e) return GX_OK;
     DeviceGuard guard(e->device);
     (void)hipDeviceSynchronize();
-    void* bufs[] = {e->b.dyn, e->b.obj, e->b.hist};
+    void* bufs[] = {e->b.dyn, e->b.obj, e->b.hist, e->haz_bounds};
     for (void* q : bufs)
         if (q) (void)hipFree(q);
     for (int i = 0; i < 2; ++i) {

@@ -10,7 +10,8 @@ namespace gx {
 struct SampleParams {
     int M;          // candidates (engine.py:263)
     int nobj_total; // goal + hazards + robot
-    float lo_x[3], hi_x[3], lo_y[3], hi_y[3];
+    float lo_x[3], hi_x[3], lo_y[3], hi_y[3]; // by type (hazards: default rectangle)
+    const float4* haz_bounds;                  // null, or per-hazard (lox, hix, loy, hiy)
     float thr[3][3]; // thr[placed type][new type] = f32(keepout_p + margin + keepout_new)
     float min_rg;    // engine.py:571
     float thr_sq[3][3]; // exact cutoffs: sqrtf(d2) < thr  <=>  d2 < thr_sq

@@ -400,13 +400,15 @@ __global__ __launch_bounds__(kSampleBlock) void sample_phase2_kernel(SampleParam
         placed[tid] = make_float2(gx, gy);
         bool success = true;
         for (int o = 1; o < nobj - 1; ++o) { // hazards
+            const float4 hb = sp.haz_bounds ? sp.haz_bounds[o - 1]
+                                            : make_float4(sp.lo_x[1], sp.hi_x[1], sp.lo_y[1], sp.hi_y[1]);
             bool conflicted = true;
             float px = -__builtin_inff(), py = -__builtin_inff();
             for (int t = 0; t < 10; ++t) {
                 uint32_t n0, n1, g0, g1;
                 split2(r0, r1, n0, n1, g0, g1); r0 = n0; r1 = n1;
                 float cx, cy;
-                draw_xy(g0, g1, sp.lo_x[1], sp.hi_x[1], sp.lo_y[1], sp.hi_y[1], cx, cy);
+                draw_xy(g0, g1, hb.x, hb.y, hb.z, hb.w, cx, cy);
                 bool flag = true;
                 for (int q = 0; q < o; ++q) { // placement_is_valid :549-555
                     const float2 pq = placed[q * kSampleBlock + tid];

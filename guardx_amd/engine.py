@@ -211,11 +211,21 @@ class Engine:
         c.placements_margin = float(self.placements_margin)
         for i in range(4):
             c.extents[i] = float(self.placements_extents[i])
-        for name, (rects, _) in self.placements.items():
-            if rects is not None:
-                raise NotImplementedError(
-                    f"explicit placements/locations for {name!r} (draw_placement's multi-rectangle "
-                    "branch uses the undefined self.rs in the reference, engine.py:616)")
+        # explicit *_placements / *_locations (engine.py:507-531): one rectangle per object
+        self._placements_arr = None
+        if any(rects is not None for rects, _ in self.placements.values()):
+            rows = []
+            for name, (rects, _) in self.placements.items():
+                if rects is None:
+                    rows.append([float(v) for v in self.placements_extents])
+                elif len(rects) == 1:
+                    rows.append([float(v) for v in rects[0]])
+                else:
+                    # draw_placement's multi-rectangle branch calls self.rs.choice (engine.py:616)
+                    raise AttributeError("'Engine' object has no attribute 'rs'")
+            arr = (C.c_double * (4 * len(rows)))(*[v for r in rows for v in r])
+            self._placements_arr = arr          # keep alive until gx_create returns
+            c.placements = C.cast(arr, C.POINTER(C.c_double))
         c.observe_goal_lidar = int(bool(self.observe_goal_lidar))
         c.observe_goal_comp = int(bool(self.observe_goal_comp))
         c.observe_hazards = int(bool(self.observe_hazards))

@@ -72,6 +72,9 @@ typedef struct gx_config {
     int32_t physics_steps;      /* engine.py:202 */
     float robot_goal_min_dist;  /* engine.py:571, 3.0 */
     int32_t device;             /* HIP device ordinal ('device_id' engine.py:100) */
+    const double* placements;   /* NULL, or (hazards_num+2) x 4 doubles: the placement rectangle
+                                 * (xmin,ymin,xmax,ymax) of goal, hazard0.., robot BEFORE the keepout
+                                 * shrink -- *_placements / *_locations, engine.py:507-531 */
 } gx_config;
 
 typedef struct gx_engine gx_engine;

@@ -265,6 +265,12 @@ int gxo_create(const gxo_config* cfg, gxo_env** out)
     if (cfg->env_offset < 0 || cfg->env_offset + cfg->env_num > cfg->env_total) return GXO_ERR_ARG;
     gxo_env* e = (gxo_env*)calloc(1, sizeof(gxo_env));
     e->cfg = *cfg;
+    if (cfg->placements) { /* own copy: the caller's array need not outlive the call */
+        const size_t n = (size_t)(cfg->hazards_num + 2) * 4;
+        double* pc = (double*)malloc(n * sizeof(double));
+        memcpy(pc, cfg->placements, n * sizeof(double));
+        e->cfg.placements = pc;
+    }
     e->N = cfg->env_num;
     e->H = cfg->hazards_num;
     e->NOBJ = 1 + e->H;
@@ -310,6 +316,7 @@ void gxo_destroy(gxo_env* e)
     free(e->qpos); free(e->qvel); free(e->pose0); free(e->pose1); free(e->objs);
     free(e->done0); free(e->done1); free(e->done2); free(e->steps); free(e->obs);
     free(e->pool);
+    free((void*)e->cfg.placements);
     free(e);
 }
 
@@ -332,9 +339,11 @@ static int sample_layout(const gxo_config* c, const uint32_t key[2], float* xy)
     int success = 1;
     for (int o = 0; o < nobj; ++o) {
         double k = obj_keepout(c, o, nobj);
-        /* constrain_placement  engine.py:574-577 (python floats -> f32 bounds) */
-        float xmin = (float)(c->extents[0] + k), ymin = (float)(c->extents[1] + k);
-        float xmax = (float)(c->extents[2] - k), ymax = (float)(c->extents[3] - k);
+        /* constrain_placement  engine.py:574-577 (python floats -> f32 bounds); the rectangle is
+         * placements_extents unless the object has its own placement / location (:600-612) */
+        const double* rc = c->placements ? &c->placements[4 * o] : c->extents;
+        float xmin = (float)(rc[0] + k), ymin = (float)(rc[1] + k);
+        float xmax = (float)(rc[2] - k), ymax = (float)(rc[3] - k);
         int conflicted = 1;
         float px = -INFINITY, py = -INFINITY;
         for (int t = 0; t < 10; ++t) { /* engine.py:562 */

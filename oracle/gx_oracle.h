@@ -59,6 +59,7 @@ typedef struct gxo_config {
     int32_t physics_steps;      /* engine.py:202 */
     float robot_goal_min_dist;  /* engine.py:571  3.0 */
     int32_t reserved;
+    const double* placements;   /* NULL or (H+2) x 4 doubles, engine.py:507-531 */
 } gxo_config;
 
 typedef struct gxo_env gxo_env;

@@ -24,6 +24,8 @@ DEFAULTS = {
     'goal_keepout': 0.5, 'goal_size': 0.5, 'reward_distance': 1.0,
     'hazards_num': 8, 'hazards_keepout': 0.4, 'hazards_size': 0.3,
     'physics_steps_per_control_step': 1,
+    'robot_placements': None, 'robot_locations': [], 'goal_placements': None, 'goal_locations': [],
+    'hazards_placements': None, 'hazards_locations': [],
 }
 
 
@@ -44,6 +46,7 @@ class Config(C.Structure):
         ("observe_vel", C.c_int32), ("observe_acc", C.c_int32),
         ("n_candidates", C.c_int32), ("physics_steps", C.c_int32),
         ("robot_goal_min_dist", C.c_float), ("reserved", C.c_int32),
+        ("placements", C.POINTER(C.c_double)),
     ]
 
 
@@ -134,6 +137,25 @@ def make_config(config, n_candidates=1_000_000, env_total=None, env_offset=0):
     c.n_candidates = int(n_candidates)
     c.physics_steps = int(cfg['physics_steps_per_control_step'])
     c.robot_goal_min_dist = 3.0
+    # engine.py:507-531: per-object rectangle from *_locations (a +-keepout box around the point,
+    # which the keepout shrink collapses back onto the point) or a single *_placements rectangle
+    rows, custom = [], False
+    for kind, count in (('goal', 1), ('hazards', c.hazards_num), ('robot', 1)):
+        locs, rects, ko = cfg[kind + '_locations'], cfg[kind + '_placements'], cfg[kind + '_keepout']
+        for i in range(count):
+            if i < len(locs):
+                x, y = locs[i]
+                k = ko + 1e-9
+                rows.append((x - k, y - k, x + k, y + k)); custom = True
+            elif rects is not None:
+                assert len(rects) == 1
+                rows.append(tuple(rects[0])); custom = True
+            else:
+                rows.append(tuple(cfg['placements_extents']))
+    if custom:
+        arr = (C.c_double * (4 * len(rows)))(*[float(v) for r in rows for v in r])
+        c._keep = arr
+        c.placements = C.cast(arr, C.POINTER(C.c_double))
     return c
 
 
