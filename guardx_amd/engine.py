@@ -37,6 +37,60 @@ _ROBOTS = {
 }
 
 
+class _LazyObsDict(dict):
+    """info['obs']: per-key views of the flat observation (engine.py:693-695), created on first
+    access -- the learners never read them (only render() does, engine.py:1054)."""
+
+    def __init__(self, obs, slices, qacc):
+        super().__init__()
+        self._src = (obs, slices, qacc)
+
+    def _fill(self):
+        if self._src is not None:
+            obs, slices, qacc = self._src
+            self._src = None
+            for k, s in slices.items():
+                dict.__setitem__(self, k, obs[:, s])
+            if qacc is not None:
+                dict.__setitem__(self, 'qacc', qacc)
+
+    def __getitem__(self, k):
+        self._fill()
+        return dict.__getitem__(self, k)
+
+    def __iter__(self):
+        self._fill()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._fill()
+        return dict.__len__(self)
+
+    def __contains__(self, k):
+        self._fill()
+        return dict.__contains__(self, k)
+
+    def keys(self):
+        self._fill()
+        return dict.keys(self)
+
+    def items(self):
+        self._fill()
+        return dict.items(self)
+
+    def values(self):
+        self._fill()
+        return dict.values(self)
+
+    def get(self, k, default=None):
+        self._fill()
+        return dict.get(self, k, default)
+
+    def __repr__(self):
+        self._fill()
+        return dict.__repr__(self)
+
+
 class Engine:
     """GUARD `Engine`: `env_num` independent Goal-task arenas stepped in lock-step.
 
@@ -135,6 +189,7 @@ class Engine:
         self.build_observation_space()
         assert self.obs_flat_size == self._lib.gx_obs_dim(self._h)
 
+        self._act_shape = torch.Size((int(self.env_num), act_dim))
         self._obs = None
         self._reward = None
         self._done = None
@@ -275,7 +330,7 @@ class Engine:
     # gym-style interface
     # ------------------------------------------------------------------
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return C.c_void_p(torch._C._cuda_getCurrentRawStream(self.device.index))
 
     def _new(self, *shape):
         return torch.empty(shape, dtype=torch.float32, device=self.device)
@@ -306,10 +361,8 @@ class Engine:
                                         cost.data_ptr(), done.data_ptr(),
                                         qacc.data_ptr() if qacc is not None else None,
                                         self._stream()))
-        info_obs = {k: obs[:, s] for k, s in self._obs_slices.items()}
-        if qacc is not None and self.observe_qacc:
-            info_obs['qacc'] = qacc
-        info = {'cost': cost, 'obs': info_obs}
+        info = {'cost': cost,
+                'obs': _LazyObsDict(obs, self._obs_slices, qacc if self.observe_qacc else None)}
         self._obs, self._reward, self._done, self._info = obs, reward, done, info
         return obs, reward, done, info
 
@@ -355,14 +408,14 @@ class Engine:
 
     def _as_action(self, action):
         a = action if torch.is_tensor(action) else torch.as_tensor(action)
+        if a.shape != self._act_shape:
+            raise ValueError(f"action shape {tuple(a.shape)} != {tuple(self._act_shape)}")
         if a.device != self.device or a.dtype != torch.float32:
             a = a.to(device=self.device, dtype=torch.float32)
-        a = a.detach()
+        if a.requires_grad:
+            a = a.detach()
         if not a.is_contiguous():
             a = a.contiguous()
-        if tuple(a.shape) != (self.env_num, self.action_space.shape[0]):
-            raise ValueError(f"action shape {tuple(a.shape)} != "
-                             f"{(self.env_num, self.action_space.shape[0])}")
         return a
 
     # ------------------------------------------------------------------
