@@ -28,6 +28,20 @@ def test_split_known_answer(oracle):
     np.testing.assert_array_equal(onp.split(np.array([0, 0], np.uint32), 2), want)
 
 
+def test_uniform_known_answers_via_published_normals(oracle):
+    """jax.random.normal(key, (1,)) = sqrt(2) * erfinv(uniform(key, (1,), minval=nextafter(-1, 0), maxval=1))
+    [jax/_src/random.py _normal_real].  Published values (JAX docs, "Sharp bits" / PRNG design):
+        random.normal(PRNGKey(0), (1,))            -> -0.20584226
+        key, subkey = split(PRNGKey(0)); random.normal(subkey, (1,)) -> -1.2515389
+    They pin the bits->float mapping and the size-1 counter layout of the `uniform` restatement."""
+    from scipy.special import erfinv
+    lo, hi = float(np.nextafter(np.float32(-1), np.float32(0))), 1.0
+    for key, want in (((0, 0), -0.20584226), (tuple(oracle.split((0, 0), 2)[1]), -1.2515389)):
+        for u in (oracle.uniform(key, lo, hi), float(onp.uniform(np.array(key, np.uint32), lo, hi))):
+            got = np.sqrt(2.0) * erfinv(np.float64(u))
+            assert abs(got - want) < 3e-7, (key, u, got, want)
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 10, 1001])
 def test_split_c_vs_numpy(oracle, n):
     rng = np.random.default_rng(n)

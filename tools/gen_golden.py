@@ -49,3 +49,6 @@ if __name__ == "__main__":
     episode("goal_point_8hazards_n4_seed0", task_config(4, seed=0, num_steps=200), 20000, 60, 0)
     # a denser case that exercises done / reset_done / timeout
     episode("goal_point_8hazards_n24_seed5", task_config(24, seed=5, num_steps=40, goal_size=1.2), 30000, 60, 1)
+    # config 2 of BASELINE.json (articulated dynamics + joint-limit rows), small
+    episode("goal_swimmer_8hazards_n12_seed2",
+            task_config(12, seed=2, num_steps=40, goal_size=1.0, robot_base='xmls/swimmer.xml'), 30000, 60, 2)
