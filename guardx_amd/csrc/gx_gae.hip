@@ -50,7 +50,7 @@ __global__ void finish_path_kernel(int N, int T, int ptr, const float* __restric
                                    const float* __restrict__ val, const float* __restrict__ last_val,
                                    const float* __restrict__ done, int* __restrict__ path_start,
                                    float gamma, double dg, double dgl, float* __restrict__ adv,
-                                   float* __restrict__ ret)
+                                   float* __restrict__ ret, int advance)
 {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= N) return;
@@ -69,12 +69,12 @@ __global__ void finish_path_kernel(int N, int T, int ptr, const float* __restric
         ret[base + t] = (float)r;
         vnext = vt;
     }
-    path_start[env] = ptr; // trpo.py:119
+    if (advance) path_start[env] = ptr; // trpo.py:119
 }
 
 // get(): per-env advantage normalisation (x - mean) / std, population std, no epsilon
 // (trpo.py:131-135 via mpi_statistics_scalar).  One wave per env.
-__global__ void adv_normalize_kernel(int N, int T, float* __restrict__ adv)
+__global__ void adv_normalize_kernel(int N, int T, float* __restrict__ adv, int scale)
 {
     const int env = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -88,7 +88,8 @@ __global__ void adv_normalize_kernel(int N, int T, float* __restrict__ adv)
     for (int t = lane; t < T; t += 64) { const float d = row[t] - mean; q += d * d; }
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
     const float sd = sqrtf(q / (float)T);
-    for (int t = lane; t < T; t += 64) row[t] = (row[t] - mean) / sd;
+    if (scale) { for (int t = lane; t < T; t += 64) row[t] = (row[t] - mean) / sd; }
+    else { for (int t = lane; t < T; t += 64) row[t] = row[t] - mean; } // cpo.py:158-162: centred, not scaled
 }
 
 } // namespace
@@ -115,7 +116,7 @@ extern "C" gx_status gx_buffer_store(int32_t env_num, int32_t max_ep_len, int32_
 extern "C" gx_status gx_gae_finish_path(int32_t env_num, int32_t max_ep_len, int32_t ptr, const float* d_rew_buf,
                                         const float* d_val_buf, const float* d_last_val, const float* d_done,
                                         int32_t* d_path_start, double gamma, double lam, float* d_adv_buf,
-                                        float* d_ret_buf, void* stream)
+                                        float* d_ret_buf, int32_t advance_path_start, void* stream)
 {
     if (env_num < 1 || max_ep_len < 1 || ptr < 0 || ptr > max_ep_len)
         return gx_fail_msg(GX_ERR_ARG, "gx_gae_finish_path: bad sizes");
@@ -125,14 +126,15 @@ extern "C" gx_status gx_gae_finish_path(int32_t env_num, int32_t max_ep_len, int
     // fp32 delta uses gamma rounded to fp32 (weak-scalar promotion)
     hipLaunchKernelGGL(finish_path_kernel, dim3((env_num + 63) / 64), dim3(64), 0, (hipStream_t)stream, env_num,
                        max_ep_len, ptr, d_rew_buf, d_val_buf, d_last_val, d_done, d_path_start, (float)gamma, gamma,
-                       gamma * lam, d_adv_buf, d_ret_buf);
+                       gamma * lam, d_adv_buf, d_ret_buf, advance_path_start);
     return hipGetLastError() == hipSuccess ? GX_OK : gx_fail_msg(GX_ERR_HIP, "gx_gae_finish_path launch failed");
 }
 
-extern "C" gx_status gx_adv_normalize(int32_t env_num, int32_t max_ep_len, float* d_adv_buf, void* stream)
+extern "C" gx_status gx_adv_normalize(int32_t env_num, int32_t max_ep_len, float* d_adv_buf, int32_t scale,
+                                      void* stream)
 {
     if (env_num < 1 || max_ep_len < 1 || !d_adv_buf) return gx_fail_msg(GX_ERR_ARG, "gx_adv_normalize: bad argument");
     hipLaunchKernelGGL(adv_normalize_kernel, dim3((env_num + 3) / 4), dim3(256), 0, (hipStream_t)stream, env_num,
-                       max_ep_len, d_adv_buf);
+                       max_ep_len, d_adv_buf, scale);
     return hipGetLastError() == hipSuccess ? GX_OK : gx_fail_msg(GX_ERR_HIP, "gx_adv_normalize launch failed");
 }

@@ -70,7 +70,7 @@ class DeviceRolloutBuffer:
         _native.check(self._lib.gx_gae_finish_path(
             N, self.max_ep_len, self.ptr, self.rew_buf.data_ptr(), self.val_buf.data_ptr(),
             last_val.data_ptr(), dptr, self.path_start_idx.data_ptr(), self.gamma, self.lam,
-            self.adv_buf.data_ptr(), self.ret_buf.data_ptr(), self._stream()))
+            self.adv_buf.data_ptr(), self.ret_buf.data_ptr(), 1, self._stream()))
 
     def get(self):
         """trpo.py:121-146: per-env normalised advantages, flattened views of every field."""
@@ -78,8 +78,51 @@ class DeviceRolloutBuffer:
         self.ptr = 0
         self.path_start_idx.zero_()
         N, T = self.env_num, self.max_ep_len
-        _native.check(self._lib.gx_adv_normalize(N, T, self.adv_buf.data_ptr(), self._stream()))
+        _native.check(self._lib.gx_adv_normalize(N, T, self.adv_buf.data_ptr(), 1, self._stream()))
         return dict(obs=self.obs_buf.view(N * T, -1), act=self.act_buf.view(N * T, -1),
                     ret=self.ret_buf.view(N * T), adv=self.adv_buf.view(N * T),
                     logp=self.logp_buf.view(N * T), mu=self.mu_buf.view(N * T, -1),
                     logstd=self.logstd_buf.view(N * T, -1))
+
+
+class DeviceCostRolloutBuffer(DeviceRolloutBuffer):
+    """`CPOBufferX` (safe_rl_libX/cpo/cpo.py:22-175): the TRPO buffer plus a cost channel
+    (`cost_buf`, `cost_val_buf` -> `adc_buf`, `cost_ret_buf`); the cost advantage is centred but
+    not scaled in `get()` (cpo.py:158-162)."""
+
+    def __init__(self, env_num, max_ep_len, obs_dim, act_dim, gamma=0.99, lam=0.95, device=None):
+        super().__init__(env_num, max_ep_len, obs_dim, act_dim, gamma, lam, device)
+        z = lambda: torch.zeros(self.env_num, self.max_ep_len, dtype=torch.float32, device=self.device)  # noqa: E731
+        self.cost_buf, self.cost_ret_buf, self.cost_val_buf, self.adc_buf = z(), z(), z(), z()
+
+    def store(self, obs, act, rew, val, logp, cost, cost_val, mu, logstd):   # cpo.py:51-69
+        p = self.ptr
+        super().store(obs, act, rew, val, logp, mu, logstd)
+        self.cost_buf[:, p] = cost.reshape(self.env_num)
+        self.cost_val_buf[:, p] = cost_val.reshape(self.env_num)
+
+    def finish_path(self, last_val=None, last_cost_val=None, done=None):     # cpo.py:71-140
+        N = self.env_num
+        zeros = lambda: torch.zeros(N, device=self.device)   # noqa: E731
+        last_val = self._f32(torch.as_tensor(zeros() if last_val is None else last_val, device=self.device).reshape(N), (N,))
+        last_cv = self._f32(torch.as_tensor(zeros() if last_cost_val is None else last_cost_val,
+                                            device=self.device).reshape(N), (N,))
+        dptr = None
+        if done is not None:
+            done = self._f32(torch.as_tensor(done, device=self.device).reshape(N), (N,))
+            dptr = done.data_ptr()
+        for rew, val, lv, adv, ret, advance in (
+                (self.cost_buf, self.cost_val_buf, last_cv, self.adc_buf, self.cost_ret_buf, 0),
+                (self.rew_buf, self.val_buf, last_val, self.adv_buf, self.ret_buf, 1)):
+            _native.check(self._lib.gx_gae_finish_path(
+                N, self.max_ep_len, self.ptr, rew.data_ptr(), val.data_ptr(), lv.data_ptr(), dptr,
+                self.path_start_idx.data_ptr(), self.gamma, self.lam, adv.data_ptr(), ret.data_ptr(),
+                advance, self._stream()))
+
+    def get(self):                                                           # cpo.py:142-175
+        data = super().get()
+        N, T = self.env_num, self.max_ep_len
+        _native.check(self._lib.gx_adv_normalize(N, T, self.adc_buf.data_ptr(), 0, self._stream()))
+        data['cost_ret'] = self.cost_ret_buf.view(N * T)
+        data['adc'] = self.adc_buf.view(N * T)
+        return data

@@ -146,7 +146,9 @@ gx_status gx_set_path(gx_engine* e, int32_t mode);
  *   gx_gae_finish_path  <- TRPOBufferX.finish_path  trpo.py:66-119  (GAE-lambda + rewards-to-go for
  *                          the envs whose d_done == 1, all envs when d_done is NULL; d_path_start is
  *                          advanced to ptr for them; no host sync, no per-env Python loop)
- *   gx_adv_normalize    <- the per-env advantage normalisation in TRPOBufferX.get  trpo.py:131-135 */
+ *   gx_adv_normalize    <- the per-env advantage normalisation in TRPOBufferX.get  trpo.py:131-135
+ * CPOBufferX (safe_rl_libX/cpo/cpo.py:22-175) is the same with a second (cost, cost_val) channel:
+ * call gx_gae_finish_path twice, advancing d_path_start only on the second call. */
 gx_status gx_buffer_store(int32_t env_num, int32_t max_ep_len, int32_t ptr, int32_t obs_dim,
                           int32_t act_dim, const float* d_obs, const float* d_act, const float* d_rew,
                           const float* d_val, const float* d_logp, const float* d_mu,
@@ -156,8 +158,11 @@ gx_status gx_buffer_store(int32_t env_num, int32_t max_ep_len, int32_t ptr, int3
 gx_status gx_gae_finish_path(int32_t env_num, int32_t max_ep_len, int32_t ptr, const float* d_rew_buf,
                              const float* d_val_buf, const float* d_last_val, const float* d_done,
                              int32_t* d_path_start, double gamma, double lam, float* d_adv_buf,
-                             float* d_ret_buf, void* stream);
-gx_status gx_adv_normalize(int32_t env_num, int32_t max_ep_len, float* d_adv_buf, void* stream);
+                             float* d_ret_buf, int32_t advance_path_start, void* stream);
+/* scale != 0: (x - mean) / std (reward advantage); scale == 0: x - mean (CPO cost advantage,
+ * safe_rl_libX/cpo/cpo.py:158-162) */
+gx_status gx_adv_normalize(int32_t env_num, int32_t max_ep_len, float* d_adv_buf, int32_t scale,
+                           void* stream);
 
 /* Device-math probe (tests): s,c = sincos(x); at2 = atan2(y,x); ex = exp(x). */
 gx_status gx_math_probe(int32_t n, const float* d_x, const float* d_y, float* d_s,

@@ -64,3 +64,41 @@ def test_device_buffer_matches_trpo_buffer(N, T, p_done):
         np.testing.assert_allclose(dg[k].cpu().numpy(), do[k], rtol=1e-6, atol=1e-6, err_msg=k)
     np.testing.assert_allclose(dg['adv'].cpu().numpy(), do['adv'], rtol=2e-5, atol=2e-5)   # fp32 mean/std order
     assert G.ptr == 0 and int(G.path_start_idx.abs().sum()) == 0
+
+
+@pytest.mark.gpu
+def test_device_cost_buffer_matches_cpo_semantics():
+    """CPOBufferX = TRPO buffer + (cost, cost_val) channel through the same GAE; cost advantage
+    centred, not scaled (cpo.py:22-175)."""
+    import torch
+    from guardx_amd.rollout_buffer import DeviceCostRolloutBuffer
+    N, T, D, A = 64, 40, 43, 2
+    rng = np.random.default_rng(0)
+    G = DeviceCostRolloutBuffer(N, T, (D,), (A,), device='cuda')
+    Or, Oc = TRPOBufferNP(N, T, D, A), TRPOBufferNP(N, T, D, A)     # reward channel, cost channel
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).cuda()   # noqa: E731
+    for t in range(T):
+        obs, act = rng.normal(size=(N, D)).astype(np.float32), rng.normal(size=(N, A)).astype(np.float32)
+        rew, val, logp, cost, cval = (rng.normal(size=N).astype(np.float32) for _ in range(5))
+        mu, ls = rng.normal(size=(N, A)).astype(np.float32), rng.normal(size=(N, A)).astype(np.float32)
+        G.store(dev(obs), dev(act), dev(rew), dev(val), dev(logp), dev(cost), dev(cval), dev(mu), dev(ls))
+        Or.store(obs, act, rew, val, logp, mu, ls)
+        Oc.store(obs, act, cost, cval, logp, mu, ls)
+        done = (rng.random(N) < 0.1).astype(np.float32)
+        if t + 1 == T:
+            G.finish_path(torch.zeros(N, device='cuda'), torch.zeros(N, device='cuda'), torch.ones(N, device='cuda'))
+            Or.finish_path(np.zeros(N), np.ones(N)); Oc.finish_path(np.zeros(N), np.ones(N))
+        elif done.any():
+            v, cv = rng.normal(size=N).astype(np.float32), rng.normal(size=N).astype(np.float32)
+            v[done == 1] = 0; cv[done == 1] = 0
+            G.finish_path(dev(v), dev(cv), dev(done))
+            Or.finish_path(v, done); Oc.finish_path(cv, done)
+    np.testing.assert_allclose(G.adc_buf.cpu().numpy(), Oc.adv_buf, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(G.cost_ret_buf.cpu().numpy(), Oc.ret_buf, rtol=1e-6, atol=1e-6)
+    adc_raw = Oc.adv_buf.copy()
+    d = G.get()
+    ro = Or.get()
+    np.testing.assert_allclose(d['adv'].cpu().numpy(), ro['adv'], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(d['adc'].cpu().numpy().reshape(N, T), adc_raw - adc_raw.mean(1, keepdims=True),
+                               rtol=2e-5, atol=2e-5)
+    assert set(d) == {'obs', 'act', 'ret', 'adv', 'cost_ret', 'adc', 'logp', 'mu', 'logstd'}
