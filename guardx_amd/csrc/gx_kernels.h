@@ -49,8 +49,7 @@ void launch_reset_apply(const Params& p, const DevBuffers& b, int nobj_total, ui
 void launch_reset_done(const Params& p, const DevBuffers& b, int nobj_total, uint32_t k10,
                        uint32_t k11, uint32_t k20, uint32_t k21, const float* obs_in,
                        float* obs_out, hipStream_t s);
-// lane-group persistent rollout (small batches); RolloutArgs is defined in gx_kernels.hip's
-// public mirror below
+// lane-group persistent rollout (small batches): arguments of one launch
 struct RolloutArgs {
     int T, do_reset, nobj_total, hist0;
     const float2* act;
