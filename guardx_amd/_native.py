@@ -34,6 +34,12 @@ class GxConfig(C.Structure):
     ]
 
 
+class GxPolicy(C.Structure):
+    """Mirror of `struct gx_policy`."""
+    _fields_ = [("struct_size", C.c_int32), ("hidden", C.c_int32), ("d_params", C.c_void_p),
+                ("seed", C.c_uint32 * 2)]
+
+
 # every symbol include/guardx.h declares: name -> (restype, argtypes)
 _FP = C.c_void_p  # device pointers travel as integers
 _HFP = C.POINTER(C.c_float)
@@ -52,6 +58,8 @@ SYMBOLS = {
     "gx_step": (C.c_int, [C.c_void_p, _FP, _FP, _FP, _FP, _FP, _FP, C.c_void_p]),
     "gx_reset_done": (C.c_int, [C.c_void_p, _FP, _FP, C.c_void_p]),
     "gx_rollout": (C.c_int, [C.c_void_p, C.c_int32, _FP, _FP, _FP, _FP, _FP, C.c_void_p]),
+    "gx_rollout_policy": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(GxPolicy)] + [_FP] * 12 + [C.c_void_p]),
+    "gx_math_probe2": (C.c_int, [C.c_int32, _FP, _FP, _FP, C.c_void_p]),
     "gx_get_state": (C.c_int, [C.c_void_p] + [_HFP] * 8 + [_U32P, _I32P]),
     "gx_set_state": (C.c_int, [C.c_void_p] + [_HFP] * 8 + [_U32P, _I32P]),
     "gx_get_pool": (C.c_int, [C.c_void_p, _HFP, C.c_int32, _I32P]),

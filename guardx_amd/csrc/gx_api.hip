@@ -49,6 +49,7 @@ struct gx_engine {
     int device;
     int nq, nv, nu, na, ndyn; // robot.nq/nv/nu (world.py:435-438), action width, float4s of state
     float4* haz_bounds;  // device copy of the per-hazard placement bounds (or null)
+    uint32_t policy_steps; // ac.step() calls made through gx_rollout_policy (noise counter)
     int path_mode;       // 0 auto, 1 thread-per-env kernels, 2 lane-group kernels
     // double-buffered layout pools + side stream: the pool of the NEXT reset() is sampled
     // while the current epoch is being stepped (the key chain is data-independent)
@@ -63,7 +64,6 @@ struct gx_engine {
     // per-step layout keys for the fused rollout: ring of pinned staging + device buffers
     static const int kKeyRing = 4;
     uint4* h_keys[kKeyRing];
-    uint4* d_keys[kKeyRing];
     int keys_cap[kKeyRing];
     hipEvent_t keys_ev[kKeyRing];
     int keys_next;
@@ -221,6 +221,7 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     e->layout_pending = false;
     e->h_layout_size = nullptr;
     e->path_mode = 0;
+    e->policy_steps = 0;
     e->haz_bounds = nullptr;
     e->cfg.placements = nullptr; // not retained (folded into SampleParams above)
     e->pf_valid = false;
@@ -229,7 +230,7 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     memset(e->pools, 0, sizeof(e->pools));
     for (int i = 0; i < 2; ++i) { e->pool_ready[i] = nullptr; e->pool_free[i] = nullptr; }
     e->keys_next = 0;
-    for (int i = 0; i < gx_engine::kKeyRing; ++i) { e->h_keys[i] = nullptr; e->d_keys[i] = nullptr; e->keys_cap[i] = 0; e->keys_ev[i] = nullptr; }
+    for (int i = 0; i < gx_engine::kKeyRing; ++i) { e->h_keys[i] = nullptr; e->keys_cap[i] = 0; e->keys_ev[i] = nullptr; }
     memset(&e->b, 0, sizeof(e->b));
 
     const size_t M = (size_t)sp.M, W = (M + 63) / 64;
@@ -305,7 +306,6 @@ extern "C" gx_status gx_destroy(gx_engine* e)
     if (e->side) (void)hipStreamDestroy(e->side);
     for (int i = 0; i < gx_engine::kKeyRing; ++i) {
         if (e->h_keys[i]) (void)hipHostFree(e->h_keys[i]);
-        if (e->d_keys[i]) (void)hipFree(e->d_keys[i]);
         if (e->keys_ev[i]) (void)hipEventDestroy(e->keys_ev[i]);
     }
     if (e->h_layout_size) (void)hipHostFree(e->h_layout_size);
@@ -446,6 +446,47 @@ extern "C" gx_status gx_reset_done(gx_engine* e, const float* d_obs_in, float* d
     return GX_OK;
 }
 
+// Per-step layout keys of a T-step fused rollout, staged in pinned device-visible host memory:
+// step t advances the key (engine.py:431), the reset_done that follows draws randint with that
+// key (engine.py:447,500).  Returns the slot; the caller records keys_ev[slot] after its launch.
+static gx_status stage_rollout_keys(gx_engine* e, int32_t T, int& slot_out, uint32_t& k0_out, uint32_t& k1_out)
+{
+    const int slot = e->keys_next;
+    e->keys_next = (slot + 1) % gx_engine::kKeyRing;
+    if (e->keys_cap[slot] < T) {
+        if (e->keys_ev[slot]) GX_HIP(hipEventSynchronize(e->keys_ev[slot]));
+        if (e->h_keys[slot]) (void)hipHostFree(e->h_keys[slot]);
+        e->h_keys[slot] = nullptr;
+        const int cap = T > 256 ? T : 256;
+        GX_HIP(hipHostMalloc((void**)&e->h_keys[slot], sizeof(uint4) * cap, hipHostMallocMapped));
+        e->keys_cap[slot] = cap;
+        if (!e->keys_ev[slot]) GX_HIP(hipEventCreateWithFlags(&e->keys_ev[slot], hipEventDisableTiming));
+    } else {
+        GX_HIP(hipEventSynchronize(e->keys_ev[slot])); // staging free again?
+    }
+    uint32_t k0 = e->key[0], k1 = e->key[1];
+    for (int32_t t = 0; t < T; ++t) {
+        uint32_t a0, a1, b0, b1;
+        split2(k0, k1, a0, a1, b0, b1);
+        k0 = a0; k1 = a1;
+        uint4 kk;
+        split2(k0, k1, kk.x, kk.y, kk.z, kk.w);
+        e->h_keys[slot][t] = kk;
+    }
+    slot_out = slot; k0_out = k0; k1_out = k1;
+    return GX_OK;
+}
+
+static void fill_rollout_args(gx_engine* e, RolloutArgs& r, int32_t T, int slot)
+{
+    memset(&r, 0, sizeof r);
+    r.T = T; r.do_reset = 1; r.nobj_total = e->nobj_total; r.hist0 = e->hist;
+    r.keys = e->h_keys[slot]; // pinned + device-visible: read over the host link only on a reset
+    r.layout_size = e->b.pool.layout_size; r.cand_of = e->b.pool.cand_of; r.cand_xy = e->b.pool.cand_xy;
+    e->p.have_last = e->hist >= 1;
+    e->p.have_last_last = e->hist >= 2;
+}
+
 extern "C" gx_status gx_rollout(gx_engine* e, int32_t T, const float* d_actions, float* d_obs,
                                 float* d_reward, float* d_cost, float* d_done, void* stream)
 {
@@ -456,40 +497,13 @@ extern "C" gx_status gx_rollout(gx_engine* e, int32_t T, const float* d_actions,
     if (use_group_path(e)) {
         DeviceGuard guard(e->device);
         hipStream_t s = (hipStream_t)stream;
-        // key chain on the host: step t advances the key (engine.py:431), the reset_done that
-        // follows draws randint with that key (engine.py:447,500)
-        const int slot = e->keys_next;
-        e->keys_next = (slot + 1) % gx_engine::kKeyRing;
-        if (e->keys_cap[slot] < T) {
-            if (e->keys_ev[slot]) GX_HIP(hipEventSynchronize(e->keys_ev[slot]));
-            if (e->h_keys[slot]) (void)hipHostFree(e->h_keys[slot]);
-            if (e->d_keys[slot]) (void)hipFree(e->d_keys[slot]);
-            e->h_keys[slot] = nullptr; e->d_keys[slot] = nullptr;
-            const int cap = T > 256 ? T : 256;
-            GX_HIP(hipHostMalloc((void**)&e->h_keys[slot], sizeof(uint4) * cap, hipHostMallocMapped));
-            e->keys_cap[slot] = cap;
-            if (!e->keys_ev[slot]) GX_HIP(hipEventCreateWithFlags(&e->keys_ev[slot], hipEventDisableTiming));
-        } else {
-            GX_HIP(hipEventSynchronize(e->keys_ev[slot])); // staging free again?
-        }
-        uint32_t k0 = e->key[0], k1 = e->key[1];
-        for (int32_t t = 0; t < T; ++t) {
-            uint32_t a0, a1, b0, b1;
-            split2(k0, k1, a0, a1, b0, b1);
-            k0 = a0; k1 = a1;
-            uint4 kk;
-            split2(k0, k1, kk.x, kk.y, kk.z, kk.w);
-            e->h_keys[slot][t] = kk;
-        }
+        int slot; uint32_t k0, k1;
+        gx_status st = stage_rollout_keys(e, T, slot, k0, k1);
+        if (st != GX_OK) return st;
         RolloutArgs r;
-        memset(&r, 0, sizeof r);
-        r.T = T; r.do_reset = 1; r.nobj_total = e->nobj_total; r.hist0 = e->hist;
+        fill_rollout_args(e, r, T, slot);
         r.act = reinterpret_cast<const float2*>(d_actions);
         r.obs = d_obs; r.rew = d_reward; r.cost = d_cost; r.done = d_done; r.qacc = nullptr;
-        r.keys = e->h_keys[slot]; // pinned + device-visible: read over the host link only on a reset
-        r.layout_size = e->b.pool.layout_size; r.cand_of = e->b.pool.cand_of; r.cand_xy = e->b.pool.cand_xy;
-        e->p.have_last = e->hist >= 1;
-        e->p.have_last_last = e->hist >= 2;
         launch_group_rollout(e->p, r, e->b, s);
         GX_HIP(hipEventRecord(e->keys_ev[slot], s)); // staging reusable once this launch is done
         GX_HIP(hipGetLastError());
@@ -505,6 +519,53 @@ extern "C" gx_status gx_rollout(gx_engine* e, int32_t T, const float* d_actions,
         st = gx_reset_done(e, obs_t, obs_t, stream);
         if (st != GX_OK) return st;
     }
+    return GX_OK;
+}
+
+extern "C" gx_status gx_rollout_policy(gx_engine* e, int32_t T, const gx_policy* pol, const float* d_obs0,
+                                       float* d_obs_in, float* d_act, float* d_logp, float* d_val,
+                                       float* d_mu, float* d_reward, float* d_cost, float* d_done,
+                                       float* d_obs_last, float* d_val_last, float* d_logstd, void* stream)
+{
+    if (!e || !pol || T < 1 || !d_obs0 || !d_obs_in || !d_act || !d_logp || !d_val || !d_mu || !d_reward ||
+        !d_cost || !d_done || !d_obs_last || !d_val_last || !d_logstd)
+        return fail(GX_ERR_ARG, "gx_rollout_policy: bad argument");
+    if (pol->struct_size != (int32_t)sizeof(gx_policy) || !pol->d_params)
+        return fail(GX_ERR_ARG, "gx_policy.struct_size mismatch or null parameters");
+    if (!e->have_reset) return fail(GX_ERR_STATE, "gx_rollout_policy before gx_reset");
+    if (pol->hidden != kPolHd)
+        return fail(GX_ERR_UNSUPPORTED, "gx_rollout_policy: hidden_sizes must be (64, 64) (the reference default)");
+    if (!policy_rollout_supported(e->p) || e->na != 2 || e->p.N > 65536)
+        return fail(GX_ERR_UNSUPPORTED, "gx_rollout_policy: needs hazards_num <= 15, lidar_num_bins <= 16, env_num <= 65536");
+    if (policy_lds_bytes(e->p) > 64 * 1024)
+        return fail(GX_ERR_UNSUPPORTED, "gx_rollout_policy: observation too wide for the LDS-resident weights");
+    DeviceGuard guard(e->device);
+    hipStream_t s = (hipStream_t)stream;
+    int slot; uint32_t k0, k1;
+    gx_status st = stage_rollout_keys(e, T, slot, k0, k1);
+    if (st != GX_OK) return st;
+    RolloutArgs r;
+    fill_rollout_args(e, r, T, slot);
+    r.rew = d_reward; r.cost = d_cost; r.done = d_done;
+    PolicyArgs pa;
+    memset(&pa, 0, sizeof pa);
+    pa.params = pol->d_params; pa.seed0 = pol->seed[0]; pa.seed1 = pol->seed[1]; pa.t0 = e->policy_steps;
+    pa.obs0 = d_obs0; pa.obs_in = d_obs_in; pa.act = d_act; pa.logp = d_logp; pa.val = d_val; pa.mu = d_mu;
+    pa.obs_last = d_obs_last; pa.val_last = d_val_last; pa.logstd = d_logstd;
+    launch_policy_rollout(e->p, r, pa, e->b, s);
+    GX_HIP(hipEventRecord(e->keys_ev[slot], s));
+    GX_HIP(hipGetLastError());
+    e->key[0] = k0; e->key[1] = k1;
+    e->hist = (e->hist + T) >= 2 ? 2 : e->hist + T;
+    e->policy_steps += (uint32_t)T;
+    return GX_OK;
+}
+
+extern "C" gx_status gx_math_probe2(int32_t n, const float* d_x, float* d_log, float* d_tanh, void* stream)
+{
+    if (n < 1 || !d_x || !d_log || !d_tanh) return fail(GX_ERR_ARG, "bad argument");
+    launch_math_probe2(n, d_x, d_log, d_tanh, (hipStream_t)stream);
+    GX_HIP(hipGetLastError());
     return GX_OK;
 }
 

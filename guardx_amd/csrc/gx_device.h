@@ -122,6 +122,36 @@ GX_D float exp_f(float x)
 }
 
 // ---------------------------------------------------------------------------
+// natural log for x > 0 (normal floats): exponent split + atanh series
+// ---------------------------------------------------------------------------
+GX_D float log_f(float x)
+{
+    const uint32_t b = f2u(x);
+    int e = (int)(b >> 23) - 127;
+    float m = u2f((b & 0x7FFFFFu) | 0x3F800000u);
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+    const float f = m - 1.0f;
+    const float s = f / (2.0f + f);
+    const float z = s * s;
+    float P = fmaf(z, 0.22222222f, 0.2857143f);
+    P = fmaf(z, P, 0.4f);
+    P = fmaf(z, P, 0.6666667f);
+    const float lnm = fmaf(s * z, P, 2.0f * s);
+    const float fe = (float)e;
+    return fmaf(fe, 0.6931471824645996f, fmaf(fe, -1.9046542121259336e-09f, lnm));
+}
+
+// tanh through exp: sign(x) * (1 - 2 / (exp(2|x|) + 1)), saturating at |x| > 9
+GX_D float tanh_f(float x)
+{
+    if (x != x) return x;
+    const float ax = fabsf(x);
+    float t = 1.0f;
+    if (ax <= 9.0f) t = 1.0f - 2.0f / (exp_f(2.0f * ax) + 1.0f);
+    return (f2u(x) >> 31) ? -t : t;
+}
+
+// ---------------------------------------------------------------------------
 // jax.random on threefry2x32 (published algorithm: Salmon et al. 2011 /
 // jax/_src/prng.py).  Used on host for the per-step key chain and on device
 // for layout sampling and layout index draws.

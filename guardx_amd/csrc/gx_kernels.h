@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "gx_device.h"
+#include "gx_policy.h"
 
 namespace gx {
 
@@ -64,6 +65,11 @@ struct RolloutArgs {
     const float2* cand_xy;
 };
 void launch_group_rollout(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s);
+void launch_policy_rollout(const Params& p, const RolloutArgs& r, const PolicyArgs& pol, const DevBuffers& b,
+                           hipStream_t s);
+bool policy_rollout_supported(const Params& p);
+size_t policy_lds_bytes(const Params& p);
+void launch_math_probe2(int n, const float* x, float* lg, float* th, hipStream_t s);
 void launch_math_probe(int n, const float* x, const float* y, float* s_, float* c, float* at2,
                        float* ex, hipStream_t s);
 void launch_split_probe(uint32_t k0, uint32_t k1, int n, uint32_t* out, hipStream_t s);

@@ -10,6 +10,7 @@
 // Reference lines: /root/reference/safe_rl_envs/safe_rl_envs/envs/engine.py.
 #include "gx_kernels.h"
 #include "gx_robot.h"
+#include "gx_policy.h"
 #include <cstdlib>
 
 namespace gx {
@@ -717,8 +718,16 @@ GX_D float pick(const float (&a)[N], int k)
     return r;
 }
 
-template <class R, int OPL, int BPL, bool kQacc, bool kDef>
-__global__ __launch_bounds__(64) void group_rollout_kernel(Params p_in, RolloutArgs r,
+GX_HD int pad4(int n) { return (n + 3) & ~3; }
+
+// dynamic LDS of the policy variant, in floats: pi image | v image | log_std, std | hbuf[4][Hd] | xrow[4][D]
+GX_HD int policy_lds_floats(int D, int A)
+{
+    return pad4(mlp_floats(D, A)) + pad4(mlp_floats(D, 1)) + pad4(2 * A) + 4 * kPolHd + 4 * pad4(D);
+}
+
+template <class R, int OPL, int BPL, bool kQacc, bool kDef, bool kPolicy>
+__global__ __launch_bounds__(64) void group_rollout_kernel(Params p_in, RolloutArgs r, PolicyArgs pol,
                                                           float4* __restrict__ dyn,
                                                           float4* __restrict__ obj,
                                                           float4* __restrict__ hist)
@@ -726,11 +735,39 @@ __global__ __launch_bounds__(64) void group_rollout_kernel(Params p_in, RolloutA
     const Params p = fold_params<R, kDef>(p_in);
     __shared__ float4 rec[OPL][64];
     __shared__ float term[OPL][64];
+    extern __shared__ float4 pol_lds4[];
     const int lane = threadIdx.x;
     const int l = lane & (kGL - 1);
     const int env = blockIdx.x * (64 / kGL) + (lane >> 4);
     const bool live = env < p.N;
     const int e = live ? env : 0;
+
+    // ---- policy: weights into LDS, entry observation into this env's LDS row
+    float* pol_lds = reinterpret_cast<float*>(pol_lds4);
+    MlpLds wpi, wv;
+    float *xrow = nullptr, *hbuf = nullptr;
+    float pstd[R::NA], plstd[R::NA];
+    if (kPolicy) {
+        const int D = p.D, A = R::NA;
+        float* pi_img = pol_lds;
+        float* v_img = pi_img + pad4(mlp_floats(D, A));
+        float* ls_img = v_img + pad4(mlp_floats(D, 1));
+        hbuf = ls_img + pad4(2 * A) + (lane >> 4) * kPolHd;
+        xrow = ls_img + pad4(2 * A) + 4 * kPolHd + (lane >> 4) * pad4(D);
+        mlp_stage(pi_img, pol.params, D, A, lane, 64);
+        mlp_stage(v_img, pol.params + mlp_floats(D, A), D, 1, lane, 64);
+        wpi = mlp_lds_view(pi_img, D, A);
+        wv = mlp_lds_view(v_img, D, 1);
+        const float* gls = pol.params + mlp_floats(D, A) + mlp_floats(D, 1);
+#pragma unroll
+        for (int d = 0; d < A; ++d) {
+            pstd[d] = exp_f(gls[d]);      // std = exp(log_std)          trpo_core.py:123
+            plstd[d] = log_f(pstd[d]);    // torch.log(pi.stddev)        trpo_core.py:173
+            if (blockIdx.x == 0 && lane == d) pol.logstd[d] = plstd[d];
+        }
+        for (int k = l; k < D; k += kGL) xrow[k] = pol.obs0[(size_t)e * D + k];
+        __syncthreads();
+    }
 
     // ---- state (every lane of the group holds a copy)
     float q[R::NQ], v[R::NV], pose0[4], done0, steps;
@@ -750,10 +787,39 @@ __global__ __launch_bounds__(64) void group_rollout_kernel(Params p_in, RolloutA
     { const float2 g = obj2[(size_t)e * 2]; gx = g.x; gy = g.y; }
     bool touched_layout = false;
 
-    float2 a_next = r.act[(size_t)e];
+    float2 a_next = make_float2(0.f, 0.f);
+    if (!kPolicy) a_next = r.act[(size_t)e];
     for (int t = 0; t < r.T; ++t) {
-        const float2 a = a_next;
-        if (t + 1 < r.T) a_next = r.act[(size_t)(t + 1) * p.N + e];
+        float2 a = a_next;
+        if (!kPolicy) {
+            if (t + 1 < r.T) a_next = r.act[(size_t)(t + 1) * p.N + e];
+        } else {
+            // ac.step(o): a ~ N(mu(o), std), logp, v(o)   trpo_core.py:166-173
+            const size_t te = (size_t)t * p.N + env;
+            float mu[R::NA], vv[1];
+            mlp_forward<R::NA>(wpi, xrow, hbuf, p.D, R::NA, l, mu);
+            mlp_forward<1>(wv, xrow, hbuf, p.D, 1, l, vv);
+            float z[2];
+            normal_pair(pol.seed0, pol.seed1, (uint32_t)(p.env_offset + env), (pol.t0 + (uint32_t)t) * 16u, z[0], z[1]);
+            float act[R::NA], lp = 0.0f;
+#pragma unroll
+            for (int d = 0; d < R::NA; ++d) {
+                act[d] = fmaf(pstd[d], z[d], mu[d]);
+                const float df = act[d] - mu[d];
+                const float var = pstd[d] * pstd[d];
+                lp = lp + ((-(df * df) / (2.0f * var) - plstd[d]) - 0.9189385332046727f);
+            }
+            a = make_float2(act[0], act[1]);
+            if (live) {
+                for (int k = l; k < p.D; k += kGL) pol.obs_in[te * p.D + k] = xrow[k];
+                if (l < R::NA) {
+                    pol.act[te * R::NA + l] = pick(act, l);
+                    pol.mu[te * R::NA + l] = pick(mu, l);
+                }
+                if (l == 0) { pol.logp[te] = lp; pol.val[te] = vv[0]; }
+            }
+            __syncthreads(); // xrow is rewritten at the end of this step
+        }
         const bool have_last = (r.hist0 + t) >= 1, have_last_last = (r.hist0 + t) >= 2;
 
         // update_data :426-431 (history shift)
@@ -863,9 +929,10 @@ __global__ __launch_bounds__(64) void group_rollout_kernel(Params p_in, RolloutA
             }
         }
 
-        if (live) {
+        if (live || kPolicy) {
             const size_t te = (size_t)t * p.N + env;
-            float* row = r.obs + te * p.D;
+            // closed loop: the post-reset row is the policy's next input (LDS); open loop: global
+            float* row = kPolicy ? xrow : r.obs + te * p.D;
 #pragma unroll
             for (int jb = 0; jb < BPL; ++jb) {
                 const int b = l + kGL * jb;
@@ -878,14 +945,24 @@ __global__ __launch_bounds__(64) void group_rollout_kernel(Params p_in, RolloutA
             if (l < R::NQ && p.off_qpos >= 0) row[p.off_qpos + l] = pick(o_q, l);
             if (l < R::NV) {
                 if (p.off_qvel >= 0) row[p.off_qvel + l] = pick(o_v, l);
-                if (kQacc) r.qacc[te * R::NV + l] = pick(qacc, l);
+                if (kQacc && live) r.qacc[te * R::NV + l] = pick(qacc, l);
             }
             if (l < 2) {
                 if (p.off_comp >= 0) row[p.off_comp + l] = (l == 0) ? ob.comp0 : ob.comp1;
                 if (p.off_vel >= 0) row[p.off_vel + l] = (l == 0) ? o_v0 : o_v1;
                 if (p.off_acc >= 0) row[p.off_acc + l] = (l == 0) ? o_a0 : o_a1;
             }
-            if (l == 0) { r.rew[te] = rw; r.cost[te] = ob.cost; r.done[te] = dn; }
+            if (l == 0 && live) { r.rew[te] = rw; r.cost[te] = ob.cost; r.done[te] = dn; }
+        }
+        if (kPolicy) __syncthreads();
+    }
+
+    if (kPolicy) { // bootstrap inputs: o_T and V(o_T)   trpo.py:523-529
+        float vv[1];
+        mlp_forward<1>(wv, xrow, hbuf, p.D, 1, l, vv);
+        if (live) {
+            for (int k = l; k < p.D; k += kGL) pol.obs_last[(size_t)env * p.D + k] = xrow[k];
+            if (l == 0) pol.val_last[env] = vv[0];
         }
     }
 
@@ -1054,12 +1131,13 @@ template <class R>
 static void launch_group_r(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s)
 {
     const dim3 grid((p.N + 3) / 4), blk(64);
+    const PolicyArgs nopol = {};
 #define GX_GROUP_LAUNCH(OPL, BPL, DEF)                                                                      \
     do {                                                                                                    \
         if (r.qacc)                                                                                         \
-            hipLaunchKernelGGL((group_rollout_kernel<R, OPL, BPL, true, DEF>), grid, blk, 0, s, p, r, b.dyn, b.obj, b.hist); \
+            hipLaunchKernelGGL((group_rollout_kernel<R, OPL, BPL, true, DEF, false>), grid, blk, 0, s, p, r, nopol, b.dyn, b.obj, b.hist); \
         else                                                                                                \
-            hipLaunchKernelGGL((group_rollout_kernel<R, OPL, BPL, false, DEF>), grid, blk, 0, s, p, r, b.dyn, b.obj, b.hist); \
+            hipLaunchKernelGGL((group_rollout_kernel<R, OPL, BPL, false, DEF, false>), grid, blk, 0, s, p, r, nopol, b.dyn, b.obj, b.hist); \
     } while (0)
     if (is_default_layout<R>(p)) GX_GROUP_LAUNCH(1, 1, true);
     else if (p.nobj <= 16 && p.bins <= 16) GX_GROUP_LAUNCH(1, 1, false);
@@ -1071,6 +1149,41 @@ void launch_group_rollout(const Params& p, const RolloutArgs& r, const DevBuffer
 {
     if (p.robot == SwimmerRobot::kId) launch_group_r<SwimmerRobot>(p, r, b, s);
     else launch_group_r<PointRobot>(p, r, b, s);
+}
+
+template <class R>
+static void launch_policy_r(const Params& p, const RolloutArgs& r, const PolicyArgs& pol, const DevBuffers& b,
+                            hipStream_t s)
+{
+    const dim3 grid((p.N + 3) / 4), blk(64);
+    const size_t lds = sizeof(float) * (size_t)policy_lds_floats(p.D, R::NA);
+    if (is_default_layout<R>(p))
+        hipLaunchKernelGGL((group_rollout_kernel<R, 1, 1, false, true, true>), grid, blk, lds, s, p, r, pol, b.dyn, b.obj, b.hist);
+    else
+        hipLaunchKernelGGL((group_rollout_kernel<R, 1, 1, false, false, true>), grid, blk, lds, s, p, r, pol, b.dyn, b.obj, b.hist);
+}
+
+bool policy_rollout_supported(const Params& p) { return p.nobj <= 16 && p.bins <= 16; }
+size_t policy_lds_bytes(const Params& p) { return sizeof(float) * (size_t)policy_lds_floats(p.D, 2); }
+
+void launch_policy_rollout(const Params& p, const RolloutArgs& r, const PolicyArgs& pol, const DevBuffers& b,
+                           hipStream_t s)
+{
+    if (p.robot == SwimmerRobot::kId) launch_policy_r<SwimmerRobot>(p, r, pol, b, s);
+    else launch_policy_r<PointRobot>(p, r, pol, b, s);
+}
+
+__global__ void math_probe2_kernel(int n, const float* x, float* lg, float* th)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    lg[i] = log_f(x[i]);
+    th[i] = tanh_f(x[i]);
+}
+
+void launch_math_probe2(int n, const float* x, float* lg, float* th, hipStream_t s)
+{
+    hipLaunchKernelGGL(math_probe2_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, x, lg, th);
 }
 
 void launch_math_probe(int n, const float* x, const float* y, float* s_, float* c, float* at2,

@@ -397,6 +397,60 @@ class Engine:
         self._info = {'cost': cost[-1]}
         return obs, reward, cost, done
 
+    # ------------------------------------------------------------------
+    # closed-loop fused rollout (policy evaluated inside the kernel)
+    # ------------------------------------------------------------------
+    @staticmethod
+    def pack_actor_critic(ac=None, *, mu_net=None, v_net=None, log_std=None, device=None):
+        """Flatten MLPActorCritic(hidden_sizes=(64,64), tanh) weights (trpo_core.py:110-164) into the
+        layout gx_rollout_policy expects.  `ac` needs .pi.mu_net, .pi.log_std, .v.v_net
+        (nn.Sequential of Linear/Tanh/Linear/Tanh/Linear[/Identity]); or pass the three pieces."""
+        if ac is not None:
+            mu_net, v_net, log_std = ac.pi.mu_net, ac.v.v_net, ac.pi.log_std
+        parts = []
+        for net in (mu_net, v_net):
+            lin = [m for m in net if isinstance(m, torch.nn.Linear)]
+            if len(lin) != 3 or lin[0].out_features != 64 or lin[1].out_features != 64:
+                raise NotImplementedError("rollout_policy supports hidden_sizes=(64, 64) (the reference default)")
+            for m in lin:
+                parts += [m.weight.detach().reshape(-1), m.bias.detach().reshape(-1)]
+        parts.append(torch.as_tensor(log_std).detach().reshape(-1))
+        flat = torch.cat([t.to(torch.float32) for t in parts])
+        return flat.to(device) if device is not None else flat
+
+    def rollout_policy(self, params, T, obs0=None, noise_seed=(0, 0)):
+        """T x (ac.step -> env.step -> reset_done) in ONE kernel launch (trpo.py:466-547 with the
+        actor-critic of trpo_core.py:110-173 evaluated on device).  `params` = pack_actor_critic(ac).
+        Returns a dict of time-major tensors: obs (T,N,D) [what the policy saw], act, mu (T,N,A),
+        logp, val, rew, cost, done (T,N), plus obs_last (N,D), val_last (N,), logstd (A,)."""
+        if obs0 is None:
+            obs0 = self._obs
+        if obs0 is None:
+            raise RuntimeError("rollout_policy() before reset()")
+        N, D, A, T = self.env_num, self.obs_flat_size, self.action_space.shape[0], int(T)
+        params = params.to(device=self.device, dtype=torch.float32).contiguous()
+        obs0 = obs0.to(device=self.device, dtype=torch.float32).contiguous()
+        assert tuple(obs0.shape) == (N, D)
+        out = dict(obs=self._new(T, N, D), act=self._new(T, N, A), logp=self._new(T, N), val=self._new(T, N),
+                   mu=self._new(T, N, A), rew=self._new(T, N), cost=self._new(T, N), done=self._new(T, N),
+                   obs_last=self._new(N, D), val_last=self._new(N), logstd=self._new(A))
+        pol = _native.GxPolicy()
+        pol.struct_size = C.sizeof(_native.GxPolicy)
+        pol.hidden = 64
+        pol.d_params = params.data_ptr()
+        pol.seed[0], pol.seed[1] = int(noise_seed[0]) & 0xFFFFFFFF, int(noise_seed[1]) & 0xFFFFFFFF
+        expect = 2 * (64 * D + 64 + 64 * 64 + 64) + (A + 1) * 64 + (A + 1) + A
+        if params.numel() != expect:
+            raise ValueError(f"params has {params.numel()} floats, expected {expect}")
+        _native.check(self._lib.gx_rollout_policy(
+            self._h, T, C.byref(pol), obs0.data_ptr(), out['obs'].data_ptr(), out['act'].data_ptr(),
+            out['logp'].data_ptr(), out['val'].data_ptr(), out['mu'].data_ptr(), out['rew'].data_ptr(),
+            out['cost'].data_ptr(), out['done'].data_ptr(), out['obs_last'].data_ptr(),
+            out['val_last'].data_ptr(), out['logstd'].data_ptr(), self._stream()))
+        self._obs, self._reward, self._done = out['obs_last'], out['rew'][-1], out['done'][-1]
+        self._info = {'cost': out['cost'][-1]}
+        return out
+
     def set_prefetch(self, steps):
         """Predicted number of step() calls between reset()s for the layout-pool prefetch
         (default num_steps); negative disables.  Never changes results."""

@@ -115,6 +115,27 @@ gx_status gx_reset_done(gx_engine* e, const float* d_obs_in, float* d_obs_out, v
 gx_status gx_rollout(gx_engine* e, int32_t T, const float* d_actions, float* d_obs,
                      float* d_reward, float* d_cost, float* d_done, void* stream);
 
+/* ---- closed-loop fused rollout with an on-device policy ------------------
+ * `ac.step(o)` of MLPActorCritic(hidden_sizes=(64,64), tanh) (safe_rl_libX/trpo/trpo_core.py:110-173)
+ * evaluated inside the persistent rollout kernel: per step  a ~ N(mu_net(o), exp(log_std)), logp,
+ * v_net(o); env.step(a); reset_done().  d_params (device, fp32, torch layouts):
+ *   mu_net {W1[64][D] b1[64] W2[64][64] b2[64] W3[A][64] b3[A]}  v_net {.. W3[1][64] b3[1]}  log_std[A]
+ * The action noise is a counter-based stream keyed by `seed` (Threefry block (env, step) -> Box-Muller),
+ * not torch's generator.  Outputs are time-major: d_obs_in[T][N][D] is the observation the policy saw at
+ * step t (what the learner stores), d_act/d_mu [T][N][A], d_logp/d_val/d_reward/d_cost/d_done [T][N];
+ * d_obs_last[N][D], d_val_last[N] = o_T and V(o_T) for the bootstrap; d_logstd[A] = log(std). */
+typedef struct gx_policy {
+    int32_t struct_size;   /* sizeof(gx_policy) */
+    int32_t hidden;        /* 64 */
+    const float* d_params; /* device pointer, layout above */
+    uint32_t seed[2];
+} gx_policy;
+gx_status gx_rollout_policy(gx_engine* e, int32_t T, const gx_policy* pol, const float* d_obs0,
+                            float* d_obs_in, float* d_act, float* d_logp, float* d_val, float* d_mu,
+                            float* d_reward, float* d_cost, float* d_done, float* d_obs_last,
+                            float* d_val_last, float* d_logstd, void* stream);
+gx_status gx_math_probe2(int32_t n, const float* d_x, float* d_log, float* d_tanh, void* stream);
+
 /* Test / checkpoint support: env-major HOST arrays (any may be NULL).
  *  qpos[N*nq] qvel[N*nv] pose0[N*4] pose1[N*2] objs[N*(1+H)*2] done0[N] done1[N]
  *  steps[N] key[2] hist[1].  Synchronous. */

@@ -105,8 +105,41 @@ static float gx_exp(float x)
     return bits_to_f(f_to_bits(e) + ((uint32_t)ki << 23));
 }
 
+/* natural log for x > 0 (normal floats): exponent split + atanh series, ~1.4e-7 relative */
+static float gx_log(float x)
+{
+    uint32_t b = f_to_bits(x);
+    int e = (int)(b >> 23) - 127;
+    float m = bits_to_f((b & 0x7FFFFFu) | 0x3F800000u);
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+    const float f = m - 1.0f;
+    const float s = f / (2.0f + f);
+    const float z = s * s;
+    float P = fmaf(z, 0.22222222f, 0.2857143f);
+    P = fmaf(z, P, 0.4f);
+    P = fmaf(z, P, 0.6666667f);
+    const float lnm = fmaf(s * z, P, 2.0f * s);
+    const float fe = (float)e;
+    return fmaf(fe, LN2_HI, fmaf(fe, LN2_LO, lnm));
+}
+
+/* tanh through exp: sign(x) * (1 - 2 / (exp(2|x|) + 1)), saturating at |x| > 9 */
+static float gx_tanh(float x)
+{
+    if (x != x) return x;
+    const float ax = fabsf(x);
+    float t = 1.0f;
+    if (ax <= 9.0f) t = 1.0f - 2.0f / (gx_exp(2.0f * ax) + 1.0f);
+    return (f_to_bits(x) >> 31) ? -t : t;
+}
+
 /* jnp.maximum: NaN-propagating */
 static float gx_max(float a, float b) { return (a > b || a != a) ? a : b; }
+
+void gxo_math_probe2(int32_t n, const float* x, float* lg, float* th)
+{
+    for (int i = 0; i < n; ++i) { lg[i] = gx_log(x[i]); th[i] = gx_tanh(x[i]); }
+}
 
 void gxo_math_probe(int32_t n, const float* x, const float* y, float* s, float* c,
                     float* at2, float* ex)
@@ -924,4 +957,115 @@ int gxo_get_pool(const gxo_env* e, float* pool, int32_t max_rows)
     int n = e->layout_size < max_rows ? e->layout_size : max_rows;
     if (n > 0) memcpy(pool, e->pool, (size_t)n * (e->H + 2) * 2 * 4);
     return n;
+}
+
+/* ------------------------------------------------------------------ */
+/* closed-loop rollout with an on-device policy      */
+/* `ac.step(o)` of safe_rl_libX/trpo/trpo_core.py:110-173 for           */
+/* MLPActorCritic(hidden_sizes=(64,64), tanh): Gaussian actor with a    */
+/* state-independent log_std, MLP critic.  The noise is our own         */
+/* counter-based stream (the reference uses torch's global generator).  */
+/* params: pi{W1[Hd][D] b1 W2[Hd][Hd] b2 W3[A][Hd] b3} v{.. W3[1][Hd] b3} log_std[A] */
+/* ------------------------------------------------------------------ */
+#define POL_HD 64
+
+static void mlp_forward(const float* w, const float* x, int D, int Out, float* out)
+{
+    const float *W1 = w, *b1 = W1 + POL_HD * D, *W2 = b1 + POL_HD, *b2 = W2 + POL_HD * POL_HD;
+    const float *W3 = b2 + POL_HD, *b3 = W3 + Out * POL_HD;
+    float h1[POL_HD], h2[POL_HD];
+    for (int j = 0; j < POL_HD; ++j) {
+        float acc = b1[j];
+        for (int k = 0; k < D; ++k) acc = fmaf(x[k], W1[j * D + k], acc);
+        h1[j] = gx_tanh(acc);
+    }
+    for (int j = 0; j < POL_HD; ++j) {
+        float acc = b2[j];
+        for (int k = 0; k < POL_HD; ++k) acc = fmaf(h1[k], W2[j * POL_HD + k], acc);
+        h2[j] = gx_tanh(acc);
+    }
+    for (int o = 0; o < Out; ++o) {
+        /* 16 lane partials over units 4l..4l+3, then a butterfly (xor 8,4,2,1) */
+        float pl[16], ql[16];
+        for (int l = 0; l < 16; ++l) {
+            float pp = 0.0f;
+            for (int c = 0; c < 4; ++c) pp = fmaf(h2[4 * l + c], W3[o * POL_HD + 4 * l + c], pp);
+            pl[l] = pp;
+        }
+        for (int off = 8; off >= 1; off >>= 1) {
+            for (int l = 0; l < 16; ++l) ql[l] = pl[l] + pl[l ^ off];
+            memcpy(pl, ql, sizeof pl);
+        }
+        out[o] = b3[o] + pl[0];
+    }
+}
+
+static int mlp_size(int D, int Out) { return POL_HD * D + POL_HD + POL_HD * POL_HD + POL_HD + Out * POL_HD + Out; }
+
+/* two standard normals from one Threefry block keyed by `seed`, counter (global env, step*16+pair) */
+static void normal_pair(const uint32_t seed[2], uint32_t env, uint32_t ctr, float* z0, float* z1)
+{
+    uint32_t b0, b1;
+    threefry2x32(seed[0], seed[1], env, ctr, &b0, &b1);
+    const float u1 = (float)((b0 >> 8) + 1u) * 5.9604644775390625e-08f; /* (0,1] */
+    const float u2 = (float)(b1 >> 8) * 5.9604644775390625e-08f;        /* [0,1) */
+    const float r = sqrtf(-2.0f * gx_log(u1));
+    float sn, cs;
+    gx_sincos(TWO_PI_F * u2, &sn, &cs);
+    *z0 = r * cs;
+    *z1 = r * sn;
+}
+
+int gxo_rollout_policy(gxo_env* e, int32_t T, int32_t hidden, const float* params, const uint32_t* seed,
+                       uint32_t t0, const float* obs0, float* obs_in, float* act, float* logp, float* val,
+                       float* mu_out, float* rew, float* cost, float* done, float* obs_last, float* val_last,
+                       float* logstd_out)
+{
+    if (hidden != POL_HD) return GXO_ERR_UNSUPPORTED;
+    const int N = e->N, D = e->D, A = e->na;
+    const float* wpi = params;
+    const float* wv = params + mlp_size(D, A);
+    const float* log_std = wv + mlp_size(D, 1);
+    float std[8], lstd[8];
+    for (int d = 0; d < A; ++d) { std[d] = gx_exp(log_std[d]); lstd[d] = gx_log(std[d]); logstd_out[d] = lstd[d]; }
+    float* cur = (float*)malloc((size_t)N * D * 4);
+    float* nxt = (float*)malloc((size_t)N * D * 4);
+    float* a_t = (float*)malloc((size_t)N * A * 4);
+    float* qa = (float*)malloc((size_t)N * e->nv * 4);
+    memcpy(cur, obs0, (size_t)N * D * 4);
+    for (int t = 0; t < T; ++t) {
+        memcpy(&obs_in[(size_t)t * N * D], cur, (size_t)N * D * 4);
+        for (int i = 0; i < N; ++i) {
+            float m[8], v1[1], z[8];
+            mlp_forward(wpi, &cur[(size_t)i * D], D, A, m);
+            mlp_forward(wv, &cur[(size_t)i * D], D, 1, v1);
+            for (int pr = 0; 2 * pr < A; ++pr)
+                normal_pair(seed, (uint32_t)(e->cfg.env_offset + i), (t0 + (uint32_t)t) * 16u + (uint32_t)pr,
+                            &z[2 * pr], &z[2 * pr + 1]);
+            float lp = 0.0f;
+            for (int d = 0; d < A; ++d) {
+                const float a = fmaf(std[d], z[d], m[d]);
+                const float df = a - m[d];
+                const float var = std[d] * std[d];
+                lp = lp + ((-(df * df) / (2.0f * var) - lstd[d]) - 0.9189385332046727f);
+                a_t[(size_t)i * A + d] = a;
+                act[((size_t)t * N + i) * A + d] = a;
+                mu_out[((size_t)t * N + i) * A + d] = m[d];
+            }
+            logp[(size_t)t * N + i] = lp;
+            val[(size_t)t * N + i] = v1[0];
+        }
+        int rc = gxo_step(e, a_t, nxt, &rew[(size_t)t * N], &cost[(size_t)t * N], &done[(size_t)t * N], qa);
+        if (rc != GXO_OK) return rc;
+        rc = gxo_reset_done(e, cur); /* post-reset observation feeds the next policy step */
+        if (rc != GXO_OK) return rc;
+    }
+    memcpy(obs_last, cur, (size_t)N * D * 4);
+    for (int i = 0; i < N; ++i) {
+        float v1[1];
+        mlp_forward(wv, &cur[(size_t)i * D], D, 1, v1);
+        val_last[i] = v1[0];
+    }
+    free(cur); free(nxt); free(a_t); free(qa);
+    return GXO_OK;
 }

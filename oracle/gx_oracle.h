@@ -101,6 +101,13 @@ float gxo_uniform(const uint32_t* key, float minval, float maxval);
 void  gxo_randint(const uint32_t* key, int32_t n, uint32_t span, int32_t* out_n);
 void  gxo_math_probe(int32_t n, const float* x, const float* y, float* s, float* c,
                      float* at2, float* ex);
+void  gxo_math_probe2(int32_t n, const float* x, float* lg, float* th);
+/* T x (ac.step -> env.step -> reset_done) with MLPActorCritic((64,64), tanh) weights
+ * (trpo_core.py:110-173) and a counter-based N(0,1) stream; time-major outputs. */
+int   gxo_rollout_policy(gxo_env* e, int32_t T, int32_t hidden, const float* params, const uint32_t* seed,
+                         uint32_t t0, const float* obs0, float* obs_in, float* act, float* logp, float* val,
+                         float* mu, float* rew, float* cost, float* done, float* obs_last, float* val_last,
+                         float* logstd);
 void  gxo_set_threads(int32_t n);
 int   gxo_get_threads(void);
 

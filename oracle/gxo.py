@@ -91,6 +91,9 @@ def lib():
         L.gxo_uniform.restype = C.c_float
         L.gxo_randint.argtypes = [u32p, C.c_int32, C.c_uint32, i32p]
         L.gxo_randint.restype = None
+        L.gxo_math_probe2.argtypes = [C.c_int32, fp, fp, fp]
+        L.gxo_math_probe2.restype = None
+        L.gxo_rollout_policy.argtypes = [C.c_void_p, C.c_int32, C.c_int32, fp, u32p, C.c_uint32] + [fp] * 12
         L.gxo_math_probe.argtypes = [C.c_int32] + [fp] * 6
         L.gxo_math_probe.restype = None
         L.gxo_set_threads.argtypes = [C.c_int32]
@@ -207,6 +210,22 @@ class OracleEngine:
         assert rc == 0, rc
         return obs
 
+    def rollout_policy(self, params, T, obs0, noise_seed=(0, 0), t0=0):
+        N, D, A = self.N, self.D, self.na
+        params = np.ascontiguousarray(params, np.float32)
+        obs0 = np.ascontiguousarray(obs0, np.float32)
+        f = np.float32
+        out = dict(obs=np.empty((T, N, D), f), act=np.empty((T, N, A), f), logp=np.empty((T, N), f),
+                   val=np.empty((T, N), f), mu=np.empty((T, N, A), f), rew=np.empty((T, N), f),
+                   cost=np.empty((T, N), f), done=np.empty((T, N), f), obs_last=np.empty((N, D), f),
+                   val_last=np.empty(N, f), logstd=np.empty(A, f))
+        seed = (C.c_uint32 * 2)(int(noise_seed[0]), int(noise_seed[1]))
+        rc = self.L.gxo_rollout_policy(self.h, T, 64, _fp(params), seed, t0, _fp(obs0), *[_fp(out[k]) for k in
+                                       ('obs', 'act', 'logp', 'val', 'mu', 'rew', 'cost', 'done', 'obs_last',
+                                        'val_last', 'logstd')])
+        assert rc == 0, rc
+        return out
+
     @property
     def layout_size(self):
         return self.L.gxo_layout_size(self.h)
@@ -272,6 +291,13 @@ def randint(key, n, span):
     out = np.empty(n, np.int32)
     lib().gxo_randint(k, n, span, out.ctypes.data_as(C.POINTER(C.c_int32)))
     return out
+
+
+def math_probe2(x):
+    x = np.ascontiguousarray(x, np.float32)
+    lg, th = np.empty(x.size, np.float32), np.empty(x.size, np.float32)
+    lib().gxo_math_probe2(x.size, _fp(x), _fp(lg), _fp(th))
+    return lg, th
 
 
 def math_probe(x, y):
