@@ -263,6 +263,31 @@ def epoch_breakdown(device):
                     "bound and bounds the epoch"}
 
 
+def closed_loop_rate(device, epochs=10):
+    """reset() + ONE rollout_policy launch per epoch: the (64,64)-tanh actor-critic of
+    trpo_core.py:110-173 (random init) evaluated inside the persistent kernel."""
+    from guardx_amd import Engine
+    env = make_engine(ENV_NUM, 0, 1)
+    D = env.obs_flat_size
+    torch.manual_seed(0)
+    mk = lambda out: torch.nn.Sequential(torch.nn.Linear(D, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64),  # noqa: E731
+                                         torch.nn.Tanh(), torch.nn.Linear(64, out))
+    params = Engine.pack_actor_critic(mu_net=mk(2), v_net=mk(1), log_std=torch.full((2,), -0.5)).to(device)
+
+    def epoch():
+        env.reset()
+        env.rollout_policy(params, EP_LEN)
+    epoch(); epoch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(epochs):
+        epoch()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    env.close()
+    return ENV_NUM * EP_LEN * epochs / dt
+
+
 def api_loop_rate(env, tape, steps):
     """Python-driven Engine.step()/reset_done() loop (what an unmodified learner drives)."""
     torch.cuda.synchronize()
@@ -330,6 +355,7 @@ def main():
             line["roofline_large_batch"] = roofline_step(1 << 22, 30, device)
             line["api_step_loop_env_steps_per_s"] = round(api_loop_rate(env, tapes[0], 1000), 1)
             line["epoch_breakdown"] = epoch_breakdown(device)
+            line["closed_loop_policy_env_steps_per_s"] = round(closed_loop_rate(device), 1)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

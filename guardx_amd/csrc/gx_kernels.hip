@@ -720,10 +720,10 @@ GX_D float pick(const float (&a)[N], int k)
 
 GX_HD int pad4(int n) { return (n + 3) & ~3; }
 
-// dynamic LDS of the policy variant, in floats: pi image | v image | log_std, std | hbuf[4][Hd] | xrow[4][D]
+// dynamic LDS of the policy variant, in floats: pi image | v image | log_std, std | hbuf[4][2][Hd] | xrow[4][D]
 GX_HD int policy_lds_floats(int D, int A)
 {
-    return pad4(mlp_floats(D, A)) + pad4(mlp_floats(D, 1)) + pad4(2 * A) + 4 * kPolHd + 4 * pad4(D);
+    return pad4(mlp_floats(D, A)) + pad4(mlp_floats(D, 1)) + pad4(2 * A) + 4 * 2 * kPolHd + 4 * pad4(D);
 }
 
 template <class R, int OPL, int BPL, bool kQacc, bool kDef, bool kPolicy>
@@ -752,8 +752,8 @@ __global__ __launch_bounds__(64) void group_rollout_kernel(Params p_in, RolloutA
         float* pi_img = pol_lds;
         float* v_img = pi_img + pad4(mlp_floats(D, A));
         float* ls_img = v_img + pad4(mlp_floats(D, 1));
-        hbuf = ls_img + pad4(2 * A) + (lane >> 4) * kPolHd;
-        xrow = ls_img + pad4(2 * A) + 4 * kPolHd + (lane >> 4) * pad4(D);
+        hbuf = ls_img + pad4(2 * A) + (lane >> 4) * 2 * kPolHd;
+        xrow = ls_img + pad4(2 * A) + 4 * 2 * kPolHd + (lane >> 4) * pad4(D);
         mlp_stage(pi_img, pol.params, D, A, lane, 64);
         mlp_stage(v_img, pol.params + mlp_floats(D, A), D, 1, lane, 64);
         wpi = mlp_lds_view(pi_img, D, A);
@@ -797,8 +797,7 @@ __global__ __launch_bounds__(64) void group_rollout_kernel(Params p_in, RolloutA
             // ac.step(o): a ~ N(mu(o), std), logp, v(o)   trpo_core.py:166-173
             const size_t te = (size_t)t * p.N + env;
             float mu[R::NA], vv[1];
-            mlp_forward<R::NA>(wpi, xrow, hbuf, p.D, R::NA, l, mu);
-            mlp_forward<1>(wv, xrow, hbuf, p.D, 1, l, vv);
+            actor_critic_forward<R::NA>(wpi, wv, xrow, hbuf, p.D, l, mu, vv[0]);
             float z[2];
             normal_pair(pol.seed0, pol.seed1, (uint32_t)(p.env_offset + env), (pol.t0 + (uint32_t)t) * 16u, z[0], z[1]);
             float act[R::NA], lp = 0.0f;
@@ -958,11 +957,10 @@ __global__ __launch_bounds__(64) void group_rollout_kernel(Params p_in, RolloutA
     }
 
     if (kPolicy) { // bootstrap inputs: o_T and V(o_T)   trpo.py:523-529
-        float vv[1];
-        mlp_forward<1>(wv, xrow, hbuf, p.D, 1, l, vv);
+        const float vlast = critic_forward(wv, xrow, hbuf, p.D, l);
         if (live) {
             for (int k = l; k < p.D; k += kGL) pol.obs_last[(size_t)env * p.D + k] = xrow[k];
-            if (l == 0) pol.val_last[env] = vv[0];
+            if (l == 0) pol.val_last[env] = vlast;
         }
     }
 

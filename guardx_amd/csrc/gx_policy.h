@@ -57,43 +57,100 @@ GX_D void mlp_stage(float* lds, const float* __restrict__ g, int D, int Out, int
     for (int i = tid; i < Out; i += nthreads) b3[i] = gb3[i];
 }
 
-// forward pass for the env group of this lane; x = LDS row of D inputs, hbuf = LDS [Hd] scratch of
-// the group.  Must be called by the whole wave.  out[o] is identical on the 16 lanes.
-template <int OUTMAX>
-GX_D void mlp_forward(const MlpLds& w, const float* x, float* hbuf, int D, int Out, int l, float (&out)[OUTMAX])
+// one fmaf step of four output columns
+#define GX_FMA4(acc, xv, wv)                                                           \
+    do { acc.x = fmaf(xv, wv.x, acc.x); acc.y = fmaf(xv, wv.y, acc.y);                 \
+         acc.z = fmaf(xv, wv.z, acc.z); acc.w = fmaf(xv, wv.w, acc.w); } while (0)
+
+GX_D float4 tanh4(float4 a) { return make_float4(tanh_f(a.x), tanh_f(a.y), tanh_f(a.z), tanh_f(a.w)); }
+
+// output layer: 16 lane partials over the lane's four hidden units, folded by a butterfly
+GX_D float head_out(const MlpLds& w, int o, int l, float4 h)
 {
-    const float4 bb1 = *reinterpret_cast<const float4*>(w.b1 + 4 * l);
-    float a0 = bb1.x, a1 = bb1.y, a2 = bb1.z, a3 = bb1.w;
+    const float4 wv = *reinterpret_cast<const float4*>(w.W3 + o * kPolHd + 4 * l);
+    float pp = 0.0f;
+    pp = fmaf(h.x, wv.x, pp); pp = fmaf(h.y, wv.y, pp); pp = fmaf(h.z, wv.z, pp); pp = fmaf(h.w, wv.w, pp);
+    pp = pp + __shfl_xor(pp, 8, 16);
+    pp = pp + __shfl_xor(pp, 4, 16);
+    pp = pp + __shfl_xor(pp, 2, 16);
+    pp = pp + __shfl_xor(pp, 1, 16);
+    return w.b3[o] + pp;
+}
+
+// actor and critic in one pass (both read the same observation): per input k one broadcast read of
+// x serves eight fmaf chains; x is fetched four at a time.  x = LDS row of D inputs (16-byte
+// aligned), hbuf = LDS [2][Hd] scratch of this env group.  Whole-wave call.  Each output is its own
+// sequential fmaf chain over k, so the values equal the one-network-at-a-time evaluation bit for bit.
+template <int A>
+GX_D void actor_critic_forward(const MlpLds& wp, const MlpLds& wc, const float* x, float* hbuf, int D, int l,
+                               float (&mu)[A], float& v)
+{
+    float4 ap = *reinterpret_cast<const float4*>(wp.b1 + 4 * l);
+    float4 ac = *reinterpret_cast<const float4*>(wc.b1 + 4 * l);
+    const int D4 = D & ~3;
+    for (int k = 0; k < D4; k += 4) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + k);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 w1 = *reinterpret_cast<const float4*>(wp.Wt1 + (k + u) * kPolHd + 4 * l);
+            const float4 w2 = *reinterpret_cast<const float4*>(wc.Wt1 + (k + u) * kPolHd + 4 * l);
+            GX_FMA4(ap, xs[u], w1);
+            GX_FMA4(ac, xs[u], w2);
+        }
+    }
+    for (int k = D4; k < D; ++k) {
+        const float xv = x[k];
+        const float4 w1 = *reinterpret_cast<const float4*>(wp.Wt1 + k * kPolHd + 4 * l);
+        const float4 w2 = *reinterpret_cast<const float4*>(wc.Wt1 + k * kPolHd + 4 * l);
+        GX_FMA4(ap, xv, w1);
+        GX_FMA4(ac, xv, w2);
+    }
+    *reinterpret_cast<float4*>(hbuf + 4 * l) = tanh4(ap);
+    *reinterpret_cast<float4*>(hbuf + kPolHd + 4 * l) = tanh4(ac);
+    __syncthreads();
+    ap = *reinterpret_cast<const float4*>(wp.b2 + 4 * l);
+    ac = *reinterpret_cast<const float4*>(wc.b2 + 4 * l);
+#pragma unroll 4
+    for (int k = 0; k < kPolHd; k += 4) {
+        const float4 xp = *reinterpret_cast<const float4*>(hbuf + k);
+        const float4 xc = *reinterpret_cast<const float4*>(hbuf + kPolHd + k);
+        const float xps[4] = {xp.x, xp.y, xp.z, xp.w}, xcs[4] = {xc.x, xc.y, xc.z, xc.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 w1 = *reinterpret_cast<const float4*>(wp.Wt2 + (k + u) * kPolHd + 4 * l);
+            const float4 w2 = *reinterpret_cast<const float4*>(wc.Wt2 + (k + u) * kPolHd + 4 * l);
+            GX_FMA4(ap, xps[u], w1);
+            GX_FMA4(ac, xcs[u], w2);
+        }
+    }
+    const float4 hp = tanh4(ap), hc = tanh4(ac);
+#pragma unroll
+    for (int o = 0; o < A; ++o) mu[o] = head_out(wp, o, l, hp);
+    v = head_out(wc, 0, l, hc);
+    __syncthreads(); // hbuf is reused by the next call
+}
+
+// critic only (bootstrap value of the final observation)
+GX_D float critic_forward(const MlpLds& wc, const float* x, float* hbuf, int D, int l)
+{
+    float4 ac = *reinterpret_cast<const float4*>(wc.b1 + 4 * l);
     for (int k = 0; k < D; ++k) {
         const float xv = x[k];
-        const float4 wv = *reinterpret_cast<const float4*>(w.Wt1 + k * kPolHd + 4 * l);
-        a0 = fmaf(xv, wv.x, a0); a1 = fmaf(xv, wv.y, a1); a2 = fmaf(xv, wv.z, a2); a3 = fmaf(xv, wv.w, a3);
+        const float4 w2 = *reinterpret_cast<const float4*>(wc.Wt1 + k * kPolHd + 4 * l);
+        GX_FMA4(ac, xv, w2);
     }
-    *reinterpret_cast<float4*>(hbuf + 4 * l) = make_float4(tanh_f(a0), tanh_f(a1), tanh_f(a2), tanh_f(a3));
+    *reinterpret_cast<float4*>(hbuf + 4 * l) = tanh4(ac);
     __syncthreads();
-    const float4 bb2 = *reinterpret_cast<const float4*>(w.b2 + 4 * l);
-    a0 = bb2.x; a1 = bb2.y; a2 = bb2.z; a3 = bb2.w;
-#pragma unroll 8
+    ac = *reinterpret_cast<const float4*>(wc.b2 + 4 * l);
     for (int k = 0; k < kPolHd; ++k) {
         const float xv = hbuf[k];
-        const float4 wv = *reinterpret_cast<const float4*>(w.Wt2 + k * kPolHd + 4 * l);
-        a0 = fmaf(xv, wv.x, a0); a1 = fmaf(xv, wv.y, a1); a2 = fmaf(xv, wv.z, a2); a3 = fmaf(xv, wv.w, a3);
+        const float4 w2 = *reinterpret_cast<const float4*>(wc.Wt2 + k * kPolHd + 4 * l);
+        GX_FMA4(ac, xv, w2);
     }
-    const float h0 = tanh_f(a0), h1 = tanh_f(a1), h2 = tanh_f(a2), h3 = tanh_f(a3);
-#pragma unroll
-    for (int o = 0; o < OUTMAX; ++o) {
-        float pp = 0.0f;
-        if (o < Out) {
-            const float4 wv = *reinterpret_cast<const float4*>(w.W3 + o * kPolHd + 4 * l);
-            pp = fmaf(h0, wv.x, pp); pp = fmaf(h1, wv.y, pp); pp = fmaf(h2, wv.z, pp); pp = fmaf(h3, wv.w, pp);
-        }
-        pp = pp + __shfl_xor(pp, 8, 16);
-        pp = pp + __shfl_xor(pp, 4, 16);
-        pp = pp + __shfl_xor(pp, 2, 16);
-        pp = pp + __shfl_xor(pp, 1, 16);
-        out[o] = (o < Out) ? w.b3[o] + pp : 0.0f;
-    }
-    __syncthreads(); // hbuf is reused by the next network
+    const float v = head_out(wc, 0, l, tanh4(ac));
+    __syncthreads();
+    return v;
 }
 
 // two standard normals from one Threefry block keyed by `seed`, counter (global env, step*16+pair)

@@ -52,5 +52,35 @@ def main():
     print(f"Engine.step python loop: {t*1e6:.2f} us/step")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 3 and sys.argv[3] == "policy"):
     main()
+
+
+def policy_bench():
+    """closed-loop epochs: reset + rollout_policy(200) with the default (64,64) tanh actor-critic"""
+    import torch
+    from guardx_amd import Engine
+    N = 2000
+    dev = torch.device("cuda", 0)
+    env = bench.make_engine(N, 0, 1)
+    D = env.obs_flat_size
+    torch.manual_seed(0)
+    mk = lambda out: torch.nn.Sequential(torch.nn.Linear(D, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64),  # noqa: E731
+                                         torch.nn.Tanh(), torch.nn.Linear(64, out))
+    params = Engine.pack_actor_critic(mu_net=mk(2), v_net=mk(1), log_std=torch.full((2,), -0.5)).to(dev)
+    env.set_prefetch(-1)
+    env.reset()
+    t_roll = timeit(lambda: env.rollout_policy(params, 200), 10)
+
+    def epoch():
+        env.reset()
+        env.rollout_policy(params, 200)
+    env.set_prefetch(200)
+    epoch()
+    t_ep = timeit(epoch, 20)
+    print(f"policy rollout(200) alone: {t_roll*1e3:.3f} ms = {t_roll/200*1e6:.2f} us/step ; closed-loop epoch "
+          f"(prefetch): {t_ep*1e3:.3f} ms -> {N*200/t_ep/1e6:.1f} M env-steps/s")
+
+
+if __name__ == "__main__" and len(sys.argv) > 3 and sys.argv[3] == "policy":
+    policy_bench()
