@@ -55,6 +55,7 @@ SYMBOLS = {
     "gx_dims": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int32)] * 4),
     "gx_reset": (C.c_int, [C.c_void_p, _FP, C.c_void_p]),
     "gx_layout_size": (C.c_int, [C.c_void_p, _I32P]),
+    "gx_layout_size_min": (C.c_int, [C.c_void_p, _I32P]),
     "gx_step": (C.c_int, [C.c_void_p, _FP, _FP, _FP, _FP, _FP, _FP, C.c_void_p]),
     "gx_reset_done": (C.c_int, [C.c_void_p, _FP, _FP, C.c_void_p]),
     "gx_rollout": (C.c_int, [C.c_void_p, C.c_int32, _FP, _FP, _FP, _FP, _FP, C.c_void_p]),

@@ -268,7 +268,7 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     }
     e->cur = 0;
     e->b.pool = e->pools[0];
-    if (err == hipSuccess) err = hipHostMalloc((void**)&e->h_layout_size, sizeof(int), hipHostMallocMapped);
+    if (err == hipSuccess) err = hipHostMalloc((void**)&e->h_layout_size, 2 * sizeof(int), hipHostMallocMapped);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&e->layout_ev, hipEventDisableTiming);
     if (err == hipSuccess) {
         // xmat of the zero pose: cos = 1 (engine.py:229 MjData default); it sits in .x of the last
@@ -282,7 +282,8 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
         gx_destroy(e);
         return fail(GX_ERR_HIP, m);
     }
-    *e->h_layout_size = 0;
+    e->h_layout_size[0] = 0;
+    e->h_layout_size[1] = 0x7fffffff;
     *out = e;
     return GX_OK;
 }
@@ -392,6 +393,26 @@ extern "C" gx_status gx_layout_size(gx_engine* e, int32_t* out)
     if (*out <= e->cfg.env_total) {
         char buf[128];
         snprintf(buf, sizeof buf, "layout_size %d <= env_num %d (engine.py:444)", *out, e->cfg.env_total);
+        return fail(GX_ERR_LAYOUT, buf);
+    }
+    return GX_OK;
+}
+
+extern "C" gx_status gx_layout_size_min(gx_engine* e, int32_t* out)
+{
+    if (!e || !out) return fail(GX_ERR_ARG, "null argument");
+    if (!e->have_reset) return fail(GX_ERR_STATE, "gx_layout_size_min before gx_reset");
+    DeviceGuard guard(e->device);
+    if (e->layout_pending) {
+        GX_HIP(hipEventSynchronize(e->layout_ev));
+        e->layout_pending = false;
+    }
+    *out = e->h_layout_size[1];
+    e->h_layout_size[1] = 0x7fffffff;
+    if (*out <= e->cfg.env_total) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "a reset since the last check had layout_size %d <= env_num %d (engine.py:444)", *out,
+                 e->cfg.env_total);
         return fail(GX_ERR_LAYOUT, buf);
     }
     return GX_OK;

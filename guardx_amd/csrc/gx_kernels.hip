@@ -527,7 +527,10 @@ __global__ __launch_bounds__(BLOCK) void reset_apply_kernel(Params p, int nobj_t
     const int L = *layout_size;
     // len(idx) for the host-side assert (engine.py:442-444): written straight into mapped pinned
     // host memory, no copy kernel on the stream
-    if (blockIdx.x == 0 && threadIdx.x == 0) *host_layout_size = L;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        host_layout_size[0] = L;
+        if (L < host_layout_size[1]) host_layout_size[1] = L; // smallest pool since the last check (resets are stream ordered)
+    }
     if (L <= 0) return; // host raises GX_ERR_LAYOUT (engine.py:444)
     const int tid = threadIdx.x;
     const int env0 = blockIdx.x * BLOCK;

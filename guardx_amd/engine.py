@@ -335,10 +335,16 @@ class Engine:
     def _new(self, *shape):
         return torch.empty(shape, dtype=torch.float32, device=self.device)
 
-    def reset(self):
-        """Resample every layout and return the (env_num, obs_dim) observation (engine.py:454-467)."""
+    def reset(self, check=True):
+        """Resample every layout and return the (env_num, obs_dim) observation (engine.py:454-467).
+
+        check=False defers the `layout_size > env_num` assert (engine.py:444) to the next
+        check_layouts() call, so that no host round trip separates consecutive epochs."""
         obs = self._new(self.env_num, self.obs_flat_size)
         _native.check(self._lib.gx_reset(self._h, obs.data_ptr(), self._stream()))
+        if not check:
+            self._obs = obs
+            return obs
         n = C.c_int32()
         st = self._lib.gx_layout_size(self._h, C.byref(n))
         self.layout_size = int(n.value)
@@ -349,6 +355,16 @@ class Engine:
         _native.check(st)
         self._obs = obs
         return obs
+
+    def check_layouts(self):
+        """The deferred engine.py:444 assert for every reset(check=False) since the last call."""
+        n = C.c_int32()
+        st = self._lib.gx_layout_size_min(self._h, C.byref(n))
+        if st == _native.GX_ERR_LAYOUT:
+            raise ResamplingError(f"number of valid layout is {int(n.value)} <= env_num {self._cfg.env_total}")
+        _native.check(st)
+        self.layout_size = int(n.value)
+        return self.layout_size
 
     def step(self, action):
         """One control step for every env (engine.py:469-495).  No auto-reset."""

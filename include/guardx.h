@@ -96,6 +96,10 @@ gx_status gx_reset(gx_engine* e, float* d_obs, void* stream);
 /* Size of the valid-layout pool of the last gx_reset.  SYNCHRONISES `stream`
  * of that reset.  Returns GX_ERR_LAYOUT if *out <= env_total (engine.py:444). */
 gx_status gx_layout_size(gx_engine* e, int32_t* out);
+/* Deferred form of the same assert: smallest pool size over all gx_reset calls since the previous
+ * gx_layout_size_min (synchronises the last reset only).  Lets a driver queue epochs without a host
+ * round trip per reset and still honour engine.py:444. */
+gx_status gx_layout_size_min(gx_engine* e, int32_t* out);
 
 /* Engine.step.  d_action (env_num x act_dim) -> d_obs (env_num x obs_dim),
  * d_reward, d_cost, d_done (env_num each; done is 0.f/1.f), d_qacc

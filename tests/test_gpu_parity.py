@@ -409,3 +409,21 @@ def test_fixed_locations_and_placement_rectangles(torch_cuda, oracle):
         np.testing.assert_array_equal(E.reset_done().cpu().numpy(), O.reset_done())
     with pytest.raises(AttributeError):      # multi-rectangle placements: self.rs is undefined (engine.py:616)
         Engine(task_config(4, goal_placements=[(-2, -2, 0, 0), (0, 0, 2, 2)]), n_candidates=1000)
+
+
+def test_deferred_layout_check(torch_cuda):
+    """reset(check=False) + check_layouts(): same assert as engine.py:444, one sync for many resets"""
+    torch = torch_cuda
+    from guardx_amd import Engine, ResamplingError
+    env = Engine(task_config(50, seed=0, num_steps=5), n_candidates=20000)
+    tape = torch.zeros(5, 50, 2, device='cuda')
+    for _ in range(3):
+        env.reset(check=False)
+        env.rollout(tape)
+    assert env.check_layouts() > 50
+    bad = Engine(task_config(500, seed=0, num_steps=5), n_candidates=2000)   # pool smaller than env_num
+    bad.reset(check=False)
+    with pytest.raises(ResamplingError):
+        bad.check_layouts()
+    with pytest.raises(ResamplingError):
+        bad.reset()
