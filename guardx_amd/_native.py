@@ -60,6 +60,7 @@ SYMBOLS = {
     "gx_reset_done": (C.c_int, [C.c_void_p, _FP, _FP, C.c_void_p]),
     "gx_rollout": (C.c_int, [C.c_void_p, C.c_int32, _FP, _FP, _FP, _FP, _FP, C.c_void_p]),
     "gx_rollout_policy": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(GxPolicy)] + [_FP] * 12 + [C.c_void_p]),
+    "gx_set_policy_impl": (C.c_int, [C.c_void_p, C.c_int32]),
     "gx_math_probe2": (C.c_int, [C.c_int32, _FP, _FP, _FP, C.c_void_p]),
     "gx_get_state": (C.c_int, [C.c_void_p] + [_HFP] * 8 + [_U32P, _I32P]),
     "gx_set_state": (C.c_int, [C.c_void_p] + [_HFP] * 8 + [_U32P, _I32P]),

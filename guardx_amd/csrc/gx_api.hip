@@ -50,6 +50,7 @@ struct gx_engine {
     int nq, nv, nu, na, ndyn; // robot.nq/nv/nu (world.py:435-438), action width, float4s of state
     float4* haz_bounds;  // device copy of the per-hazard placement bounds (or null)
     uint32_t policy_steps; // ac.step() calls made through gx_rollout_policy (noise counter)
+    int policy_impl;       // 0 auto (MFMA), 1 VALU fmaf chains, 2 fp32 MFMA tiles
     int path_mode;       // 0 auto, 1 thread-per-env kernels, 2 lane-group kernels
     // double-buffered layout pools + side stream: the pool of the NEXT reset() is sampled
     // while the current epoch is being stepped (the key chain is data-independent)
@@ -222,6 +223,7 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     e->h_layout_size = nullptr;
     e->path_mode = 0;
     e->policy_steps = 0;
+    e->policy_impl = 0;
     e->haz_bounds = nullptr;
     e->cfg.placements = nullptr; // not retained (folded into SampleParams above)
     e->pf_valid = false;
@@ -558,7 +560,8 @@ extern "C" gx_status gx_rollout_policy(gx_engine* e, int32_t T, const gx_policy*
         return fail(GX_ERR_UNSUPPORTED, "gx_rollout_policy: hidden_sizes must be (64, 64) (the reference default)");
     if (!policy_rollout_supported(e->p) || e->na != 2 || e->p.N > 65536)
         return fail(GX_ERR_UNSUPPORTED, "gx_rollout_policy: needs hazards_num <= 15, lidar_num_bins <= 16, env_num <= 65536");
-    if (policy_lds_bytes(e->p) > 64 * 1024)
+    const int impl = e->policy_impl == 1 ? 1 : 2; // auto = MFMA
+    if (policy_lds_bytes(e->p, impl) > 150 * 1024)
         return fail(GX_ERR_UNSUPPORTED, "gx_rollout_policy: observation too wide for the LDS-resident weights");
     DeviceGuard guard(e->device);
     hipStream_t s = (hipStream_t)stream;
@@ -573,12 +576,19 @@ extern "C" gx_status gx_rollout_policy(gx_engine* e, int32_t T, const gx_policy*
     pa.params = pol->d_params; pa.seed0 = pol->seed[0]; pa.seed1 = pol->seed[1]; pa.t0 = e->policy_steps;
     pa.obs0 = d_obs0; pa.obs_in = d_obs_in; pa.act = d_act; pa.logp = d_logp; pa.val = d_val; pa.mu = d_mu;
     pa.obs_last = d_obs_last; pa.val_last = d_val_last; pa.logstd = d_logstd;
-    launch_policy_rollout(e->p, r, pa, e->b, s);
+    launch_policy_rollout(e->p, r, pa, e->b, impl, s);
     GX_HIP(hipEventRecord(e->keys_ev[slot], s));
     GX_HIP(hipGetLastError());
     e->key[0] = k0; e->key[1] = k1;
     e->hist = (e->hist + T) >= 2 ? 2 : e->hist + T;
     e->policy_steps += (uint32_t)T;
+    return GX_OK;
+}
+
+extern "C" gx_status gx_set_policy_impl(gx_engine* e, int32_t impl)
+{
+    if (!e || impl < 0 || impl > 2) return fail(GX_ERR_ARG, "gx_set_policy_impl: 0 auto, 1 VALU, 2 MFMA");
+    e->policy_impl = impl;
     return GX_OK;
 }
 

@@ -66,9 +66,9 @@ struct RolloutArgs {
 };
 void launch_group_rollout(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s);
 void launch_policy_rollout(const Params& p, const RolloutArgs& r, const PolicyArgs& pol, const DevBuffers& b,
-                           hipStream_t s);
+                           int impl, hipStream_t s);
 bool policy_rollout_supported(const Params& p);
-size_t policy_lds_bytes(const Params& p);
+size_t policy_lds_bytes(const Params& p, int impl);
 void launch_math_probe2(int n, const float* x, float* lg, float* th, hipStream_t s);
 void launch_math_probe(int n, const float* x, const float* y, float* s_, float* c, float* at2,
                        float* ex, hipStream_t s);

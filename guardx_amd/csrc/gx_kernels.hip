@@ -651,8 +651,10 @@ template <int OPL, int BPL>
 struct GroupObs { float gl[BPL], hl[BPL], comp0, comp1, cost; bool bad; };
 
 // object phase + LDS exchange + bin phase for one pose
-template <int OPL, int BPL>
-GX_D GroupObs<OPL, BPL> group_observe(const Params& p, float4 (*rec)[64], float (*term)[64], int lane,
+// `lane` = thread index in the workgroup (BT threads = BT/16 environments); must be reached by the
+// whole workgroup.
+template <int OPL, int BPL, int BT>
+GX_D GroupObs<OPL, BPL> group_observe(const Params& p, float4 (*rec)[BT], float (*term)[BT], int lane,
                                       const float (&pose)[4], float gx, float gy,
                                       const float (&ox)[OPL], const float (&oy)[OPL])
 {
@@ -706,7 +708,7 @@ GX_D GroupObs<OPL, BPL> group_observe(const Params& p, float4 (*rec)[64], float 
     }
     // any lane of this env's group
     const unsigned long long m = __ballot(bad);
-    out.bad = ((m >> gbase) & 0xFFFFull) != 0ull;
+    out.bad = ((m >> (gbase & 63)) & 0xFFFFull) != 0ull;
     __syncthreads();
     return out;
 }
@@ -723,44 +725,68 @@ GX_D float pick(const float (&a)[N], int k)
 
 GX_HD int pad4(int n) { return (n + 3) & ~3; }
 
-// dynamic LDS of the policy variant, in floats: pi image | v image | log_std, std | hbuf[4][2][Hd] | xrow[4][D]
-GX_HD int policy_lds_floats(int D, int A)
+// dynamic LDS of the policy variants, in floats.
+//  VALU form (64 threads, 4 envs):   pi image | v image | log_std,std | hbuf[4][2][Hd] | xrow[4][pad4 D]
+//  MFMA form (256 threads, 16 envs): pi image | v image (Wt1 zero-padded to pad4 D rows) | log_std,std |
+//                                    X[16][pad4 D + 1] | H1[2][16][68] | H2[2][16][68]
+GX_HD int policy_lds_floats(int D, int A, int pol)
 {
+    if (pol == 2)
+        return pad4(mlp_lds_floats(pad4(D), A)) + pad4(mlp_lds_floats(pad4(D), 1)) + pad4(2 * A) +
+               16 * (pad4(D) + 1) + 3 + 2 * 2 * 16 * kPolHS;
     return pad4(mlp_floats(D, A)) + pad4(mlp_floats(D, 1)) + pad4(2 * A) + 4 * 2 * kPolHd + 4 * pad4(D);
 }
 
-template <class R, int OPL, int BPL, bool kQacc, bool kDef, bool kPolicy>
-__global__ __launch_bounds__(64) void group_rollout_kernel(Params p_in, RolloutArgs r, PolicyArgs pol,
-                                                          float4* __restrict__ dyn,
-                                                          float4* __restrict__ obj,
-                                                          float4* __restrict__ hist)
+// kPol: 0 open loop (action tape), 1 policy evaluated with VALU fmaf chains (one wave per workgroup),
+//       2 policy evaluated with fp32 MFMA tiles (four waves = 16 envs per workgroup)
+template <class R, int OPL, int BPL, bool kQacc, bool kDef, int kPol>
+__global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Params p_in, RolloutArgs r,
+                                                                            PolicyArgs pol,
+                                                                            float4* __restrict__ dyn,
+                                                                            float4* __restrict__ obj,
+                                                                            float4* __restrict__ hist)
 {
+    constexpr int BT = (kPol == 2) ? 256 : 64;
+    constexpr bool kPolicy = kPol != 0;
     const Params p = fold_params<R, kDef>(p_in);
-    __shared__ float4 rec[OPL][64];
-    __shared__ float term[OPL][64];
+    __shared__ float4 rec[OPL][BT];
+    __shared__ float term[OPL][BT];
     extern __shared__ float4 pol_lds4[];
-    const int lane = threadIdx.x;
-    const int l = lane & (kGL - 1);
-    const int env = blockIdx.x * (64 / kGL) + (lane >> 4);
+    const int lane = threadIdx.x;           // thread in the workgroup
+    const int l = lane & (kGL - 1);         // lane within the env's 16-lane group
+    const int env = blockIdx.x * (BT / kGL) + (lane >> 4);
     const bool live = env < p.N;
     const int e = live ? env : 0;
 
     // ---- policy: weights into LDS, entry observation into this env's LDS row
     float* pol_lds = reinterpret_cast<float*>(pol_lds4);
     MlpLds wpi, wv;
-    float *xrow = nullptr, *hbuf = nullptr;
+    float *xrow = nullptr, *hbuf = nullptr, *X = nullptr, *H1 = nullptr, *H2 = nullptr;
+    int XS = 0;
     float pstd[R::NA], plstd[R::NA];
     if (kPolicy) {
         const int D = p.D, A = R::NA;
+        const int rows = (kPol == 2) ? pad4(D) : D;
         float* pi_img = pol_lds;
-        float* v_img = pi_img + pad4(mlp_floats(D, A));
-        float* ls_img = v_img + pad4(mlp_floats(D, 1));
-        hbuf = ls_img + pad4(2 * A) + (lane >> 4) * 2 * kPolHd;
-        xrow = ls_img + pad4(2 * A) + 4 * 2 * kPolHd + (lane >> 4) * pad4(D);
-        mlp_stage(pi_img, pol.params, D, A, lane, 64);
-        mlp_stage(v_img, pol.params + mlp_floats(D, A), D, 1, lane, 64);
-        wpi = mlp_lds_view(pi_img, D, A);
-        wv = mlp_lds_view(v_img, D, 1);
+        float* v_img = pi_img + pad4(mlp_lds_floats(rows, A));
+        float* ls_img = v_img + pad4(mlp_lds_floats(rows, 1));
+        float* rest = ls_img + pad4(2 * A);
+        if (kPol == 2) {
+            XS = pad4(D) + 1;
+            X = rest;
+            H1 = X + pad4(16 * XS);
+            H2 = H1 + 2 * 16 * kPolHS;
+            xrow = X + (lane >> 4) * XS;
+            hbuf = H1 + (lane >> 4) * kPolHS; // scratch for the final critic pass
+            for (int i = lane; i < 16 * XS; i += BT) X[i] = 0.0f; // zero padding columns
+        } else {
+            hbuf = rest + (lane >> 4) * 2 * kPolHd;
+            xrow = rest + 4 * 2 * kPolHd + (lane >> 4) * pad4(D);
+        }
+        mlp_stage(pi_img, pol.params, D, rows, A, lane, BT);
+        mlp_stage(v_img, pol.params + mlp_floats(D, A), D, rows, 1, lane, BT);
+        wpi = mlp_lds_view(pi_img, rows, A);
+        wv = mlp_lds_view(v_img, rows, 1);
         const float* gls = pol.params + mlp_floats(D, A) + mlp_floats(D, 1);
 #pragma unroll
         for (int d = 0; d < A; ++d) {
@@ -768,6 +794,7 @@ __global__ __launch_bounds__(64) void group_rollout_kernel(Params p_in, RolloutA
             plstd[d] = log_f(pstd[d]);    // torch.log(pi.stddev)        trpo_core.py:173
             if (blockIdx.x == 0 && lane == d) pol.logstd[d] = plstd[d];
         }
+        __syncthreads();
         for (int k = l; k < D; k += kGL) xrow[k] = pol.obs0[(size_t)e * D + k];
         __syncthreads();
     }
@@ -800,7 +827,17 @@ __global__ __launch_bounds__(64) void group_rollout_kernel(Params p_in, RolloutA
             // ac.step(o): a ~ N(mu(o), std), logp, v(o)   trpo_core.py:166-173
             const size_t te = (size_t)t * p.N + env;
             float mu[R::NA], vv[1];
-            actor_critic_forward<R::NA>(wpi, wv, xrow, hbuf, p.D, l, mu, vv[0]);
+            if (kPol == 2) {
+                mfma_hidden(wpi, wv, X, XS, pad4(p.D), H1, H2, lane >> 6, lane & 63);
+                const float* h2p = H2 + (lane >> 4) * kPolHS + 4 * l;
+                const float4 hp = *reinterpret_cast<const float4*>(h2p);
+                const float4 hc = *reinterpret_cast<const float4*>(h2p + 16 * kPolHS);
+#pragma unroll
+                for (int o = 0; o < R::NA; ++o) mu[o] = head_out(wpi, o, l, hp);
+                vv[0] = head_out(wv, 0, l, hc);
+            } else {
+                actor_critic_forward<R::NA>(wpi, wv, xrow, hbuf, p.D, l, mu, vv[0]);
+            }
             float z[2];
             normal_pair(pol.seed0, pol.seed1, (uint32_t)(p.env_offset + env), (pol.t0 + (uint32_t)t) * 16u, z[0], z[1]);
             float act[R::NA], lp = 0.0f;
@@ -843,7 +880,7 @@ __global__ __launch_bounds__(64) void group_rollout_kernel(Params p_in, RolloutA
             ego_vel_acc(p, pose, L1x, L1y, P2x, P2y, last_done, done2, have_last, have_last_last, vel0, vel1,
                         acc0, acc1);
 
-        GroupObs<OPL, BPL> ob = group_observe<OPL, BPL>(p, rec, term, lane, pose, gx, gy, ox, oy);
+        GroupObs<OPL, BPL> ob = group_observe<OPL, BPL, BT>(p, rec, term, lane, pose, gx, gy, ox, oy);
         bool bad = ob.bad;
         if (p.off_acc >= 0) bad = bad || notfinite(acc0) || notfinite(acc1);
         if (p.off_ctrl >= 0) {
@@ -892,7 +929,7 @@ __global__ __launch_bounds__(64) void group_rollout_kernel(Params p_in, RolloutA
         if (r.do_reset) {
             const int L = *r.layout_size;
             const bool rs = live && dn > 0.0f && L > 0;
-            if (__ballot(rs) != 0ull) {
+            if (__syncthreads_or(rs ? 1 : 0)) { // workgroup-uniform gate
                 float nox[OPL], noy[OPL], ngx = gx, ngy = gy, rx = q[0], ry = q[1];
 #pragma unroll
                 for (int j = 0; j < OPL; ++j) { nox[j] = ox[j]; noy[j] = oy[j]; }
@@ -910,7 +947,7 @@ __global__ __launch_bounds__(64) void group_rollout_kernel(Params p_in, RolloutA
                     ngx = g.x; ngy = g.y; rx = rb.x; ry = rb.y;
                 }
                 const float rpose[4] = {rx, ry, 1.0f, 0.0f};
-                const GroupObs<OPL, BPL> rob = group_observe<OPL, BPL>(p, rec, term, lane, rpose, ngx, ngy, nox, noy);
+                const GroupObs<OPL, BPL> rob = group_observe<OPL, BPL, BT>(p, rec, term, lane, rpose, ngx, ngy, nox, noy);
                 if (rs) {
 #pragma unroll
                     for (int j = 0; j < OPL; ++j) { ox[j] = nox[j]; oy[j] = noy[j]; }
@@ -1136,9 +1173,9 @@ static void launch_group_r(const Params& p, const RolloutArgs& r, const DevBuffe
 #define GX_GROUP_LAUNCH(OPL, BPL, DEF)                                                                      \
     do {                                                                                                    \
         if (r.qacc)                                                                                         \
-            hipLaunchKernelGGL((group_rollout_kernel<R, OPL, BPL, true, DEF, false>), grid, blk, 0, s, p, r, nopol, b.dyn, b.obj, b.hist); \
+            hipLaunchKernelGGL((group_rollout_kernel<R, OPL, BPL, true, DEF, 0>), grid, blk, 0, s, p, r, nopol, b.dyn, b.obj, b.hist); \
         else                                                                                                \
-            hipLaunchKernelGGL((group_rollout_kernel<R, OPL, BPL, false, DEF, false>), grid, blk, 0, s, p, r, nopol, b.dyn, b.obj, b.hist); \
+            hipLaunchKernelGGL((group_rollout_kernel<R, OPL, BPL, false, DEF, 0>), grid, blk, 0, s, p, r, nopol, b.dyn, b.obj, b.hist); \
     } while (0)
     if (is_default_layout<R>(p)) GX_GROUP_LAUNCH(1, 1, true);
     else if (p.nobj <= 16 && p.bins <= 16) GX_GROUP_LAUNCH(1, 1, false);
@@ -1152,26 +1189,37 @@ void launch_group_rollout(const Params& p, const RolloutArgs& r, const DevBuffer
     else launch_group_r<PointRobot>(p, r, b, s);
 }
 
-template <class R>
-static void launch_policy_r(const Params& p, const RolloutArgs& r, const PolicyArgs& pol, const DevBuffers& b,
-                            hipStream_t s)
+template <class R, int kPol>
+static void launch_policy_rp(const Params& p, const RolloutArgs& r, const PolicyArgs& pol, const DevBuffers& b,
+                             hipStream_t s)
 {
-    const dim3 grid((p.N + 3) / 4), blk(64);
-    const size_t lds = sizeof(float) * (size_t)policy_lds_floats(p.D, R::NA);
-    if (is_default_layout<R>(p))
-        hipLaunchKernelGGL((group_rollout_kernel<R, 1, 1, false, true, true>), grid, blk, lds, s, p, r, pol, b.dyn, b.obj, b.hist);
-    else
-        hipLaunchKernelGGL((group_rollout_kernel<R, 1, 1, false, false, true>), grid, blk, lds, s, p, r, pol, b.dyn, b.obj, b.hist);
+    constexpr int BT = (kPol == 2) ? 256 : 64;
+    const dim3 grid((p.N + BT / 16 - 1) / (BT / 16)), blk(BT);
+    const size_t lds = sizeof(float) * (size_t)policy_lds_floats(p.D, R::NA, kPol);
+    auto launch = [&](auto kern) {
+        if (lds > 64 * 1024) // more dynamic LDS than the default cap: raise it for this kernel
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds);
+        hipLaunchKernelGGL(kern, grid, blk, lds, s, p, r, pol, b.dyn, b.obj, b.hist);
+    };
+    if (is_default_layout<R>(p)) launch(group_rollout_kernel<R, 1, 1, false, true, kPol>);
+    else launch(group_rollout_kernel<R, 1, 1, false, false, kPol>);
 }
 
 bool policy_rollout_supported(const Params& p) { return p.nobj <= 16 && p.bins <= 16; }
-size_t policy_lds_bytes(const Params& p) { return sizeof(float) * (size_t)policy_lds_floats(p.D, 2); }
+size_t policy_lds_bytes(const Params& p, int impl) { return sizeof(float) * (size_t)policy_lds_floats(p.D, 2, impl); }
 
+// impl: 1 = VALU fmaf chains (one wave per workgroup), 2 = fp32 MFMA tiles (16 envs per workgroup)
 void launch_policy_rollout(const Params& p, const RolloutArgs& r, const PolicyArgs& pol, const DevBuffers& b,
-                           hipStream_t s)
+                           int impl, hipStream_t s)
 {
-    if (p.robot == SwimmerRobot::kId) launch_policy_r<SwimmerRobot>(p, r, pol, b, s);
-    else launch_policy_r<PointRobot>(p, r, pol, b, s);
+    if (p.robot == SwimmerRobot::kId) {
+        if (impl == 2) launch_policy_rp<SwimmerRobot, 2>(p, r, pol, b, s);
+        else launch_policy_rp<SwimmerRobot, 1>(p, r, pol, b, s);
+    } else {
+        if (impl == 2) launch_policy_rp<PointRobot, 2>(p, r, pol, b, s);
+        else launch_policy_rp<PointRobot, 1>(p, r, pol, b, s);
+    }
 }
 
 __global__ void math_probe2_kernel(int n, const float* x, float* lg, float* th)

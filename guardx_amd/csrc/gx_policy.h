@@ -30,27 +30,30 @@ struct PolicyArgs {
     float* logstd;         // [A]    log(std) as ac.step returns it
 };
 
+GX_HD int mlp_lds_floats(int rows, int Out) { return kPolHd * rows + kPolHd + kPolHd * kPolHd + kPolHd + Out * kPolHd + Out; }
 GX_HD int mlp_floats(int D, int Out) { return kPolHd * D + kPolHd + kPolHd * kPolHd + kPolHd + Out * kPolHd + Out; }
 
 // LDS image of one network: Wt1[D][Hd] b1[Hd] Wt2[Hd][Hd] b2[Hd] W3[Out][Hd] b3[Out]
 struct MlpLds { const float *Wt1, *b1, *Wt2, *b2, *W3, *b3; };
 
-GX_D MlpLds mlp_lds_view(const float* base, int D, int Out)
+// `rows` = input rows allocated for Wt1 (D, or D padded to a multiple of 4 with zero rows for MFMA)
+GX_D MlpLds mlp_lds_view(const float* base, int rows, int Out)
 {
     MlpLds m;
-    m.Wt1 = base; m.b1 = m.Wt1 + kPolHd * D; m.Wt2 = m.b1 + kPolHd; m.b2 = m.Wt2 + kPolHd * kPolHd;
+    m.Wt1 = base; m.b1 = m.Wt1 + kPolHd * rows; m.Wt2 = m.b1 + kPolHd; m.b2 = m.Wt2 + kPolHd * kPolHd;
     m.W3 = m.b2 + kPolHd; m.b3 = m.W3 + Out * kPolHd;
     return m;
 }
 
 // cooperative load of one network from global (torch layout [out][in]) into its LDS image
-GX_D void mlp_stage(float* lds, const float* __restrict__ g, int D, int Out, int tid, int nthreads)
+GX_D void mlp_stage(float* lds, const float* __restrict__ g, int D, int rows, int Out, int tid, int nthreads)
 {
     const float* gW1 = g; const float* gb1 = gW1 + kPolHd * D; const float* gW2 = gb1 + kPolHd;
     const float* gb2 = gW2 + kPolHd * kPolHd; const float* gW3 = gb2 + kPolHd; const float* gb3 = gW3 + Out * kPolHd;
-    float* Wt1 = lds; float* b1 = Wt1 + kPolHd * D; float* Wt2 = b1 + kPolHd; float* b2 = Wt2 + kPolHd * kPolHd;
+    float* Wt1 = lds; float* b1 = Wt1 + kPolHd * rows; float* Wt2 = b1 + kPolHd; float* b2 = Wt2 + kPolHd * kPolHd;
     float* W3 = b2 + kPolHd; float* b3 = W3 + Out * kPolHd;
     for (int i = tid; i < kPolHd * D; i += nthreads) { const int j = i / D, k = i - j * D; Wt1[k * kPolHd + j] = gW1[i]; }
+    for (int i = tid + kPolHd * D; i < kPolHd * rows; i += nthreads) Wt1[i] = 0.0f; // zero padding rows
     for (int i = tid; i < kPolHd * kPolHd; i += nthreads) { const int j = i >> 6, k = i & 63; Wt2[k * kPolHd + j] = gW2[i]; }
     for (int i = tid; i < kPolHd; i += nthreads) { b1[i] = gb1[i]; b2[i] = gb2[i]; }
     for (int i = tid; i < Out * kPolHd; i += nthreads) W3[i] = gW3[i];
@@ -151,6 +154,49 @@ GX_D float critic_forward(const MlpLds& wc, const float* x, float* hbuf, int D, 
     const float v = head_out(wc, 0, l, tanh4(ac));
     __syncthreads();
     return v;
+}
+
+// ---------------------------------------------------------------------------
+// MFMA form (256-thread workgroup = 4 waves = 16 environments).  Each hidden layer is
+// H[16 envs][64 units] = X[16][K] * Wt[K][64] for both networks: 8 output tiles of 16x16, two per
+// wave, each a chain of v_mfma_f32_16x16x4_f32 over K.  That instruction accumulates exactly like a
+// sequential fmaf chain over k (tools/probes/mfma_f32_probe.hip: 0 mismatches), so the results are
+// bit-identical to the VALU form and to the CPU restatement.  Operand layout: A lane = k*16 + env,
+// B lane = k*16 + unit, D lane holds envs 4*(lane/16)..+3 of unit lane%16.
+// ---------------------------------------------------------------------------
+typedef float mfma_f4 __attribute__((ext_vector_type(4)));
+constexpr int kPolHS = 68; // LDS row stride of the hidden activations (16-byte aligned rows)
+
+GX_D void mfma_layer(const MlpLds& wp, const MlpLds& wc, bool second, const float* in, int in_stride,
+                     int in_net_stride, int K, float* out, int wave, int lw)
+{
+    const int c16 = lw & 15, kq = lw >> 4;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int t = 2 * wave + tt, net = t >> 2, ut = t & 3;
+        const MlpLds& w = net ? wc : wp;
+        const float* Wt = second ? w.Wt2 : w.Wt1;
+        const float bias = (second ? w.b2 : w.b1)[16 * ut + c16];
+        mfma_f4 acc = {bias, bias, bias, bias};
+        const float* arow = in + net * in_net_stride + c16 * in_stride + kq;
+        const float* bcol = Wt + kq * kPolHd + 16 * ut + c16;
+        for (int k0 = 0; k0 < K; k0 += 4)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[k0], bcol[k0 * kPolHd], acc, 0, 0, 0);
+        float* o = out + net * 16 * kPolHS + 16 * ut + c16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[(4 * kq + r) * kPolHS] = tanh_f(acc[r]);
+    }
+}
+
+// both hidden layers for the 16 envs of the workgroup; X = [16][XS] observations (zero padded to Kp),
+// H1/H2 = [2 nets][16][kPolHS].  Whole-workgroup call.
+GX_D void mfma_hidden(const MlpLds& wp, const MlpLds& wc, const float* X, int XS, int Kp, float* H1, float* H2,
+                      int wave, int lw)
+{
+    mfma_layer(wp, wc, false, X, XS, 0, Kp, H1, wave, lw);
+    __syncthreads();
+    mfma_layer(wp, wc, true, H1, kPolHS, 16 * kPolHS, kPolHd, H2, wave, lw);
+    __syncthreads();
 }
 
 // two standard normals from one Threefry block keyed by `seed`, counter (global env, step*16+pair)

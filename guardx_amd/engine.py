@@ -467,6 +467,10 @@ class Engine:
         self._info = {'cost': out['cost'][-1]}
         return out
 
+    def set_policy_impl(self, impl):
+        """rollout_policy hidden layers: 0 auto, 1 VALU fmaf chains, 2 fp32 MFMA tiles (same bits)."""
+        _native.check(self._lib.gx_set_policy_impl(self._h, int(impl)))
+
     def set_prefetch(self, steps):
         """Predicted number of step() calls between reset()s for the layout-pool prefetch
         (default num_steps); negative disables.  Never changes results."""

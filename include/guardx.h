@@ -138,6 +138,9 @@ gx_status gx_rollout_policy(gx_engine* e, int32_t T, const gx_policy* pol, const
                             float* d_obs_in, float* d_act, float* d_logp, float* d_val, float* d_mu,
                             float* d_reward, float* d_cost, float* d_done, float* d_obs_last,
                             float* d_val_last, float* d_logstd, void* stream);
+/* How the two hidden layers are evaluated: 0 auto (= 2), 1 VALU fmaf chains with one wave per
+ * workgroup, 2 v_mfma_f32_16x16x4_f32 tiles with 16 envs per workgroup.  Bit-identical results. */
+gx_status gx_set_policy_impl(gx_engine* e, int32_t impl);
 gx_status gx_math_probe2(int32_t n, const float* d_x, float* d_log, float* d_tanh, void* stream);
 
 /* Test / checkpoint support: env-major HOST arrays (any may be NULL).

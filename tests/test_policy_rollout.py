@@ -76,14 +76,16 @@ def test_device_log_tanh_bitexact(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("impl", ["valu", "mfma"])
 @pytest.mark.parametrize("robot", ["point", "swimmer"])
-def test_policy_rollout_parity(oracle, robot):
+def test_policy_rollout_parity(oracle, robot, impl):
     import torch
     from guardx_amd import Engine
     N, T = 203, 50
     extra = SWIMMER if robot == "swimmer" else {}
     cfg = task_config(N, seed=3, num_steps=30, goal_size=0.9, **extra)
     E = Engine(cfg, n_candidates=40000)
+    E.set_policy_impl({"valu": 1, "mfma": 2}[impl])
     O = oracle.OracleEngine(cfg, n_candidates=40000)
     og, oo = E.reset(), O.reset()
     np.testing.assert_array_equal(og.cpu().numpy(), oo)
