@@ -68,9 +68,13 @@ def policy_bench():
     mk = lambda out: torch.nn.Sequential(torch.nn.Linear(D, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64),  # noqa: E731
                                          torch.nn.Tanh(), torch.nn.Linear(64, out))
     params = Engine.pack_actor_critic(mu_net=mk(2), v_net=mk(1), log_std=torch.full((2,), -0.5)).to(dev)
-    env.set_prefetch(-1)
-    env.reset()
-    t_roll = timeit(lambda: env.rollout_policy(params, 200), 10)
+    for impl in (1, 2):
+        env.set_policy_impl(impl)
+        env.set_prefetch(-1)
+        env.reset()
+        t_roll = timeit(lambda: env.rollout_policy(params, 200), 10)
+        print(f"impl={impl} ({'VALU' if impl == 1 else 'MFMA'}): policy rollout(200) alone {t_roll*1e3:.3f} ms = "
+              f"{t_roll/200*1e6:.2f} us/step")
 
     def epoch():
         env.reset()
