@@ -69,6 +69,7 @@ SYMBOLS = {
     "gx_set_path": (C.c_int, [C.c_void_p, C.c_int32]),
     "gx_buffer_store": (C.c_int, [C.c_int32] * 5 + [_FP] * 14 + [C.c_void_p]),
     "gx_gae_finish_path": (C.c_int, [C.c_int32] * 3 + [_FP] * 5 + [C.c_double, C.c_double, _FP, _FP, C.c_int32, C.c_void_p]),
+    "gx_gae_rollout": (C.c_int, [C.c_int32, C.c_int32, _FP, _FP, _FP, _FP, C.c_double, C.c_double, _FP, _FP, C.c_void_p]),
     "gx_adv_normalize": (C.c_int, [C.c_int32, C.c_int32, _FP, C.c_int32, C.c_void_p]),
     "gx_math_probe": (C.c_int, [C.c_int32, _FP, _FP, _FP, _FP, _FP, _FP, C.c_void_p]),
     "gx_split_probe": (C.c_int, [_U32P, C.c_int32, _FP, C.c_void_p]),

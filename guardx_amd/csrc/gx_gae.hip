@@ -92,6 +92,31 @@ __global__ void adv_normalize_kernel(int N, int T, float* __restrict__ adv, int 
     else { for (int t = lane; t < T; t += 64) row[t] = row[t] - mean; } // cpo.py:158-162: centred, not scaled
 }
 
+// GAE over a whole fused rollout (time-major [T][N] arrays): the same arithmetic as finish_path,
+// with a path ending wherever done[t] == 1 (bootstrap 0, trpo.py:530-531) and at the end of the tape
+// (bootstrap `last_val[env]`, which the caller zeroes when it mirrors trpo.py:506-515).
+__global__ void gae_rollout_kernel(int N, int T, const float* __restrict__ rew, const float* __restrict__ val,
+                                   const float* __restrict__ done, const float* __restrict__ last_val,
+                                   float gamma, double dg, double dgl, float* __restrict__ adv,
+                                   float* __restrict__ ret)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= N) return;
+    double a = 0.0, r = (double)last_val[env];
+    float vnext = last_val[env];
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t i = (size_t)t * N + env;
+        if (done[i] == 1.0f) { a = 0.0; r = 0.0; vnext = 0.0f; } // step t closes a path
+        const float rt = rew[i], vt = val[i];
+        const float delta = (rt + gamma * vnext) - vt;
+        a = (double)delta + dgl * a;
+        r = (double)rt + dg * r;
+        adv[i] = (float)a;
+        ret[i] = (float)r;
+        vnext = vt;
+    }
+}
+
 } // namespace
 
 extern "C" gx_status gx_buffer_store(int32_t env_num, int32_t max_ep_len, int32_t ptr, int32_t obs_dim,
@@ -137,4 +162,15 @@ extern "C" gx_status gx_adv_normalize(int32_t env_num, int32_t max_ep_len, float
     hipLaunchKernelGGL(adv_normalize_kernel, dim3((env_num + 3) / 4), dim3(256), 0, (hipStream_t)stream, env_num,
                        max_ep_len, d_adv_buf, scale);
     return hipGetLastError() == hipSuccess ? GX_OK : gx_fail_msg(GX_ERR_HIP, "gx_adv_normalize launch failed");
+}
+
+extern "C" gx_status gx_gae_rollout(int32_t env_num, int32_t T, const float* d_rew, const float* d_val,
+                                    const float* d_done, const float* d_last_val, double gamma, double lam,
+                                    float* d_adv, float* d_ret, void* stream)
+{
+    if (env_num < 1 || T < 1 || !d_rew || !d_val || !d_done || !d_last_val || !d_adv || !d_ret)
+        return gx_fail_msg(GX_ERR_ARG, "gx_gae_rollout: bad argument");
+    hipLaunchKernelGGL(gae_rollout_kernel, dim3((env_num + 63) / 64), dim3(64), 0, (hipStream_t)stream, env_num, T,
+                       d_rew, d_val, d_done, d_last_val, (float)gamma, gamma, gamma * lam, d_adv, d_ret);
+    return hipGetLastError() == hipSuccess ? GX_OK : gx_fail_msg(GX_ERR_HIP, "gx_gae_rollout launch failed");
 }

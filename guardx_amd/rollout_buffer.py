@@ -126,3 +126,20 @@ class DeviceCostRolloutBuffer(DeviceRolloutBuffer):
         data['cost_ret'] = self.cost_ret_buf.view(N * T)
         data['adc'] = self.adc_buf.view(N * T)
         return data
+
+
+def gae_rollout(rew, val, done, last_val=None, gamma=0.99, lam=0.95):
+    """GAE-lambda advantages and rewards-to-go for a whole fused rollout (time-major (T, N) tensors from
+    Engine.rollout / rollout_policy): equivalent to TRPOBufferX.store + finish_path at every done step +
+    the closing finish_path (trpo.py:466-547), in one kernel launch.  Returns (adv, ret), both (T, N)."""
+    T, N = rew.shape
+    dev = rew.device
+    f = lambda x: x.to(torch.float32).contiguous()   # noqa: E731
+    rew, val, done = f(rew), f(val), f(done)
+    last_val = torch.zeros(N, device=dev) if last_val is None else f(last_val.reshape(N))
+    adv, ret = torch.empty_like(rew), torch.empty_like(rew)
+    lib = _native.load()
+    _native.check(lib.gx_gae_rollout(N, T, rew.data_ptr(), val.data_ptr(), done.data_ptr(), last_val.data_ptr(),
+                                     float(gamma), float(lam), adv.data_ptr(), ret.data_ptr(),
+                                     C.c_void_p(torch._C._cuda_getCurrentRawStream(dev.index))))
+    return adv, ret

@@ -187,6 +187,13 @@ gx_status gx_gae_finish_path(int32_t env_num, int32_t max_ep_len, int32_t ptr, c
                              const float* d_val_buf, const float* d_last_val, const float* d_done,
                              int32_t* d_path_start, double gamma, double lam, float* d_adv_buf,
                              float* d_ret_buf, int32_t advance_path_start, void* stream);
+/* GAE-lambda over the time-major outputs of gx_rollout / gx_rollout_policy ([T][env_num] arrays): what
+ * store() + finish_path() at every done step + the closing finish_path() of trpo.py:466-547 produce, in
+ * one launch.  A path ends at every step with d_done == 1 (bootstrap 0) and at the end of the tape
+ * (bootstrap d_last_val[env]; pass zeros to mirror trpo.py:506-515). */
+gx_status gx_gae_rollout(int32_t env_num, int32_t T, const float* d_rew, const float* d_val,
+                         const float* d_done, const float* d_last_val, double gamma, double lam,
+                         float* d_adv, float* d_ret, void* stream);
 /* scale != 0: (x - mean) / std (reward advantage); scale == 0: x - mean (CPO cost advantage,
  * safe_rl_libX/cpo/cpo.py:158-162) */
 gx_status gx_adv_normalize(int32_t env_num, int32_t max_ep_len, float* d_adv_buf, int32_t scale,

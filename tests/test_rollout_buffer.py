@@ -102,3 +102,26 @@ def test_device_cost_buffer_matches_cpo_semantics():
     np.testing.assert_allclose(d['adc'].cpu().numpy().reshape(N, T), adc_raw - adc_raw.mean(1, keepdims=True),
                                rtol=2e-5, atol=2e-5)
     assert set(d) == {'obs', 'act', 'ret', 'adv', 'cost_ret', 'adc', 'logp', 'mu', 'logstd'}
+
+
+@pytest.mark.gpu
+def test_gae_rollout_equals_stepwise_buffer():
+    """gx_gae_rollout on (T, N) arrays == store() + finish_path() at every done step + closing
+    finish_path(), i.e. the TRPO collection loop (trpo.py:466-547)."""
+    import torch
+    from guardx_amd.rollout_buffer import gae_rollout
+    N, T, D, A = 300, 70, 5, 2
+    rng = np.random.default_rng(3)
+    rew, val = rng.normal(size=(T, N)).astype(np.float32), rng.normal(size=(T, N)).astype(np.float32)
+    done = (rng.random((T, N)) < 0.05).astype(np.float32)
+    O = TRPOBufferNP(N, T, D, A)
+    z = np.zeros
+    for t in range(T):
+        O.store(z((N, D)), z((N, A)), rew[t], val[t], z(N), z((N, A)), z((N, A)))
+        if t + 1 == T:
+            O.finish_path(z(N, np.float32), np.ones(N))
+        elif done[t].any():
+            O.finish_path(z(N, np.float32), done[t])       # v = 0 for the done envs (trpo.py:530-531)
+    adv, ret = gae_rollout(torch.from_numpy(rew).cuda(), torch.from_numpy(val).cuda(), torch.from_numpy(done).cuda())
+    np.testing.assert_allclose(adv.cpu().numpy().T, O.adv_buf, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(ret.cpu().numpy().T, O.ret_buf, rtol=1e-6, atol=1e-6)
