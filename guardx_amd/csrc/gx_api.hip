@@ -120,8 +120,9 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     if (!cfg || !out) return fail(GX_ERR_ARG, "null argument");
     if (cfg->struct_size != (int32_t)sizeof(gx_config))
         return fail(GX_ERR_ARG, "gx_config.struct_size mismatch");
-    if (cfg->robot != PointRobot::kId && cfg->robot != SwimmerRobot::kId)
-        return fail(GX_ERR_UNSUPPORTED, "robots with HIP dynamics: 0 = xmls/point.xml, 1 = xmls/swimmer.xml");
+    if (cfg->robot != PointRobot::kId && cfg->robot != SwimmerRobot::kId && cfg->robot != AntRobot::kId)
+        return fail(GX_ERR_UNSUPPORTED,
+                    "robots with HIP dynamics: 0 = xmls/point.xml, 1 = xmls/swimmer.xml, 2 = xmls/ant.xml");
     if (cfg->env_num < 1 || cfg->env_total < cfg->env_num || cfg->env_offset < 0 ||
         cfg->env_offset + cfg->env_num > cfg->env_total)
         return fail(GX_ERR_ARG, "bad env_num/env_total/env_offset");
@@ -145,6 +146,9 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     if (cfg->robot == SwimmerRobot::kId) {
         e->nq = SwimmerRobot::NQ; e->nv = SwimmerRobot::NV; e->nu = SwimmerRobot::NU;
         e->na = SwimmerRobot::NA; e->ndyn = SwimmerRobot::NDYN;
+    } else if (cfg->robot == AntRobot::kId) {
+        e->nq = AntRobot::NQ; e->nv = AntRobot::NV; e->nu = AntRobot::NU;
+        e->na = AntRobot::NA; e->ndyn = AntRobot::NDYN;
     } else {
         e->nq = PointRobot::NQ; e->nv = PointRobot::NV; e->nu = PointRobot::NU;
         e->na = PointRobot::NA; e->ndyn = PointRobot::NDYN;
@@ -178,7 +182,10 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     p.reward_distance = cfg->reward_distance;
     p.num_steps_f = (float)cfg->num_steps;
     p.physics_steps = cfg->physics_steps;
-    p.dt = (cfg->robot == SwimmerRobot::kId ? SwimmerRobot::kH : PointRobot::kH) * (float)cfg->physics_steps; // engine.py:235
+    const float h_robot = cfg->robot == SwimmerRobot::kId ? SwimmerRobot::kH
+                          : cfg->robot == AntRobot::kId   ? AntRobot::kH
+                                                          : PointRobot::kH;
+    p.dt = h_robot * (float)cfg->physics_steps; // engine.py:235
     p.env_total = cfg->env_total;
     p.env_offset = cfg->env_offset;
     p.have_last = p.have_last_last = 0;
@@ -439,7 +446,7 @@ extern "C" gx_status gx_step(gx_engine* e, const float* d_action, float* d_obs, 
         RolloutArgs r;
         memset(&r, 0, sizeof r);
         r.T = 1; r.do_reset = 0; r.nobj_total = e->nobj_total; r.hist0 = e->hist;
-        r.act = reinterpret_cast<const float2*>(d_action);
+        r.act = static_cast<const float*>(d_action);
         r.obs = d_obs; r.rew = d_reward; r.cost = d_cost; r.done = d_done; r.qacc = d_qacc;
         launch_group_rollout(e->p, r, e->b, (hipStream_t)stream);
     } else {
@@ -525,7 +532,7 @@ extern "C" gx_status gx_rollout(gx_engine* e, int32_t T, const float* d_actions,
         if (st != GX_OK) return st;
         RolloutArgs r;
         fill_rollout_args(e, r, T, slot);
-        r.act = reinterpret_cast<const float2*>(d_actions);
+        r.act = static_cast<const float*>(d_actions);
         r.obs = d_obs; r.rew = d_reward; r.cost = d_cost; r.done = d_done; r.qacc = nullptr;
         launch_group_rollout(e->p, r, e->b, s);
         GX_HIP(hipEventRecord(e->keys_ev[slot], s)); // staging reusable once this launch is done

@@ -53,7 +53,7 @@ void launch_reset_done(const Params& p, const DevBuffers& b, int nobj_total, uin
 // lane-group persistent rollout (small batches): arguments of one launch
 struct RolloutArgs {
     int T, do_reset, nobj_total, hist0;
-    const float2* act;
+    const float* act;
     float* obs;
     float* rew;
     float* cost;

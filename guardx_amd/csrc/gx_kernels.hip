@@ -153,11 +153,31 @@ GX_D void ego_vel_acc(const Params& p, const float (&pose)[4], float L1x, float 
     acc1 = awx * (-pose[3]) + awy * pose[2];
 }
 
+// action row of env `i` ((N, NA) row-major): one 8/16-byte load per 2/4 floats when the base allows it
+template <class R>
+GX_D void load_action(const float* __restrict__ act, size_t i, float (&a)[R::NA])
+{
+    const float* row = act + i * R::NA;
+    if (R::NA == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(row); // every entry point checks 8-byte alignment
+        a[0] = t.x; a[1] = t.y;
+    } else if (R::NA % 4 == 0 && (reinterpret_cast<uintptr_t>(act) & 15u) == 0) {
+#pragma unroll
+        for (int k = 0; k < R::NA / 4; ++k) {
+            const float4 t = reinterpret_cast<const float4*>(row)[k];
+            a[4 * k] = t.x; a[4 * k + 1] = t.y; a[4 * k + 2] = t.z; a[4 * k + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < R::NA; ++k) a[k] = row[k];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Engine.step (engine.py:469-495 + mjx_step :659-700), thread-per-env form.
 // ---------------------------------------------------------------------------
 template <class R, int BLOCK, int PMAX, bool kQacc, bool kDef>
-__global__ __launch_bounds__(BLOCK) void step_kernel(Params p_in, const float2* __restrict__ act,
+__global__ __launch_bounds__(BLOCK) void step_kernel(Params p_in, const float* __restrict__ act,
                                                      float4* __restrict__ dyn,
                                                      const float4* __restrict__ obj,
                                                      float4* __restrict__ hist,
@@ -176,7 +196,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p_in, const float2* 
     const bool live = i < p.N;
 
     // ---- coalesced loads (arrays are padded to Npad, every lane may load)
-    const float2 a = live ? act[i] : make_float2(0.f, 0.f);
+    float a[R::NA];
+    load_action<R>(act, live ? i : 0, a);
     float q[R::NQ], v[R::NV], pose0[4], last_done, steps;
     R::load(dyn, p.Npad, i, q, v, pose0, last_done, steps);
     float4 ob[PMAX];
@@ -188,7 +209,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p_in, const float2* 
     const float P1x = pose0[0], P1y = pose0[1]; // last_data.xpos
 
     float ctrl[R::NU];
-    R::convert_action(pose0, a.x, a.y, ctrl); // :672-685, PRE-step xmat
+    R::convert_action(pose0, a, ctrl); // :672-685, PRE-step xmat
     float pose[4], qacc[R::NV];
 #pragma unroll
     for (int k = 0; k < R::NV; ++k) qacc[k] = 0.f;
@@ -550,7 +571,7 @@ __global__ __launch_bounds__(BLOCK) void reset_apply_kernel(Params p, int nobj_t
     for (int k = 0; k < R::NV; ++k) v[k] = 0.f;
 #pragma unroll
     for (int k = 0; k < R::NU; ++k) ctrl[k] = 0.f;
-    q[0] = rx; q[1] = ry;
+    R::place(q, rx, ry);
     const float pose[4] = {rx, ry, 1.0f, 0.0f};
     float* row = tile + tid * p.D;
     build_obs_row<R, PMAX>(p, row, pose, ob, ctrl, q, v, 0.f, 0.f, 0.f, 0.f);
@@ -613,9 +634,19 @@ __global__ __launch_bounds__(BLOCK) void reset_done_kernel(Params p, int nobj_to
         for (int k = 0; k < R::NV; ++k) v[k] = 0.f;
 #pragma unroll
         for (int k = 0; k < R::NU; ++k) ctrl[k] = 0.f;
-        q[0] = rx; q[1] = ry;
-        const float pose[4] = {rx, ry, 1.0f, 0.0f};
-        build_obs_row<R, PMAX>(p, tile + tid * p.D, pose, ob, ctrl, q, v, 0.f, 0.f, 0.f, 0.f);
+        R::place(q, rx, ry);
+        float pose[4] = {rx, ry, 1.0f, 0.0f};
+        if (R::kRestFixed) {
+            build_obs_row<R, PMAX>(p, tile + tid * p.D, pose, ob, ctrl, q, v, 0.f, 0.f, 0.f, 0.f);
+        } else { // the fake step moves the robot: its qpos/qvel feed the obs only
+            float fq[R::NQ], fv[R::NV], fa[R::NV];
+#pragma unroll
+            for (int k = 0; k < R::NQ; ++k) fq[k] = q[k];
+#pragma unroll
+            for (int k = 0; k < R::NV; ++k) fv[k] = 0.f;
+            for (int k = 0; k < p.physics_steps; ++k) R::template substep<false>(fq, fv, ctrl, pose, fa);
+            build_obs_row<R, PMAX>(p, tile + tid * p.D, pose, ob, ctrl, fq, fv, 0.f, 0.f, 0.f, 0.f);
+        }
         R::store(dyn, p.Npad, i, q, v, opose, odone, osteps);
 #pragma unroll
         for (int k = 0; k < PMAX; ++k)
@@ -817,12 +848,16 @@ __global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Par
     { const float2 g = obj2[(size_t)e * 2]; gx = g.x; gy = g.y; }
     bool touched_layout = false;
 
-    float2 a_next = make_float2(0.f, 0.f);
-    if (!kPolicy) a_next = r.act[(size_t)e];
+    float a_next[R::NA];
+#pragma unroll
+    for (int d = 0; d < R::NA; ++d) a_next[d] = 0.f;
+    if (!kPolicy) load_action<R>(r.act, (size_t)e, a_next);
     for (int t = 0; t < r.T; ++t) {
-        float2 a = a_next;
+        float a[R::NA];
+#pragma unroll
+        for (int d = 0; d < R::NA; ++d) a[d] = a_next[d];
         if (!kPolicy) {
-            if (t + 1 < r.T) a_next = r.act[(size_t)(t + 1) * p.N + e];
+            if (t + 1 < r.T) load_action<R>(r.act, (size_t)(t + 1) * p.N + e, a_next);
         } else {
             // ac.step(o): a ~ N(mu(o), std), logp, v(o)   trpo_core.py:166-173
             const size_t te = (size_t)t * p.N + env;
@@ -838,8 +873,11 @@ __global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Par
             } else {
                 actor_critic_forward<R::NA>(wpi, wv, xrow, hbuf, p.D, l, mu, vv[0]);
             }
-            float z[2];
-            normal_pair(pol.seed0, pol.seed1, (uint32_t)(p.env_offset + env), (pol.t0 + (uint32_t)t) * 16u, z[0], z[1]);
+            float z[R::NA];
+#pragma unroll
+            for (int j = 0; j < R::NA / 2; ++j) // one counter per pair of action dimensions
+                normal_pair(pol.seed0, pol.seed1, (uint32_t)(p.env_offset + env), (pol.t0 + (uint32_t)t) * 16u + (uint32_t)j,
+                            z[2 * j], z[2 * j + 1]);
             float act[R::NA], lp = 0.0f;
 #pragma unroll
             for (int d = 0; d < R::NA; ++d) {
@@ -848,7 +886,8 @@ __global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Par
                 const float var = pstd[d] * pstd[d];
                 lp = lp + ((-(df * df) / (2.0f * var) - plstd[d]) - 0.9189385332046727f);
             }
-            a = make_float2(act[0], act[1]);
+#pragma unroll
+            for (int d = 0; d < R::NA; ++d) a[d] = act[d];
             if (live) {
                 for (int k = l; k < p.D; k += kGL) pol.obs_in[te * p.D + k] = xrow[k];
                 if (l < R::NA) {
@@ -869,7 +908,7 @@ __global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Par
 
         // convert_action :672-685, mjx.step :689
         float ctrl[R::NU];
-        R::convert_action(pose0, a.x, a.y, ctrl);
+        R::convert_action(pose0, a, ctrl);
         float pose[4], qacc[R::NV];
 #pragma unroll
         for (int k = 0; k < R::NV; ++k) qacc[k] = 0.f;
@@ -930,7 +969,7 @@ __global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Par
             const int L = *r.layout_size;
             const bool rs = live && dn > 0.0f && L > 0;
             if (__syncthreads_or(rs ? 1 : 0)) { // workgroup-uniform gate
-                float nox[OPL], noy[OPL], ngx = gx, ngy = gy, rx = q[0], ry = q[1];
+                float nox[OPL], noy[OPL], ngx = gx, ngy = gy, rx = 0.f, ry = 0.f;
 #pragma unroll
                 for (int j = 0; j < OPL; ++j) { nox[j] = ox[j]; noy[j] = oy[j]; }
                 if (rs) {
@@ -946,19 +985,31 @@ __global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Par
                     const float2 g = rowp[0], rb = rowp[r.nobj_total - 1];
                     ngx = g.x; ngy = g.y; rx = rb.x; ry = rb.y;
                 }
-                const float rpose[4] = {rx, ry, 1.0f, 0.0f};
+                float rpose[4] = {rx, ry, 1.0f, 0.0f};
+                float fq[R::NQ], fv[R::NV];
+#pragma unroll
+                for (int k = 0; k < R::NQ; ++k) fq[k] = 0.f;
+#pragma unroll
+                for (int k = 0; k < R::NV; ++k) fv[k] = 0.f;
+                R::place(fq, rx, ry);
+                if (!R::kRestFixed) { // the fake step (:719-724) moves the robot: its qpos/qvel feed the obs only
+                    float fa[R::NV], zc[R::NU];
+#pragma unroll
+                    for (int k = 0; k < R::NU; ++k) zc[k] = 0.f;
+                    for (int k = 0; k < p.physics_steps; ++k) R::template substep<false>(fq, fv, zc, rpose, fa);
+                }
                 const GroupObs<OPL, BPL> rob = group_observe<OPL, BPL, BT>(p, rec, term, lane, rpose, ngx, ngy, nox, noy);
                 if (rs) {
 #pragma unroll
                     for (int j = 0; j < OPL; ++j) { ox[j] = nox[j]; oy[j] = noy[j]; }
                     gx = ngx; gy = ngy;
 #pragma unroll
-                    for (int k = 0; k < R::NQ; ++k) { q[k] = 0.f; o_q[k] = 0.f; }
+                    for (int k = 0; k < R::NQ; ++k) { q[k] = 0.f; o_q[k] = fq[k]; }
 #pragma unroll
-                    for (int k = 0; k < R::NV; ++k) { v[k] = 0.f; o_v[k] = 0.f; }
+                    for (int k = 0; k < R::NV; ++k) { v[k] = 0.f; o_v[k] = fv[k]; }
 #pragma unroll
                     for (int k = 0; k < R::NU; ++k) o_ctrl[k] = 0.f;
-                    q[0] = rx; q[1] = ry; o_q[0] = rx; o_q[1] = ry;
+                    R::place(q, rx, ry);
 #pragma unroll
                     for (int jb = 0; jb < BPL; ++jb) { ob.gl[jb] = rob.gl[jb]; ob.hl[jb] = rob.hl[jb]; }
                     ob.comp0 = rob.comp0; ob.comp1 = rob.comp1;
@@ -1066,7 +1117,7 @@ static void launch_step_bp(const Params& p, const DevBuffers& b, const float* ac
 {
     const dim3 grid((p.N + BLOCK - 1) / BLOCK), blk(BLOCK);
     const size_t lds = step_lds_bytes(p, BLOCK);
-    const float2* a2 = reinterpret_cast<const float2*>(act);
+    const float* a2 = act;
     if (PMAX == 5 && is_default_layout<R>(p)) {
         if (qacc)
             hipLaunchKernelGGL((step_kernel<R, BLOCK, 5, true, true>), grid, blk, lds, s, p, a2, b.dyn, b.obj, b.hist,
@@ -1100,6 +1151,7 @@ static void launch_step_bp(const Params& p, const DevBuffers& b, const float* ac
 #define GX_DISPATCH_BP(FN, ...)                                        \
     do {                                                               \
         if (p.robot == SwimmerRobot::kId) GX_DISPATCH_BP_R(SwimmerRobot, FN, __VA_ARGS__); \
+        else if (p.robot == AntRobot::kId) GX_DISPATCH_BP_R(AntRobot, FN, __VA_ARGS__);    \
         else GX_DISPATCH_BP_R(PointRobot, FN, __VA_ARGS__);            \
     } while (0)
 
@@ -1186,6 +1238,7 @@ static void launch_group_r(const Params& p, const RolloutArgs& r, const DevBuffe
 void launch_group_rollout(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s)
 {
     if (p.robot == SwimmerRobot::kId) launch_group_r<SwimmerRobot>(p, r, b, s);
+    else if (p.robot == AntRobot::kId) launch_group_r<AntRobot>(p, r, b, s);
     else launch_group_r<PointRobot>(p, r, b, s);
 }
 
@@ -1207,7 +1260,10 @@ static void launch_policy_rp(const Params& p, const RolloutArgs& r, const Policy
 }
 
 bool policy_rollout_supported(const Params& p) { return p.nobj <= 16 && p.bins <= 16; }
-size_t policy_lds_bytes(const Params& p, int impl) { return sizeof(float) * (size_t)policy_lds_floats(p.D, 2, impl); }
+size_t policy_lds_bytes(const Params& p, int impl)
+{
+    return sizeof(float) * (size_t)policy_lds_floats(p.D, p.robot == AntRobot::kId ? AntRobot::NA : 2, impl);
+}
 
 // impl: 1 = VALU fmaf chains (one wave per workgroup), 2 = fp32 MFMA tiles (16 envs per workgroup)
 void launch_policy_rollout(const Params& p, const RolloutArgs& r, const PolicyArgs& pol, const DevBuffers& b,
@@ -1216,6 +1272,9 @@ void launch_policy_rollout(const Params& p, const RolloutArgs& r, const PolicyAr
     if (p.robot == SwimmerRobot::kId) {
         if (impl == 2) launch_policy_rp<SwimmerRobot, 2>(p, r, pol, b, s);
         else launch_policy_rp<SwimmerRobot, 1>(p, r, pol, b, s);
+    } else if (p.robot == AntRobot::kId) {
+        if (impl == 2) launch_policy_rp<AntRobot, 2>(p, r, pol, b, s);
+        else launch_policy_rp<AntRobot, 1>(p, r, pol, b, s);
     } else {
         if (impl == 2) launch_policy_rp<PointRobot, 2>(p, r, pol, b, s);
         else launch_policy_rp<PointRobot, 1>(p, r, pol, b, s);

@@ -38,10 +38,13 @@ struct PointRobot {
         dyn[2 * Npad + i] = make_float4(pose0[2], pose0[3], done0, steps);
     }
     // convert_action :672-685: (a0,0,0) rotated by the PRE-step xmat, a1 on the hinge
-    GX_D static void convert_action(const float (&pose0)[4], float a0, float a1, float (&ctrl)[NU])
+    GX_D static void convert_action(const float (&pose0)[4], const float (&a)[NA], float (&ctrl)[NU])
     {
-        ctrl[0] = pose0[2] * a0; ctrl[1] = pose0[3] * a0; ctrl[2] = a1;
+        ctrl[0] = pose0[2] * a[0]; ctrl[1] = pose0[3] * a[0]; ctrl[2] = a[1];
     }
+    // layout2qpos (:635-638): robot_x / robot_y slide joints; a step from rest with zero ctrl is a fixed point
+    static constexpr bool kRestFixed = true;
+    GX_D static void place(float (&q)[NQ], float rx, float ry) { q[0] = rx; q[1] = ry; }
 
     template <bool kQacc>
     GX_D static void substep(float (&q)[NQ], float (&v)[NV], const float (&ctrl)[NU], float (&pose)[4],
@@ -119,10 +122,12 @@ struct SwimmerRobot {
         dyn[2 * Npad + i] = make_float4(v[3], v[4], pose0[0], pose0[1]);
         dyn[3 * Npad + i] = make_float4(pose0[2], pose0[3], done0, steps);
     }
-    GX_D static void convert_action(const float (&)[4], float a0, float a1, float (&ctrl)[NU])
+    GX_D static void convert_action(const float (&)[4], const float (&a)[NA], float (&ctrl)[NU])
     {
-        ctrl[0] = a0; ctrl[1] = a1; // non-point robots: the action is the ctrl (:673)
+        ctrl[0] = a[0]; ctrl[1] = a[1]; // non-point robots: the action is the ctrl (:673)
     }
+    static constexpr bool kRestFixed = true;
+    GX_D static void place(float (&q)[NQ], float rx, float ry) { q[0] = rx; q[1] = ry; }
 
     struct Ldl3 { float rd0, rd1, rd2, l10, l20, l21; };
     GX_D static void ldl_solve(const Ldl3& f, float b0, float b1, float b2, float (&x)[3])
@@ -276,3 +281,5 @@ struct SwimmerRobot {
 };
 
 } // namespace gx
+
+#include "gx_robot_ant.h"

@@ -108,6 +108,9 @@ int   gxo_rollout_policy(gxo_env* e, int32_t T, int32_t hidden, const float* par
                          uint32_t t0, const float* obs0, float* obs_in, float* act, float* logp, float* val,
                          float* mu, float* rew, float* cost, float* done, float* obs_last, float* val_last,
                          float* logstd);
+/* one ant.xml mjx.step (test probe): dbg = 121 dense mass matrix + 11 smooth force, qpos coordinates */
+void  gxo_ant_probe(const float* q, const float* v, const float* ctrl, float* q2, float* v2, float* qacc,
+                    float* pose, float* dbg);
 void  gxo_set_threads(int32_t n);
 int   gxo_get_threads(void);
 

@@ -5,14 +5,14 @@ These are SELF-CONSISTENCY vectors: the reference cannot run here (SURVEY.md sec
 so they pin the restatement (and, on the GPU, the HIP path) against regressions; they
 are not reference outputs.
 
-    python tools/gen_golden.py
+    python tests/golden/gen_golden.py
 """
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import task_config  # noqa: E402

@@ -17,11 +17,15 @@ def task_config(env_num, seed=0, num_steps=200, **over):
 
 
 SWIMMER = {'robot_base': 'xmls/swimmer.xml'}
+ANT = {'robot_base': 'xmls/ant.xml'}
+ANT_SIGMA = np.array([1, -1, -1, 1], np.float32)     # sign of the ankle axes, ant.xml:27,44,61,77
 
 
 def random_state(N, H, rng, spread=2.5, done_frac=0.1, near_frac=0.3, robot='point'):
     """A random but plausible engine state (env-major arrays, see gx_get_state)."""
     f = np.float32
+    if robot == 'ant':
+        return _random_state_ant(N, H, rng, spread, done_frac, near_frac)
     nq = 3 if robot == 'point' else 5
     qpos = np.empty((N, nq), f)
     qpos[:, :2] = rng.uniform(-spread, spread, (N, 2))
@@ -49,6 +53,43 @@ def random_state(N, H, rng, spread=2.5, done_frac=0.1, near_frac=0.3, robot='poi
     objs[near, 0] = qpos[near, :2] + rng.uniform(-0.6, 0.6, (near.sum(), 2)).astype(f)
     nearh = rng.random(N) < near_frac
     objs[nearh, 1] = qpos[nearh, :2] + rng.uniform(-0.35, 0.35, (nearh.sum(), 2)).astype(f)
+    done0 = (rng.random(N) < done_frac).astype(f)
+    done1 = (rng.random(N) < done_frac).astype(f)
+    steps = rng.integers(0, 250, N).astype(f)
+    return dict(qpos=qpos, qvel=qvel, pose0=pose0, pose1=pose1, objs=objs,
+                done0=done0, done1=done1, steps=steps,
+                key=np.array([rng.integers(0, 2**32), rng.integers(0, 2**32)], np.uint32), hist=2)
+
+
+def _random_state_ant(N, H, rng, spread, done_frac, near_frac):
+    """qpos = (x, th, y, hip1, ankle1, ..., hip4, ankle4); a mix of in-range legs, legs beyond their
+    joint limits and feet pressed into the floor (ankle beyond ~58 deg); headings away from the
+    |th| = pi/2 singularity of the x / body-y slide pair."""
+    f = np.float32
+    qpos = np.zeros((N, 11), f); qvel = np.zeros((N, 11), f)
+    qpos[:, 0] = rng.uniform(-spread, spread, N)
+    qpos[:, 1] = rng.uniform(-1.1, 1.1, N)
+    qpos[:, 2] = rng.uniform(-spread, spread, N)
+    for leg in range(4):
+        qpos[:, 3 + 2 * leg] = rng.uniform(-0.8, 0.8, N)
+        qpos[:, 4 + 2 * leg] = ANT_SIGMA[leg] * rng.uniform(0.0, 1.5, N)
+    rest = rng.random(N) < 0.1            # freshly reset robots: all joints at zero
+    qpos[rest, 1] = 0.0; qpos[rest, 3:] = 0.0
+    qvel[:, 0] = rng.uniform(-1, 1, N); qvel[:, 2] = rng.uniform(-1, 1, N)
+    qvel[:, 1] = rng.uniform(-3, 3, N)
+    qvel[:, 3:] = rng.uniform(-6, 6, (N, 8))
+    qvel[rest] = 0.0
+    th_prev = qpos[:, 1] + rng.uniform(-0.1, 0.1, N)
+    pose0 = np.empty((N, 4), f)
+    pose0[:, 0] = qpos[:, 0] - np.sin(qpos[:, 1]) * qpos[:, 2] - rng.uniform(-0.05, 0.05, N)
+    pose0[:, 1] = np.cos(qpos[:, 1]) * qpos[:, 2] - rng.uniform(-0.05, 0.05, N)
+    pose0[:, 2] = np.cos(th_prev); pose0[:, 3] = np.sin(th_prev)
+    pose1 = (pose0[:, :2] - rng.uniform(-0.05, 0.05, (N, 2))).astype(f)
+    objs = rng.uniform(-2, 2, (N, 1 + H, 2)).astype(f)
+    near = rng.random(N) < near_frac
+    objs[near, 0] = pose0[near, :2] + rng.uniform(-0.6, 0.6, (near.sum(), 2)).astype(f)
+    nearh = rng.random(N) < near_frac
+    objs[nearh, 1] = pose0[nearh, :2] + rng.uniform(-0.35, 0.35, (nearh.sum(), 2)).astype(f)
     done0 = (rng.random(N) < done_frac).astype(f)
     done1 = (rng.random(N) < done_frac).astype(f)
     steps = rng.integers(0, 250, N).astype(f)

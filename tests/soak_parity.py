@@ -2,7 +2,7 @@
 """Soak test (MI355X box): HIP vs CPU restatement on many more random states and longer episodes
 than the unit tests, looking for rare floating-point divergences.  Exits non-zero on any mismatch.
 
-    python tools/soak_parity.py [point|swimmer] [n_states] [episode_envs] [episode_steps]
+    python tests/soak_parity.py [point|swimmer] [n_states] [episode_envs] [episode_steps]
 """
 import os
 import sys

@@ -1,4 +1,4 @@
-"""Committed self-consistency vectors (tools/gen_golden.py): the CPU restatement must
+"""Committed self-consistency vectors (tests/golden/gen_golden.py): the CPU restatement must
 reproduce them bit for bit on any host, and the HIP path must reproduce them on the GPU
 without the oracle in the loop.  They are NOT reference outputs (parity unpinned)."""
 import glob

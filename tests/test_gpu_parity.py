@@ -7,7 +7,7 @@ tests actually demand exact equality of every output and of the state.
 import numpy as np
 import pytest
 
-from helpers import task_config, random_state, assert_state_equal, SWIMMER
+from helpers import task_config, random_state, assert_state_equal, SWIMMER, ANT
 
 pytestmark = pytest.mark.gpu
 
@@ -383,6 +383,56 @@ def test_swimmer_rollout_parity(torch_cuda, oracle, path):
         np.testing.assert_array_equal(done[t].cpu().numpy(), d)
         np.testing.assert_array_equal(cost[t].cpu().numpy(), info['cost'])
     assert hit > 0 and done.sum().item() > 0
+    assert_state_equal(E.get_state(), O.get_state())
+    np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
+
+
+# ---------------------------------------------------------------------------
+# Ant (Goal_Ant_8Hazards): 11-DOF tree, joint-limit rows, foot-floor contacts with friction pyramids
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("path", ["thread", "group"])
+@pytest.mark.parametrize("N", [5, 64, 2000])
+def test_ant_step_parity_random_states(torch_cuda, oracle, N, path):
+    torch = torch_cuda
+    E, O = _engines(task_config(N, seed=3, **ANT), oracle, path=path)
+    assert E.obs_flat_size == O.D == 64 and E.action_space.shape == (8,)
+    assert float(E.action_space.low[0]) == -1.0 and float(E.action_space.high[7]) == 1.0
+    rng = np.random.default_rng(N)
+    for trial in range(3):
+        s = random_state(N, 8, rng, robot='ant')
+        s['hist'] = [2, 1, 0][trial]
+        E.set_state(s)
+        O.set_state(s)
+        act = rng.uniform(-1.4, 1.4, (N, 8)).astype(np.float32)      # beyond ctrlrange: clipped for the force
+        out_g = E.step(torch.from_numpy(act).cuda())
+        out_o = O.step(act)
+        _cmp_step(out_g, out_o)
+        assert_state_equal(E.get_state(), O.get_state())
+
+
+@pytest.mark.parametrize("path", ["thread", "group"])
+def test_ant_rollout_parity(torch_cuda, oracle, path):
+    torch = torch_cuda
+    N, T = 300, 100
+    E, O = _engines(task_config(N, seed=6, num_steps=60, goal_size=1.0, **ANT), oracle,
+                    n_candidates=60000, path=path)
+    np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
+    rng = np.random.RandomState(1)
+    for t in range(30):                       # step()/reset_done() API
+        act = rng.uniform(-1, 1, (N, 8)).astype(np.float32)
+        _cmp_step(E.step(torch.from_numpy(act).cuda()), O.step(act))
+        np.testing.assert_array_equal(E.reset_done().cpu().numpy(), O.reset_done())
+    acts = rng.uniform(-1, 1, (T, N, 8)).astype(np.float32)   # fused rollout
+    obs, rew, cost, done = E.rollout(torch.from_numpy(acts).cuda())
+    floor = 0
+    for t in range(T):
+        o, r, d, info = O.step(acts[t])
+        floor += int((np.abs(O.get_state()['qpos'][:, 4::2]) > 1.02).sum())   # ankle past ~58 deg: foot on the floor
+        np.testing.assert_array_equal(obs[t].cpu().numpy(), O.reset_done())
+        np.testing.assert_array_equal(rew[t].cpu().numpy(), r)
+        np.testing.assert_array_equal(done[t].cpu().numpy(), d)
+        np.testing.assert_array_equal(cost[t].cpu().numpy(), info['cost'])
+    assert floor > 0 and done.sum().item() > 0
     assert_state_equal(E.get_state(), O.get_state())
     np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
 
