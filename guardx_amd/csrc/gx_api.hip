@@ -565,7 +565,7 @@ extern "C" gx_status gx_rollout_policy(gx_engine* e, int32_t T, const gx_policy*
     if (!e->have_reset) return fail(GX_ERR_STATE, "gx_rollout_policy before gx_reset");
     if (pol->hidden != kPolHd)
         return fail(GX_ERR_UNSUPPORTED, "gx_rollout_policy: hidden_sizes must be (64, 64) (the reference default)");
-    if (!policy_rollout_supported(e->p) || e->na != 2 || e->p.N > 65536)
+    if (!policy_rollout_supported(e->p) || (e->na & 1) || e->na > 16 || e->p.N > 65536)
         return fail(GX_ERR_UNSUPPORTED, "gx_rollout_policy: needs hazards_num <= 15, lidar_num_bins <= 16, env_num <= 65536");
     const int impl = e->policy_impl == 1 ? 1 : 2; // auto = MFMA
     if (policy_lds_bytes(e->p, impl) > 150 * 1024)

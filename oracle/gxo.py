@@ -96,6 +96,8 @@ def lib():
         L.gxo_rollout_policy.argtypes = [C.c_void_p, C.c_int32, C.c_int32, fp, u32p, C.c_uint32] + [fp] * 12
         L.gxo_math_probe.argtypes = [C.c_int32] + [fp] * 6
         L.gxo_math_probe.restype = None
+        L.gxo_ant_probe.argtypes = [fp] * 8
+        L.gxo_ant_probe.restype = None
         L.gxo_set_threads.argtypes = [C.c_int32]
         L.gxo_set_threads.restype = None
         L.gxo_get_threads.restype = C.c_int32
@@ -291,6 +293,16 @@ def randint(key, n, span):
     out = np.empty(n, np.int32)
     lib().gxo_randint(k, n, span, out.ctypes.data_as(C.POINTER(C.c_int32)))
     return out
+
+
+def ant_probe(q, v, ctrl):
+    """one ant.xml mjx.step: (q2, v2, qacc, pose, dense mass matrix, smooth force), qpos coordinates"""
+    q = np.ascontiguousarray(q, np.float32); v = np.ascontiguousarray(v, np.float32)
+    ctrl = np.ascontiguousarray(ctrl, np.float32)
+    q2 = np.zeros(11, np.float32); v2 = np.zeros(11, np.float32); qacc = np.zeros(11, np.float32)
+    pose = np.zeros(4, np.float32); dbg = np.zeros(132, np.float32)
+    lib().gxo_ant_probe(_fp(q), _fp(v), _fp(ctrl), _fp(q2), _fp(v2), _fp(qacc), _fp(pose), _fp(dbg))
+    return q2, v2, qacc, pose, dbg[:121].reshape(11, 11).copy(), dbg[121:].copy()
 
 
 def math_probe2(x):

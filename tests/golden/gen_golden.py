@@ -27,7 +27,7 @@ def episode(name, cfg, n_candidates, T, seed_act):
     rec = {'reset_obs': E.reset(check=False), 'layout_size': np.int64(E.layout_size),
            'pool_head': E.get_pool(8)}
     rng = np.random.RandomState(seed_act)
-    acts = rng.uniform(-1, 1, (T, N, 2)).astype(np.float32)
+    acts = rng.uniform(-1, 1, (T, N, E.na)).astype(np.float32)
     obs, rew, done, cost, rdo, qacc = [], [], [], [], [], []
     for t in range(T):
         o, r, d, info = E.step(acts[t])
@@ -52,3 +52,6 @@ if __name__ == "__main__":
     # config 2 of BASELINE.json (articulated dynamics + joint-limit rows), small
     episode("goal_swimmer_8hazards_n12_seed2",
             task_config(12, seed=2, num_steps=40, goal_size=1.0, robot_base='xmls/swimmer.xml'), 30000, 60, 2)
+    # Goal_Ant_8Hazards (11-DOF tree, joint limits, foot-floor contacts), small
+    episode("goal_ant_8hazards_n12_seed4",
+            task_config(12, seed=4, num_steps=40, goal_size=1.0, robot_base='xmls/ant.xml'), 30000, 60, 3)

@@ -15,6 +15,8 @@ CASES = {
     "goal_point_8hazards_n24_seed5": (task_config(24, seed=5, num_steps=40, goal_size=1.2), 30000),
     "goal_swimmer_8hazards_n12_seed2": (task_config(12, seed=2, num_steps=40, goal_size=1.0,
                                                     robot_base='xmls/swimmer.xml'), 30000),
+    "goal_ant_8hazards_n12_seed4": (task_config(12, seed=4, num_steps=40, goal_size=1.0,
+                                                robot_base='xmls/ant.xml'), 30000),
 }
 
 

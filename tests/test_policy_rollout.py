@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from helpers import task_config, assert_state_equal, SWIMMER
+from helpers import task_config, assert_state_equal, SWIMMER, ANT
 
 
 def _torch_ac(D, A, seed=0):
@@ -17,7 +17,7 @@ def _torch_ac(D, A, seed=0):
             if isinstance(m, torch.nn.Linear):
                 torch.nn.init.normal_(m.weight, std=0.5)
                 torch.nn.init.normal_(m.bias, std=0.3)
-    log_std = torch.tensor([-0.5, -0.3][:A])
+    log_std = torch.tensor([-0.5, -0.3, -0.7, -0.1, -0.9, -0.4, -0.6, -0.2][:A])
     return mu_net, v_net, log_std
 
 
@@ -77,19 +77,19 @@ def test_device_log_tanh_bitexact(oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("impl", ["valu", "mfma"])
-@pytest.mark.parametrize("robot", ["point", "swimmer"])
+@pytest.mark.parametrize("robot", ["point", "swimmer", "ant"])
 def test_policy_rollout_parity(oracle, robot, impl):
     import torch
     from guardx_amd import Engine
     N, T = 203, 50
-    extra = SWIMMER if robot == "swimmer" else {}
+    extra = {"point": {}, "swimmer": SWIMMER, "ant": ANT}[robot]
     cfg = task_config(N, seed=3, num_steps=30, goal_size=0.9, **extra)
     E = Engine(cfg, n_candidates=40000)
     E.set_policy_impl({"valu": 1, "mfma": 2}[impl])
     O = oracle.OracleEngine(cfg, n_candidates=40000)
     og, oo = E.reset(), O.reset()
     np.testing.assert_array_equal(og.cpu().numpy(), oo)
-    D, A = E.obs_flat_size, 2
+    D, A = E.obs_flat_size, E.action_space.shape[0]
     mu_net, v_net, log_std = _torch_ac(D, A, seed=5)
     params = Engine.pack_actor_critic(mu_net=mu_net, v_net=v_net, log_std=log_std)
     g = E.rollout_policy(params.cuda(), T, noise_seed=(11, 13))
@@ -104,7 +104,7 @@ def test_policy_rollout_parity(oracle, robot, impl):
     for k in ('obs', 'act', 'logp', 'val', 'rew', 'done'):
         np.testing.assert_array_equal(g2[k].cpu().numpy(), o2[k], err_msg=k)
     # and the ordinary API still lines up afterwards
-    act = np.zeros((N, 2), np.float32)
+    act = np.zeros((N, A), np.float32)
     og3, _, dg3, _ = E.step(torch.from_numpy(act).cuda())
     oo3, _, do3, _ = O.step(act)
     np.testing.assert_array_equal(og3.cpu().numpy(), oo3)
