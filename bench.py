@@ -44,9 +44,9 @@ def make_engine(env_num, rank, world, seed=0, n_candidates=1_000_000, robot_base
     return Engine(cfg, shard=(rank, world) if world > 1 else None, n_candidates=n_candidates)
 
 
-def action_tape(T, N, seed, device):
+def action_tape(T, N, seed, device, act_dim=2):
     g = torch.Generator(device=device).manual_seed(seed)
-    return torch.rand(T, N, 2, device=device, generator=g) * 2 - 1   # a ~ U(-1,1), myTest.py:28-31
+    return torch.rand(T, N, act_dim, device=device, generator=g) * 2 - 1   # a ~ U(-1,1), myTest.py:28-31
 
 
 class RolloutHandoff:

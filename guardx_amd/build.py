@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libguardx_hip.so")
 SOURCES = ["gx_api.hip", "gx_kernels.hip", "gx_gae.hip"]
-HEADERS = ["gx_device.h", "gx_robot.h", "gx_policy.h", "gx_kernels.h", os.path.join("..", "..", "include", "guardx.h")]
+HEADERS = ["gx_device.h", "gx_robot.h", "gx_robot_ant.h", "gx_policy.h", "gx_kernels.h", os.path.join("..", "..", "include", "guardx.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
          "-Wall", "-Wno-unused-function"]
 

@@ -87,11 +87,66 @@ struct AntRobot {
         float C[4][3][2]; // base x (hip, beta) per leg
         float Lhh[4], Lhb[4], Lbb[4];
     };
+    // constraint rows of one leg, stored compactly (registers): two joint-limit rows (sg = 0: absent) and
+    // the foot contact (four pyramid edges  Jn +- mu T1, Jn +- mu T2 built from the two tangent rows)
+    struct Lim { float sg, aref, D; };
+    struct Foot {
+        int on;
+        float T1[3], T2[3]; // theta, hip, beta entries of the tangent rows (x and y entries are 0/1 and c/-s)
+        float jbz, D, aref[4];
+    };
+    struct Rows {
+        Lim lim[4][2];
+        Foot foot[4];
+        float c, s;
+    };
     struct Row {
         int present;
         float J[5]; // over (x, th, y, hip_l, beta_l)
         float aref, D;
     };
+    // Opaque identity on the compact rows.  Every product D J J' of the Newton matrix is invariant across
+    // the solver iterations (only the active mask changes), so the optimiser would hoist all ~500 of them
+    // out of the loop and spill; rebuilding them per iteration from 72 registers is far cheaper.
+    GX_D static void keep_compact(Rows& rs)
+    {
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                asm volatile("" : "+v"(rs.lim[l][k].sg), "+v"(rs.lim[l][k].aref), "+v"(rs.lim[l][k].D));
+            Foot& ft = rs.foot[l];
+            asm volatile("" : "+v"(ft.T1[0]), "+v"(ft.T1[1]), "+v"(ft.T1[2]), "+v"(ft.T2[0]), "+v"(ft.T2[1]), "+v"(ft.T2[2]));
+            asm volatile("" : "+v"(ft.jbz), "+v"(ft.D), "+v"(ft.aref[0]), "+v"(ft.aref[1]), "+v"(ft.aref[2]), "+v"(ft.aref[3]));
+        }
+    }
+    // the full row k of leg l, rebuilt with the operations that defined it
+    GX_D static Row row_of(const Rows& rs, int l, int k)
+    {
+        Row R;
+        if (k < 2) {
+            const Lim& m = rs.lim[l][k];
+            R.present = m.sg != 0.0f;
+            R.J[0] = 0.0f; R.J[1] = 0.0f; R.J[2] = 0.0f;
+            R.J[3] = (k == 0) ? m.sg : 0.0f;
+            R.J[4] = (k == 1) ? m.sg : 0.0f;
+            R.aref = m.aref; R.D = m.D;
+        } else {
+            const Foot& ft = rs.foot[l];
+            const int kk = k - 2;
+            const float sgn = (kk & 1) ? -kMu : kMu;
+            R.present = ft.on;
+            if (kk < 2) {
+                R.J[0] = sgn * 0.0f; R.J[1] = sgn * ft.T1[0]; R.J[2] = sgn * rs.c; R.J[3] = sgn * ft.T1[1];
+                R.J[4] = ft.jbz + sgn * ft.T1[2];
+            } else {
+                R.J[0] = sgn * 1.0f; R.J[1] = sgn * ft.T2[0]; R.J[2] = sgn * (-rs.s); R.J[3] = sgn * ft.T2[1];
+                R.J[4] = ft.jbz + sgn * ft.T2[2];
+            }
+            R.aref = ft.aref[kk]; R.D = ft.D;
+        }
+        return R;
+    }
     struct Ldl3 { float rd0, rd1, rd2, l10, l20, l21; };
 
     GX_D static void ldl_factor(const float (&S)[3][3], Ldl3& f)
@@ -122,20 +177,26 @@ struct AntRobot {
     {
         float S[3][3], g[3] = {r[0], r[1], r[2]};
         float i00[4], i01[4], i11[4];
+#pragma unroll
         for (int b = 0; b < 3; ++b)
+#pragma unroll
             for (int c = 0; c < 3; ++c) S[b][c] = (c <= b) ? A.B[b][c] : 0.0f;
+#pragma unroll
         for (int l = 0; l < 4; ++l) {
             const float det = A.Lhh[l] * A.Lbb[l] - A.Lhb[l] * A.Lhb[l];
             const float rdet = 1.0f / det;
             i00[l] = A.Lbb[l] * rdet; i01[l] = -(A.Lhb[l] * rdet); i11[l] = A.Lhh[l] * rdet;
             float W[3][2];
+#pragma unroll
             for (int b = 0; b < 3; ++b) {
                 W[b][0] = A.C[l][b][0] * i00[l] + A.C[l][b][1] * i01[l];
                 W[b][1] = A.C[l][b][0] * i01[l] + A.C[l][b][1] * i11[l];
             }
             const float r0 = r[3 + 2 * l], r1 = r[4 + 2 * l];
+#pragma unroll
             for (int b = 0; b < 3; ++b) {
                 g[b] = g[b] - (W[b][0] * r0 + W[b][1] * r1);
+#pragma unroll
                 for (int c = 0; c <= b; ++c) S[b][c] = S[b][c] - (W[b][0] * A.C[l][c][0] + W[b][1] * A.C[l][c][1]);
             }
         }
@@ -144,6 +205,7 @@ struct AntRobot {
         float xb[3];
         ldl_solve(F, g, xb);
         x[0] = xb[0]; x[1] = xb[1]; x[2] = xb[2];
+#pragma unroll
         for (int l = 0; l < 4; ++l) {
             const float t0 = r[3 + 2 * l] - ((A.C[l][0][0] * xb[0] + A.C[l][1][0] * xb[1]) + A.C[l][2][0] * xb[2]);
             const float t1 = r[4 + 2 * l] - ((A.C[l][0][1] * xb[0] + A.C[l][1][1] * xb[1]) + A.C[l][2][1] * xb[2]);
@@ -165,18 +227,15 @@ struct AntRobot {
         if (ix > 1.0f) imp = 0.95f;
         return imp;
     }
-    GX_D static void limit_row(Row& R, int k, float qj, float vel, float lo, float hi, float invw)
+    GX_D static void limit_row(Lim& R, float qj, float vel, float lo, float hi, float invw)
     {
         const float dlo = qj - lo, dhi = hi - qj;
         const float pos = dlo < dhi ? dlo : dhi;
         const float sg = dlo < dhi ? 1.0f : -1.0f;
-        R.present = 0;
-        for (int j = 0; j < 5; ++j) R.J[j] = 0.0f;
-        R.aref = 0.0f; R.D = 0.0f;
+        R.sg = 0.0f; R.aref = 0.0f; R.D = 0.0f;
         if (!(pos < 0.0f)) return;
         const float imp = impedance(pos);
-        R.present = 1;
-        R.J[k] = sg;
+        R.sg = sg;
         R.aref = -(kB * (sg * vel)) - (kK * imp) * pos;
         float rr = ((1.0f - imp) * invw) / imp;
         if (rr < 1e-15f) rr = 1e-15f;
@@ -186,28 +245,36 @@ struct AntRobot {
     {
         return (((J[0] * a[0] + J[1] * a[1]) + J[2] * a[2]) + J[3] * a[3 + 2 * l]) + J[4] * a[4 + 2 * l];
     }
-    GX_D static uint32_t active_set(const Row (&rows)[4][kRows], const float* a)
+    GX_D static uint32_t active_set(const Rows& rows, const float* a)
     {
         uint32_t m = 0;
+#pragma unroll
         for (int l = 0; l < 4; ++l)
-            for (int k = 0; k < kRows; ++k)
-                if (rows[l][k].present && (dot5(rows[l][k].J, a, l) - rows[l][k].aref < 0.0f))
-                    m |= 1u << (l * kRows + k);
+#pragma unroll
+            for (int k = 0; k < kRows; ++k) {
+                const Row R = row_of(rows, l, k);
+                if (R.present && (dot5(R.J, a, l) - R.aref < 0.0f)) m |= 1u << (l * kRows + k);
+            }
         return m;
     }
     // minimiser of the quadratic piece selected by `act`: (M + J_A' D J_A) a = f + J_A' D aref_A
-    GX_D static void newton_solve(const Arrow& M, const float* f, const Row (&rows)[4][kRows], uint32_t act, float* a)
+    GX_D static void newton_solve(const Arrow& M, const float* f, const Rows& rows, uint32_t act, float* a)
     {
         Arrow Hm = M;
         float r[11];
+#pragma unroll
         for (int k = 0; k < 11; ++k) r[k] = f[k];
+#pragma unroll
         for (int l = 0; l < 4; ++l)
+#pragma unroll
             for (int k = 0; k < kRows; ++k) {
                 if (!((act >> (l * kRows + k)) & 1u)) continue;
-                const Row& R = rows[l][k];
+                const Row R = row_of(rows, l, k);
                 const float da = R.D * R.aref;
+#pragma unroll
                 for (int b = 0; b < 3; ++b) {
                     const float dj = R.D * R.J[b];
+#pragma unroll
                     for (int c = 0; c <= b; ++c) Hm.B[b][c] = Hm.B[b][c] + dj * R.J[c];
                     Hm.C[l][b][0] = Hm.C[l][b][0] + dj * R.J[3];
                     Hm.C[l][b][1] = Hm.C[l][b][1] + dj * R.J[4];
@@ -235,7 +302,7 @@ struct AntRobot {
     }
     GX_D static float clip1(float u) { return u < -1.0f ? -1.0f : (u > 1.0f ? 1.0f : u); }
 
-    GX_D __attribute__((noinline)) static void substep_impl(float* q, float* v, const float* ctrl, float (&pose)[4],
+    GX_D static void substep_impl(float* q, float* v, const float* ctrl, float (&pose)[4],
                                                             float* qacc)
     {
         const float kDx[4] = {kD7, -kD7, -kD7, kD7};
@@ -248,7 +315,9 @@ struct AntRobot {
         const float Ax = -(2.0f * (vy * om)), Ay = -(y * wh);
         Arrow M;
         float f[11];
+#pragma unroll
         for (int b = 0; b < 3; ++b)
+#pragma unroll
             for (int cc = 0; cc < 3; ++cc) M.B[b][cc] = 0.0f;
         M.B[0][0] = kMtot; M.B[2][2] = kMtot; M.B[2][0] = -(s * kMtot);
         float Btt = kMB * (y * y) + kIB;
@@ -257,8 +326,10 @@ struct AntRobot {
         float cx = kMB * (c * Ax - s * Ay);
         float cy = kMB * Ay;
         float ct = -(kMB * (y * Ax));
-        Row rows[4][kRows];
+        Rows rows;
+        rows.c = c; rows.s = s;
         int any_row = 0;
+#pragma unroll
         for (int l = 0; l < 4; ++l) {
             const float dx = kDx[l], dy = kDy[l], sg = kSg[l];
             const float phi = q[3 + 2 * l], beta = sg * q[4 + 2 * l];
@@ -307,14 +378,16 @@ struct AntRobot {
             const float cb_ = kMK * ((bx * a2x + by * a2y) + bz * a2z) - kDIK * (ww * (sb * cb));
             f[3 + 2 * l] = (-ch_ - dphi) + kGear * clip1(ctrl[2 * l]);
             f[4 + 2 * l] = (-cb_ - dbeta) + sg * (kGear * clip1(ctrl[2 * l + 1]));
-            limit_row(rows[l][0], 3, phi, dphi, -kLim30, kLim30, kInvwHip);
-            limit_row(rows[l][1], 4, beta, dbeta, kLim30, kLim70, kInvwAnk);
+            limit_row(rows.lim[l][0], phi, dphi, -kLim30, kLim30, kInvwHip);
+            limit_row(rows.lim[l][1], beta, dbeta, kLim30, kLim70, kInvwAnk);
             const float dist = (kZ0 - kL * sb) - kRf;
             const float pos = dist - kMargin;
-            for (int k = 2; k < kRows; ++k) {
-                rows[l][k].present = 0; rows[l][k].aref = 0.0f; rows[l][k].D = 0.0f;
-                for (int j = 0; j < 5; ++j) rows[l][k].J[j] = 0.0f;
-            }
+            Foot& ft = rows.foot[l];
+            ft.on = 0; ft.jbz = 0.0f; ft.D = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { ft.T1[k] = 0.0f; ft.T2[k] = 0.0f; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ft.aref[k] = 0.0f;
             if (pos < 0.0f) {
                 const float zc = kRf + 0.5f * dist;
                 const float lf = kA + kL * cb;
@@ -329,19 +402,17 @@ struct AntRobot {
                 float rr = ((1.0f - imp) * kInvwPyr) / imp;
                 if (rr < 1e-15f) rr = 1e-15f;
                 const float Dc = 1.0f / rr;
+                ft.on = 1; ft.jbz = jbz; ft.D = Dc;
+                ft.T1[0] = T1[1]; ft.T1[1] = T1[3]; ft.T1[2] = T1[4];
+                ft.T2[0] = T2[1]; ft.T2[1] = T2[3]; ft.T2[2] = T2[4];
+#pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    Row& R = rows[l][2 + k];
-                    const float* T = (k < 2) ? T1 : T2;
-                    const float sgn = (k & 1) ? -kMu : kMu;
-                    for (int j = 0; j < 5; ++j) R.J[j] = sgn * T[j];
-                    R.J[4] = jbz + sgn * T[4];
-                    R.present = 1;
-                    R.D = Dc;
+                    const Row R = row_of(rows, l, 2 + k);
                     const float jv = (((R.J[0] * v[0] + R.J[1] * om) + R.J[2] * vy) + R.J[3] * dphi) + R.J[4] * dbeta;
-                    R.aref = -(kB * jv) - (kK * imp) * pos;
+                    ft.aref[k] = -(kB * jv) - (kK * imp) * pos;
                 }
             }
-            for (int k = 0; k < kRows; ++k) any_row |= rows[l][k].present;
+            any_row |= (rows.lim[l][0].sg != 0.0f) | (rows.lim[l][1].sg != 0.0f) | ft.on;
         }
         M.B[1][1] = Btt; M.B[1][0] = Bxt; M.B[2][1] = Bty;
         f[0] = -cx - 0.1f * v[0];
@@ -350,18 +421,23 @@ struct AntRobot {
         float a[11];
         arrow_solve(M, f, a);
         float fc[11];
+#pragma unroll
         for (int k = 0; k < 11; ++k) fc[k] = f[k];
         if (any_row) {
             uint32_t act = active_set(rows, a);
             for (int it = 0; it < kIters; ++it) {
+                keep_compact(rows);
                 newton_solve(M, f, rows, act, a);
                 const uint32_t nact = active_set(rows, a);
                 if (nact == act) break;
                 act = nact;
             }
+            keep_compact(rows);
+#pragma unroll
             for (int l = 0; l < 4; ++l)
+#pragma unroll
                 for (int k = 0; k < kRows; ++k) {
-                    const Row& R = rows[l][k];
+                    const Row R = row_of(rows, l, k);
                     if (!R.present) continue;
                     const float res = dot5(R.J, a, l) - R.aref;
                     if (!(res < 0.0f)) continue;
@@ -378,16 +454,21 @@ struct AntRobot {
         Md.B[0][0] = Md.B[0][0] + kH * 0.1f;
         Md.B[1][1] = Md.B[1][1] + kH * 0.01f;
         Md.B[2][2] = Md.B[2][2] + kH * 0.1f;
+#pragma unroll
         for (int l = 0; l < 4; ++l) { Md.Lhh[l] = Md.Lhh[l] + kH; Md.Lbb[l] = Md.Lbb[l] + kH; }
         float ai[11];
         arrow_solve(Md, fc, ai);
+#pragma unroll
         for (int k = 0; k < 3; ++k) qacc[k] = a[k];
+#pragma unroll
         for (int l = 0; l < 4; ++l) {
             qacc[3 + 2 * l] = a[3 + 2 * l];
             qacc[4 + 2 * l] = kSg[l] * a[4 + 2 * l];
             ai[4 + 2 * l] = kSg[l] * ai[4 + 2 * l];
         }
+#pragma unroll
         for (int k = 0; k < 11; ++k) v[k] = v[k] + kH * ai[k];
+#pragma unroll
         for (int k = 0; k < 11; ++k) q[k] = q[k] + kH * v[k];
     }
 

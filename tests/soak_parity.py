@@ -2,7 +2,7 @@
 """Soak test (MI355X box): HIP vs CPU restatement on many more random states and longer episodes
 than the unit tests, looking for rare floating-point divergences.  Exits non-zero on any mismatch.
 
-    python tests/soak_parity.py [point|swimmer] [n_states] [episode_envs] [episode_steps]
+    python tests/soak_parity.py [point|swimmer|ant] [n_states] [episode_envs] [episode_steps]
 """
 import os
 import sys
@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from helpers import task_config, random_state, SWIMMER  # noqa: E402
+from helpers import task_config, random_state, SWIMMER, ANT  # noqa: E402
 from guardx_amd import Engine  # noqa: E402
 from oracle import gxo  # noqa: E402
 
@@ -24,7 +24,8 @@ def main():
     n_states = int(sys.argv[2]) if len(sys.argv) > 2 else 400000
     N = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
     T = int(sys.argv[4]) if len(sys.argv) > 4 else 600
-    extra = SWIMMER if robot == "swimmer" else {}
+    extra = {"point": {}, "swimmer": SWIMMER, "ant": ANT}[robot]
+    A = 8 if robot == "ant" else 2
     bad = 0
     t0 = time.time()
     # 1. single steps from random states, both kernel families
@@ -36,7 +37,7 @@ def main():
         for trial in range(3):
             s = random_state(n_states, 8, rng, robot=robot, spread=[2.5, 30.0, 0.3][trial])
             E.set_state(s); O.set_state(s)
-            act = (rng.uniform(-1, 1, (n_states, 2)) * [1.0, 30.0, 0.01][trial]).astype(np.float32)
+            act = (rng.uniform(-1, 1, (n_states, A)) * [1.0, 30.0, 0.01][trial]).astype(np.float32)
             og, rg, dg, ig = E.step(torch.from_numpy(act).cuda())
             oo, ro, do, io = O.step(act)
             for name, a, b in (("obs", og.cpu().numpy(), oo), ("rew", rg.cpu().numpy(), ro),
@@ -60,7 +61,7 @@ def main():
     np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
     rng = np.random.default_rng(9)
     for chunk in range(T // 100):
-        acts = rng.uniform(-1, 1, (100, N, 2)).astype(np.float32)
+        acts = rng.uniform(-1, 1, (100, N, A)).astype(np.float32)
         obs, rew, cost, done = E.rollout(torch.from_numpy(acts).cuda())
         obs, rew, cost, done = (x.cpu().numpy() for x in (obs, rew, cost, done))
         for t in range(100):

@@ -27,7 +27,7 @@ def main():
     torch.cuda.set_device(0)
     env = bench.make_engine(N, 0, 1, robot_base=robot)
     print("robot", env.robot_base, "obs", env.obs_flat_size)
-    tape = bench.action_tape(200, N, 0, dev)
+    tape = bench.action_tape(200, N, 0, dev, env.action_space.shape[0])
     env.set_prefetch(-1)
     env.reset()
     t_roll = timeit(lambda: env.rollout(tape), 20)
