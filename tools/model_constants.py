@@ -1,84 +1,91 @@
 #!/usr/bin/env python3
-"""Model constants of the robots the HIP path implements, derived in float64 the way the
-MuJoCo compiler derives them from the robot MJCF (removes hand-copied
-numbers as a source of silent error).  The geometric inputs are restated here with the
-reference line they come from; the printed values are what oracle/gx_oracle.c and
-guardx_amd/csrc/gx_robot.h carry.
+"""Constants carried by guardx_amd/csrc/gx_robot.h / gx_robot_ant.h (and by the CPU checker), derived in
+float64 from the robot MJCF files themselves by tools/mjcf_model.py (no hand-copied
+numbers, no `mujoco`).
 
-[derived]: MuJoCo's geom mass/inertia formulas (user_objects.cc SetInertia), mj_setConst's
-dof_invweight0 = diag(M(qpos0)^-1), degrees->radians of joint ranges.
+    python tools/model_constants.py /path/to/safe_rl_envs/safe_rl_envs/xmls
+
+`constants(xml_dir)` returns {robot: {name: value}} with the names used in the headers;
+tests/test_model_constants.py checks the headers against it whenever the MJCF files are available.
+[derived]: MuJoCo compile rules and mj_setConst, see tools/mjcf_model.py.
 """
+import os
+import sys
+
 import numpy as np
 
-pi = np.pi
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from mjcf_model import Model  # noqa: E402
+
+SOLIMP = (0.9, 0.95, 0.001, 0.5, 2.0)      # MuJoCo defaults (no solimp/solref attribute in the robot files)
+SOLREF = (0.02, 1.0)
 
 
-def sphere(r, rho):
-    m = rho * 4 / 3 * pi * r ** 3
-    return m, 0.4 * m * r * r
+def _kb(timestep):
+    tc = max(SOLREF[0], 2 * timestep)       # refsafe
+    return 1 / (SOLIMP[1] ** 2 * tc ** 2 * SOLREF[1] ** 2), 2 / (SOLIMP[1] * tc)
 
 
-def box(hx, hy, hz, rho):
-    m = rho * 8 * hx * hy * hz
-    return m, m / 3 * (hx * hx + hy * hy)          # about z
+def point(m):
+    r = m.body('robot')
+    mass = m.mass[r]
+    # planar: x, y slides + hinge about z through the body origin
+    io = m.inertia[r][2, 2] + mass * (m.ipos[r][0] ** 2 + m.ipos[r][1] ** 2)
+    d = [j['damping'] for j in m.dof_joint]
+    h = m.timestep
+    return dict(kH=h, kM=mass, kMxc=mass * m.ipos[r][0], kIo=io, kDxy=d[0], kDt=d[2], kGear=m.actuators[0]['gear'],
+                kInvM=1 / mass, kInvA=1 / (mass + h * d[0]), kEi=io + h * d[2])
 
 
-def capsule_perp(r, length, rho):
-    """capsule of cylinder length `length`: mass and inertia about an axis perpendicular to it"""
-    vc, vs = pi * r * r * length, 4 / 3 * pi * r ** 3
-    m = rho * (vc + vs)
-    mc, ms = rho * vc, rho * vs
-    i = mc * (3 * r * r + length * length) / 12
-    i += 2 * ms * r * r / 5 + ms * length * (3 * r + 2 * length) / 8
-    return m, i
+def swimmer(m):
+    links = [m.body('robot'), m.body('mid'), m.body('back')]
+    k, b = _kb(m.timestep)
+    out = dict(kH=m.timestep, kM=m.mass[links[0]], kIc=m.inertia[links[0]][2, 2], kArm=m.dof_joint[0]['armature'],
+               kGear=m.actuators[0]['gear'], kLim=m.dof_joint[3]['range'][1],
+               kInvW2=m.dof_invweight0[3], kInvW3=m.dof_invweight0[4], kK=k, kB=b)
+    # COM_i = p + sum_k a[i][k] u(alpha_k): body offsets and geom centres along the link axes
+    out.update(A11=m.ipos[links[0]][0], A21=m.bodies[links[1]]['pos'][0], A22=m.ipos[links[1]][0],
+               A31=m.bodies[links[1]]['pos'][0], A32=m.bodies[links[2]]['pos'][0], A33=m.ipos[links[2]][0])
+    out['kImu'] = 1 / (3 * out['kM'] + out['kArm'])
+    return out
 
 
-def point():
-    # xmls/point.xml:5 density 1; :19 sphere r=.1 at origin; :20 box half .05 at (.1,0,0)
-    ms, Is = sphere(0.1, 1.0)
-    mb, Ib = box(0.05, 0.05, 0.05, 1.0)
-    m = ms + mb
-    mxc = mb * 0.1
-    Io = Is + Ib + mb * 0.1 ** 2
-    print("POINT  m=%.17g  m*xc=%.17g  Io=%.17g" % (m, mxc, Io))
-    print("       h=0.02 (point.xml:3)  damping .01 .01 .005 (:16-18)  gear .3 (:37-39)")
-    print("       1/m=%.17g  1/(m+h*d)=%.17g  Io+h*dz=%.17g" % (1 / m, 1 / (m + 0.02 * 0.01), Io + 0.02 * 0.005))
+def ant(m):
+    robot, leg, aux = m.body('robot'), m.body('front_left_leg'), m.body('aux_1')
+    ank = aux + 1                                           # the unnamed ankle body
+    a = np.linalg.norm(m.bodies[aux]['pos'])
+    foot = [g for g in m.bodies[ank]['geoms'] if g['contype']][0]
+    length = np.linalg.norm(foot['pos'])
+    lc = np.linalg.norm(m.ipos[ank])
+    u = m.ipos[ank] / lc
+    iak = u @ m.inertia[ank] @ u
+    itk = m.inertia[ank][2, 2]
+    mb = m.mass[robot] + 4 * m.mass[leg]
+    ib = m.inertia[robot][2, 2] + 4 * (m.inertia[leg][2, 2] + m.mass[leg] * (m.ipos[leg][0] ** 2 + m.ipos[leg][1] ** 2))
+    k, b = _kb(m.timestep)
+    mu = max(foot['friction'][0], m.bodies[0]['geoms'][0]['friction'][0])
+    t = m.body_invweight0[ank, 0]
+    hip, ankle = m.dof_joint[3], m.dof_joint[4]
+    return dict(kH=m.timestep, kA=a, kA2=a / 2, kL=length, kRf=foot['size'][0], kZ0=m.bodies[robot]['pos'][2],
+                kMargin=max(foot['margin'], m.bodies[0]['geoms'][0]['margin']), kMu=mu,
+                kMB=mb, kIB=ib, kMA=m.mass[aux], kITA=m.inertia[aux][2, 2], kMK=m.mass[ank], kLC=lc,
+                kITK=itk, kDIK=iak - itk, kMtot=m.mass.sum(), kLbb=m.mass[ank] * lc * lc + itk + ankle['armature'],
+                kInvwHip=m.dof_invweight0[3], kInvwAnk=m.dof_invweight0[4],
+                kInvwPyr=(t + mu * mu * t) * 2 * mu * mu,       # impratio 1
+                kK=k, kB=b, kLim30=hip['range'][1], kLim70=ankle['range'][1], kGear=m.actuators[0]['gear'],
+                kD7=abs(m.bodies[aux]['pos'][0]) / a)
 
 
-def swimmer():
-    # xmls/swimmer.xml:3 timestep .03; :6 armature .1; :18,23,27 capsules r=.02 density 1000,
-    # fromto (.3..15), (0..-.15), (0..-.15); bodies at (0,0,.03), (.15,0,0), (-.15,0,0);
-    # :24,28 hinge range +-100 deg; :58-59 motors gear 20 ctrlrange +-1
-    m, Ic = capsule_perp(0.02, 0.15, 1000.0)
-    arm = 0.1
-    a = np.array([[0.225, 0.0, 0.0],
-                  [0.15, -0.075, 0.0],
-                  [0.15, -0.15, -0.075]])       # COM_i = p + sum_k a[i,k] u(alpha_k)
-    # M at qpos0 (all angles 0): n_k = (0, 1)
-    g = np.zeros((3, 3, 2))
-    n = np.array([0.0, 1.0])
-    for i in range(3):
-        for j in range(3):
-            g[i, j] = sum(a[i, k] * n for k in range(j, 3))
-    M = np.zeros((5, 5))
-    M[0, 0] = M[1, 1] = 3 * m
-    for j in range(3):
-        M[0, 2 + j] = M[2 + j, 0] = m * sum(g[i, j, 0] for i in range(3))
-        M[1, 2 + j] = M[2 + j, 1] = m * sum(g[i, j, 1] for i in range(3))
-        for k in range(3):
-            M[2 + j, 2 + k] = m * sum(g[i, j] @ g[i, k] for i in range(3)) + Ic * (3 - max(j, k))
-    M += arm * np.eye(5)
-    A = np.linalg.inv(M)
-    lim = 100 * pi / 180
-    print("SWIMMER link mass=%.17g  I_perp=%.17g  armature=%.3g  total mass+arm=%.17g" % (m, Ic, arm, 3 * m + arm))
-    print("        a =", a.tolist())
-    print("        dof_invweight0[motor1_rot]=%.17g  [motor2_rot]=%.17g" % (A[3, 3], A[4, 4]))
-    print("        range=+-%.17g rad   h=0.03  gear=20" % lim)
-    dmax, tc = 0.95, max(0.02, 2 * 0.03)
-    print("        solref: timeconst=max(.02, 2h)=%.3g -> b=%.17g k=%.17g ; solimp=(.9,.95,.001,.5,2)"
-          % (tc, 2 / (dmax * tc), 1 / (dmax * dmax * tc * tc)))
+def constants(xml_dir):
+    return dict(point=point(Model(os.path.join(xml_dir, 'point.xml'))),
+                swimmer=swimmer(Model(os.path.join(xml_dir, 'swimmer.xml'))),
+                ant=ant(Model(os.path.join(xml_dir, 'ant.xml'))))
 
 
 if __name__ == "__main__":
-    point()
-    swimmer()
+    if len(sys.argv) < 2:
+        sys.exit(__doc__)
+    for robot, vals in constants(sys.argv[1]).items():
+        print(robot.upper())
+        for k, v in vals.items():
+            print("    %-10s %.17g" % (k, v))
