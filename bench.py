@@ -289,6 +289,31 @@ def closed_loop_rate(device, epochs=10):
     return ENV_NUM * EP_LEN * epochs / dt
 
 
+def other_robots(device, epochs=10):
+    """the same epoch (reset + one 200-step rollout launch, env_num=2000) for the articulated robots:
+    BASELINE config 3 (Goal_Swimmer_8Hazards) and Goal_Ant_8Hazards (contact + joint-limit solver)"""
+    out = {}
+    for name, xml in (("Goal_Swimmer_8Hazards", "xmls/swimmer.xml"), ("Goal_Ant_8Hazards", "xmls/ant.xml")):
+        env = make_engine(ENV_NUM, 0, 1, robot_base=xml)
+        tape = action_tape(EP_LEN, ENV_NUM, 0, device, env.action_space.shape[0])
+
+        def epoch():
+            env.reset(check=False)
+            env.rollout(tape)
+        epoch(); epoch()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(epochs):
+            epoch()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        env.check_layouts()
+        env.close()
+        out[name] = {"env_steps_per_s": round(ENV_NUM * EP_LEN * epochs / dt, 1), "obs_dim": env.obs_flat_size,
+                     "ms_per_epoch": round(dt / epochs * 1e3, 4)}
+    return out
+
+
 def api_loop_rate(env, tape, steps):
     """Python-driven Engine.step()/reset_done() loop (what an unmodified learner drives)."""
     torch.cuda.synchronize()
@@ -357,6 +382,7 @@ def main():
             line["api_step_loop_env_steps_per_s"] = round(api_loop_rate(env, tapes[0], 1000), 1)
             line["epoch_breakdown"] = epoch_breakdown(device)
             line["closed_loop_policy_env_steps_per_s"] = round(closed_loop_rate(device), 1)
+            line["other_robots"] = other_robots(device)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

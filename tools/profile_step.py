@@ -20,21 +20,24 @@ def main():
     ap.add_argument("--env-num", type=int, default=1 << 22)
     ap.add_argument("--launches", type=int, default=20)
     ap.add_argument("--mode", default="step", choices=["step", "rollout"])
+    ap.add_argument("--robot", default=None, help="e.g. xmls/ant.xml (default: point)")
     a = ap.parse_args()
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     from guardx_amd import ResamplingError
-    env = bench.make_engine(a.env_num, 0, 1, n_candidates=200_000 if a.env_num > 100_000 else 1_000_000)
+    env = bench.make_engine(a.env_num, 0, 1, n_candidates=200_000 if a.env_num > 100_000 else 1_000_000,
+                            robot_base=a.robot)
+    A = env.action_space.shape[0]
     try:
         env.reset()
     except ResamplingError:
         pass
     if a.mode == "step":
-        act = bench.action_tape(1, a.env_num, 3, dev)[0]
+        act = bench.action_tape(1, a.env_num, 3, dev, A)[0]
         for _ in range(a.launches):
             env.step(act)
     else:
-        acts = bench.action_tape(a.launches, a.env_num, 3, dev)
+        acts = bench.action_tape(a.launches, a.env_num, 3, dev, A)
         env.rollout(acts)
     torch.cuda.synchronize()
     print("done", a.env_num, a.launches)
