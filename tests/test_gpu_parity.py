@@ -190,9 +190,12 @@ def test_fused_rollout_equals_stepwise(torch_cuda, oracle, path):
     assert_state_equal(E.get_state(), O.get_state())
 
 
+@pytest.mark.parametrize("robot", ["point", "swimmer", "ant"])
 @pytest.mark.parametrize("path", ["thread", "group"])
-def test_variant_configs(torch_cuda, oracle, path):
+def test_variant_configs(torch_cuda, oracle, path, robot):
     torch = torch_cuda
+    extra = {"point": {}, "swimmer": SWIMMER, "ant": ANT}[robot]
+    A = 8 if robot == "ant" else 2
     variants = [
         dict(hazards_num=3, lidar_num_bins=8),
         dict(hazards_num=12, lidar_num_bins=24, lidar_alias=False, hazards_keepout=0.25),
@@ -204,19 +207,19 @@ def test_variant_configs(torch_cuda, oracle, path):
     ]
     for v in variants:
         N = 130
-        cfg = task_config(N, seed=9, num_steps=50, **v)
+        cfg = task_config(N, seed=9, num_steps=50, **v, **extra)
         E, O = _engines(cfg, oracle, n_candidates=30000, path=path)
         assert E.obs_flat_size == O.D
         np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset(check=False))
         rng = np.random.default_rng(3)
         for t in range(60):   # crosses the num_steps timeout (engine.py:492)
-            act = rng.uniform(-1, 1, (N, 2)).astype(np.float32)
+            act = rng.uniform(-1, 1, (N, A)).astype(np.float32)
             out_g, out_o = E.step(torch.from_numpy(act).cuda()), O.step(act)
             _cmp_step(out_g, out_o)
             if t % 7 == 6:
                 np.testing.assert_array_equal(E.reset_done().cpu().numpy(), O.reset_done())
         # and a fused stretch on top (group path: persistent kernel with in-kernel reset_done)
-        acts = rng.uniform(-1, 1, (9, N, 2)).astype(np.float32)
+        acts = rng.uniform(-1, 1, (9, N, A)).astype(np.float32)
         obs, rew, cost, done = E.rollout(torch.from_numpy(acts).cuda())
         for t in range(9):
             o, r, d, info = O.step(acts[t])
