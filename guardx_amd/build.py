@@ -14,27 +14,53 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB = os.path.join(LIB_DIR, "libguardx_hip.so")
-SOURCES = ["gx_api.hip", "gx_kernels.hip", "gx_gae.hip"]
-HEADERS = ["gx_device.h", "gx_robot.h", "gx_robot_ant.h", "gx_policy.h", "gx_kernels.h", os.path.join("..", "..", "include", "guardx.h")]
-FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-         "-Wall", "-Wno-unused-function"]
+# one translation unit per robot (gx_robot_kernels.inl instantiated for it), compiled in parallel
+SOURCES = ["gx_api.hip", "gx_kernels.hip", "gx_gae.hip", "gx_kernels_point.hip", "gx_kernels_swimmer.hip",
+           "gx_kernels_ant.hip"]
+HEADERS = ["gx_device.h", "gx_robot.h", "gx_robot_ant.h", "gx_policy.h", "gx_kernels.h", "gx_robot_kernels.inl",
+           os.path.join("..", "..", "include", "guardx.h")]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+
+
+def _deps_mtime():
+    deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    return max(os.path.getmtime(d) for d in deps if os.path.exists(d))
+
+
+def _obj(src):
+    return os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
 
 
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    return _deps_mtime() > t or any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in SOURCES)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, jobs=None):
     if not force and not needs_build():
         return LIB
-    os.makedirs(LIB_DIR, exist_ok=True)
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    hdr_t = _deps_mtime()
+
+    def compile_one(src):
+        path, obj = os.path.join(CSRC, src), _obj(src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_t):
+            return
+        cmd = [hipcc] + FLAGS + ["-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    jobs = jobs or int(os.environ.get("GX_BUILD_JOBS", "0")) or min(len(SOURCES), os.cpu_count() or 1)
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + [_obj(s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

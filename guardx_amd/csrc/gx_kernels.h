@@ -67,6 +67,19 @@ struct RolloutArgs {
 void launch_group_rollout(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s);
 void launch_policy_rollout(const Params& p, const RolloutArgs& r, const PolicyArgs& pol, const DevBuffers& b,
                            int impl, hipStream_t s);
+// per-robot launchers: defined in gx_robot_kernels.inl, instantiated once per robot in gx_kernels_<robot>.hip
+template <class R>
+struct RobotLaunch {
+    static void step(const Params& p, const DevBuffers& b, const float* act, float* obs, float* rew, float* cost,
+                     float* done, float* qacc, hipStream_t s);
+    static void reset_apply(const Params& p, const DevBuffers& b, int nobj_total, uint32_t k10, uint32_t k11,
+                            uint32_t k20, uint32_t k21, float* obs, int* host_layout_size, hipStream_t s);
+    static void reset_done(const Params& p, const DevBuffers& b, int nobj_total, uint32_t k10, uint32_t k11,
+                           uint32_t k20, uint32_t k21, const float* obs_in, float* obs_out, hipStream_t s);
+    static void group(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s);
+    static void policy(const Params& p, const RolloutArgs& r, const PolicyArgs& pol, const DevBuffers& b, int impl,
+                       hipStream_t s);
+};
 bool policy_rollout_supported(const Params& p);
 size_t policy_lds_bytes(const Params& p, int impl);
 void launch_math_probe2(int n, const float* x, float* lg, float* th, hipStream_t s);

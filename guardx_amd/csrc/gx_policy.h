@@ -213,4 +213,18 @@ GX_D void normal_pair(uint32_t s0, uint32_t s1, uint32_t env, uint32_t ctr, floa
     z1 = r * sn;
 }
 
+GX_HD int pad4(int n) { return (n + 3) & ~3; }
+
+// dynamic LDS of the policy variants, in floats.
+//  VALU form (64 threads, 4 envs):   pi image | v image | log_std,std | hbuf[4][2][Hd] | xrow[4][pad4 D]
+//  MFMA form (256 threads, 16 envs): pi image | v image (Wt1 zero-padded to pad4 D rows) | log_std,std |
+//                                    X[16][pad4 D + 1] | H1[2][16][68] | H2[2][16][68]
+GX_HD int policy_lds_floats(int D, int A, int pol)
+{
+    if (pol == 2)
+        return pad4(mlp_lds_floats(pad4(D), A)) + pad4(mlp_lds_floats(pad4(D), 1)) + pad4(2 * A) +
+               16 * (pad4(D) + 1) + 3 + 2 * 2 * 16 * kPolHS;
+    return pad4(mlp_floats(D, A)) + pad4(mlp_floats(D, 1)) + pad4(2 * A) + 4 * 2 * kPolHd + 4 * pad4(D);
+}
+
 } // namespace gx

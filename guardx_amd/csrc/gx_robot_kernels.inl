@@ -1,0 +1,954 @@
+// gx_robot_kernels.inl -- the robot-templated kernels of the GUARD batched environment step (gfx950)
+// and their launchers.  Included by one translation unit per robot (gx_kernels_<robot>.hip), each of
+// which instantiates RobotLaunch<R> for its robot, so the robots compile in parallel.
+//
+// One thread owns one environment.  Environment state is struct-of-arrays of
+// float4 (`dyn`, `obj`), so each wave64 load/store is one coalesced 1 KiB
+// transaction.  The learner-facing observation is env-major (N, D) (the learner
+// writes obs_buf[:, t, :] = obs, reference trpo.py:58), so every thread builds
+// its D-float row in LDS -- the lidar bins are scatter-max'ed in place there --
+// and the block then streams the whole tile out as contiguous float4 stores.
+//
+// Reference lines: /root/reference/safe_rl_envs/safe_rl_envs/envs/engine.py.
+#pragma once
+#include "gx_kernels.h"
+#include "gx_robot.h"
+#include "gx_policy.h"
+
+namespace gx {
+
+// ---------------------------------------------------------------------------
+// observation row (engine.py:738-778) built in this thread's LDS row.
+// `ob` holds the object pairs: ob[k] = (obj 2k xy, obj 2k+1 xy); obj 0 = goal.
+// ---------------------------------------------------------------------------
+template <class R, int PMAX>
+GX_D bool build_obs_row(const Params& p, float* row, const float (&pose)[4],
+                        const float4 (&ob)[PMAX], const float (&ctrl)[R::NU], const float (&q)[R::NQ],
+                        const float (&v)[R::NV], float vel0, float vel1, float acc0, float acc1)
+{
+    bool bad = false;
+    if (p.off_acc >= 0) {
+        row[p.off_acc] = acc0; row[p.off_acc + 1] = acc1;
+        bad = bad || notfinite(acc0) || notfinite(acc1);
+    }
+    if (p.off_ctrl >= 0) {
+#pragma unroll
+        for (int k = 0; k < R::NU; ++k) { row[p.off_ctrl + k] = ctrl[k]; bad = bad || notfinite(ctrl[k]); }
+    }
+    if (p.off_comp >= 0) { // obs_compass :834-844
+        const float dx = ob[0].x - pose[0], dy = ob[0].y - pose[1];
+        const float zx = dx * pose[2] + dy * pose[3];
+        const float zy = dx * (-pose[3]) + dy * pose[2];
+        row[p.off_comp] = zx; row[p.off_comp + 1] = zy;
+        bad = bad || notfinite(zx) || notfinite(zy);
+    }
+    if (p.off_gl >= 0) {
+        float* r = row + p.off_gl;
+        for (int b = 0; b < p.bins; ++b) r[b] = 0.0f;
+        bad = lidar_one(p, r, ob[0].x, ob[0].y, pose) || bad;
+    }
+    if (p.off_hl >= 0) {
+        float* r = row + p.off_hl;
+        for (int b = 0; b < p.bins; ++b) r[b] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < PMAX; ++k) {
+            // objects 2k and 2k+1; object 0 is the goal
+            if (k > 0 && 2 * k < p.nobj) bad = lidar_one(p, r, ob[k].x, ob[k].y, pose) || bad;
+            if (2 * k + 1 < p.nobj) bad = lidar_one(p, r, ob[k].z, ob[k].w, pose) || bad;
+        }
+    }
+    if (p.off_qpos >= 0) {
+#pragma unroll
+        for (int k = 0; k < R::NQ; ++k) { row[p.off_qpos + k] = q[k]; bad = bad || notfinite(q[k]); }
+    }
+    if (p.off_qvel >= 0) {
+#pragma unroll
+        for (int k = 0; k < R::NV; ++k) { row[p.off_qvel + k] = v[k]; bad = bad || notfinite(v[k]); }
+    }
+    if (p.off_vel >= 0) {
+        row[p.off_vel] = vel0; row[p.off_vel + 1] = vel1;
+        bad = bad || notfinite(vel0) || notfinite(vel1);
+    }
+    return bad;
+}
+
+// stream the block's LDS tile (nenv rows of D floats, env-major) to global.
+// float4 stores when the destination is 16-byte aligned (always true for an
+// (N, D) tensor; a time-major slice with odd N*D may not be), dwords otherwise.
+template <int BLOCK>
+GX_D void flush_tile(const float* tile, float* gbase, int total)
+{
+    if ((reinterpret_cast<uintptr_t>(gbase) & 15u) == 0) {
+        const int nvec = total >> 2;
+        const float4* t4 = reinterpret_cast<const float4*>(tile);
+        float4* g4 = reinterpret_cast<float4*>(gbase);
+        for (int v = threadIdx.x; v < nvec; v += BLOCK) g4[v] = t4[v];
+        for (int k = (nvec << 2) + threadIdx.x; k < total; k += BLOCK) gbase[k] = tile[k];
+    } else {
+        for (int k = threadIdx.x; k < total; k += BLOCK) gbase[k] = tile[k];
+    }
+}
+
+template <int BLOCK>
+GX_D void stage_tile(float* tile, const float* gbase, int total)
+{
+    if ((reinterpret_cast<uintptr_t>(gbase) & 15u) == 0) {
+        const int nvec = total >> 2;
+        float4* t4 = reinterpret_cast<float4*>(tile);
+        const float4* g4 = reinterpret_cast<const float4*>(gbase);
+        for (int v = threadIdx.x; v < nvec; v += BLOCK) t4[v] = g4[v];
+        for (int k = (nvec << 2) + threadIdx.x; k < total; k += BLOCK) tile[k] = gbase[k];
+    } else {
+        for (int k = threadIdx.x; k < total; k += BLOCK) tile[k] = gbase[k];
+    }
+}
+
+GX_D float dist2(float ax, float ay, float bx, float by)
+{
+    const float dx = ax - bx, dy = ay - by;
+    return sqrtf(dx * dx + dy * dy);
+}
+
+// Fold the integer layout of the default Goal_<Robot>_8Hazards observation (8 hazards, 16
+// bins, every observe_* flag at its default, aliasing on, exponential lidar, 1 physics step)
+// into compile-time constants: loops unroll, flag tests and their scalar bookkeeping disappear.
+template <class R>
+static bool is_default_layout(const Params& p)
+{
+    return p.nobj == 9 && p.bins == 16 && p.D == R::kD && p.off_acc == -1 && p.off_ctrl == R::kOffCtrl &&
+           p.off_comp == R::kOffComp && p.off_gl == R::kOffGl && p.off_hl == R::kOffHl &&
+           p.off_qpos == R::kOffQpos && p.off_qvel == R::kOffQvel && p.off_vel == -1 && p.lidar_alias == 1 &&
+           p.lidar_max_dist_set == 0 && p.physics_steps == 1 && p.hist_on == 0;
+}
+
+template <class R, bool kDef>
+GX_D Params fold_params(Params p)
+{
+    if (kDef) {
+        p.H = 8; p.nobj = 9; p.P = 5; p.bins = 16; p.D = R::kD;
+        p.off_acc = -1; p.off_ctrl = R::kOffCtrl; p.off_comp = R::kOffComp; p.off_gl = R::kOffGl;
+        p.off_hl = R::kOffHl; p.off_qpos = R::kOffQpos; p.off_qvel = R::kOffQvel; p.off_vel = -1;
+        p.lidar_alias = 1; p.lidar_max_dist_set = 0; p.physics_steps = 1; p.hist_on = 0;
+    }
+    return p;
+}
+
+// ego_vel_acc (engine.py:902-929)
+GX_D void ego_vel_acc(const Params& p, const float (&pose)[4], float L1x, float L1y, float P2x, float P2y,
+                      float last_done, float done2, bool have_last, bool have_last_last, float& vel0,
+                      float& vel1, float& acc0, float& acc1)
+{
+    float plx = pose[0], ply = pose[1], pllx = pose[0], plly = pose[1];
+    if (have_last) {
+        if (!(last_done > 0.0f)) { plx = L1x; ply = L1y; }
+        if (have_last_last) {
+            if (done2 + last_done > 0.0f) { pllx = plx; plly = ply; }
+            else { pllx = P2x; plly = P2y; }
+        }
+    }
+    const float vwx = (pose[0] - plx) / p.dt, vwy = (pose[1] - ply) / p.dt;
+    const float lvx = (plx - pllx) / p.dt, lvy = (ply - plly) / p.dt;
+    const float awx = (vwx - lvx) / p.dt, awy = (vwy - lvy) / p.dt;
+    vel0 = vwx * pose[2] + vwy * pose[3];
+    vel1 = vwx * (-pose[3]) + vwy * pose[2];
+    acc0 = awx * pose[2] + awy * pose[3];
+    acc1 = awx * (-pose[3]) + awy * pose[2];
+}
+
+// action row of env `i` ((N, NA) row-major): one 8/16-byte load per 2/4 floats when the base allows it
+template <class R>
+GX_D void load_action(const float* __restrict__ act, size_t i, float (&a)[R::NA])
+{
+    const float* row = act + i * R::NA;
+    if (R::NA == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(row); // every entry point checks 8-byte alignment
+        a[0] = t.x; a[1] = t.y;
+    } else if (R::NA % 4 == 0 && (reinterpret_cast<uintptr_t>(act) & 15u) == 0) {
+#pragma unroll
+        for (int k = 0; k < R::NA / 4; ++k) {
+            const float4 t = reinterpret_cast<const float4*>(row)[k];
+            a[4 * k] = t.x; a[4 * k + 1] = t.y; a[4 * k + 2] = t.z; a[4 * k + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < R::NA; ++k) a[k] = row[k];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Engine.step (engine.py:469-495 + mjx_step :659-700), thread-per-env form.
+// ---------------------------------------------------------------------------
+template <class R, int BLOCK, int PMAX, bool kQacc, bool kDef>
+__global__ __launch_bounds__(BLOCK) void step_kernel(Params p_in, const float* __restrict__ act,
+                                                     float4* __restrict__ dyn,
+                                                     const float4* __restrict__ obj,
+                                                     float4* __restrict__ hist,
+                                                     float* __restrict__ obs,
+                                                     float* __restrict__ rew,
+                                                     float* __restrict__ cost,
+                                                     float* __restrict__ done,
+                                                     float* __restrict__ qacc_out)
+{
+    const Params p = fold_params<R, kDef>(p_in);
+    extern __shared__ float4 tile4[];
+    float* tile = reinterpret_cast<float*>(tile4);
+    const int tid = threadIdx.x;
+    const int env0 = blockIdx.x * BLOCK;
+    const int i = env0 + tid;
+    const bool live = i < p.N;
+
+    // ---- coalesced loads (arrays are padded to Npad, every lane may load)
+    float a[R::NA];
+    load_action<R>(act, live ? i : 0, a);
+    float q[R::NQ], v[R::NV], pose0[4], last_done, steps;
+    R::load(dyn, p.Npad, i, q, v, pose0, last_done, steps);
+    float4 ob[PMAX];
+#pragma unroll
+    for (int k = 0; k < PMAX; ++k)
+        ob[k] = (k < p.P) ? obj[(size_t)k * p.Npad + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 hs = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.hist_on) hs = hist[i];
+    const float P1x = pose0[0], P1y = pose0[1]; // last_data.xpos
+
+    float ctrl[R::NU];
+    R::convert_action(pose0, a, ctrl); // :672-685, PRE-step xmat
+    float pose[4], qacc[R::NV];
+#pragma unroll
+    for (int k = 0; k < R::NV; ++k) qacc[k] = 0.f;
+    for (int k = 0; k < p.physics_steps; ++k) R::template substep<kQacc>(q, v, ctrl, pose, qacc);
+
+    float vel0 = 0.f, vel1 = 0.f, acc0 = 0.f, acc1 = 0.f;
+    if (p.hist_on)
+        ego_vel_acc(p, pose, P1x, P1y, hs.x, hs.y, last_done, hs.z, p.have_last != 0, p.have_last_last != 0,
+                    vel0, vel1, acc0, acc1);
+
+    float* row = tile + tid * p.D;
+    const bool bad = build_obs_row<R, PMAX>(p, row, pose, ob, ctrl, q, v, vel0, vel1, acc0, acc1);
+
+    // reward_done :787-802
+    const float dg = dist2(ob[0].x, ob[0].y, pose[0], pose[1]);
+    float last = dg;
+    if (p.have_last && !(last_done > 0.0f)) last = dist2(ob[0].x, ob[0].y, P1x, P1y);
+    const float dd = last - dg;
+    float r = dd * p.reward_distance;
+    float dn = dg < p.goal_size ? 1.0f : 0.0f;
+    if (fabsf(dd) > 1.0f) { dn = 1.0f; r = 0.0f; }
+
+    // cost :804-811
+    float cs = 0.0f;
+#pragma unroll
+    for (int k = 0; k < PMAX; ++k) {
+        if (k > 0 && 2 * k < p.nobj) {
+            const float dh = dist2(ob[k].x, ob[k].y, pose[0], pose[1]);
+            float below = dh < p.hazards_size ? dh : p.hazards_size;
+            if (dh != dh) below = dh;
+            cs = cs + (p.hazards_size - below);
+        }
+        if (2 * k + 1 < p.nobj) {
+            const float dh = dist2(ob[k].z, ob[k].w, pose[0], pose[1]);
+            float below = dh < p.hazards_size ? dh : p.hazards_size;
+            if (dh != dh) below = dh;
+            cs = cs + (p.hazards_size - below);
+        }
+    }
+
+    // NaN/Inf guard :696-699, timeout + step counter :492-493
+    if (bad) { r = 0.0f; dn = 1.0f; }
+    if (steps > p.num_steps_f) dn = 1.0f;
+    const float nsteps = dn > 0.0f ? 0.0f : steps + 1.0f;
+
+    if (live) {
+        R::store(dyn, p.Npad, i, q, v, pose, dn, nsteps);
+        if (p.hist_on) hist[i] = make_float4(P1x, P1y, last_done, 0.f);
+        rew[i] = r;
+        cost[i] = cs;
+        done[i] = dn;
+        if (kQacc) {
+#pragma unroll
+            for (int k = 0; k < R::NV; ++k) qacc_out[R::NV * i + k] = qacc[k];
+        }
+    }
+
+    __syncthreads();
+    const int nenv = min(BLOCK, p.N - env0);
+    flush_tile<BLOCK>(tile, obs + (size_t)env0 * p.D, nenv * p.D);
+}
+
+// ---------------------------------------------------------------------------
+// Engine.reset (engine.py:454-467): get_layout + mjx_reset for every env
+// ---------------------------------------------------------------------------
+template <int PMAX>
+GX_D void load_layout(const Params& p, const float2* __restrict__ cand_xy, int nobj_total, int j,
+                      float4 (&ob)[PMAX], float& rx, float& ry)
+{
+    const float2* rowp = cand_xy + (size_t)j * nobj_total;
+#pragma unroll
+    for (int k = 0; k < PMAX; ++k) {
+        float2 a = make_float2(0.f, 0.f), b = make_float2(0.f, 0.f);
+        if (2 * k < p.nobj) a = rowp[2 * k];
+        if (2 * k + 1 < p.nobj) b = rowp[2 * k + 1];
+        ob[k] = make_float4(a.x, a.y, b.x, b.y);
+    }
+    const float2 rb = rowp[nobj_total - 1];
+    rx = rb.x; ry = rb.y;
+}
+
+template <class R, int BLOCK, int PMAX>
+__global__ __launch_bounds__(BLOCK) void reset_apply_kernel(Params p, int nobj_total, uint32_t k10,
+                                                            uint32_t k11, uint32_t k20, uint32_t k21,
+                                                            const int* __restrict__ layout_size,
+                                                            const int* __restrict__ cand_of,
+                                                            const float2* __restrict__ cand_xy,
+                                                            float4* __restrict__ dyn,
+                                                            float4* __restrict__ obj,
+                                                            float* __restrict__ obs,
+                                                            int* __restrict__ host_layout_size)
+{
+    extern __shared__ float4 tile4[];
+    float* tile = reinterpret_cast<float*>(tile4);
+    const int L = *layout_size;
+    // len(idx) for the host-side assert (engine.py:442-444): written straight into mapped pinned
+    // host memory, no copy kernel on the stream
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        host_layout_size[0] = L;
+        if (L < host_layout_size[1]) host_layout_size[1] = L; // smallest pool since the last check (resets are stream ordered)
+    }
+    if (L <= 0) return; // host raises GX_ERR_LAYOUT (engine.py:444)
+    const int tid = threadIdx.x;
+    const int env0 = blockIdx.x * BLOCK;
+    const int i = env0 + tid;
+    const bool live = i < p.N;
+    const uint32_t gi = (uint32_t)(p.env_offset + (live ? i : 0));
+    const uint32_t idx = randint_at(k10, k11, k20, k21, (uint32_t)p.env_total, (uint32_t)L, gi);
+    const int j = cand_of[idx];
+    float4 ob[PMAX];
+    float rx, ry;
+    load_layout<PMAX>(p, cand_xy, nobj_total, j, ob, rx, ry);
+    // mjx_reset :644-657: qpos from layout, qvel = ctrl = 0, forward -> pose
+    float q[R::NQ], v[R::NV], ctrl[R::NU];
+#pragma unroll
+    for (int k = 0; k < R::NQ; ++k) q[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < R::NV; ++k) v[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < R::NU; ++k) ctrl[k] = 0.f;
+    R::place(q, rx, ry);
+    const float pose[4] = {rx, ry, 1.0f, 0.0f};
+    float* row = tile + tid * p.D;
+    build_obs_row<R, PMAX>(p, row, pose, ob, ctrl, q, v, 0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        float oq[R::NQ], ov[R::NV], opose[4], odone, osteps;
+        R::load(dyn, p.Npad, i, oq, ov, opose, odone, osteps);
+        R::store(dyn, p.Npad, i, q, v, pose, odone, 0.0f); // _done kept, _steps = 0 (:463)
+#pragma unroll
+        for (int k = 0; k < PMAX; ++k)
+            if (k < p.P) obj[(size_t)k * p.Npad + i] = ob[k];
+    }
+    __syncthreads();
+    const int nenv = min(BLOCK, p.N - env0);
+    flush_tile<BLOCK>(tile, obs + (size_t)env0 * p.D, nenv * p.D);
+}
+
+// ---------------------------------------------------------------------------
+// Engine.reset_done (engine.py:497-505, mjx_reset_done :702-731)
+// ---------------------------------------------------------------------------
+template <class R, int BLOCK, int PMAX>
+__global__ __launch_bounds__(BLOCK) void reset_done_kernel(Params p, int nobj_total, uint32_t k10,
+                                                           uint32_t k11, uint32_t k20, uint32_t k21,
+                                                           const int* __restrict__ layout_size,
+                                                           const int* __restrict__ cand_of,
+                                                           const float2* __restrict__ cand_xy,
+                                                           float4* __restrict__ dyn,
+                                                           float4* __restrict__ obj,
+                                                           const float* obs_in, float* obs_out)
+{
+    extern __shared__ float4 tile4[];
+    float* tile = reinterpret_cast<float*>(tile4);
+    const int tid = threadIdx.x;
+    const int env0 = blockIdx.x * BLOCK;
+    const int i = env0 + tid;
+    const bool live = i < p.N;
+    const int L = *layout_size;
+    float oq[R::NQ], ov[R::NV], opose[4], odone, osteps;
+    R::load(dyn, p.Npad, i, oq, ov, opose, odone, osteps);
+    const bool dn = live && (odone > 0.0f) && (L > 0);
+    const int any = __syncthreads_or(dn ? 1 : 0);
+    const int nenv = min(BLOCK, p.N - env0);
+    const int total = nenv * p.D;
+    if (!any && obs_in == obs_out) return; // nothing to do for this tile
+    // stage the old rows (self._obs) in LDS
+    stage_tile<BLOCK>(tile, obs_in + (size_t)env0 * p.D, total);
+    __syncthreads();
+    if (dn) {
+        const uint32_t gi = (uint32_t)(p.env_offset + i);
+        const uint32_t idx = randint_at(k10, k11, k20, k21, (uint32_t)p.env_total, (uint32_t)L, gi);
+        const int j = cand_of[idx];
+        float4 ob[PMAX];
+        float rx, ry;
+        load_layout<PMAX>(p, cand_xy, nobj_total, j, ob, rx, ry);
+        // "fake step" (:719-724) from rest with zero ctrl leaves qpos/qvel unchanged;
+        // its forward() gives pose(qpos_reset) for the obs; data keeps the STALE xpos/xmat (:731)
+        float q[R::NQ], v[R::NV], ctrl[R::NU];
+#pragma unroll
+        for (int k = 0; k < R::NQ; ++k) q[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < R::NV; ++k) v[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < R::NU; ++k) ctrl[k] = 0.f;
+        R::place(q, rx, ry);
+        float pose[4] = {rx, ry, 1.0f, 0.0f};
+        if (R::kRestFixed) {
+            build_obs_row<R, PMAX>(p, tile + tid * p.D, pose, ob, ctrl, q, v, 0.f, 0.f, 0.f, 0.f);
+        } else { // the fake step moves the robot: its qpos/qvel feed the obs only
+            float fq[R::NQ], fv[R::NV], fa[R::NV];
+#pragma unroll
+            for (int k = 0; k < R::NQ; ++k) fq[k] = q[k];
+#pragma unroll
+            for (int k = 0; k < R::NV; ++k) fv[k] = 0.f;
+            for (int k = 0; k < p.physics_steps; ++k) R::template substep<false>(fq, fv, ctrl, pose, fa);
+            build_obs_row<R, PMAX>(p, tile + tid * p.D, pose, ob, ctrl, fq, fv, 0.f, 0.f, 0.f, 0.f);
+        }
+        R::store(dyn, p.Npad, i, q, v, opose, odone, osteps);
+#pragma unroll
+        for (int k = 0; k < PMAX; ++k)
+            if (k < p.P) obj[(size_t)k * p.Npad + i] = ob[k];
+    }
+    __syncthreads();
+    flush_tile<BLOCK>(tile, obs_out + (size_t)env0 * p.D, total);
+}
+
+// ---------------------------------------------------------------------------
+// Lane-group kernel for SMALL batches (latency regime, env_num ~ 10^3..10^4).
+//
+// 16 lanes cooperate on one environment, 4 environments per wave64, one wave per
+// workgroup: env_num=2000 becomes 500 single-wave workgroups spread over the
+// chip instead of 32 waves each grinding through 9 objects serially.
+//   * every lane carries the env's dynamic state and integrates it (redundantly:
+//     identical operations, identical bits) -- no broadcast on the critical path;
+//   * lane o evaluates object o (goal, hazard0..): ego vector, sqrt, atan2, exp,
+//     alias, hazard cost term -- the 9 transcendental chains run side by side;
+//   * the per-object (bin, sensor, a1, a2) records are exchanged through 1 KiB of
+//     LDS and lane b folds them into lidar bin b (the scatter-max becomes a
+//     gather-max with the same operand order, so results are bit-identical to the
+//     thread-per-env kernel);
+//   * the kernel is persistent over T steps: state and layout stay in registers,
+//     per step it reads 8 B of action and writes the obs row + 3 scalars;
+//   * reset_done (engine.py:497-505) is folded in: a wave-uniform ballot of the done
+//     flags gates the re-draw of the layout index and the rebuild of the obs row.
+// ---------------------------------------------------------------------------
+
+constexpr int kGL = 16; // lanes per environment
+
+template <int OPL, int BPL>
+struct GroupObs { float gl[BPL], hl[BPL], comp0, comp1, cost; bool bad; };
+
+// object phase + LDS exchange + bin phase for one pose
+// `lane` = thread index in the workgroup (BT threads = BT/16 environments); must be reached by the
+// whole workgroup.
+template <int OPL, int BPL, int BT>
+GX_D GroupObs<OPL, BPL> group_observe(const Params& p, float4 (*rec)[BT], float (*term)[BT], int lane,
+                                      const float (&pose)[4], float gx, float gy,
+                                      const float (&ox)[OPL], const float (&oy)[OPL])
+{
+    const int l = lane & (kGL - 1), gbase = lane & ~(kGL - 1);
+    GroupObs<OPL, BPL> out;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < OPL; ++j) {
+        const int o = l + kGL * j;
+        const bool valid = o < p.nobj;
+        LidarTerms t = lidar_terms(p, ox[j], oy[j], pose);
+        const bool enabled = (o == 0) ? (p.off_gl >= 0) : (p.off_hl >= 0);
+        if (valid && enabled) bad = bad || lidar_bad(p, t);
+        float tc = 0.0f;
+        if (valid && o >= 1) { // cost term :804-811
+            const float dh = dist2(ox[j], oy[j], pose[0], pose[1]);
+            float below = dh < p.hazards_size ? dh : p.hazards_size;
+            if (dh != dh) below = dh;
+            tc = p.hazards_size - below;
+        }
+        if (!valid) { t.bin = -1000; t.sensor = 0.f; t.a1 = 0.f; t.a2 = 0.f; }
+        rec[j][lane] = make_float4(__int_as_float(t.bin), t.sensor, t.a1, t.a2);
+        term[j][lane] = tc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int jb = 0; jb < BPL; ++jb) {
+        const int b = l + kGL * jb;
+        float gl = 0.0f, hl = 0.0f;
+#pragma unroll 9
+        for (int o = 0; o < p.nobj; ++o) {
+            const float4 rc = rec[o >> 4][gbase + (o & 15)];
+            LidarTerms t;
+            t.bin = __float_as_int(rc.x); t.sensor = rc.y; t.a1 = rc.z; t.a2 = rc.w;
+            const float c = lidar_contrib(p, t, b);
+            if (o == 0) gl = nmax(gl, c);
+            else hl = nmax(hl, c);
+        }
+        out.gl[jb] = gl;
+        out.hl[jb] = hl;
+    }
+    float cs = 0.0f;
+#pragma unroll 8
+    for (int o = 1; o < p.nobj; ++o) cs = cs + term[o >> 4][gbase + (o & 15)];
+    out.cost = cs;
+    { // obs_compass :834-844 (same expression as ego_xy of the goal)
+        const float dx = gx - pose[0], dy = gy - pose[1];
+        out.comp0 = dx * pose[2] + dy * pose[3];
+        out.comp1 = dx * (-pose[3]) + dy * pose[2];
+        if (p.off_comp >= 0) bad = bad || notfinite(out.comp0) || notfinite(out.comp1);
+    }
+    // any lane of this env's group
+    const unsigned long long m = __ballot(bad);
+    out.bad = ((m >> (gbase & 63)) & 0xFFFFull) != 0ull;
+    __syncthreads();
+    return out;
+}
+
+// value k of a small register array selected by a per-lane index (compare-select chain)
+template <int N>
+GX_D float pick(const float (&a)[N], int k)
+{
+    float r = a[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) r = (k == i) ? a[i] : r;
+    return r;
+}
+
+// kPol: 0 open loop (action tape), 1 policy evaluated with VALU fmaf chains (one wave per workgroup),
+//       2 policy evaluated with fp32 MFMA tiles (four waves = 16 envs per workgroup)
+template <class R, int OPL, int BPL, bool kQacc, bool kDef, int kPol>
+__global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Params p_in, RolloutArgs r,
+                                                                            PolicyArgs pol,
+                                                                            float4* __restrict__ dyn,
+                                                                            float4* __restrict__ obj,
+                                                                            float4* __restrict__ hist)
+{
+    constexpr int BT = (kPol == 2) ? 256 : 64;
+    constexpr bool kPolicy = kPol != 0;
+    const Params p = fold_params<R, kDef>(p_in);
+    __shared__ float4 rec[OPL][BT];
+    __shared__ float term[OPL][BT];
+    extern __shared__ float4 pol_lds4[];
+    const int lane = threadIdx.x;           // thread in the workgroup
+    const int l = lane & (kGL - 1);         // lane within the env's 16-lane group
+    const int env = blockIdx.x * (BT / kGL) + (lane >> 4);
+    const bool live = env < p.N;
+    const int e = live ? env : 0;
+
+    // ---- policy: weights into LDS, entry observation into this env's LDS row
+    float* pol_lds = reinterpret_cast<float*>(pol_lds4);
+    MlpLds wpi, wv;
+    float *xrow = nullptr, *hbuf = nullptr, *X = nullptr, *H1 = nullptr, *H2 = nullptr;
+    int XS = 0;
+    float pstd[R::NA], plstd[R::NA];
+    if (kPolicy) {
+        const int D = p.D, A = R::NA;
+        const int rows = (kPol == 2) ? pad4(D) : D;
+        float* pi_img = pol_lds;
+        float* v_img = pi_img + pad4(mlp_lds_floats(rows, A));
+        float* ls_img = v_img + pad4(mlp_lds_floats(rows, 1));
+        float* rest = ls_img + pad4(2 * A);
+        if (kPol == 2) {
+            XS = pad4(D) + 1;
+            X = rest;
+            H1 = X + pad4(16 * XS);
+            H2 = H1 + 2 * 16 * kPolHS;
+            xrow = X + (lane >> 4) * XS;
+            hbuf = H1 + (lane >> 4) * kPolHS; // scratch for the final critic pass
+            for (int i = lane; i < 16 * XS; i += BT) X[i] = 0.0f; // zero padding columns
+        } else {
+            hbuf = rest + (lane >> 4) * 2 * kPolHd;
+            xrow = rest + 4 * 2 * kPolHd + (lane >> 4) * pad4(D);
+        }
+        mlp_stage(pi_img, pol.params, D, rows, A, lane, BT);
+        mlp_stage(v_img, pol.params + mlp_floats(D, A), D, rows, 1, lane, BT);
+        wpi = mlp_lds_view(pi_img, rows, A);
+        wv = mlp_lds_view(v_img, rows, 1);
+        const float* gls = pol.params + mlp_floats(D, A) + mlp_floats(D, 1);
+#pragma unroll
+        for (int d = 0; d < A; ++d) {
+            pstd[d] = exp_f(gls[d]);      // std = exp(log_std)          trpo_core.py:123
+            plstd[d] = log_f(pstd[d]);    // torch.log(pi.stddev)        trpo_core.py:173
+            if (blockIdx.x == 0 && lane == d) pol.logstd[d] = plstd[d];
+        }
+        __syncthreads();
+        for (int k = l; k < D; k += kGL) xrow[k] = pol.obs0[(size_t)e * D + k];
+        __syncthreads();
+    }
+
+    // ---- state (every lane of the group holds a copy)
+    float q[R::NQ], v[R::NV], pose0[4], done0, steps;
+    R::load(dyn, p.Npad, e, q, v, pose0, done0, steps);
+    float P1x = 0.f, P1y = 0.f, done1 = 0.f;
+    if (p.hist_on) { const float4 h = hist[e]; P1x = h.x; P1y = h.y; done1 = h.z; }
+    const float2* obj2 = reinterpret_cast<const float2*>(obj);
+    float ox[OPL], oy[OPL];
+#pragma unroll
+    for (int j = 0; j < OPL; ++j) {
+        const int o = l + kGL * j;
+        float2 t = make_float2(0.f, 0.f);
+        if (o < p.nobj) t = obj2[((size_t)(o >> 1) * p.Npad + e) * 2 + (o & 1)];
+        ox[j] = t.x; oy[j] = t.y;
+    }
+    float gx, gy;
+    { const float2 g = obj2[(size_t)e * 2]; gx = g.x; gy = g.y; }
+    bool touched_layout = false;
+
+    float a_next[R::NA];
+#pragma unroll
+    for (int d = 0; d < R::NA; ++d) a_next[d] = 0.f;
+    if (!kPolicy) load_action<R>(r.act, (size_t)e, a_next);
+    for (int t = 0; t < r.T; ++t) {
+        float a[R::NA];
+#pragma unroll
+        for (int d = 0; d < R::NA; ++d) a[d] = a_next[d];
+        if (!kPolicy) {
+            if (t + 1 < r.T) load_action<R>(r.act, (size_t)(t + 1) * p.N + e, a_next);
+        } else {
+            // ac.step(o): a ~ N(mu(o), std), logp, v(o)   trpo_core.py:166-173
+            const size_t te = (size_t)t * p.N + env;
+            float mu[R::NA], vv[1];
+            if (kPol == 2) {
+                mfma_hidden(wpi, wv, X, XS, pad4(p.D), H1, H2, lane >> 6, lane & 63);
+                const float* h2p = H2 + (lane >> 4) * kPolHS + 4 * l;
+                const float4 hp = *reinterpret_cast<const float4*>(h2p);
+                const float4 hc = *reinterpret_cast<const float4*>(h2p + 16 * kPolHS);
+#pragma unroll
+                for (int o = 0; o < R::NA; ++o) mu[o] = head_out(wpi, o, l, hp);
+                vv[0] = head_out(wv, 0, l, hc);
+            } else {
+                actor_critic_forward<R::NA>(wpi, wv, xrow, hbuf, p.D, l, mu, vv[0]);
+            }
+            float z[R::NA];
+#pragma unroll
+            for (int j = 0; j < R::NA / 2; ++j) // one counter per pair of action dimensions
+                normal_pair(pol.seed0, pol.seed1, (uint32_t)(p.env_offset + env), (pol.t0 + (uint32_t)t) * 16u + (uint32_t)j,
+                            z[2 * j], z[2 * j + 1]);
+            float act[R::NA], lp = 0.0f;
+#pragma unroll
+            for (int d = 0; d < R::NA; ++d) {
+                act[d] = fmaf(pstd[d], z[d], mu[d]);
+                const float df = act[d] - mu[d];
+                const float var = pstd[d] * pstd[d];
+                lp = lp + ((-(df * df) / (2.0f * var) - plstd[d]) - 0.9189385332046727f);
+            }
+#pragma unroll
+            for (int d = 0; d < R::NA; ++d) a[d] = act[d];
+            if (live) {
+                for (int k = l; k < p.D; k += kGL) pol.obs_in[te * p.D + k] = xrow[k];
+                if (l < R::NA) {
+                    pol.act[te * R::NA + l] = pick(act, l);
+                    pol.mu[te * R::NA + l] = pick(mu, l);
+                }
+                if (l == 0) { pol.logp[te] = lp; pol.val[te] = vv[0]; }
+            }
+            __syncthreads(); // xrow is rewritten at the end of this step
+        }
+        const bool have_last = (r.hist0 + t) >= 1, have_last_last = (r.hist0 + t) >= 2;
+
+        // update_data :426-431 (history shift)
+        const float done2 = done1;
+        const float last_done = done0;
+        const float P2x = P1x, P2y = P1y;
+        const float L1x = pose0[0], L1y = pose0[1]; // last_data.xpos
+
+        // convert_action :672-685, mjx.step :689
+        float ctrl[R::NU];
+        R::convert_action(pose0, a, ctrl);
+        float pose[4], qacc[R::NV];
+#pragma unroll
+        for (int k = 0; k < R::NV; ++k) qacc[k] = 0.f;
+        for (int k = 0; k < p.physics_steps; ++k) R::template substep<kQacc>(q, v, ctrl, pose, qacc);
+
+        float vel0 = 0.f, vel1 = 0.f, acc0 = 0.f, acc1 = 0.f;
+        if (p.hist_on)
+            ego_vel_acc(p, pose, L1x, L1y, P2x, P2y, last_done, done2, have_last, have_last_last, vel0, vel1,
+                        acc0, acc1);
+
+        GroupObs<OPL, BPL> ob = group_observe<OPL, BPL, BT>(p, rec, term, lane, pose, gx, gy, ox, oy);
+        bool bad = ob.bad;
+        if (p.off_acc >= 0) bad = bad || notfinite(acc0) || notfinite(acc1);
+        if (p.off_ctrl >= 0) {
+#pragma unroll
+            for (int k = 0; k < R::NU; ++k) bad = bad || notfinite(ctrl[k]);
+        }
+        if (p.off_qpos >= 0) {
+#pragma unroll
+            for (int k = 0; k < R::NQ; ++k) bad = bad || notfinite(q[k]);
+        }
+        if (p.off_qvel >= 0) {
+#pragma unroll
+            for (int k = 0; k < R::NV; ++k) bad = bad || notfinite(v[k]);
+        }
+        if (p.off_vel >= 0) bad = bad || notfinite(vel0) || notfinite(vel1);
+
+        // reward_done :787-802
+        const float dg = dist2(gx, gy, pose[0], pose[1]);
+        float last = dg;
+        if (have_last && !(last_done > 0.0f)) last = dist2(gx, gy, L1x, L1y);
+        const float dd = last - dg;
+        float rw = dd * p.reward_distance;
+        float dn = dg < p.goal_size ? 1.0f : 0.0f;
+        if (fabsf(dd) > 1.0f) { dn = 1.0f; rw = 0.0f; }
+        if (bad) { rw = 0.0f; dn = 1.0f; }          // :696-699
+        if (steps > p.num_steps_f) dn = 1.0f;        // :492
+        steps = dn > 0.0f ? 0.0f : steps + 1.0f;     // :493
+
+        // commit the history
+        P1x = L1x; P1y = L1y; done1 = last_done;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pose0[k] = pose[k];
+        done0 = dn;
+
+        // values of this env's obs row
+        float o_ctrl[R::NU], o_q[R::NQ], o_v[R::NV];
+#pragma unroll
+        for (int k = 0; k < R::NU; ++k) o_ctrl[k] = ctrl[k];
+#pragma unroll
+        for (int k = 0; k < R::NQ; ++k) o_q[k] = q[k];
+#pragma unroll
+        for (int k = 0; k < R::NV; ++k) o_v[k] = v[k];
+        float o_v0 = vel0, o_v1 = vel1, o_a0 = acc0, o_a1 = acc1;
+
+        // reset_done :497-505 folded in (wave-uniform gate)
+        if (r.do_reset) {
+            const int L = *r.layout_size;
+            const bool rs = live && dn > 0.0f && L > 0;
+            if (__syncthreads_or(rs ? 1 : 0)) { // workgroup-uniform gate
+                float nox[OPL], noy[OPL], ngx = gx, ngy = gy, rx = 0.f, ry = 0.f;
+#pragma unroll
+                for (int j = 0; j < OPL; ++j) { nox[j] = ox[j]; noy[j] = oy[j]; }
+                if (rs) {
+                    const uint4 kk = r.keys[t];
+                    const uint32_t idx = randint_at(kk.x, kk.y, kk.z, kk.w, (uint32_t)p.env_total, (uint32_t)L,
+                                                    (uint32_t)(p.env_offset + env));
+                    const float2* rowp = r.cand_xy + (size_t)r.cand_of[idx] * r.nobj_total;
+#pragma unroll
+                    for (int j = 0; j < OPL; ++j) {
+                        const int o = l + kGL * j;
+                        if (o < p.nobj) { const float2 t2 = rowp[o]; nox[j] = t2.x; noy[j] = t2.y; }
+                    }
+                    const float2 g = rowp[0], rb = rowp[r.nobj_total - 1];
+                    ngx = g.x; ngy = g.y; rx = rb.x; ry = rb.y;
+                }
+                float rpose[4] = {rx, ry, 1.0f, 0.0f};
+                float fq[R::NQ], fv[R::NV];
+#pragma unroll
+                for (int k = 0; k < R::NQ; ++k) fq[k] = 0.f;
+#pragma unroll
+                for (int k = 0; k < R::NV; ++k) fv[k] = 0.f;
+                R::place(fq, rx, ry);
+                if (!R::kRestFixed) { // the fake step (:719-724) moves the robot: its qpos/qvel feed the obs only
+                    float fa[R::NV], zc[R::NU];
+#pragma unroll
+                    for (int k = 0; k < R::NU; ++k) zc[k] = 0.f;
+                    for (int k = 0; k < p.physics_steps; ++k) R::template substep<false>(fq, fv, zc, rpose, fa);
+                }
+                const GroupObs<OPL, BPL> rob = group_observe<OPL, BPL, BT>(p, rec, term, lane, rpose, ngx, ngy, nox, noy);
+                if (rs) {
+#pragma unroll
+                    for (int j = 0; j < OPL; ++j) { ox[j] = nox[j]; oy[j] = noy[j]; }
+                    gx = ngx; gy = ngy;
+#pragma unroll
+                    for (int k = 0; k < R::NQ; ++k) { q[k] = 0.f; o_q[k] = fq[k]; }
+#pragma unroll
+                    for (int k = 0; k < R::NV; ++k) { v[k] = 0.f; o_v[k] = fv[k]; }
+#pragma unroll
+                    for (int k = 0; k < R::NU; ++k) o_ctrl[k] = 0.f;
+                    R::place(q, rx, ry);
+#pragma unroll
+                    for (int jb = 0; jb < BPL; ++jb) { ob.gl[jb] = rob.gl[jb]; ob.hl[jb] = rob.hl[jb]; }
+                    ob.comp0 = rob.comp0; ob.comp1 = rob.comp1;
+                    o_v0 = o_v1 = o_a0 = o_a1 = 0.f;
+                    touched_layout = true;
+                }
+            }
+        }
+
+        if (live || kPolicy) {
+            const size_t te = (size_t)t * p.N + env;
+            // closed loop: the post-reset row is the policy's next input (LDS); open loop: global
+            float* row = kPolicy ? xrow : r.obs + te * p.D;
+#pragma unroll
+            for (int jb = 0; jb < BPL; ++jb) {
+                const int b = l + kGL * jb;
+                if (b < p.bins) {
+                    if (p.off_gl >= 0) row[p.off_gl + b] = ob.gl[jb];
+                    if (p.off_hl >= 0) row[p.off_hl + b] = ob.hl[jb];
+                }
+            }
+            if (l < R::NU && p.off_ctrl >= 0) row[p.off_ctrl + l] = pick(o_ctrl, l);
+            if (l < R::NQ && p.off_qpos >= 0) row[p.off_qpos + l] = pick(o_q, l);
+            if (l < R::NV) {
+                if (p.off_qvel >= 0) row[p.off_qvel + l] = pick(o_v, l);
+                if (kQacc && live) r.qacc[te * R::NV + l] = pick(qacc, l);
+            }
+            if (l < 2) {
+                if (p.off_comp >= 0) row[p.off_comp + l] = (l == 0) ? ob.comp0 : ob.comp1;
+                if (p.off_vel >= 0) row[p.off_vel + l] = (l == 0) ? o_v0 : o_v1;
+                if (p.off_acc >= 0) row[p.off_acc + l] = (l == 0) ? o_a0 : o_a1;
+            }
+            if (l == 0 && live) { r.rew[te] = rw; r.cost[te] = ob.cost; r.done[te] = dn; }
+        }
+        if (kPolicy) __syncthreads();
+    }
+
+    if (kPolicy) { // bootstrap inputs: o_T and V(o_T)   trpo.py:523-529
+        const float vlast = critic_forward(wv, xrow, hbuf, p.D, l);
+        if (live) {
+            for (int k = l; k < p.D; k += kGL) pol.obs_last[(size_t)env * p.D + k] = xrow[k];
+            if (l == 0) pol.val_last[env] = vlast;
+        }
+    }
+
+    if (live) {
+        if (l == 0) {
+            R::store(dyn, p.Npad, env, q, v, pose0, done0, steps);
+            if (p.hist_on) hist[env] = make_float4(P1x, P1y, done1, 0.f);
+        }
+        if (touched_layout) {
+            float2* objw = reinterpret_cast<float2*>(obj);
+#pragma unroll
+            for (int j = 0; j < OPL; ++j) {
+                const int o = l + kGL * j;
+                if (o < p.nobj) objw[((size_t)(o >> 1) * p.Npad + env) * 2 + (o & 1)] = make_float2(ox[j], oy[j]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launchers (per robot)
+// ---------------------------------------------------------------------------
+template <class R, int BLOCK, int PMAX>
+static void launch_step_bp(const Params& p, const DevBuffers& b, const float* act, float* obs,
+                           float* rew, float* cost, float* done, float* qacc, hipStream_t s)
+{
+    const dim3 grid((p.N + BLOCK - 1) / BLOCK), blk(BLOCK);
+    const size_t lds = step_lds_bytes(p, BLOCK);
+    const float* a2 = act;
+    if (PMAX == 5 && is_default_layout<R>(p)) {
+        if (qacc)
+            hipLaunchKernelGGL((step_kernel<R, BLOCK, 5, true, true>), grid, blk, lds, s, p, a2, b.dyn, b.obj, b.hist,
+                               obs, rew, cost, done, qacc);
+        else
+            hipLaunchKernelGGL((step_kernel<R, BLOCK, 5, false, true>), grid, blk, lds, s, p, a2, b.dyn, b.obj, b.hist,
+                               obs, rew, cost, done, qacc);
+    } else if (qacc)
+        hipLaunchKernelGGL((step_kernel<R, BLOCK, PMAX, true, false>), grid, blk, lds, s, p, a2, b.dyn, b.obj, b.hist,
+                           obs, rew, cost, done, qacc);
+    else
+        hipLaunchKernelGGL((step_kernel<R, BLOCK, PMAX, false, false>), grid, blk, lds, s, p, a2, b.dyn, b.obj, b.hist,
+                           obs, rew, cost, done, qacc);
+}
+
+#define GX_DISPATCH_BP_R(R, FN, ...)                                   \
+    do {                                                               \
+        const int blk_ = pick_block(p);                                \
+        if (p.P <= 5) {                                                \
+            if (blk_ == 64) FN<R, 64, 5>(__VA_ARGS__);                 \
+            else FN<R, 256, 5>(__VA_ARGS__);                           \
+        } else if (p.P <= 9) {                                         \
+            if (blk_ == 64) FN<R, 64, 9>(__VA_ARGS__);                 \
+            else FN<R, 256, 9>(__VA_ARGS__);                           \
+        } else {                                                       \
+            if (blk_ == 64) FN<R, 64, 33>(__VA_ARGS__);                \
+            else FN<R, 256, 33>(__VA_ARGS__);                          \
+        }                                                              \
+    } while (0)
+
+template <class R, int BLOCK, int PMAX>
+static void launch_reset_apply_bp(const Params& p, const DevBuffers& b, int nobj_total, uint32_t k10,
+                                  uint32_t k11, uint32_t k20, uint32_t k21, float* obs, int* host_ls,
+                                  hipStream_t s)
+{
+    const dim3 grid((p.N + BLOCK - 1) / BLOCK), blk(BLOCK);
+    hipLaunchKernelGGL((reset_apply_kernel<R, BLOCK, PMAX>), grid, blk, step_lds_bytes(p, BLOCK), s, p,
+                       nobj_total, k10, k11, k20, k21, b.pool.layout_size, b.pool.cand_of, b.pool.cand_xy, b.dyn, b.obj,
+                       obs, host_ls);
+}
+
+
+template <class R, int BLOCK, int PMAX>
+static void launch_reset_done_bp(const Params& p, const DevBuffers& b, int nobj_total, uint32_t k10,
+                                 uint32_t k11, uint32_t k20, uint32_t k21, const float* obs_in,
+                                 float* obs_out, hipStream_t s)
+{
+    const dim3 grid((p.N + BLOCK - 1) / BLOCK), blk(BLOCK);
+    hipLaunchKernelGGL((reset_done_kernel<R, BLOCK, PMAX>), grid, blk, step_lds_bytes(p, BLOCK), s, p,
+                       nobj_total, k10, k11, k20, k21, b.pool.layout_size, b.pool.cand_of, b.pool.cand_xy, b.dyn, b.obj,
+                       obs_in, obs_out);
+}
+
+
+template <class R>
+static void launch_group_r(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s)
+{
+    const dim3 grid((p.N + 3) / 4), blk(64);
+    const PolicyArgs nopol = {};
+#define GX_GROUP_LAUNCH(OPL, BPL, DEF)                                                                      \
+    do {                                                                                                    \
+        if (r.qacc)                                                                                         \
+            hipLaunchKernelGGL((group_rollout_kernel<R, OPL, BPL, true, DEF, 0>), grid, blk, 0, s, p, r, nopol, b.dyn, b.obj, b.hist); \
+        else                                                                                                \
+            hipLaunchKernelGGL((group_rollout_kernel<R, OPL, BPL, false, DEF, 0>), grid, blk, 0, s, p, r, nopol, b.dyn, b.obj, b.hist); \
+    } while (0)
+    if (is_default_layout<R>(p)) GX_GROUP_LAUNCH(1, 1, true);
+    else if (p.nobj <= 16 && p.bins <= 16) GX_GROUP_LAUNCH(1, 1, false);
+    else GX_GROUP_LAUNCH(5, 4, false);
+#undef GX_GROUP_LAUNCH
+}
+
+
+template <class R, int kPol>
+static void launch_policy_rp(const Params& p, const RolloutArgs& r, const PolicyArgs& pol, const DevBuffers& b,
+                             hipStream_t s)
+{
+    constexpr int BT = (kPol == 2) ? 256 : 64;
+    const dim3 grid((p.N + BT / 16 - 1) / (BT / 16)), blk(BT);
+    const size_t lds = sizeof(float) * (size_t)policy_lds_floats(p.D, R::NA, kPol);
+    auto launch = [&](auto kern) {
+        if (lds > 64 * 1024) // more dynamic LDS than the default cap: raise it for this kernel
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds);
+        hipLaunchKernelGGL(kern, grid, blk, lds, s, p, r, pol, b.dyn, b.obj, b.hist);
+    };
+    if (is_default_layout<R>(p)) launch(group_rollout_kernel<R, 1, 1, false, true, kPol>);
+    else launch(group_rollout_kernel<R, 1, 1, false, false, kPol>);
+}
+
+
+
+template <class R>
+void RobotLaunch<R>::step(const Params& p, const DevBuffers& b, const float* act, float* obs, float* rew,
+                          float* cost, float* done, float* qacc, hipStream_t s)
+{
+    GX_DISPATCH_BP_R(R, launch_step_bp, p, b, act, obs, rew, cost, done, qacc, s);
+}
+template <class R>
+void RobotLaunch<R>::reset_apply(const Params& p, const DevBuffers& b, int nobj_total, uint32_t k10, uint32_t k11,
+                                 uint32_t k20, uint32_t k21, float* obs, int* host_ls, hipStream_t s)
+{
+    GX_DISPATCH_BP_R(R, launch_reset_apply_bp, p, b, nobj_total, k10, k11, k20, k21, obs, host_ls, s);
+}
+template <class R>
+void RobotLaunch<R>::reset_done(const Params& p, const DevBuffers& b, int nobj_total, uint32_t k10, uint32_t k11,
+                                uint32_t k20, uint32_t k21, const float* obs_in, float* obs_out, hipStream_t s)
+{
+    GX_DISPATCH_BP_R(R, launch_reset_done_bp, p, b, nobj_total, k10, k11, k20, k21, obs_in, obs_out, s);
+}
+template <class R>
+void RobotLaunch<R>::group(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s)
+{
+    launch_group_r<R>(p, r, b, s);
+}
+template <class R>
+void RobotLaunch<R>::policy(const Params& p, const RolloutArgs& r, const PolicyArgs& pol, const DevBuffers& b,
+                            int impl, hipStream_t s)
+{
+    if (impl == 2) launch_policy_rp<R, 2>(p, r, pol, b, s);
+    else launch_policy_rp<R, 1>(p, r, pol, b, s);
+}
+
+} // namespace gx
