@@ -206,6 +206,32 @@ def roofline_step(env_num, nlaunch, device):
             "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP}
 
 
+def large_batch_fused(env_num, K, device, reps=4):
+    """Bandwidth regime with K steps fused per launch (SURVEY 8d "K=32 fused steps"; K=16 keeps the
+    time-major outputs at 11.5 GB): Engine.rollout on the thread-per-env persistent kernel.  State, layout
+    and history stay in registers, so an env-step moves action 8 + obs 172 + reward/cost/done 12 B plus
+    1/K of the 180 B state round trip."""
+    env = _fresh_engine(env_num)
+    tape = action_tape(K, env_num, 3, device)
+    env.rollout(tape)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        env.rollout(tape)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    env.close()
+    del tape
+    torch.cuda.empty_cache()
+    bytes_step = 192 + (ALGO_BYTES_PER_ENV_STEP - 192) / K
+    ach = bytes_step * env_num * K / dt / 1e9
+    return {"kernel": "gx::thread_rollout_kernel<PointRobot,64,5,true>", "env_num": env_num, "steps_per_launch": K,
+            "us_per_step": round(dt / K * 1e6, 2), "env_steps_per_s": round(env_num * K / dt, 1),
+            "algorithmic_bytes_per_env_step": round(bytes_step, 1), "achieved": round(ach, 2), "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4),
+            "note": "includes the in-kernel reset_done; VALU/occupancy bound (133 VGPRs), not HBM bound"}
+
+
 def cpu_baseline(epochs=8):
     """The CPU restatement (oracle/, 'port') timed on the host cores on a bounded sample."""
     from oracle import gxo
@@ -379,6 +405,7 @@ def main():
         if not args.no_extras:
             # bandwidth regime: the thread-per-env step kernel at 2^22 envs
             line["roofline_large_batch"] = roofline_step(1 << 22, 30, device)
+            line["large_batch_fused"] = large_batch_fused(1 << 22, 16, device)
             line["api_step_loop_env_steps_per_s"] = round(api_loop_rate(env, tapes[0], 1000), 1)
             line["epoch_breakdown"] = epoch_breakdown(device)
             line["closed_loop_policy_env_steps_per_s"] = round(closed_loop_rate(device), 1)

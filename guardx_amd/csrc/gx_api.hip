@@ -523,32 +523,21 @@ extern "C" gx_status gx_rollout(gx_engine* e, int32_t T, const float* d_actions,
     if (!e || !d_actions || !d_obs || !d_reward || !d_cost || !d_done || T < 1)
         return fail(GX_ERR_ARG, "bad argument");
     if (!e->have_reset) return fail(GX_ERR_STATE, "gx_rollout before gx_reset");
-    const size_t N = (size_t)e->p.N, D = (size_t)e->p.D;
-    if (use_group_path(e)) {
-        DeviceGuard guard(e->device);
-        hipStream_t s = (hipStream_t)stream;
-        int slot; uint32_t k0, k1;
-        gx_status st = stage_rollout_keys(e, T, slot, k0, k1);
-        if (st != GX_OK) return st;
-        RolloutArgs r;
-        fill_rollout_args(e, r, T, slot);
-        r.act = static_cast<const float*>(d_actions);
-        r.obs = d_obs; r.rew = d_reward; r.cost = d_cost; r.done = d_done; r.qacc = nullptr;
-        launch_group_rollout(e->p, r, e->b, s);
-        GX_HIP(hipEventRecord(e->keys_ev[slot], s)); // staging reusable once this launch is done
-        GX_HIP(hipGetLastError());
-        e->key[0] = k0; e->key[1] = k1;
-        e->hist = (e->hist + T) >= 2 ? 2 : e->hist + T;
-        return GX_OK;
-    }
-    for (int32_t t = 0; t < T; ++t) {
-        float* obs_t = d_obs + (size_t)t * N * D;
-        gx_status st = gx_step(e, d_actions + (size_t)t * N * e->na, obs_t, d_reward + (size_t)t * N,
-                               d_cost + (size_t)t * N, d_done + (size_t)t * N, nullptr, stream);
-        if (st != GX_OK) return st;
-        st = gx_reset_done(e, obs_t, obs_t, stream);
-        if (st != GX_OK) return st;
-    }
+    DeviceGuard guard(e->device);
+    hipStream_t s = (hipStream_t)stream;
+    int slot; uint32_t k0, k1;
+    gx_status st = stage_rollout_keys(e, T, slot, k0, k1);
+    if (st != GX_OK) return st;
+    RolloutArgs r;
+    fill_rollout_args(e, r, T, slot);
+    r.act = static_cast<const float*>(d_actions);
+    r.obs = d_obs; r.rew = d_reward; r.cost = d_cost; r.done = d_done; r.qacc = nullptr;
+    if (use_group_path(e)) launch_group_rollout(e->p, r, e->b, s);   // latency regime: 16 lanes per env
+    else launch_thread_rollout(e->p, r, e->b, s);                     // bandwidth regime: one thread per env
+    GX_HIP(hipEventRecord(e->keys_ev[slot], s)); // staging reusable once this launch is done
+    GX_HIP(hipGetLastError());
+    e->key[0] = k0; e->key[1] = k1;
+    e->hist = (e->hist + T) >= 2 ? 2 : e->hist + T;
     return GX_OK;
 }
 

@@ -65,6 +65,8 @@ struct RolloutArgs {
     const float2* cand_xy;
 };
 void launch_group_rollout(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s);
+// thread-per-env persistent rollout (large batches)
+void launch_thread_rollout(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s);
 void launch_policy_rollout(const Params& p, const RolloutArgs& r, const PolicyArgs& pol, const DevBuffers& b,
                            int impl, hipStream_t s);
 // per-robot launchers: defined in gx_robot_kernels.inl, instantiated once per robot in gx_kernels_<robot>.hip
@@ -77,6 +79,7 @@ struct RobotLaunch {
     static void reset_done(const Params& p, const DevBuffers& b, int nobj_total, uint32_t k10, uint32_t k11,
                            uint32_t k20, uint32_t k21, const float* obs_in, float* obs_out, hipStream_t s);
     static void group(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s);
+    static void thread_rollout(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s);
     static void policy(const Params& p, const RolloutArgs& r, const PolicyArgs& pol, const DevBuffers& b, int impl,
                        hipStream_t s);
 };

@@ -343,6 +343,11 @@ void launch_group_rollout(const Params& p, const RolloutArgs& r, const DevBuffer
     GX_ROBOT_DISPATCH(group(p, r, b, s));
 }
 
+void launch_thread_rollout(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s)
+{
+    GX_ROBOT_DISPATCH(thread_rollout(p, r, b, s));
+}
+
 bool policy_rollout_supported(const Params& p) { return p.nobj <= 16 && p.bins <= 16; }
 size_t policy_lds_bytes(const Params& p, int impl)
 {

@@ -418,6 +418,147 @@ __global__ __launch_bounds__(BLOCK) void reset_done_kernel(Params p, int nobj_to
 }
 
 // ---------------------------------------------------------------------------
+// T x (Engine.step -> Engine.reset_done) for LARGE batches, thread-per-env: the state, the layout and
+// the history stay in registers across the T steps of one launch, so per env-step only the action is
+// read and the obs row, reward, cost and done are written (192 B for the Point task instead of 372 B);
+// the layout row of a re-initialised env is fetched when its episode ends.  Same arithmetic as
+// step_kernel + reset_done_kernel, hence the same bits.
+// ---------------------------------------------------------------------------
+template <class R, int BLOCK, int PMAX, bool kDef>
+__global__ __launch_bounds__(BLOCK) void thread_rollout_kernel(Params p_in, RolloutArgs r,
+                                                               float4* __restrict__ dyn,
+                                                               float4* __restrict__ obj,
+                                                               float4* __restrict__ hist)
+{
+    const Params p = fold_params<R, kDef>(p_in);
+    extern __shared__ float4 tile4[];
+    float* tile = reinterpret_cast<float*>(tile4);
+    const int tid = threadIdx.x;
+    const int env0 = blockIdx.x * BLOCK;
+    const int i = env0 + tid;
+    const bool live = i < p.N;
+    const int nenv = min(BLOCK, p.N - env0);
+
+    float q[R::NQ], v[R::NV], pose0[4], done0, steps;
+    R::load(dyn, p.Npad, i, q, v, pose0, done0, steps);
+    float4 ob[PMAX];
+#pragma unroll
+    for (int k = 0; k < PMAX; ++k)
+        ob[k] = (k < p.P) ? obj[(size_t)k * p.Npad + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float P1x = 0.f, P1y = 0.f, done1 = 0.f;   // last_last_data.xpos, last_last_done
+    if (p.hist_on) { const float4 h = hist[i]; P1x = h.x; P1y = h.y; done1 = h.z; }
+    bool touched_layout = false;
+    float* row = tile + tid * p.D;
+
+    for (int t = 0; t < r.T; ++t) {
+        float a[R::NA];
+        load_action<R>(r.act, (size_t)t * p.N + (live ? i : 0), a);
+        const bool have_last = (r.hist0 + t) >= 1, have_last_last = (r.hist0 + t) >= 2;
+        const float last_done = done0, done2 = done1;
+        const float L1x = pose0[0], L1y = pose0[1], P2x = P1x, P2y = P1y;
+
+        float ctrl[R::NU];
+        R::convert_action(pose0, a, ctrl); // :672-685, PRE-step xmat
+        float pose[4], qacc[R::NV];
+#pragma unroll
+        for (int k = 0; k < R::NV; ++k) qacc[k] = 0.f;
+        for (int k = 0; k < p.physics_steps; ++k) R::template substep<false>(q, v, ctrl, pose, qacc);
+
+        float vel0 = 0.f, vel1 = 0.f, acc0 = 0.f, acc1 = 0.f;
+        if (p.hist_on)
+            ego_vel_acc(p, pose, L1x, L1y, P2x, P2y, last_done, done2, have_last, have_last_last, vel0, vel1, acc0,
+                        acc1);
+        const bool bad = build_obs_row<R, PMAX>(p, row, pose, ob, ctrl, q, v, vel0, vel1, acc0, acc1);
+
+        // reward_done :787-802
+        const float dg = dist2(ob[0].x, ob[0].y, pose[0], pose[1]);
+        float last = dg;
+        if (have_last && !(last_done > 0.0f)) last = dist2(ob[0].x, ob[0].y, L1x, L1y);
+        const float dd = last - dg;
+        float rw = dd * p.reward_distance;
+        float dn = dg < p.goal_size ? 1.0f : 0.0f;
+        if (fabsf(dd) > 1.0f) { dn = 1.0f; rw = 0.0f; }
+        // cost :804-811
+        float cs = 0.0f;
+#pragma unroll
+        for (int k = 0; k < PMAX; ++k) {
+            if (k > 0 && 2 * k < p.nobj) {
+                const float dh = dist2(ob[k].x, ob[k].y, pose[0], pose[1]);
+                float below = dh < p.hazards_size ? dh : p.hazards_size;
+                if (dh != dh) below = dh;
+                cs = cs + (p.hazards_size - below);
+            }
+            if (2 * k + 1 < p.nobj) {
+                const float dh = dist2(ob[k].z, ob[k].w, pose[0], pose[1]);
+                float below = dh < p.hazards_size ? dh : p.hazards_size;
+                if (dh != dh) below = dh;
+                cs = cs + (p.hazards_size - below);
+            }
+        }
+        if (bad) { rw = 0.0f; dn = 1.0f; }           // :696-699
+        if (steps > p.num_steps_f) dn = 1.0f;         // :492
+        steps = dn > 0.0f ? 0.0f : steps + 1.0f;      // :493
+
+        if (live) {
+            const size_t te = (size_t)t * p.N + i;
+            r.rew[te] = rw; r.cost[te] = cs; r.done[te] = dn;
+        }
+
+        // commit the history
+        P1x = L1x; P1y = L1y; done1 = last_done;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pose0[k] = pose[k];
+        done0 = dn;
+
+        // reset_done :497-505 for the envs that just finished
+        if (r.do_reset) {
+            const int L = *r.layout_size;
+            if (live && dn > 0.0f && L > 0) {
+                const uint4 kk = r.keys[t];
+                const uint32_t idx = randint_at(kk.x, kk.y, kk.z, kk.w, (uint32_t)p.env_total, (uint32_t)L,
+                                                (uint32_t)(p.env_offset + i));
+                float rx, ry;
+                load_layout<PMAX>(p, r.cand_xy, r.nobj_total, r.cand_of[idx], ob, rx, ry);
+                float zc[R::NU];
+#pragma unroll
+                for (int k = 0; k < R::NQ; ++k) q[k] = 0.f;
+#pragma unroll
+                for (int k = 0; k < R::NV; ++k) v[k] = 0.f;
+#pragma unroll
+                for (int k = 0; k < R::NU; ++k) zc[k] = 0.f;
+                R::place(q, rx, ry);
+                float rpose[4] = {rx, ry, 1.0f, 0.0f};
+                if (R::kRestFixed) {
+                    build_obs_row<R, PMAX>(p, row, rpose, ob, zc, q, v, 0.f, 0.f, 0.f, 0.f);
+                } else { // the fake step (:719-724) moves the robot: its qpos/qvel feed the obs only
+                    float fq[R::NQ], fv[R::NV], fa[R::NV];
+#pragma unroll
+                    for (int k = 0; k < R::NQ; ++k) fq[k] = q[k];
+#pragma unroll
+                    for (int k = 0; k < R::NV; ++k) fv[k] = 0.f;
+                    for (int k = 0; k < p.physics_steps; ++k) R::template substep<false>(fq, fv, zc, rpose, fa);
+                    build_obs_row<R, PMAX>(p, row, rpose, ob, zc, fq, fv, 0.f, 0.f, 0.f, 0.f);
+                }
+                touched_layout = true;
+            }
+        }
+        __syncthreads();
+        flush_tile<BLOCK>(tile, r.obs + ((size_t)t * p.N + env0) * p.D, nenv * p.D);
+        __syncthreads(); // the tile is rewritten by the next step
+    }
+
+    if (live) {
+        R::store(dyn, p.Npad, i, q, v, pose0, done0, steps);
+        if (p.hist_on) hist[i] = make_float4(P1x, P1y, done1, 0.f);
+        if (touched_layout) {
+#pragma unroll
+            for (int k = 0; k < PMAX; ++k)
+                if (k < p.P) obj[(size_t)k * p.Npad + i] = ob[k];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Lane-group kernel for SMALL batches (latency regime, env_num ~ 10^3..10^4).
 //
 // 16 lanes cooperate on one environment, 4 environments per wave64, one wave per
@@ -843,19 +984,20 @@ static void launch_step_bp(const Params& p, const DevBuffers& b, const float* ac
                            obs, rew, cost, done, qacc);
 }
 
+// workgroup size x object-pair capacity.  256-thread workgroups are a tuning option (GX_BLOCK=256) kept for
+// the light robots only: the Ant step is ~8k instructions and every extra instantiation costs build time.
+#define GX_DISPATCH_P(R, FN, BLK, ...)                                 \
+    do {                                                               \
+        if (p.P <= 5) FN<R, BLK, 5>(__VA_ARGS__);                      \
+        else if (p.P <= 9) FN<R, BLK, 9>(__VA_ARGS__);                 \
+        else FN<R, BLK, 33>(__VA_ARGS__);                              \
+    } while (0)
 #define GX_DISPATCH_BP_R(R, FN, ...)                                   \
     do {                                                               \
-        const int blk_ = pick_block(p);                                \
-        if (p.P <= 5) {                                                \
-            if (blk_ == 64) FN<R, 64, 5>(__VA_ARGS__);                 \
-            else FN<R, 256, 5>(__VA_ARGS__);                           \
-        } else if (p.P <= 9) {                                         \
-            if (blk_ == 64) FN<R, 64, 9>(__VA_ARGS__);                 \
-            else FN<R, 256, 9>(__VA_ARGS__);                           \
-        } else {                                                       \
-            if (blk_ == 64) FN<R, 64, 33>(__VA_ARGS__);                \
-            else FN<R, 256, 33>(__VA_ARGS__);                          \
+        if constexpr (R::kRestFixed) {                                 \
+            if (pick_block(p) == 256) { GX_DISPATCH_P(R, FN, 256, __VA_ARGS__); break; } \
         }                                                              \
+        GX_DISPATCH_P(R, FN, 64, __VA_ARGS__);                         \
     } while (0)
 
 template <class R, int BLOCK, int PMAX>
@@ -919,6 +1061,23 @@ static void launch_policy_rp(const Params& p, const RolloutArgs& r, const Policy
 }
 
 
+
+template <class R, int BLOCK, int PMAX>
+static void launch_thread_rollout_bp(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s)
+{
+    const dim3 grid((p.N + BLOCK - 1) / BLOCK), blk(BLOCK);
+    const size_t lds = step_lds_bytes(p, BLOCK);
+    if (PMAX == 5 && is_default_layout<R>(p))
+        hipLaunchKernelGGL((thread_rollout_kernel<R, BLOCK, 5, true>), grid, blk, lds, s, p, r, b.dyn, b.obj, b.hist);
+    else
+        hipLaunchKernelGGL((thread_rollout_kernel<R, BLOCK, PMAX, false>), grid, blk, lds, s, p, r, b.dyn, b.obj, b.hist);
+}
+
+template <class R>
+void RobotLaunch<R>::thread_rollout(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s)
+{
+    GX_DISPATCH_BP_R(R, launch_thread_rollout_bp, p, r, b, s);
+}
 
 template <class R>
 void RobotLaunch<R>::step(const Params& p, const DevBuffers& b, const float* act, float* obs, float* rew,

@@ -54,24 +54,26 @@ def main():
                     print(f"MISMATCH state {k} path={path} trial={trial}")
         E.close()
         print(f"path {path}: 3 x {n_states} single steps compared  ({time.time() - t0:.1f} s)", flush=True)
-    # 2. long fused episodes with resets
-    cfg = task_config(N, seed=7, num_steps=150, goal_size=0.8, **extra)
-    E = Engine(cfg, n_candidates=1000000)
-    O = gxo.OracleEngine(cfg, n_candidates=1000000)
-    np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
-    rng = np.random.default_rng(9)
-    for chunk in range(T // 100):
-        acts = rng.uniform(-1, 1, (100, N, A)).astype(np.float32)
-        obs, rew, cost, done = E.rollout(torch.from_numpy(acts).cuda())
-        obs, rew, cost, done = (x.cpu().numpy() for x in (obs, rew, cost, done))
-        for t in range(100):
-            o, r, d, info = O.step(acts[t])
-            o = O.reset_done()
-            for name, a, b in (("obs", obs[t], o), ("rew", rew[t], r), ("done", done[t], d), ("cost", cost[t], info['cost'])):
-                if not np.array_equal(a, b, equal_nan=True):
-                    bad += 1
-                    print(f"MISMATCH rollout chunk={chunk} t={t} {name}")
-        print(f"rollout chunk {chunk}: {100 * N} env-steps compared, dones so far {int(done.sum())}  ({time.time() - t0:.1f} s)", flush=True)
+    # 2. long fused episodes with resets, on both persistent kernels
+    for path in (2, 1):
+        cfg = task_config(N, seed=7, num_steps=150, goal_size=0.8, **extra)
+        E = Engine(cfg, n_candidates=1000000); E.set_path(path)
+        O = gxo.OracleEngine(cfg, n_candidates=1000000)
+        np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
+        rng = np.random.default_rng(9)
+        for chunk in range(T // 100):
+            acts = rng.uniform(-1, 1, (100, N, A)).astype(np.float32)
+            obs, rew, cost, done = E.rollout(torch.from_numpy(acts).cuda())
+            obs, rew, cost, done = (x.cpu().numpy() for x in (obs, rew, cost, done))
+            for t in range(100):
+                o, r, d, info = O.step(acts[t])
+                o = O.reset_done()
+                for name, a, b in (("obs", obs[t], o), ("rew", rew[t], r), ("done", done[t], d), ("cost", cost[t], info['cost'])):
+                    if not np.array_equal(a, b, equal_nan=True):
+                        bad += 1
+                        print(f"MISMATCH rollout path={path} chunk={chunk} t={t} {name}")
+            print(f"rollout path {path} chunk {chunk}: {100 * N} env-steps compared, dones in chunk {int(done.sum())}  ({time.time() - t0:.1f} s)", flush=True)
+        E.close()
     print("TOTAL MISMATCHES:", bad)
     sys.exit(1 if bad else 0)
 
