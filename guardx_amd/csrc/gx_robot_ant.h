@@ -81,6 +81,7 @@ struct AntRobot {
     static constexpr float kK = 34.198556820902162f, kB = 11.695906432748538f;
     static constexpr float kLim30 = 0.52359877559829882f, kLim70 = 1.2217304763960306f, kGear = 70.0f;
     static constexpr float kD7 = 0.70710678118654757f;
+    static constexpr float kGK = 0.00096505793162098648f; // MK * 9.81 * LC: gravity torque of the ankle link per cos(beta)
 
     struct Arrow {
         float B[3][3];    // base block (x, th, y), lower triangle used
@@ -381,7 +382,8 @@ struct AntRobot {
             const float ch_ = (kMA * (h1x * a1x + h1y * a1y) + kMK * (h2x * a2x + h2y * a2y)) + nz;
             const float cb_ = kMK * ((bx * a2x + by * a2y) + bz * a2z) - kDIK * (ww * (sb * cb));
             f[3 + 2 * l] = (-ch_ - dphi) + kGear * clip1(ctrl[2 * l]);
-            f[4 + 2 * l] = (-cb_ - dbeta) + sg * (kGear * clip1(ctrl[2 * l + 1]));
+            // gravity (0, 0, -9.81) only has a generalized component on the ankle pitch
+            f[4 + 2 * l] = ((-cb_ - dbeta) + kGK * cb) + sg * (kGear * clip1(ctrl[2 * l + 1]));
             limit_row(rows.lim[l][0], phi, dphi, -kLim30, kLim30, kInvwHip);
             limit_row(rows.lim[l][1], beta, dbeta, kLim30, kLim70, kInvwAnk);
             const float dist = (kZ0 - kL * sb) - kRf;

@@ -13,7 +13,8 @@ the published MuJoCo computation chapter and the MJX sources as documented in DE
   * compile: geom mass/inertia (sphere, capsule), body COM/inertia, degrees -> radians,
     mj_setConst (dof_invweight0 = diag M(qpos0)^-1, body_invweight0 = tr(J M^-1 J^T)/3 at the COM)
   * kinematics: joints of one body are applied in order, each in the frame left by the previous
-  * forward: M (incl. armature), bias, passive (damping, spring), motors gear*clip(ctrl)
+  * forward: M (incl. armature), bias (velocity products and gravity), passive (damping, spring),
+    motors gear*clip(ctrl)
   * constraints: joint-limit rows and sphere-plane contacts with pyramidal friction cones,
     impedance/reference from solref/solimp (refsafe), R = (1-imp)/imp * diagApprox
   * the convex constraint problem is solved to convergence; Euler with implicit joint damping.
@@ -31,6 +32,7 @@ RHO = 5.0                   # :6 density
 FRICTION = 0.75             # :6 (both geoms; max rule)
 MARGIN = 0.01               # :6 (both geoms; max rule)
 GEAR = 70.0                 # :7
+GRAVITY = np.array([0.0, 0.0, -9.81])   # MuJoCo default (no <option gravity> in the file)
 SOLREF = (0.02, 1.0)        # MuJoCo default
 SOLIMP = (0.9, 0.95, 0.001, 0.5, 2.0)
 LEG_SIGN = [(1, 1), (-1, 1), (-1, -1), (1, -1)]         # :21,38,55,71 fromto signs
@@ -263,10 +265,14 @@ class AntModel:
         return out
 
     # -- one mjx.step ---------------------------------------------------------------------------
+    def gravity_force(self, q):
+        """generalized gravity force  sum_b m_b Jp_b' g  (part of MuJoCo's qfrc_bias, with the opposite sign)"""
+        return sum(m * jp.T @ GRAVITY for m, _, jp, _ in self.body_jacs(q))
+
     def smooth_force(self, q, v, ctrl):
         tau = np.zeros(self.nv)
         tau[3:] = GEAR * np.clip(ctrl, -1, 1)
-        return -self.bias(q, v) - self.damping * v - self.stiffness * q + tau
+        return -self.bias(q, v) + self.gravity_force(q) - self.damping * v - self.stiffness * q + tau
 
     def solve(self, M, a0, rows):
         """min 1/2 (a-a0)' M (a-a0) + sum 1/2 D min(0, J a - aref)^2 : Newton with exact line search"""

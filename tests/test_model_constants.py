@@ -41,7 +41,7 @@ C_POINT = _c_defines(os.path.join(ROOT, "oracle/gx_oracle.c"), "PT")
 ANT_NAMES = {'H': 'kH', 'A': 'kA', 'A2': 'kA2', 'L': 'kL', 'RF': 'kRf', 'Z0': 'kZ0', 'MARGIN': 'kMargin', 'MU': 'kMu',
              'MB': 'kMB', 'IB': 'kIB', 'MA': 'kMA', 'ITA': 'kITA', 'MK': 'kMK', 'LC': 'kLC', 'ITK': 'kITK',
              'DIK': 'kDIK', 'MTOT': 'kMtot', 'LBB': 'kLbb', 'INVW_HIP': 'kInvwHip', 'INVW_ANK': 'kInvwAnk',
-             'INVW_PYR': 'kInvwPyr', 'K': 'kK', 'B': 'kB', 'LIM30': 'kLim30', 'LIM70': 'kLim70', 'GEAR': 'kGear'}
+             'INVW_PYR': 'kInvwPyr', 'K': 'kK', 'B': 'kB', 'LIM30': 'kLim30', 'LIM70': 'kLim70', 'GEAR': 'kGear', 'GK': 'kGK'}
 SWIM_NAMES = {'H': 'kH', 'M': 'kM', 'IC': 'kIc', 'ARM': 'kArm', 'GEAR': 'kGear', 'LIM': 'kLim', 'INVW2': 'kInvW2',
               'INVW3': 'kInvW3', 'K': 'kK', 'B': 'kB', 'A11': 'A11', 'A21': 'A21', 'A22': 'A22', 'A31': 'A31',
               'A32': 'A32', 'A33': 'A33'}
@@ -85,7 +85,7 @@ def test_headers_match_the_mjcf_files():
             if name in hip:
                 assert abs(hip[name] - val) <= 2e-7 * abs(val) + 1e-30, (robot, name, hip[name], val)
                 checked += 1
-        assert checked >= {"point": 5, "swimmer": 14, "ant": 26}[robot], (robot, checked)
+        assert checked >= {"point": 5, "swimmer": 14, "ant": 27}[robot], (robot, checked)
     # Point: the mass enters through literal expressions
     txt = _struct_text(os.path.join(ROOT, "guardx_amd/csrc/gx_robot.h"), "PointRobot")
     assert "0.005188790204786391" in txt and abs(0.005188790204786391 - derived['point']['kM']) < 1e-17

@@ -149,3 +149,17 @@ def test_reset_done_obs_comes_from_the_fake_step(oracle):
     assert np.all(st['qpos'][:, 3:] == 0) and np.all(st['qvel'] == 0)
     assert np.all(np.abs(o2[:, 42 + 4:53:2]) > 0.05)               # ankles moved in the obs
     np.testing.assert_array_equal(o2[:, 42], st['qpos'][:, 0])     # base x unchanged by the fake step (to fp32)
+
+
+def test_gravity_pulls_the_feet_down(oracle, model):
+    """legs inside their ranges, at rest, no ctrl: the only generalized force is the weight of the ankle
+    links about the ankle joints (MK g LC cos(beta) per unit armature) -- every foot accelerates downwards"""
+    q = np.zeros(11)
+    for leg in range(4):
+        q[4 + 2 * leg] = ANT_SIGMA[leg] * 0.8
+    assert not model.rows(q, np.zeros(11))
+    _, _, qacc, _, _, f = oracle.ant_probe(q, np.zeros(11), np.zeros(8))
+    expect = 0.0012236798040145848 * 9.81 * 0.080392694440424323 * np.cos(0.8)
+    np.testing.assert_allclose(f[4::2] * ANT_SIGMA, expect, rtol=1e-5)
+    assert np.all(qacc[4::2] * ANT_SIGMA > 0.9 * expect / 1.00002)
+    np.testing.assert_allclose(model.gravity_force(q)[4::2] * ANT_SIGMA, expect, rtol=1e-7)

@@ -73,7 +73,7 @@ def ant(m):
                 kInvwHip=m.dof_invweight0[3], kInvwAnk=m.dof_invweight0[4],
                 kInvwPyr=(t + mu * mu * t) * 2 * mu * mu,       # impratio 1
                 kK=k, kB=b, kLim30=hip['range'][1], kLim70=ankle['range'][1], kGear=m.actuators[0]['gear'],
-                kD7=abs(m.bodies[aux]['pos'][0]) / a)
+                kD7=abs(m.bodies[aux]['pos'][0]) / a, kGK=m.mass[ank] * 9.81 * lc)   # default gravity
 
 
 def constants(xml_dir):
