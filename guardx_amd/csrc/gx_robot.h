@@ -283,3 +283,4 @@ struct SwimmerRobot {
 } // namespace gx
 
 #include "gx_robot_ant.h"
+#include "gx_robot_ant_group.h"

@@ -259,6 +259,8 @@ struct AntRobot {
         return m;
     }
     // minimiser of the quadratic piece selected by `act`: (M + J_A' D J_A) a = f + J_A' D aref_A
+    // every leg first sums its own rows (leg-local partial sums), then the base block and the base right-hand
+    // side take the four partials in leg order -- the order the leg-parallel form (substep_group) reproduces
     GX_D static void newton_solve(const Arrow& M, const float* f, const Rows& rows, uint32_t act, float* a)
     {
         Arrow Hm = M;
@@ -266,7 +268,12 @@ struct AntRobot {
 #pragma unroll
         for (int k = 0; k < 11; ++k) r[k] = f[k];
 #pragma unroll
-        for (int l = 0; l < 4; ++l)
+        for (int l = 0; l < 4; ++l) {
+            float PB[3][3], Pr[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) PB[b][c] = 0.0f;
 #pragma unroll
             for (int k = 0; k < kRows; ++k) {
                 if (!((act >> (l * kRows + k)) & 1u)) continue;
@@ -276,10 +283,10 @@ struct AntRobot {
                 for (int b = 0; b < 3; ++b) {
                     const float dj = R.D * R.J[b];
 #pragma unroll
-                    for (int c = 0; c <= b; ++c) Hm.B[b][c] = Hm.B[b][c] + dj * R.J[c];
+                    for (int c = 0; c <= b; ++c) PB[b][c] = PB[b][c] + dj * R.J[c];
                     Hm.C[l][b][0] = Hm.C[l][b][0] + dj * R.J[3];
                     Hm.C[l][b][1] = Hm.C[l][b][1] + dj * R.J[4];
-                    r[b] = r[b] + da * R.J[b];
+                    Pr[b] = Pr[b] + da * R.J[b];
                 }
                 const float d3 = R.D * R.J[3], d4 = R.D * R.J[4];
                 Hm.Lhh[l] = Hm.Lhh[l] + d3 * R.J[3];
@@ -288,6 +295,13 @@ struct AntRobot {
                 r[3 + 2 * l] = r[3 + 2 * l] + da * R.J[3];
                 r[4 + 2 * l] = r[4 + 2 * l] + da * R.J[4];
             }
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+#pragma unroll
+                for (int c = 0; c <= b; ++c) Hm.B[b][c] = Hm.B[b][c] + PB[b][c];
+                r[b] = r[b] + Pr[b];
+            }
+        }
         arrow_solve(Hm, r, a);
     }
 
@@ -440,7 +454,8 @@ struct AntRobot {
             }
             keep_compact(rows);
 #pragma unroll
-            for (int l = 0; l < 4; ++l)
+            for (int l = 0; l < 4; ++l) {
+                float Pf[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
                 for (int k = 0; k < kRows; ++k) {
                     const Row R = row_of(rows, l, k);
@@ -448,12 +463,14 @@ struct AntRobot {
                     const float res = dot5(R.J, a, l) - R.aref;
                     if (!(res < 0.0f)) continue;
                     const float frc = R.D * (-res);
-                    fc[0] = fc[0] + frc * R.J[0];
-                    fc[1] = fc[1] + frc * R.J[1];
-                    fc[2] = fc[2] + frc * R.J[2];
+                    Pf[0] = Pf[0] + frc * R.J[0];
+                    Pf[1] = Pf[1] + frc * R.J[1];
+                    Pf[2] = Pf[2] + frc * R.J[2];
                     fc[3 + 2 * l] = fc[3 + 2 * l] + frc * R.J[3];
                     fc[4 + 2 * l] = fc[4 + 2 * l] + frc * R.J[4];
                 }
+                fc[0] = fc[0] + Pf[0]; fc[1] = fc[1] + Pf[1]; fc[2] = fc[2] + Pf[2];
+            }
         }
         // Euler with implicit joint damping: (M + h diag(damping)) qacc_int = f + J' force
         Arrow Md = M;

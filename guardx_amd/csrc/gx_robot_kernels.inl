@@ -800,7 +800,7 @@ __global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Par
         float pose[4], qacc[R::NV];
 #pragma unroll
         for (int k = 0; k < R::NV; ++k) qacc[k] = 0.f;
-        for (int k = 0; k < p.physics_steps; ++k) R::template substep<kQacc>(q, v, ctrl, pose, qacc);
+        for (int k = 0; k < p.physics_steps; ++k) group_substep<R, kQacc>(q, v, ctrl, pose, qacc, l);
 
         float vel0 = 0.f, vel1 = 0.f, acc0 = 0.f, acc1 = 0.f;
         if (p.hist_on)
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Par
                     float fa[R::NV], zc[R::NU];
 #pragma unroll
                     for (int k = 0; k < R::NU; ++k) zc[k] = 0.f;
-                    for (int k = 0; k < p.physics_steps; ++k) R::template substep<false>(fq, fv, zc, rpose, fa);
+                    for (int k = 0; k < p.physics_steps; ++k) group_substep<R, false>(fq, fv, zc, rpose, fa, l);
                 }
                 const GroupObs<OPL, BPL> rob = group_observe<OPL, BPL, BT>(p, rec, term, lane, rpose, ngx, ngy, nox, noy);
                 if (rs) {
