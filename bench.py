@@ -402,17 +402,30 @@ def main():
                    "layout_candidates_per_reset": 1_000_000},
     }
     if rank == 0:
-        line["roofline"] = roofline_rollout(ENV_NUM, EP_LEN, 30, device)
-        if not args.no_extras:
+        try:
+            line["roofline"] = roofline_rollout(ENV_NUM, EP_LEN, 30, device)
+        except Exception as exc:  # noqa: BLE001
+            line["roofline"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        if not args.no_extras and world == 1:
+            # supplementary measurements; none of them may take the headline line down with it
+            def extra(key, fn):
+                try:
+                    line[key] = fn()
+                except Exception as exc:  # noqa: BLE001 - reported in the line instead
+                    line[key] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+                    torch.cuda.empty_cache()
             # bandwidth regime: the thread-per-env step kernel at 2^22 envs
-            line["roofline_large_batch"] = roofline_step(1 << 22, 30, device)
-            line["large_batch_fused"] = large_batch_fused(1 << 22, 16, device)
-            line["api_step_loop_env_steps_per_s"] = round(api_loop_rate(env, tapes[0], 1000), 1)
-            line["epoch_breakdown"] = epoch_breakdown(device)
-            line["closed_loop_policy_env_steps_per_s"] = round(closed_loop_rate(device), 1)
-            line["other_robots"] = other_robots(device)
+            extra("roofline_large_batch", lambda: roofline_step(1 << 22, 30, device))
+            extra("large_batch_fused", lambda: large_batch_fused(1 << 22, 16, device))
+            extra("api_step_loop_env_steps_per_s", lambda: round(api_loop_rate(env, tapes[0], 1000), 1))
+            extra("epoch_breakdown", lambda: epoch_breakdown(device))
+            extra("closed_loop_policy_env_steps_per_s", lambda: round(closed_loop_rate(device), 1))
+            extra("other_robots", lambda: other_robots(device))
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            try:
+                line["cpu_baseline"] = cpu_baseline()
+            except Exception as exc:  # noqa: BLE001
+                line["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         print(json.dumps(line), flush=True)
     gxd.barrier()
     env.close()
