@@ -82,7 +82,7 @@ def build_tables():
     return bodies
 
 
-def _geom_inertial(g):
+def _geom_inertial(g, RHO=RHO):
     """(mass, com, inertia tensor about the com) in the body frame; MuJoCo geom formulas"""
     if g['type'] == 'sphere':
         m = RHO * 4 / 3 * np.pi * g['r'] ** 3
@@ -97,15 +97,18 @@ def _geom_inertial(g):
     return mc + ms, 0.5 * (a + b), it * np.eye(3) + (ia - it) * np.outer(u, u)
 
 
-class AntModel:
-    def __init__(self):
-        self.bodies = build_tables()
+class TreeModel:
+    """generic float64 rigid-body tree (slide/hinge joints, sphere/capsule geoms, foot spheres on a floor plane)"""
+
+    def __init__(self, bodies, h, rho, friction, margin, gear):
+        self.bodies = bodies
+        self.h, self.friction, self.margin = h, friction, margin
         nb = len(self.bodies)
         self.mass = np.zeros(nb)
         self.ipos = np.zeros((nb, 3))
         self.inertia = np.zeros((nb, 3, 3))
         for k, b in enumerate(self.bodies):
-            parts = [_geom_inertial(g) for g in b.geoms]
+            parts = [_geom_inertial(g, rho) for g in b.geoms]
             m = sum(p[0] for p in parts)
             if m == 0:
                 continue
@@ -125,6 +128,8 @@ class AntModel:
         self.damping = np.array([j['damping'] for j in self.dof_joint])
         self.armature = np.array([j['armature'] for j in self.dof_joint])
         self.stiffness = np.array([j['stiffness'] for j in self.dof_joint])
+        self.gear = np.zeros(self.nv)
+        self.gear[self.nv - len(gear):] = gear              # the motors drive the trailing (leg) DOFs in order
         self.foot = [(k, np.asarray(g['pos'], float), g['r']) for k, b in enumerate(self.bodies)
                      for g in b.geoms if g.get('contact')]
         # mj_setConst at qpos0 = 0
@@ -152,7 +157,7 @@ class AntModel:
             p = xpos[b.parent] + R[b.parent] @ b.pos
             Rk = R[b.parent].copy()
             for j in b.joints:
-                jpos = np.zeros(3)
+                jpos = np.asarray(j.get('pos', (0.0, 0.0, 0.0)), float)
                 anchor[d] = p + Rk @ jpos
                 axis[d] = Rk @ np.asarray(j['axis'], float)
                 if j['type'] == 'slide':
@@ -216,9 +221,8 @@ class AntModel:
         return c
 
     # -- constraint rows --------------------------------------------------------------------
-    @staticmethod
-    def _kbi(pos):
-        tc = max(SOLREF[0], 2 * H)
+    def _kbi(self, pos):
+        tc = max(SOLREF[0], 2 * self.h)
         dmin, dmax, width, mid, power = SOLIMP
         b = 2 / (dmax * tc)
         k = 1 / (dmax * dmax * tc * tc * SOLREF[1] ** 2)
@@ -248,14 +252,14 @@ class AntModel:
         for body, gpos, r in self.foot:
             centre = kin['xpos'][body] + kin['R'][body] @ gpos
             dist = centre[2] - r                       # floor plane z = 0, normal +z
-            pos = dist - MARGIN
+            pos = dist - self.margin
             if pos >= 0:
                 continue
             cpos = centre - np.array([0, 0, r + 0.5 * dist])
             jp, _ = self.jac(kin, body, cpos)
             k, b, imp = self._kbi(pos)
             t = self.body_invweight0[body, 0]
-            mu = FRICTION
+            mu = self.friction
             invw = (t + mu * mu * t) * 2 * mu * mu / 1.0       # impratio 1
             R = max(1e-15, (1 - imp) / imp * invw)
             for tang in (np.array([0.0, 1.0, 0.0]), np.array([-1.0, 0.0, 0.0])):
@@ -271,7 +275,8 @@ class AntModel:
 
     def smooth_force(self, q, v, ctrl):
         tau = np.zeros(self.nv)
-        tau[3:] = GEAR * np.clip(ctrl, -1, 1)
+        nu = len(ctrl)
+        tau[self.nv - nu:] = self.gear[self.nv - nu:] * np.clip(ctrl, -1, 1)
         return -self.bias(q, v) + self.gravity_force(q) - self.damping * v - self.stiffness * q + tau
 
     def solve(self, M, a0, rows):
@@ -314,12 +319,17 @@ class AntModel:
         f = self.smooth_force(q, v, np.asarray(ctrl, float))
         a0 = np.linalg.solve(M, f)
         qacc, fc = self.solve(M, a0, self.rows(q, v))
-        qint = np.linalg.solve(M + H * np.diag(self.damping), f + fc)
-        v2 = v + H * qint
-        q2 = q + H * v2
+        qint = np.linalg.solve(M + self.h * np.diag(self.damping), f + fc)
+        v2 = v + self.h * qint
+        q2 = q + self.h * v2
         kin = self.kinematics(q)
         pose = np.array([kin['xpos'][1][0], kin['xpos'][1][1], kin['R'][1][0, 0], kin['R'][1][1, 0]])
         return pose, qacc, q2, v2
+
+
+class AntModel(TreeModel):
+    def __init__(self):
+        super().__init__(build_tables(), H, RHO, FRICTION, MARGIN, [GEAR] * 8)
 
 
 def _rot(axis, angle):

@@ -292,7 +292,7 @@ int gxo_layout_size(const gxo_env* e) { return e->layout_size; }
 int gxo_create(const gxo_config* cfg, gxo_env** out)
 {
     if (!cfg || !out || cfg->struct_size != (int32_t)sizeof(gxo_config)) return GXO_ERR_ARG;
-    if (cfg->robot < 0 || cfg->robot > 2) return GXO_ERR_UNSUPPORTED;
+    if (cfg->robot < 0 || cfg->robot > 3) return GXO_ERR_UNSUPPORTED;
     if (cfg->env_num < 1 || cfg->hazards_num < 1 || cfg->hazards_num > 64) return GXO_ERR_ARG;
     if (cfg->lidar_num_bins < 3 || cfg->lidar_num_bins > 64) return GXO_ERR_ARG;
     if (cfg->env_offset < 0 || cfg->env_offset + cfg->env_num > cfg->env_total) return GXO_ERR_ARG;
@@ -310,7 +310,8 @@ int gxo_create(const gxo_config* cfg, gxo_env** out)
     e->bins = cfg->lidar_num_bins;
     if (cfg->robot == 0) { e->nq = 3; e->nv = 3; e->nu = 3; e->na = 2; e->h = PT_H; }   /* point.xml */
     else if (cfg->robot == 1) { e->nq = 5; e->nv = 5; e->nu = 2; e->na = 2; e->h = 0.03f; } /* swimmer.xml */
-    else { e->nq = 11; e->nv = 11; e->nu = 8; e->na = 8; e->h = 0.09f; }                   /* ant.xml */
+    else if (cfg->robot == 2) { e->nq = 11; e->nv = 11; e->nu = 8; e->na = 8; e->h = 0.09f; } /* ant.xml */
+    else { e->nq = 13; e->nv = 13; e->nu = 10; e->na = 10; e->h = 0.02f; }                 /* walker.xml */
     /* flat obs = concat over sorted(obs_space_dict keys)  engine.py:386-409,773-777 */
     int o = 0;
     e->off_acc = e->off_ctrl = e->off_comp = e->off_glidar = e->off_hlidar = -1;
@@ -667,6 +668,20 @@ static void swimmer_substep(float q[5], float v[5], const float ctrl[2], float p
 
 #include "gx_oracle_ant.inc"
 
+#include "gx_oracle_legs.inc"
+
+/* probe: one walker mjx.step; dbg = nv*nv dense mass matrix + nv smooth force (nv = 13) */
+void gxo_walker_probe(const float* q, const float* v, const float* ctrl, float* q2, float* v2, float* qacc,
+                      float* pose, float* dbg)
+{
+    float qq[13], vv[13];
+    for (int k = 0; k < 13; ++k) { qq[k] = q[k]; vv[k] = v[k]; }
+    g_legs_dbg = dbg;
+    legs_substep(&LG_WALKER, qq, vv, ctrl, pose, qacc);
+    g_legs_dbg = NULL;
+    for (int k = 0; k < 13; ++k) { q2[k] = qq[k]; v2[k] = vv[k]; }
+}
+
 /* probe: one ant mjx.step from (q, v, ctrl); dense M (qpos coordinates) and smooth force in dbg[132] */
 void gxo_ant_probe(const float* q, const float* v, const float* ctrl, float* q2, float* v2, float* qacc,
                    float* pose, float* dbg)
@@ -679,13 +694,14 @@ void gxo_ant_probe(const float* q, const float* v, const float* ctrl, float* q2,
     for (int k = 0; k < 11; ++k) { q2[k] = qq[k]; v2[k] = vv[k]; }
 }
 
-#define GX_MAXQ 11
+#define GX_MAXQ 13
 /* one mjx.step of the configured robot */
 static void robot_substep(const gxo_env* e, float* q, float* v, const float* ctrl, float pose[4], float* qacc)
 {
     if (e->cfg.robot == 0) point_substep(q, v, ctrl, pose, qacc);
     else if (e->cfg.robot == 1) swimmer_substep(q, v, ctrl, pose, qacc);
-    else ant_substep(q, v, ctrl, pose, qacc);
+    else if (e->cfg.robot == 2) ant_substep(q, v, ctrl, pose, qacc);
+    else legs_substep(&LG_WALKER, q, v, ctrl, pose, qacc);
 }
 
 /* convert_action engine.py:672-685: Point rotates (a0,0,0) by the PRE-step xmat; others pass through */
@@ -698,7 +714,7 @@ static void convert_action(const gxo_env* e, const float pose0[4], const float* 
 /* pose of the robot body from qpos (mjx.forward kinematics), qpos with zero angles */
 static void pose_of_rest(const gxo_env* e, const float* q, float pose[4])
 {
-    if (e->cfg.robot == 2) { ant_pose(q, pose); return; }
+    if (e->cfg.robot >= 2) { ant_pose(q, pose); return; } /* ant, walker: x slide, z hinge, body-y slide */
     float sh, ch;
     gx_sincos(0.5f * q[2], &sh, &ch);
     pose[0] = q[0]; pose[1] = q[1]; pose[2] = ch * ch - sh * sh; pose[3] = 2.0f * (ch * sh);
@@ -773,9 +789,9 @@ static void load_layout(gxo_env* e, int i, const float* lay)
     float* v = &e->qvel[(size_t)i * e->nv];
     for (int k = 0; k < e->nq; ++k) q[k] = 0.0f;
     for (int k = 0; k < e->nv; ++k) v[k] = 0.0f;
-    /* robot_x / robot_y joints by NAME (:635-638): qpos 0,1 for point and swimmer, 0,2 for the ant */
+    /* robot_x / robot_y joints by NAME (:635-638): qpos 0,1 for point and swimmer, 0,2 for the ant and the walker */
     q[0] = lay[2 * e->NOBJ];
-    q[e->cfg.robot == 2 ? 2 : 1] = lay[2 * e->NOBJ + 1];
+    q[e->cfg.robot >= 2 ? 2 : 1] = lay[2 * e->NOBJ + 1];
 }
 
 /* get_layout engine.py:446-452: idx = randint(key, (env_num,), 0, layout_size) */

@@ -27,7 +27,7 @@ extern "C" {
  * checker does not include product headers). */
 typedef struct gxo_config {
     int32_t struct_size;        /* sizeof(gxo_config), ABI check */
-    int32_t robot;              /* 0 = xmls/point.xml, 1 = xmls/swimmer.xml, 2 = xmls/ant.xml */
+    int32_t robot;              /* 0 = xmls/point.xml, 1 = xmls/swimmer.xml, 2 = xmls/ant.xml, 3 = xmls/walker.xml */
     int32_t env_num;            /* envs owned by this instance */
     int32_t env_total;          /* env_num of the whole (possibly sharded) batch */
     int32_t env_offset;         /* global index of local env 0 */
@@ -111,6 +111,9 @@ int   gxo_rollout_policy(gxo_env* e, int32_t T, int32_t hidden, const float* par
 /* one ant.xml mjx.step (test probe): dbg = 121 dense mass matrix + 11 smooth force, qpos coordinates */
 void  gxo_ant_probe(const float* q, const float* v, const float* ctrl, float* q2, float* v2, float* qacc,
                     float* pose, float* dbg);
+/* one walker.xml mjx.step (test probe): dbg = 169 dense mass matrix + 13 smooth force */
+void  gxo_walker_probe(const float* q, const float* v, const float* ctrl, float* q2, float* v2, float* qacc,
+                       float* pose, float* dbg);
 void  gxo_set_threads(int32_t n);
 int   gxo_get_threads(void);
 

@@ -98,6 +98,8 @@ def lib():
         L.gxo_math_probe.restype = None
         L.gxo_ant_probe.argtypes = [fp] * 8
         L.gxo_ant_probe.restype = None
+        L.gxo_walker_probe.argtypes = [fp] * 8
+        L.gxo_walker_probe.restype = None
         L.gxo_set_threads.argtypes = [C.c_int32]
         L.gxo_set_threads.restype = None
         L.gxo_get_threads.restype = C.c_int32
@@ -115,7 +117,7 @@ def make_config(config, n_candidates=1_000_000, env_total=None, env_offset=0):
     c = Config()
     c.struct_size = C.sizeof(Config)
     base = cfg['robot_base']
-    c.robot = {'xmls/point.xml': 0, 'xmls/swimmer.xml': 1, 'xmls/ant.xml': 2}.get(base, 99)
+    c.robot = {'xmls/point.xml': 0, 'xmls/swimmer.xml': 1, 'xmls/ant.xml': 2, 'xmls/walker.xml': 3}.get(base, 99)
     c.env_num = int(cfg['env_num'])
     c.env_total = int(env_total if env_total is not None else cfg['env_num'])
     c.env_offset = int(env_offset)
@@ -303,6 +305,16 @@ def ant_probe(q, v, ctrl):
     pose = np.zeros(4, np.float32); dbg = np.zeros(132, np.float32)
     lib().gxo_ant_probe(_fp(q), _fp(v), _fp(ctrl), _fp(q2), _fp(v2), _fp(qacc), _fp(pose), _fp(dbg))
     return q2, v2, qacc, pose, dbg[:121].reshape(11, 11).copy(), dbg[121:].copy()
+
+
+def walker_probe(q, v, ctrl):
+    """one walker.xml mjx.step: (q2, v2, qacc, pose, dense mass matrix, smooth force)"""
+    q = np.ascontiguousarray(q, np.float32); v = np.ascontiguousarray(v, np.float32)
+    ctrl = np.ascontiguousarray(ctrl, np.float32)
+    q2 = np.zeros(13, np.float32); v2 = np.zeros(13, np.float32); qacc = np.zeros(13, np.float32)
+    pose = np.zeros(4, np.float32); dbg = np.zeros(169 + 13, np.float32)
+    lib().gxo_walker_probe(_fp(q), _fp(v), _fp(ctrl), _fp(q2), _fp(v2), _fp(qacc), _fp(pose), _fp(dbg))
+    return q2, v2, qacc, pose, dbg[:169].reshape(13, 13).copy(), dbg[169:].copy()
 
 
 def math_probe2(x):
