@@ -120,9 +120,10 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     if (!cfg || !out) return fail(GX_ERR_ARG, "null argument");
     if (cfg->struct_size != (int32_t)sizeof(gx_config))
         return fail(GX_ERR_ARG, "gx_config.struct_size mismatch");
-    if (cfg->robot != PointRobot::kId && cfg->robot != SwimmerRobot::kId && cfg->robot != AntRobot::kId)
+    if (cfg->robot < PointRobot::kId || cfg->robot > WalkerRobot::kId)
         return fail(GX_ERR_UNSUPPORTED,
-                    "robots with HIP dynamics: 0 = xmls/point.xml, 1 = xmls/swimmer.xml, 2 = xmls/ant.xml");
+                    "robots with HIP dynamics: 0 = xmls/point.xml, 1 = xmls/swimmer.xml, 2 = xmls/ant.xml, "
+                    "3 = xmls/walker.xml");
     if (cfg->env_num < 1 || cfg->env_total < cfg->env_num || cfg->env_offset < 0 ||
         cfg->env_offset + cfg->env_num > cfg->env_total)
         return fail(GX_ERR_ARG, "bad env_num/env_total/env_offset");
@@ -149,6 +150,9 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     } else if (cfg->robot == AntRobot::kId) {
         e->nq = AntRobot::NQ; e->nv = AntRobot::NV; e->nu = AntRobot::NU;
         e->na = AntRobot::NA; e->ndyn = AntRobot::NDYN;
+    } else if (cfg->robot == WalkerRobot::kId) {
+        e->nq = WalkerRobot::NQ; e->nv = WalkerRobot::NV; e->nu = WalkerRobot::NU;
+        e->na = WalkerRobot::NA; e->ndyn = WalkerRobot::NDYN;
     } else {
         e->nq = PointRobot::NQ; e->nv = PointRobot::NV; e->nu = PointRobot::NU;
         e->na = PointRobot::NA; e->ndyn = PointRobot::NDYN;
@@ -184,6 +188,7 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     p.physics_steps = cfg->physics_steps;
     const float h_robot = cfg->robot == SwimmerRobot::kId ? SwimmerRobot::kH
                           : cfg->robot == AntRobot::kId   ? AntRobot::kH
+                          : cfg->robot == WalkerRobot::kId ? WalkerRobot::kH
                                                           : PointRobot::kH;
     p.dt = h_robot * (float)cfg->physics_steps; // engine.py:235
     p.env_total = cfg->env_total;

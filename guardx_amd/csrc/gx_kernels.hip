@@ -316,6 +316,7 @@ void launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s)
     do {                                                                     \
         if (p.robot == SwimmerRobot::kId) RobotLaunch<SwimmerRobot>::CALL;   \
         else if (p.robot == AntRobot::kId) RobotLaunch<AntRobot>::CALL;      \
+        else if (p.robot == WalkerRobot::kId) RobotLaunch<WalkerRobot>::CALL; \
         else RobotLaunch<PointRobot>::CALL;                                  \
     } while (0)
 
@@ -351,7 +352,7 @@ void launch_thread_rollout(const Params& p, const RolloutArgs& r, const DevBuffe
 bool policy_rollout_supported(const Params& p) { return p.nobj <= 16 && p.bins <= 16; }
 size_t policy_lds_bytes(const Params& p, int impl)
 {
-    return sizeof(float) * (size_t)policy_lds_floats(p.D, p.robot == AntRobot::kId ? AntRobot::NA : 2, impl);
+    return sizeof(float) * (size_t)policy_lds_floats(p.D, p.robot == AntRobot::kId ? AntRobot::NA : (p.robot == WalkerRobot::kId ? WalkerRobot::NA : 2), impl);
 }
 
 // impl: 1 = VALU fmaf chains (one wave per workgroup), 2 = fp32 MFMA tiles (16 envs per workgroup)

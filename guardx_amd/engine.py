@@ -35,6 +35,7 @@ _ROBOTS = {
     'xmls/point.xml': (0, 3, 3, 3, 0.1, 0.02, (-np.inf, np.inf, 2)),      # point.xml:3,16-18,37-39
     'xmls/swimmer.xml': (1, 5, 5, 2, 0.03, 0.03, (-1.0, 1.0, 2)),         # swimmer.xml:3,14,58-59
     'xmls/ant.xml': (2, 11, 11, 8, 0.15, 0.09, (-1.0, 1.0, 8)),           # ant.xml:2,7,14,137-146
+    'xmls/walker.xml': (3, 13, 13, 10, 0.42, 0.02, (-1.0, 1.0, 10)),      # walker.xml:9,12,99-111
 }
 
 

@@ -38,6 +38,10 @@ def configuration_list(task):
             'sensors_obs': ['accelerometer', 'velocimeter', 'gyro', 'magnetometer',
                             'touch_ankle_1a', 'touch_ankle_2a', 'touch_ankle_3a', 'touch_ankle_4a',
                             'touch_ankle_1b', 'touch_ankle_2b', 'touch_ankle_3b', 'touch_ankle_4b']})
+    if task == "Goal_Walker_8Hazards":       # :254-279
+        return _goal_task('xmls/walker.xml', {
+            'sensors_obs': ['accelerometer', 'velocimeter', 'gyro', 'magnetometer',
+                            'touch_right_foot', 'touch_left_foot']})
     return {}  # unknown names fall through to Engine defaults, as in the reference
 
 

@@ -18,6 +18,9 @@ def task_config(env_num, seed=0, num_steps=200, **over):
 
 SWIMMER = {'robot_base': 'xmls/swimmer.xml'}
 ANT = {'robot_base': 'xmls/ant.xml'}
+WALKER = {'robot_base': 'xmls/walker.xml'}
+WALKER_LO = np.array([-25, -30, -100, -100, -45] * 2, np.float32) * np.float32(np.pi / 180)   # walker.xml joint ranges
+WALKER_HI = np.array([5, 35, 10, 0, 20] * 2, np.float32) * np.float32(np.pi / 180)
 ANT_SIGMA = np.array([1, -1, -1, 1], np.float32)     # sign of the ankle axes, ant.xml:27,44,61,77
 
 
@@ -26,6 +29,8 @@ def random_state(N, H, rng, spread=2.5, done_frac=0.1, near_frac=0.3, robot='poi
     f = np.float32
     if robot == 'ant':
         return _random_state_ant(N, H, rng, spread, done_frac, near_frac)
+    if robot == 'walker':
+        return _random_state_walker(N, H, rng, spread, done_frac, near_frac)
     nq = 3 if robot == 'point' else 5
     qpos = np.empty((N, nq), f)
     qpos[:, :2] = rng.uniform(-spread, spread, (N, 2))
@@ -96,6 +101,24 @@ def _random_state_ant(N, H, rng, spread, done_frac, near_frac):
     return dict(qpos=qpos, qvel=qvel, pose0=pose0, pose1=pose1, objs=objs,
                 done0=done0, done1=done1, steps=steps,
                 key=np.array([rng.integers(0, 2**32), rng.integers(0, 2**32)], np.uint32), hist=2)
+
+
+def _random_state_walker(N, H, rng, spread, done_frac, near_frac):
+    """qpos = (x, th, y, right leg 5, left leg 5): legs inside and beyond their joint ranges (feet pressed into
+    the floor when the foot joint pitches down), headings away from the |th| = pi/2 singularity."""
+    f = np.float32
+    s = _random_state_ant(N, H, rng, spread, done_frac, near_frac)
+    qpos = np.zeros((N, 13), f); qvel = np.zeros((N, 13), f)
+    qpos[:, :3] = s['qpos'][:, :3]
+    w = WALKER_HI - WALKER_LO
+    qpos[:, 3:] = WALKER_LO - 0.15 * w + rng.uniform(0, 1.3, (N, 10)).astype(f) * w
+    rest = rng.random(N) < 0.1
+    qpos[rest, 1] = 0.0; qpos[rest, 3:] = 0.0
+    qvel[:, :3] = s['qvel'][:, :3]
+    qvel[:, 3:] = rng.uniform(-6, 6, (N, 10))
+    qvel[rest] = 0.0
+    s.update(qpos=qpos, qvel=qvel)
+    return s
 
 
 def assert_state_equal(a, b, fields=('qpos', 'qvel', 'pose0', 'objs', 'done0', 'steps')):

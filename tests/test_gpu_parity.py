@@ -7,7 +7,7 @@ tests actually demand exact equality of every output and of the state.
 import numpy as np
 import pytest
 
-from helpers import task_config, random_state, assert_state_equal, SWIMMER, ANT
+from helpers import task_config, random_state, assert_state_equal, SWIMMER, ANT, WALKER
 
 pytestmark = pytest.mark.gpu
 
@@ -436,6 +436,53 @@ def test_ant_rollout_parity(torch_cuda, oracle, path):
         np.testing.assert_array_equal(done[t].cpu().numpy(), d)
         np.testing.assert_array_equal(cost[t].cpu().numpy(), info['cost'])
     assert floor > 0 and done.sum().item() > 0
+    assert_state_equal(E.get_state(), O.get_state())
+    np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
+
+
+# ---------------------------------------------------------------------------
+# Walker (Goal_Walker_8Hazards): 13-DOF tree with 3-D leg chains, joint limits, springs, gravity, foot contacts
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("path", ["thread", "group"])
+@pytest.mark.parametrize("N", [5, 64, 2000])
+def test_walker_step_parity_random_states(torch_cuda, oracle, N, path):
+    torch = torch_cuda
+    E, O = _engines(task_config(N, seed=3, **WALKER), oracle, path=path)
+    assert E.obs_flat_size == O.D == 70 and E.action_space.shape == (10,)
+    rng = np.random.default_rng(N)
+    for trial in range(3):
+        s = random_state(N, 8, rng, robot='walker')
+        s['hist'] = [2, 1, 0][trial]
+        E.set_state(s)
+        O.set_state(s)
+        act = rng.uniform(-1.4, 1.4, (N, 10)).astype(np.float32)
+        out_g = E.step(torch.from_numpy(act).cuda())
+        out_o = O.step(act)
+        _cmp_step(out_g, out_o)
+        assert_state_equal(E.get_state(), O.get_state())
+
+
+@pytest.mark.parametrize("path", ["thread", "group"])
+def test_walker_rollout_parity(torch_cuda, oracle, path):
+    torch = torch_cuda
+    N, T = 300, 100
+    E, O = _engines(task_config(N, seed=6, num_steps=60, goal_size=1.0, **WALKER), oracle,
+                    n_candidates=60000, path=path)
+    np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
+    rng = np.random.RandomState(1)
+    for t in range(30):                       # step()/reset_done() API
+        act = rng.uniform(-1, 1, (N, 10)).astype(np.float32)
+        _cmp_step(E.step(torch.from_numpy(act).cuda()), O.step(act))
+        np.testing.assert_array_equal(E.reset_done().cpu().numpy(), O.reset_done())
+    acts = rng.uniform(-1, 1, (T, N, 10)).astype(np.float32)   # fused rollout
+    obs, rew, cost, done = E.rollout(torch.from_numpy(acts).cuda())
+    for t in range(T):
+        o, r, d, info = O.step(acts[t])
+        np.testing.assert_array_equal(obs[t].cpu().numpy(), O.reset_done())
+        np.testing.assert_array_equal(rew[t].cpu().numpy(), r)
+        np.testing.assert_array_equal(done[t].cpu().numpy(), d)
+        np.testing.assert_array_equal(cost[t].cpu().numpy(), info['cost'])
+    assert done.sum().item() > 0
     assert_state_equal(E.get_state(), O.get_state())
     np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
 
