@@ -320,7 +320,8 @@ def other_robots(device, epochs=10):
     """the same epoch (reset + one 200-step rollout launch, env_num=2000) for the articulated robots:
     BASELINE config 3 (Goal_Swimmer_8Hazards) and Goal_Ant_8Hazards (contact + joint-limit solver)"""
     out = {}
-    for name, xml in (("Goal_Swimmer_8Hazards", "xmls/swimmer.xml"), ("Goal_Ant_8Hazards", "xmls/ant.xml")):
+    for name, xml in (("Goal_Swimmer_8Hazards", "xmls/swimmer.xml"), ("Goal_Ant_8Hazards", "xmls/ant.xml"),
+                      ("Goal_Walker_8Hazards", "xmls/walker.xml")):
         env = make_engine(ENV_NUM, 0, 1, robot_base=xml)
         tape = action_tape(EP_LEN, ENV_NUM, 0, device, env.action_space.shape[0])
 

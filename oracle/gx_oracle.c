@@ -1060,7 +1060,7 @@ int gxo_rollout_policy(gxo_env* e, int32_t T, int32_t hidden, const float* param
     const float* wpi = params;
     const float* wv = params + mlp_size(D, A);
     const float* log_std = wv + mlp_size(D, 1);
-    float std[8], lstd[8];
+    float std[16], lstd[16];
     for (int d = 0; d < A; ++d) { std[d] = gx_exp(log_std[d]); lstd[d] = gx_log(std[d]); logstd_out[d] = lstd[d]; }
     float* cur = (float*)malloc((size_t)N * D * 4);
     float* nxt = (float*)malloc((size_t)N * D * 4);
@@ -1070,7 +1070,7 @@ int gxo_rollout_policy(gxo_env* e, int32_t T, int32_t hidden, const float* param
     for (int t = 0; t < T; ++t) {
         memcpy(&obs_in[(size_t)t * N * D], cur, (size_t)N * D * 4);
         for (int i = 0; i < N; ++i) {
-            float m[8], v1[1], z[8];
+            float m[16], v1[1], z[16];
             mlp_forward(wpi, &cur[(size_t)i * D], D, A, m);
             mlp_forward(wv, &cur[(size_t)i * D], D, 1, v1);
             for (int pr = 0; 2 * pr < A; ++pr)

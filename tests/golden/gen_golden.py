@@ -55,3 +55,6 @@ if __name__ == "__main__":
     # Goal_Ant_8Hazards (11-DOF tree, joint limits, foot-floor contacts), small
     episode("goal_ant_8hazards_n12_seed4",
             task_config(12, seed=4, num_steps=40, goal_size=1.0, robot_base='xmls/ant.xml'), 30000, 60, 3)
+    # Goal_Walker_8Hazards (13-DOF tree with 3-D leg chains), small
+    episode("goal_walker_8hazards_n12_seed6",
+            task_config(12, seed=6, num_steps=40, goal_size=1.0, robot_base='xmls/walker.xml'), 30000, 60, 4)

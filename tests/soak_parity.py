@@ -2,7 +2,7 @@
 """Soak test (MI355X box): HIP vs CPU restatement on many more random states and longer episodes
 than the unit tests, looking for rare floating-point divergences.  Exits non-zero on any mismatch.
 
-    python tests/soak_parity.py [point|swimmer|ant] [n_states] [episode_envs] [episode_steps]
+    python tests/soak_parity.py [point|swimmer|ant|walker] [n_states] [episode_envs] [episode_steps]
 """
 import os
 import sys
@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from helpers import task_config, random_state, SWIMMER, ANT  # noqa: E402
+from helpers import task_config, random_state, SWIMMER, ANT, WALKER  # noqa: E402
 from guardx_amd import Engine  # noqa: E402
 from oracle import gxo  # noqa: E402
 
@@ -24,8 +24,8 @@ def main():
     n_states = int(sys.argv[2]) if len(sys.argv) > 2 else 400000
     N = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
     T = int(sys.argv[4]) if len(sys.argv) > 4 else 600
-    extra = {"point": {}, "swimmer": SWIMMER, "ant": ANT}[robot]
-    A = 8 if robot == "ant" else 2
+    extra = {"point": {}, "swimmer": SWIMMER, "ant": ANT, "walker": WALKER}[robot]
+    A = {"ant": 8, "walker": 10}.get(robot, 2)
     bad = 0
     t0 = time.time()
     # 1. single steps from random states, both kernel families

@@ -17,6 +17,8 @@ CASES = {
                                                     robot_base='xmls/swimmer.xml'), 30000),
     "goal_ant_8hazards_n12_seed4": (task_config(12, seed=4, num_steps=40, goal_size=1.0,
                                                 robot_base='xmls/ant.xml'), 30000),
+    "goal_walker_8hazards_n12_seed6": (task_config(12, seed=6, num_steps=40, goal_size=1.0,
+                                                   robot_base='xmls/walker.xml'), 30000),
 }
 
 

@@ -190,12 +190,12 @@ def test_fused_rollout_equals_stepwise(torch_cuda, oracle, path):
     assert_state_equal(E.get_state(), O.get_state())
 
 
-@pytest.mark.parametrize("robot", ["point", "swimmer", "ant"])
+@pytest.mark.parametrize("robot", ["point", "swimmer", "ant", "walker"])
 @pytest.mark.parametrize("path", ["thread", "group"])
 def test_variant_configs(torch_cuda, oracle, path, robot):
     torch = torch_cuda
-    extra = {"point": {}, "swimmer": SWIMMER, "ant": ANT}[robot]
-    A = 8 if robot == "ant" else 2
+    extra = {"point": {}, "swimmer": SWIMMER, "ant": ANT, "walker": WALKER}[robot]
+    A = {"ant": 8, "walker": 10}.get(robot, 2)
     variants = [
         dict(hazards_num=3, lidar_num_bins=8),
         dict(hazards_num=12, lidar_num_bins=24, lidar_alias=False, hazards_keepout=0.25),

@@ -103,3 +103,25 @@ def test_parser_agrees_with_hand_tables_on_the_ant():
     q = np.random.default_rng(0).uniform(-1, 1, 11)
     np.testing.assert_allclose(pm.mass_matrix(q), hm.mass_matrix(q), rtol=1e-12, atol=1e-18)
     assert pm.timestep == ant_np.H
+
+
+@pytest.mark.skipif(not os.path.isdir(XML_DIR), reason="robot MJCF files (reference checkout) not present")
+def test_walker_tables_match_the_mjcf_file():
+    """the generated tables carried by gx_robot_legs.h / gx_oracle_legs.inc are what the generator derives now,
+    and the generator's parser agrees with the hand-restated tables of oracle/walker_np.py"""
+    sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, ROOT)
+    import gen_legs_tables
+    from mjcf_model import Model
+    from oracle import walker_np
+    T = gen_legs_tables.tables(os.path.join(XML_DIR, "walker.xml"))
+    hip = open(os.path.join(ROOT, "guardx_amd/csrc/gx_robot_legs.h")).read()
+    cin = open(os.path.join(ROOT, "oracle/gx_oracle_legs.inc")).read()
+    for line in gen_legs_tables.emit(T, 'hip').splitlines()[1:]:
+        assert line.strip() in hip, line[:80]
+    for line in gen_legs_tables.emit(T, 'c').splitlines()[1:]:
+        assert line.strip() in cin, line[:80]
+    pm, hm = Model(os.path.join(XML_DIR, "walker.xml")), walker_np.WalkerModel()
+    np.testing.assert_allclose(pm.mass, hm.mass, rtol=1e-14)
+    np.testing.assert_allclose(pm.dof_invweight0, hm.dof_invweight0, rtol=1e-10)
+    q = np.random.default_rng(0).uniform(-0.5, 0.5, 13)
+    np.testing.assert_allclose(pm.mass_matrix(q), hm.mass_matrix(q), rtol=1e-10, atol=1e-16)

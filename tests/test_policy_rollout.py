@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from helpers import task_config, assert_state_equal, SWIMMER, ANT
+from helpers import task_config, assert_state_equal, SWIMMER, ANT, WALKER
 
 
 def _torch_ac(D, A, seed=0):
@@ -17,7 +17,7 @@ def _torch_ac(D, A, seed=0):
             if isinstance(m, torch.nn.Linear):
                 torch.nn.init.normal_(m.weight, std=0.5)
                 torch.nn.init.normal_(m.bias, std=0.3)
-    log_std = torch.tensor([-0.5, -0.3, -0.7, -0.1, -0.9, -0.4, -0.6, -0.2][:A])
+    log_std = torch.tensor([-0.5, -0.3, -0.7, -0.1, -0.9, -0.4, -0.6, -0.2, -0.8, -0.35][:A])
     return mu_net, v_net, log_std
 
 
@@ -77,12 +77,12 @@ def test_device_log_tanh_bitexact(oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("impl", ["valu", "mfma"])
-@pytest.mark.parametrize("robot", ["point", "swimmer", "ant"])
+@pytest.mark.parametrize("robot", ["point", "swimmer", "ant", "walker"])
 def test_policy_rollout_parity(oracle, robot, impl):
     import torch
     from guardx_amd import Engine
     N, T = 203, 50
-    extra = {"point": {}, "swimmer": SWIMMER, "ant": ANT}[robot]
+    extra = {"point": {}, "swimmer": SWIMMER, "ant": ANT, "walker": WALKER}[robot]
     cfg = task_config(N, seed=3, num_steps=30, goal_size=0.9, **extra)
     E = Engine(cfg, n_candidates=40000)
     E.set_policy_impl({"valu": 1, "mfma": 2}[impl])
