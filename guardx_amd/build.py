@@ -19,7 +19,7 @@ LIB = os.path.join(LIB_DIR, "libguardx_hip.so")
 # one translation unit per robot (gx_robot_kernels.inl instantiated for it), compiled in parallel
 SOURCES = ["gx_api.hip", "gx_kernels.hip", "gx_gae.hip", "gx_kernels_point.hip", "gx_kernels_swimmer.hip",
            "gx_kernels_ant.hip", "gx_kernels_walker.hip"]
-HEADERS = ["gx_device.h", "gx_robot.h", "gx_robot_ant.h", "gx_robot_ant_group.h", "gx_robot_legs.h", "gx_policy.h", "gx_kernels.h", "gx_robot_kernels.inl",
+HEADERS = ["gx_device.h", "gx_robot.h", "gx_robot_ant.h", "gx_robot_ant_group.h", "gx_robot_legs.h", "gx_robot_legs_group.h", "gx_policy.h", "gx_kernels.h", "gx_robot_kernels.inl",
            os.path.join("..", "..", "include", "guardx.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

@@ -285,3 +285,4 @@ struct SwimmerRobot {
 #include "gx_robot_ant.h"
 #include "gx_robot_ant_group.h"
 #include "gx_robot_legs.h"
+#include "gx_robot_legs_group.h"

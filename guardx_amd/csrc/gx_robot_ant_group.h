@@ -349,13 +349,4 @@ struct AntGroup {
     }
 };
 
-// one mjx.step inside the lane-group kernel: `lane` = lane within the env's 16-lane group
-template <class R, bool kQacc>
-GX_D void group_substep(float (&q)[R::NQ], float (&v)[R::NV], const float (&ctrl)[R::NU], float (&pose)[4],
-                        float (&qacc)[R::NV], int lane)
-{
-    if constexpr (R::kId == AntRobot::kId) AntGroup::substep_call(q, v, ctrl, pose, qacc, lane & 3);
-    else R::template substep<kQacc>(q, v, ctrl, pose, qacc);
-}
-
 } // namespace gx

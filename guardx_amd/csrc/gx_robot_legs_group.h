@@ -1,0 +1,405 @@
+// gx_robot_legs_group.h -- the Walker step (gx_robot_legs.h) evaluated leg-parallel by the 16 lanes that own
+// one environment in the lane-group kernel: lane l works on leg (l & 1); lanes 0/1 of every quad hold the two
+// legs of the env (lanes 2/3 and the other quads are replicas).  Per-leg arithmetic is that of the serial form
+// (table entries selected by the leg index instead of being compile-time constants); every sum over the legs
+// -- base accumulators, the Schur complement of the arrow solve, the base block of the Newton matrix, the base
+// entries of the constraint force -- takes the two per-leg terms in leg order through DPP quad broadcasts, the
+// order the serial form and the CPU checker use, so the forms agree bit for bit.
+#pragma once
+#include "gx_robot_legs.h"
+#include "gx_robot_ant_group.h"
+
+namespace gx {
+
+struct WalkerGroup {
+    using W = WalkerRobot;
+    using V3 = WalkerRobot::V3;
+    using M3 = WalkerRobot::M3;
+    using Lim = WalkerRobot::Lim;
+    static constexpr int K = WalkerRobot::kK, ND = WalkerRobot::ND;
+    static_assert(WalkerRobot::kLegs == 2, "two legs: lanes 0/1 of a quad");
+    static_assert(W::c_blink[0][0] == W::c_blink[1][0] && W::c_blink[0][1] == W::c_blink[1][1] &&
+                  W::c_blink[0][2] == W::c_blink[1][2], "same link layout on both legs");
+
+    template <int Q> GX_D static float quad(float x) { return AntGroup::quad<Q>(x); }
+    template <int Q> GX_D static int quadi(int x) { return AntGroup::quadi<Q>(x); }
+    GX_D static float add_legs(float x, float t) { x = x + quad<0>(t); x = x + quad<1>(t); return x; }
+    GX_D static float sub_legs(float x, float t) { x = x - quad<0>(t); x = x - quad<1>(t); return x; }
+    // table entry of this lane's leg
+    GX_D static float ts(int L, float a0, float a1) { return L ? a1 : a0; }
+#define GX_T2(tab, ...) ts(L, W::tab[0] __VA_ARGS__, W::tab[1] __VA_ARGS__)
+
+    struct LegBlk { float C[3][K], L[K][K]; };
+    struct FootR { int on; float J[4][ND], aref[4], D; };
+
+    // eliminate this leg: Wl = L^-1 [C_x, C_th, C_y, r_leg]; contributions tg, tS to the base system
+    GX_D static void eliminate(const LegBlk& B, const float (&rl)[K], float (&Wl)[4][K], float (&tg)[3], float (&tS)[3][3])
+    {
+        float Lc[K][K];
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+#pragma unroll
+            for (int k = 0; k < K; ++k) Lc[i][k] = (k <= i) ? B.L[i][k] : 0.0f;
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int i = 0; i < K; ++i) Wl[b][i] = B.C[b][i];
+#pragma unroll
+        for (int i = 0; i < K; ++i) Wl[3][i] = rl[i];
+        W::ldl_solve(Lc, Wl);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            float s = 0.0f;
+#pragma unroll
+            for (int i = 0; i < K; ++i) s = s + B.C[b][i] * Wl[3][i];
+            tg[b] = s;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float t = 0.0f;
+                if (c <= b) {
+#pragma unroll
+                    for (int i = 0; i < K; ++i) t = t + B.C[b][i] * Wl[c][i];
+                }
+                tS[b][c] = t;
+            }
+        }
+    }
+    // arrow solve: base block Bb, this leg's blocks, base rhs rb, this leg's rhs rl -> xb, xl
+    GX_D static void arrow_solve(const float (&Bb)[3][3], const LegBlk& Blk, const float (&rb)[3], const float (&rl)[K],
+                                 float (&xb)[3], float (&xl)[K])
+    {
+        float Wl[4][K], tg[3], tS[3][3];
+        eliminate(Blk, rl, Wl, tg, tS);
+        float S[3][3], g[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            g[b] = sub_legs(rb[b], tg[b]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) S[b][c] = (c <= b) ? sub_legs(Bb[b][c], tS[b][c]) : 0.0f;
+        }
+        AntRobot::Ldl3 F;
+        AntRobot::ldl_factor(S, F);
+        AntRobot::ldl_solve(F, g, xb);
+#pragma unroll
+        for (int i = 0; i < K; ++i) xl[i] = Wl[3][i] - ((Wl[0][i] * xb[0] + Wl[1][i] * xb[1]) + Wl[2][i] * xb[2]);
+    }
+    GX_D static float row_dot(const float* J, const float (&ab)[3], const float (&al)[K])
+    {
+        float s = (J[0] * ab[0] + J[1] * ab[1]) + J[2] * ab[2];
+#pragma unroll
+        for (int i = 0; i < K; ++i) s = s + J[3 + i] * al[i];
+        return s;
+    }
+    // this leg's 16-bit active mask (bit i: limit row of joint i; bit 8+k: pyramid row k)
+    GX_D static uint32_t active_leg(const Lim (&lim)[K], const FootR& ft, const float (&ab)[3], const float (&al)[K])
+    {
+        uint32_t m = 0;
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+            if (lim[i].sg != 0.0f && (lim[i].sg * al[i] - lim[i].aref < 0.0f)) m |= 1u << i;
+        if (ft.on) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (row_dot(ft.J[k], ab, al) - ft.aref[k] < 0.0f) m |= 1u << (8 + k);
+        }
+        return m;
+    }
+    GX_D static uint32_t gather_mask(uint32_t own)
+    {
+        return (uint32_t)quadi<0>((int)own) | ((uint32_t)quadi<1>((int)own) << 16);
+    }
+
+    __device__ __attribute__((noinline)) static void substep_call(float* q, float* v, const float* ctrl, float* pose,
+                                                                  float* qacc, int L)
+    {
+        substep(*reinterpret_cast<float (*)[13]>(q), *reinterpret_cast<float (*)[13]>(v),
+                *reinterpret_cast<const float (*)[10]>(ctrl), *reinterpret_cast<float (*)[4]>(pose),
+                *reinterpret_cast<float (*)[13]>(qacc), L);
+    }
+
+    GX_D static void substep(float (&q)[13], float (&v)[13], const float (&ctrl)[10], float (&pose)[4], float (&qacc)[13],
+                             int L)
+    {
+        AntRobot::pose_of(q, pose);
+        const float c = pose[2], s = pose[3];
+        const float y = q[2], om = v[1], vy = v[2];
+        const float wh = om * om;
+        const V3 Pacc = W::lv(-(2.0f * (vy * om)), -(y * wh), 0.0f);
+        const V3 ex = W::lv(c, -s, 0.0f);
+        const V3 ez = W::lv(0.0f, 0.0f, 1.0f);
+        // ---- this lane's leg: joint state
+        float ql[K], vl[K], ul[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            ql[i] = L ? q[3 + K + i] : q[3 + i];
+            vl[i] = L ? v[3 + K + i] : v[3 + i];
+            ul[i] = L ? ctrl[K + i] : ctrl[i];
+        }
+        M3 R = {W::lv(1.0f, 0.0f, 0.0f), W::lv(0.0f, 1.0f, 0.0f), W::lv(0.0f, 0.0f, 1.0f)};
+        M3 Rj[K];
+        V3 Aj[K], uj[K], wj[K], alj[K], aAj[K];
+        V3 Aprev = W::lv(0.0f, 0.0f, 0.0f), w = W::lv(0.0f, 0.0f, om), al = W::lv(0.0f, 0.0f, 0.0f), aA = Pacc;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const V3 d = W::lmul(R, W::lv(GX_T2(c_dp, [j][0]), GX_T2(c_dp, [j][1]), GX_T2(c_dp, [j][2])));
+            Aj[j] = W::ladd(Aprev, d);
+            uj[j] = W::lmul(R, W::lv(GX_T2(c_axis, [j][0]), GX_T2(c_axis, [j][1]), GX_T2(c_axis, [j][2])));
+            aAj[j] = W::ladd(W::ladd(aA, W::lcross(al, d)), W::lcross(w, W::lcross(w, d)));
+            const float qd = vl[j];
+            alj[j] = W::ladd(al, W::lscale(W::lcross(w, uj[j]), qd));
+            wj[j] = W::ladd(w, W::lscale(uj[j], qd));
+            float sj, cj;
+            sincos_f(ql[j], sj, cj);
+            R.c0 = W::lrot(uj[j], sj, cj, R.c0); R.c1 = W::lrot(uj[j], sj, cj, R.c1); R.c2 = W::lrot(uj[j], sj, cj, R.c2);
+            Rj[j] = R;
+            Aprev = Aj[j]; w = wj[j]; al = alj[j]; aA = aAj[j];
+        }
+        float tBtt = 0.0f, tBxt = 0.0f, tBty = 0.0f, tcx = 0.0f, tcy = 0.0f, tct = 0.0f;
+        float cl[K], gl[K];
+        LegBlk Mk;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            cl[i] = 0.0f; gl[i] = 0.0f;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) Mk.C[b][i] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) Mk.L[i][k] = 0.0f;
+        }
+#pragma unroll
+        for (int b = 0; b < W::kNb; ++b) {
+            constexpr int kZero = 0;
+            const int j = W::c_blink[kZero][b];
+            const float m = GX_T2(c_bm, [b]);
+            const V3 rr = W::lmul(Rj[j], W::lv(GX_T2(c_bc, [b][0]), GX_T2(c_bc, [b][1]), GX_T2(c_bc, [b][2])));
+            const V3 X = W::ladd(Aj[j], rr);
+            const V3 acom = W::ladd(W::ladd(aAj[j], W::lcross(alj[j], rr)), W::lcross(wj[j], W::lcross(wj[j], rr)));
+            const V3 F = W::lscale(acom, m);
+            float Ib[6];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) Ib[e] = GX_T2(c_bI, [b][e]);
+            const V3 Iw_w = W::lmul(Rj[j], W::lsym(Ib, W::lmulT(Rj[j], wj[j])));
+            const V3 N = W::ladd(W::lmul(Rj[j], W::lsym(Ib, W::lmulT(Rj[j], alj[j]))), W::lcross(wj[j], Iw_w));
+            const V3 jt = W::lv(-(X.y + y), X.x, 0.0f);
+            const V3 Iz = W::lmul(Rj[j], W::lsym(Ib, W::lmulT(Rj[j], ez)));
+            tBtt = tBtt + (m * W::ldot(jt, jt) + Iz.z);
+            tBxt = tBxt + m * W::ldot(ex, jt);
+            tBty = tBty + m * jt.y;
+            tcx = tcx + W::ldot(ex, F);
+            tcy = tcy + F.y;
+            tct = tct + (W::ldot(jt, F) + N.z);
+            V3 jj[K], Iu[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                if (i > j) continue;
+                jj[i] = W::lcross(uj[i], W::lsub(X, Aj[i]));
+                Iu[i] = W::lmul(Rj[j], W::lsym(Ib, W::lmulT(Rj[j], uj[i])));
+                Mk.C[0][i] = Mk.C[0][i] + m * W::ldot(ex, jj[i]);
+                Mk.C[1][i] = Mk.C[1][i] + (m * W::ldot(jt, jj[i]) + Iu[i].z);
+                Mk.C[2][i] = Mk.C[2][i] + m * jj[i].y;
+#pragma unroll
+                for (int k = 0; k <= i; ++k) Mk.L[i][k] = Mk.L[i][k] + (m * W::ldot(jj[i], jj[k]) + W::ldot(uj[i], Iu[k]));
+                cl[i] = cl[i] + (W::ldot(jj[i], F) + W::ldot(uj[i], N));
+                gl[i] = gl[i] - (m * W::kGrav) * jj[i].z;
+            }
+        }
+        float fl[K];
+        Lim lim[K];
+        int own_any = 0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            Mk.L[i][i] = Mk.L[i][i] + GX_T2(c_arm, [i]);
+            float u = ul[i];
+            u = u < -1.0f ? -1.0f : (u > 1.0f ? 1.0f : u);
+            fl[i] = ((((-cl[i]) + gl[i]) - GX_T2(c_damp, [i]) * vl[i]) - GX_T2(c_stiff, [i]) * ql[i]) + GX_T2(c_gear, [i]) * u;
+            W::limit_row(lim[i], ql[i], vl[i], GX_T2(c_lo, [i]), GX_T2(c_hi, [i]), GX_T2(c_invw, [i]));
+            own_any |= lim[i].sg != 0.0f;
+        }
+        FootR ft;
+        {
+            constexpr int j = W::kFlink;
+            ft.on = 0; ft.D = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ft.aref[k] = 0.0f;
+#pragma unroll
+                for (int d = 0; d < ND; ++d) ft.J[k][d] = 0.0f;
+            }
+            const V3 Xs = W::ladd(Aj[j], W::lmul(Rj[j], W::lv(GX_T2(c_fs, [0]), GX_T2(c_fs, [1]), GX_T2(c_fs, [2]))));
+            const float dist = (W::c_z0 + Xs.z) - W::c_fr;
+            const float pos = dist - W::c_margin;
+            if (pos < 0.0f) {
+                const V3 Xc = W::lv(Xs.x, Xs.y, Xs.z - (W::c_fr + 0.5f * dist));
+                const V3 jt = W::lv(-(Xc.y + y), Xc.x, 0.0f);
+                float Jn[ND], T1[ND], T2[ND];
+                Jn[0] = 0.0f; Jn[1] = 0.0f; Jn[2] = 0.0f;
+                T1[0] = 0.0f; T1[1] = s * jt.x + c * jt.y; T1[2] = c;
+                T2[0] = 1.0f; T2[1] = c * jt.x - s * jt.y; T2[2] = -s;
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    const V3 jc = W::lcross(uj[i], W::lsub(Xc, Aj[i]));
+                    Jn[3 + i] = jc.z;
+                    T1[3 + i] = s * jc.x + c * jc.y;
+                    T2[3 + i] = c * jc.x - s * jc.y;
+                }
+                const float imp = AntRobot::impedance(pos);
+                float rr = ((1.0f - imp) * W::c_invw_pyr) / imp;
+                if (rr < 1e-15f) rr = 1e-15f;
+                ft.on = 1; ft.D = 1.0f / rr;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float sgn = (k & 1) ? -W::c_mu : W::c_mu;
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) ft.J[k][d] = Jn[d] + sgn * ((k < 2) ? T1[d] : T2[d]);
+                    float jv = (ft.J[k][0] * v[0] + ft.J[k][1] * om) + ft.J[k][2] * vy;
+#pragma unroll
+                    for (int i = 0; i < K; ++i) jv = jv + ft.J[k][3 + i] * vl[i];
+                    ft.aref[k] = -(W::c_kB * jv) - (W::c_kK * imp) * pos;
+                }
+                own_any = 1;
+            }
+        }
+        const int any_row = quadi<0>(own_any) | quadi<1>(own_any);
+
+        // ---- base block and base smooth force: per-leg terms in leg order
+        float B[3][3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) B[b][cc] = 0.0f;
+        B[0][0] = W::c_mtot; B[2][2] = W::c_mtot; B[2][0] = -(s * W::c_mtot);
+        B[1][1] = add_legs(W::c_mB * (y * y) + W::c_IB, tBtt);
+        B[1][0] = add_legs(-(W::c_mB * (c * y)), tBxt);
+        B[2][1] = add_legs(0.0f, tBty);
+        const float cx = add_legs(W::c_mB * (c * Pacc.x - s * Pacc.y), tcx);
+        const float cy = add_legs(W::c_mB * Pacc.y, tcy);
+        const float ct = add_legs(-(W::c_mB * (y * Pacc.x)), tct);
+        float fbase[3];
+        fbase[0] = -cx - W::c_dbx * v[0];
+        fbase[1] = (-ct - W::c_dbt * om) - W::c_kt * q[1];
+        fbase[2] = -cy - W::c_dby * vy;
+
+        float ab[3], alq[K];
+        arrow_solve(B, Mk, fbase, fl, ab, alq);
+        float fcb[3] = {fbase[0], fbase[1], fbase[2]};
+        float fcl[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) fcl[i] = fl[i];
+        if (any_row) {
+            uint32_t act = gather_mask(active_leg(lim, ft, ab, alq));
+            for (int it = 0; it < W::kIters; ++it) {
+                const uint32_t own = (act >> (16 * L)) & 0xFFFFu;
+                LegBlk Hk = Mk;
+                float PB[3][3], Pr[3] = {0.0f, 0.0f, 0.0f};
+                float rl[K];
+#pragma unroll
+                for (int i = 0; i < K; ++i) rl[i] = fl[i];
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) PB[b][cc] = 0.0f;
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    if (!((own >> i) & 1u)) continue;
+                    Hk.L[i][i] = Hk.L[i][i] + lim[i].D;
+                    rl[i] = rl[i] + (lim[i].D * lim[i].aref) * lim[i].sg;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (!((own >> (8 + k)) & 1u)) continue;
+                    const float* J = ft.J[k];
+                    const float D = ft.D, da = D * ft.aref[k];
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        const float dj = D * J[b];
+#pragma unroll
+                        for (int cc = 0; cc <= b; ++cc) PB[b][cc] = PB[b][cc] + dj * J[cc];
+#pragma unroll
+                        for (int i = 0; i < K; ++i) Hk.C[b][i] = Hk.C[b][i] + dj * J[3 + i];
+                        Pr[b] = Pr[b] + da * J[b];
+                    }
+#pragma unroll
+                    for (int i = 0; i < K; ++i) {
+                        const float di = D * J[3 + i];
+#pragma unroll
+                        for (int cc = 0; cc <= i; ++cc) Hk.L[i][cc] = Hk.L[i][cc] + di * J[3 + cc];
+                        rl[i] = rl[i] + da * J[3 + i];
+                    }
+                }
+                float HB[3][3], rb[3];
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) HB[b][cc] = (cc <= b) ? add_legs(B[b][cc], PB[b][cc]) : 0.0f;
+                    rb[b] = add_legs(fbase[b], Pr[b]);
+                }
+                arrow_solve(HB, Hk, rb, rl, ab, alq);
+                const uint32_t nact = gather_mask(active_leg(lim, ft, ab, alq));
+                if (nact == act) break;
+                act = nact;
+            }
+            float Pf[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                if (lim[i].sg == 0.0f) continue;
+                const float res = lim[i].sg * alq[i] - lim[i].aref;
+                if (!(res < 0.0f)) continue;
+                fcl[i] = fcl[i] + (lim[i].D * (-res)) * lim[i].sg;
+            }
+            if (ft.on) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float* J = ft.J[k];
+                    const float res = row_dot(J, ab, alq) - ft.aref[k];
+                    if (!(res < 0.0f)) continue;
+                    const float frc = ft.D * (-res);
+                    Pf[0] = Pf[0] + frc * J[0]; Pf[1] = Pf[1] + frc * J[1]; Pf[2] = Pf[2] + frc * J[2];
+#pragma unroll
+                    for (int i = 0; i < K; ++i) fcl[i] = fcl[i] + frc * J[3 + i];
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 3; ++b) fcb[b] = add_legs(fcb[b], Pf[b]);
+        }
+        // ---- Euler with implicit joint damping
+        float Bd[3][3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) Bd[b][cc] = B[b][cc];
+        Bd[0][0] = Bd[0][0] + W::c_h * W::c_dbx;
+        Bd[1][1] = Bd[1][1] + W::c_h * W::c_dbt;
+        Bd[2][2] = Bd[2][2] + W::c_h * W::c_dby;
+        LegBlk Kd = Mk;
+#pragma unroll
+        for (int i = 0; i < K; ++i) Kd.L[i][i] = Kd.L[i][i] + W::c_h * GX_T2(c_damp, [i]);
+        float aib[3], ail[K];
+        arrow_solve(Bd, Kd, fcb, fcl, aib, ail);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            qacc[k] = ab[k];
+            v[k] = v[k] + W::c_h * aib[k];
+            q[k] = q[k] + W::c_h * v[k];
+        }
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const float v2 = vl[i] + W::c_h * ail[i];
+            const float q2 = ql[i] + W::c_h * v2;
+            qacc[3 + i] = quad<0>(alq[i]); qacc[3 + K + i] = quad<1>(alq[i]);
+            v[3 + i] = quad<0>(v2); v[3 + K + i] = quad<1>(v2);
+            q[3 + i] = quad<0>(q2); q[3 + K + i] = quad<1>(q2);
+        }
+    }
+#undef GX_T2
+};
+
+// one mjx.step inside the lane-group kernel: `lane` = lane within the env's 16-lane group
+template <class R, bool kQacc>
+GX_D void group_substep(float (&q)[R::NQ], float (&v)[R::NV], const float (&ctrl)[R::NU], float (&pose)[4],
+                        float (&qacc)[R::NV], int lane)
+{
+    if constexpr (R::kId == AntRobot::kId) AntGroup::substep_call(q, v, ctrl, pose, qacc, lane & 3);
+    else if constexpr (R::kId == WalkerRobot::kId) WalkerGroup::substep_call(q, v, ctrl, pose, qacc, lane & 1);
+    else R::template substep<kQacc>(q, v, ctrl, pose, qacc);
+}
+
+} // namespace gx
