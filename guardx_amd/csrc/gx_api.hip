@@ -265,8 +265,10 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
         Pool& pl = e->pools[i];
         alloc((void**)&pl.cand_ok, M);
         alloc((void**)&pl.cand_xy, sizeof(float2) * M * e->nobj_total);
-        alloc((void**)&pl.wave_cnt, sizeof(int) * W);
-        alloc((void**)&pl.wave_off, sizeof(int) * W);
+        // padded to whole scan tiles (the fast scan reads and writes 16 ints per thread); alloc() zero-fills
+        const size_t Wpad = ((size_t)W + kScanTile - 1) / kScanTile * kScanTile;
+        alloc((void**)&pl.wave_cnt, sizeof(int) * Wpad);
+        alloc((void**)&pl.wave_off, sizeof(int) * Wpad);
         alloc((void**)&pl.cand_of, sizeof(int) * M);
         alloc((void**)&pl.layout_size, sizeof(int));
         alloc((void**)&pl.n_surv, 2 * sizeof(int));
@@ -342,13 +344,14 @@ extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
     hipStream_t s = (hipStream_t)stream;
     const int other = 1 - e->cur;
     const bool hit = e->pf_valid && e->pf_key[0] == e->key[0] && e->pf_key[1] == e->key[1];
+    const bool swap = hit || e->have_reset;
+    // the old pool is free once everything ALREADY queued on `s` has run: recorded before `s` starts to wait
+    // for the side stream, so the next prefetch (which reuses the old pool) follows the current one
+    // back to back instead of one cross-stream round trip later
+    if (swap) GX_HIP(hipEventRecord(e->pool_free[e->cur], s));
     if (e->pf_valid) // whatever the side stream is doing to pools[other] finishes first
         GX_HIP(hipStreamWaitEvent(s, e->pool_ready[other], 0));
-    if (hit || e->have_reset) {
-        // switch pools; the old one is free once everything already queued on `s` has run
-        GX_HIP(hipEventRecord(e->pool_free[e->cur], s));
-        e->cur = other;
-    }
+    if (swap) e->cur = other;
     if (!hit) { // reset_layout on the caller's stream  engine.py:433-444
         e->sp.k0 = e->key[0];
         e->sp.k1 = e->key[1];

@@ -20,6 +20,8 @@ struct SampleParams {
     uint32_t k0, k1; // engine key at reset time
 };
 
+constexpr int kScanTile = 16 * 1024; // counts per tile of scan_kernel: wave_cnt / wave_off are padded to whole tiles
+
 // valid-layout pool of one reset_layout() (engine.py:433-444); two of them are kept so the
 // next epoch's pool can be sampled on a side stream while the current one is in use
 struct Pool {
