@@ -162,19 +162,29 @@ __global__ __launch_bounds__(kSampleBlock) void sample_phase2_kernel(SampleParam
         for (int o = 1; o < nobj - 1; ++o) { // hazards
             const float4 hb = sp.haz_bounds ? sp.haz_bounds[o - 1]
                                             : make_float4(sp.lo_x[1], sp.hi_x[1], sp.lo_y[1], sp.hi_y[1]);
+            // draw_placement :579-621 keeps the LAST valid of the 10 tries.  The `rng, rng1 = split(rng)` chain has
+            // to be walked in order (20 blocks), but the draws (4 blocks each) are evaluated from the last try
+            // backwards and stop at the first valid one -- the same winner, ~3 draws per wave instead of 10.
+            uint32_t gk[10][2];
+#pragma unroll
+            for (int t = 0; t < 10; ++t) {
+                uint32_t n0, n1;
+                split2(r0, r1, n0, n1, gk[t][0], gk[t][1]); r0 = n0; r1 = n1;
+            }
             bool conflicted = true;
             float px = -__builtin_inff(), py = -__builtin_inff();
-            for (int t = 0; t < 10; ++t) {
-                uint32_t n0, n1, g0, g1;
-                split2(r0, r1, n0, n1, g0, g1); r0 = n0; r1 = n1;
-                float cx, cy;
-                draw_xy(g0, g1, hb.x, hb.y, hb.z, hb.w, cx, cy);
-                bool flag = true;
-                for (int q = 0; q < o; ++q) { // placement_is_valid :549-555
-                    const float2 pq = placed[q * kSampleBlock + tid];
-                    if (dsq(cx, cy, pq.x, pq.y) < sp.thr_sq[q == 0 ? 0 : 1][1]) flag = false;
+#pragma unroll
+            for (int t = 9; t >= 0; --t) {
+                if (conflicted) {
+                    float cx, cy;
+                    draw_xy(gk[t][0], gk[t][1], hb.x, hb.y, hb.z, hb.w, cx, cy);
+                    bool flag = true;
+                    for (int q = 0; q < o; ++q) { // placement_is_valid :549-555
+                        const float2 pq = placed[q * kSampleBlock + tid];
+                        if (dsq(cx, cy, pq.x, pq.y) < sp.thr_sq[q == 0 ? 0 : 1][1]) flag = false;
+                    }
+                    if (flag) { px = cx; py = cy; conflicted = false; }
                 }
-                if (flag) { px = cx; py = cy; conflicted = false; }
             }
             placed[o * kSampleBlock + tid] = make_float2(px, py);
             if (conflicted) success = false;
