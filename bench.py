@@ -287,7 +287,7 @@ def epoch_breakdown(device):
             "reset_inline_sampler_us": round(t_reset * 1e6, 1),
             "epoch_overlapped_us": round(t_epoch * 1e6, 1),
             "note": "reset() = exact restatement of the reference's 1e6-candidate rejection sampler "
-                    "(6e8 -> 3.2e8 Threefry-2x32 blocks after two exact early-rejection stages); it is integer-VALU "
+                    "(6e8 Threefry-2x32 blocks cut to under 3e8 by exact early rejection and lazy evaluation of the draws); it is integer-VALU "
                     "bound and bounds the epoch"}
 
 
