@@ -62,6 +62,7 @@ struct gx_engine {
     bool pf_valid;            // pools[1-cur] holds (or will hold) the pool for key pf_key
     uint32_t pf_key[2];
     int prefetch_steps;       // predicted step() calls between resets; < 0 disables prefetch
+    bool last_policy = false; // the last hot-path call was gx_rollout_policy
     // per-step layout keys for the fused rollout: ring of pinned staging + device buffers
     static const int kKeyRing = 4;
     uint4* h_keys[kKeyRing];
@@ -379,6 +380,10 @@ extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
         }
         const int tgt = 1 - e->cur;
         if (!first) GX_HIP(hipStreamWaitEvent(e->side, e->pool_free[tgt], 0));
+        // The closed-loop policy kernel (256-thread workgroups holding ~150 KB of LDS each) loses ~15 % when the
+        // sampler's grids reach the CUs first; after a policy rollout the prefetch therefore starts behind
+        // reset_apply.  The open-loop kernels are insensitive and keep the back-to-back sampler chain.
+        if (e->last_policy) GX_HIP(hipStreamWaitEvent(e->side, e->layout_ev, 0));
         SampleParams sp = e->sp;
         sp.k0 = k0; sp.k1 = k1;
         launch_sample(sp, e->pools[tgt], e->side);
@@ -450,6 +455,7 @@ extern "C" gx_status gx_step(gx_engine* e, const float* d_action, float* d_obs, 
     e->key[1] = a1;
     e->p.have_last = e->hist >= 1;
     e->p.have_last_last = e->hist >= 2;
+    e->last_policy = false;
     if (use_group_path(e)) {
         RolloutArgs r;
         memset(&r, 0, sizeof r);
@@ -540,6 +546,7 @@ extern "C" gx_status gx_rollout(gx_engine* e, int32_t T, const float* d_actions,
     fill_rollout_args(e, r, T, slot);
     r.act = static_cast<const float*>(d_actions);
     r.obs = d_obs; r.rew = d_reward; r.cost = d_cost; r.done = d_done; r.qacc = nullptr;
+    e->last_policy = false;
     if (use_group_path(e)) launch_group_rollout(e->p, r, e->b, s);   // latency regime: 16 lanes per env
     else launch_thread_rollout(e->p, r, e->b, s);                     // bandwidth regime: one thread per env
     GX_HIP(hipEventRecord(e->keys_ev[slot], s)); // staging reusable once this launch is done
@@ -581,6 +588,7 @@ extern "C" gx_status gx_rollout_policy(gx_engine* e, int32_t T, const gx_policy*
     pa.obs0 = d_obs0; pa.obs_in = d_obs_in; pa.act = d_act; pa.logp = d_logp; pa.val = d_val; pa.mu = d_mu;
     pa.obs_last = d_obs_last; pa.val_last = d_val_last; pa.logstd = d_logstd;
     launch_policy_rollout(e->p, r, pa, e->b, impl, s);
+    e->last_policy = true;
     GX_HIP(hipEventRecord(e->keys_ev[slot], s));
     GX_HIP(hipGetLastError());
     e->key[0] = k0; e->key[1] = k1;
