@@ -360,8 +360,8 @@ def api_loop_rate(env, tape, steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10000)    # 50 epochs of 200 steps
-    ap.add_argument("--warmup", type=int, default=1000)    # 5 epochs
+    ap.add_argument("--steps", type=int, default=40000)    # 200 epochs of 200 steps
+    ap.add_argument("--warmup", type=int, default=2000)    # 10 epochs
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
