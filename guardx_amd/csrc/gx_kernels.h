@@ -37,7 +37,7 @@ struct Pool {
 };
 
 struct DevBuffers {
-    float4* dyn;   // [3][Npad]: (x,y,th,vx) (vy,om,px,py) (pc,ps,done0,steps)
+    float4* dyn;   // [NDYN][Npad] planes of (qpos, qvel, pose0 = (px,py,cos,sin), done0, steps); Point: 3 planes
     float4* obj;   // [P][Npad]: object pairs (goal,h0) (h1,h2) ...
     float4* hist;  // [Npad]: (p1x,p1y,done1,0)   (only when hist_on)
     Pool pool;     // the pool the envs are currently drawn from

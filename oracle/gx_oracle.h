@@ -2,7 +2,7 @@
  * gx_oracle.h -- TEST INFRASTRUCTURE ONLY.
  *
  * CPU restatement (plain C, fp32) of the guardX `safe_rl_envs` Engine hot path
- * for the Goal_<Point>_<N>Hazards family.  It exists to CHECK the HIP path; it
+ * for the Goal_<Robot>_<N>Hazards family (Point, Swimmer, Ant, Walker).  It exists to CHECK the HIP path; it
  * is never shipped, never imported by guardx_amd/, and only tests/,
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
  *
