@@ -425,7 +425,8 @@ __global__ __launch_bounds__(BLOCK) void reset_done_kernel(Params p, int nobj_to
 // step_kernel + reset_done_kernel, hence the same bits.
 // ---------------------------------------------------------------------------
 template <class R, int BLOCK, int PMAX, bool kDef>
-__global__ __launch_bounds__(BLOCK) void thread_rollout_kernel(Params p_in, RolloutArgs r,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(R::kRestFixed ? (PMAX <= 9 ? 4 : 2) : 1)))
+void thread_rollout_kernel(Params p_in, RolloutArgs r,
                                                                float4* __restrict__ dyn,
                                                                float4* __restrict__ obj,
                                                                float4* __restrict__ hist)
