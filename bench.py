@@ -389,6 +389,22 @@ def main():
     dt = gxd.max_over_ranks(time.perf_counter() - t0, device)
 
     value = ENV_NUM * world * args.steps / dt
+    stepping_only = None
+    if gather:
+        # the same loop without the hand-off: what the sharded stepping alone sustains (no collective on the
+        # data path), so the cost of the mandated all-gather can be read off the two numbers
+        gxd.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_epochs(env, tapes, args.steps, None)
+        torch.cuda.synchronize()
+        gxd.barrier()
+        dt1 = gxd.max_over_ranks(time.perf_counter() - t1, device)
+        stepping_only = {"value": round(ENV_NUM * world * args.steps / dt1, 1), "unit": "env-steps/s",
+                         "ms_per_step": round(dt1 / args.steps * 1e3, 6),
+                         "handoff_bytes_received_per_rank_per_epoch": int((world - 1) * EP_LEN * ENV_NUM *
+                                                                          (env.obs_flat_size + 2 + 3) * 4),
+                         "note": "same epochs with the rollout hand-off switched off; `value` above includes it"}
     line = {
         "metric": "env-steps/sec", "value": round(value, 1), "unit": "env-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -402,6 +418,8 @@ def main():
                    "driver": "gx_rollout: one persistent lane-group kernel launch per 200-step epoch, layout pool of the next epoch prefetched on a side stream",
                    "layout_candidates_per_reset": 1_000_000},
     }
+    if stepping_only is not None:
+        line["stepping_only"] = stepping_only
     if rank == 0:
         try:
             line["roofline"] = roofline_rollout(ENV_NUM, EP_LEN, 30, device)
