@@ -291,7 +291,7 @@ def epoch_breakdown(device):
                     "bound and bounds the epoch"}
 
 
-def closed_loop_rate(device, epochs=10):
+def closed_loop_rate(device, epochs=50):
     """reset() + ONE rollout_policy launch per epoch: the (64,64)-tanh actor-critic of
     trpo_core.py:110-173 (random init) evaluated inside the persistent kernel."""
     from guardx_amd import Engine
@@ -316,7 +316,7 @@ def closed_loop_rate(device, epochs=10):
     return ENV_NUM * EP_LEN * epochs / dt
 
 
-def other_robots(device, epochs=10):
+def other_robots(device, epochs=50):
     """the same epoch (reset + one 200-step rollout launch, env_num=2000) for the articulated robots:
     BASELINE config 3 (Goal_Swimmer_8Hazards) and Goal_Ant_8Hazards (contact + joint-limit solver)"""
     out = {}
