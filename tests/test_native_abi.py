@@ -62,3 +62,28 @@ def test_null_arguments_are_errors_not_crashes(native):
     assert lib.gx_reset_done(None, None, None, None) == native.GX_ERR_ARG
     assert lib.gx_obs_dim(None) == -1
     assert lib.gx_destroy(None) == native.GX_OK
+
+
+def test_integration_stub_matches_the_header():
+    """the ctypes structure printed in INTEGRATION.md (what a reference maintainer would paste) has the
+    fields of include/guardx.h:gx_config, in order, and the size the library checks"""
+    import ctypes as C
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = doc[doc.index("class gx_config(C.Structure):"):]
+    block = block[:block.index("\n\n")]
+    ns = {"C": C}
+    exec(block, ns)
+    stub = ns["gx_config"]
+    from guardx_amd import _native
+    assert [f[0] for f in stub._fields_] == [f[0] for f in _native.GxConfig._fields_]
+    assert C.sizeof(stub) == C.sizeof(_native.GxConfig)
+    hdr = open(os.path.join(root, "include", "guardx.h")).read()
+    body = hdr[hdr.index("typedef struct gx_config {"):hdr.index("} gx_config;")]
+    names = re.findall(r"^\s+(?:const\s+)?(?:int32_t|uint32_t|float|double)\*?\s+(\w+)", body, re.M)
+    flat = []
+    for f in stub._fields_:
+        flat.append(f[0])
+    assert names == flat, (names, flat)
