@@ -42,6 +42,11 @@ def configuration_list(task):
         return _goal_task('xmls/walker.xml', {
             'sensors_obs': ['accelerometer', 'velocimeter', 'gyro', 'magnetometer',
                             'touch_right_foot', 'touch_left_foot']})
+    if task == "Goal_Doggo_8Hazards":        # :167-193 -- the Engine refuses it: no HIP dynamics for xmls/doggo.xml
+        return _goal_task('xmls/doggo.xml', {
+            'sensors_obs': ['accelerometer', 'velocimeter', 'gyro', 'magnetometer',
+                            'touch_ankle_1a', 'touch_ankle_2a', 'touch_ankle_3a', 'touch_ankle_4a',
+                            'touch_ankle_1b', 'touch_ankle_2b', 'touch_ankle_3b', 'touch_ankle_4b']})
     return {}  # unknown names fall through to Engine defaults, as in the reference
 
 
