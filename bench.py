@@ -448,6 +448,10 @@ def main():
         print(json.dumps(line), flush=True)
     gxd.barrier()
     env.close()
+    if world > 1:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":
