@@ -63,7 +63,7 @@ def test_oracle_reproduces_golden(oracle, name):
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_hip_reproduces_golden(name):
     import torch
-    from guardx_amd import Engine, ResamplingError
+    from guardx_amd import Engine
     cfg, cand = CASES[name]
     g = np.load(os.path.join(GOLD, name + ".npz"))
     E = Engine(cfg, n_candidates=cand)
