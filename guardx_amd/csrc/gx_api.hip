@@ -121,10 +121,10 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     if (!cfg || !out) return fail(GX_ERR_ARG, "null argument");
     if (cfg->struct_size != (int32_t)sizeof(gx_config))
         return fail(GX_ERR_ARG, "gx_config.struct_size mismatch");
-    if (cfg->robot < PointRobot::kId || cfg->robot > WalkerRobot::kId)
+    if (cfg->robot < PointRobot::kId || cfg->robot > PointBareRobot::kId)
         return fail(GX_ERR_UNSUPPORTED,
                     "robots with HIP dynamics: 0 = xmls/point.xml, 1 = xmls/swimmer.xml, 2 = xmls/ant.xml, "
-                    "3 = xmls/walker.xml");
+                    "3 = xmls/walker.xml, 4 = xmls/point.xml without the actuator class defaults");
     if (cfg->env_num < 1 || cfg->env_total < cfg->env_num || cfg->env_offset < 0 ||
         cfg->env_offset + cfg->env_num > cfg->env_total)
         return fail(GX_ERR_ARG, "bad env_num/env_total/env_offset");

@@ -351,6 +351,7 @@ void launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s)
         if (p.robot == SwimmerRobot::kId) RobotLaunch<SwimmerRobot>::CALL;   \
         else if (p.robot == AntRobot::kId) RobotLaunch<AntRobot>::CALL;      \
         else if (p.robot == WalkerRobot::kId) RobotLaunch<WalkerRobot>::CALL; \
+        else if (p.robot == PointBareRobot::kId) RobotLaunch<PointBareRobot>::CALL; \
         else RobotLaunch<PointRobot>::CALL;                                  \
     } while (0)
 

@@ -12,12 +12,19 @@ namespace gx {
 
 // ===========================================================================
 // Point (xmls/point.xml): slide-x, slide-y, hinge-z; sphere r=.1 + box .05 at
-// x=.1, density 1 (:5,19-20); damping .01 .01 .005 (:16-18); general actuators
-// gear .3 without ctrl limits (:37-39); h=.02 (:3).
+// x=.1, density 1 (:5,19-20); damping .01 .01 .005 (:16-18); h=.02 (:3).
+// Actuators: three <general gear=".3"> (:37-39) that set no gain/bias/limit attribute of
+// their own and therefore inherit the class's ONE actuator default, which <motor> and then
+// <velocity> (:7-8) wrote in document order [derived: MuJoCo XML reference, default/motor ..
+// default/velocity "set the attributes of the general element using Actuator shortcuts"]:
+// ctrllimited +-1, forcelimited +-.05, gain fixed 1, bias affine (0, 0, -kv), kv = 1.  Force on a
+// DOF = gear * clip(clip(ctrl, +-1) - kv * gear * qvel, +-.05).  kBare = the round-1 reading
+// (no class defaults: gear * ctrl), kept selectable as robot id 4.
 // dyn: (x,y,th,vx) (vy,om,px,py) (pc,ps,done0,steps)
 // ===========================================================================
-struct PointRobot {
-    static constexpr int kId = 0, NQ = 3, NV = 3, NU = 3, NA = 2, NDYN = 3;
+template <bool kBare>
+struct PointRobotT {
+    static constexpr int kId = kBare ? 4 : 0, NQ = 3, NV = 3, NU = 3, NA = 2, NDYN = 3;
     static constexpr float kH = 0.02f;
     // default Goal_Point_8Hazards observation: ctrl[0:3] compass[3:5] glidar[5:21] hlidar[21:37] qpos[37:40] qvel[40:43]
     static constexpr int kD = 43, kOffCtrl = 0, kOffComp = 3, kOffGl = 5, kOffHl = 21, kOffQpos = 37, kOffQvel = 40;
@@ -46,11 +53,22 @@ struct PointRobot {
     static constexpr bool kRestFixed = true;
     GX_D static void place(float (&q)[NQ], float rx, float ry) { q[0] = rx; q[1] = ry; }
 
+    GX_D static float clip(float x, float lim) { return x < -lim ? -lim : (x > lim ? lim : x); } // jp.clip: NaN stays
+    // qfrc_actuator of one DOF [derived: mjx fwd_actuation]
+    GX_D static float actuate(float ctrl, float vel)
+    {
+        constexpr float kGear = 0.3f, kCtrlLim = 1.0f, kForceLim = 0.05f, kKv = 1.0f;
+        if (kBare) return kGear * ctrl;
+        const float u = clip(ctrl, kCtrlLim);
+        const float force = clip(u - kKv * (kGear * vel), kForceLim);
+        return kGear * force;
+    }
+
     template <bool kQacc>
     GX_D static void substep(float (&q)[NQ], float (&v)[NV], const float (&ctrl)[NU], float (&pose)[4],
                              float (&qacc)[NV])
     {
-        constexpr float kMxc = 0.0001f, kDxy = 0.01f, kDt = 0.005f, kGear = 0.3f;
+        constexpr float kMxc = 0.0001f, kDxy = 0.01f, kDt = 0.005f;
         constexpr float kIo = 2.842182748581224e-05f;
         constexpr float kInvM = (float)(1.0 / 0.005188790204786391);
         constexpr float kInvA = (float)(1.0 / (0.005188790204786391 + 0.02 * 0.01));
@@ -62,9 +80,9 @@ struct PointRobot {
         pose[0] = q[0]; pose[1] = q[1]; pose[2] = c; pose[3] = sn;
         const float b = -(kMxc * sn), d = kMxc * c;
         const float w2 = v[2] * v[2];
-        const float fx = (-(kDxy * v[0]) - (-(d * w2))) + kGear * ctrl[0];
-        const float fy = (-(kDxy * v[1]) - (b * w2)) + kGear * ctrl[1];
-        const float ft = (-(kDt * v[2]) - 0.0f) + kGear * ctrl[2];
+        const float fx = (-(kDxy * v[0]) - (-(d * w2))) + actuate(ctrl[0], v[0]);
+        const float fy = (-(kDxy * v[1]) - (b * w2)) + actuate(ctrl[1], v[1]);
+        const float ft = (-(kDt * v[2]) - 0.0f) + actuate(ctrl[2], v[2]);
         const float t = b * fx + d * fy;
         const float s2 = b * b + d * d;
         if (kQacc) {
@@ -88,6 +106,9 @@ struct PointRobot {
         q[2] = q[2] + kH * v[2];
     }
 };
+
+using PointRobot = PointRobotT<false>;     // xmls/point.xml as MuJoCo compiles it (class defaults inherited)
+using PointBareRobot = PointRobotT<true>;  // round-1 reading, robot id 4
 
 // ===========================================================================
 // Swimmer (xmls/swimmer.xml): slide-x, slide-y, hinge-z at the head link, two

@@ -32,7 +32,9 @@ class ResamplingError(AssertionError):
 #   nq/nv/nu/z_height as world.py:422-438 reads them from the robot-only MJCF; action bounds =
 #   actuator ctrlrange where ctrllimited, else +-inf, Point keeps its first 2 rows (engine.py:291-297)
 _ROBOTS = {
-    'xmls/point.xml': (0, 3, 3, 3, 0.1, 0.02, (-np.inf, np.inf, 2)),      # point.xml:3,16-18,37-39
+    # point.xml:3,7-8,16-18,37-39: the <general> actuators inherit ctrllimited / ctrlrange +-1 from the class
+    # default (written by <motor>, <velocity>), so actuator_ctrllimited == 1 and the Box is [-1, 1]^2
+    'xmls/point.xml': (0, 3, 3, 3, 0.1, 0.02, (-1.0, 1.0, 2)),
     'xmls/swimmer.xml': (1, 5, 5, 2, 0.03, 0.03, (-1.0, 1.0, 2)),         # swimmer.xml:3,14,58-59
     'xmls/ant.xml': (2, 11, 11, 8, 0.15, 0.09, (-1.0, 1.0, 8)),           # ant.xml:2,7,14,137-146
     'xmls/walker.xml': (3, 13, 13, 10, 0.42, 0.02, (-1.0, 1.0, 10)),      # walker.xml:9,12,99-111
@@ -102,6 +104,10 @@ class Engine:
                     of a global batch of `env_num * world` envs and reproduces exactly
                     the rows an unsharded Engine(env_num*world) would produce
       emit_qacc     fill info['obs']['qacc'] (engine.py:763-764); costs one more output array
+      point_actuators  'mjcf' (default): point.xml's <general> actuators inherit the class defaults the way
+                    MuJoCo compiles them (ctrl clamp +-1, velocity-servo bias, force clamp +-.05, action
+                    space Box(-1, 1)); 'bare': the round-1 reading without the defaults (force = 0.3*ctrl,
+                    unbounded actions) -- see DESIGN.md section 0
     """
 
     # Interface restatement of Engine.DEFAULT (engine.py:98-204): the key set is
@@ -141,9 +147,12 @@ class Engine:
         '_seed': 0,
     }
 
-    def __init__(self, config={}, *, n_candidates=1_000_000, shard=None, emit_qacc=True):
+    def __init__(self, config={}, *, n_candidates=1_000_000, shard=None, emit_qacc=True, point_actuators='mjcf'):
         self._ctor_config = deepcopy(config)
-        self._ctor_kwargs = dict(n_candidates=n_candidates, shard=shard, emit_qacc=emit_qacc)
+        self._ctor_kwargs = dict(n_candidates=n_candidates, shard=shard, emit_qacc=emit_qacc,
+                                 point_actuators=point_actuators)
+        if point_actuators not in ('mjcf', 'bare'):
+            raise ValueError("point_actuators must be 'mjcf' or 'bare'")
         self.parse(config)
         self._h = None
         self._lib = _native.load()
@@ -166,6 +175,8 @@ class Engine:
         if self.robot_rot not in (None, 0, 0.0):
             raise NotImplementedError("robot_rot other than None/0")
         robot_id, nq, nv, nu, z_height, timestep, (act_lo, act_hi, act_dim) = _ROBOTS[self.robot_base]
+        if robot_id == 0 and point_actuators == 'bare':
+            robot_id, act_lo, act_hi = 4, -np.inf, np.inf
         self.robot = type('Robot', (), dict(nq=nq, nv=nv, nu=nu, z_height=z_height))()
 
         if not torch.cuda.is_available():

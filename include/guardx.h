@@ -40,7 +40,9 @@ typedef enum gx_status {
 /* Subset of Engine.DEFAULT (engine.py:98-204) that the hot path reads. */
 typedef struct gx_config {
     int32_t struct_size;        /* sizeof(gx_config) */
-    int32_t robot;              /* 0 point.xml, 1 swimmer.xml, 2 ant.xml, 3 walker.xml ('robot_base' engine.py:113) */
+    int32_t robot;              /* 0 point.xml, 1 swimmer.xml, 2 ant.xml, 3 walker.xml ('robot_base' engine.py:113);
+                                 * 4 point.xml with the actuator class defaults (point.xml:7-8) NOT applied to its
+                                 * <general> actuators -- the round-1 reading, kept selectable */
     int32_t env_num;            /* envs owned by this handle (local shard) */
     int32_t env_total;          /* env_num of the whole batch (== env_num unsharded) */
     int32_t env_offset;         /* global index of local env 0 */

@@ -256,6 +256,15 @@ void gxo_randint(const uint32_t* key, int32_t n, uint32_t span, int32_t* out_n)
 #define PT_DXY 0.01f            /* point.xml:16-17 damping */
 #define PT_DT 0.005f            /* point.xml:18 */
 #define PT_GEAR 0.3f            /* point.xml:37-39 */
+/* Actuator defaults the three <general gear="0.3"> elements inherit (point.xml:7-8,37-39) [derived:
+ * MuJoCo XML reference, default/motor..velocity: "set the attributes of the general element using
+ * Actuator shortcuts ... replacing any previous settings" -- ONE actuator default per class, written
+ * by <motor> and then by <velocity> in document order]: ctrllimited, ctrlrange +-1; forcelimited,
+ * forcerange +-.05; gain fixed 1; bias affine (0, 0, -kv), kv = 1 (velocity servo). */
+#define PT_CTRLLIM 1.0f         /* point.xml:7-8 ctrlrange */
+#define PT_FORCELIM 0.05f       /* point.xml:7-8 forcerange */
+#define PT_KV 1.0f              /* <velocity> without kv: gainprm[0] stays 1, biasprm[2] = -1 */
+#define GXO_ROBOT_POINT_BARE 4  /* round-1 reading kept selectable: general actuators WITHOUT the class defaults */
 
 struct gxo_env {
     gxo_config cfg;
@@ -292,7 +301,7 @@ int gxo_layout_size(const gxo_env* e) { return e->layout_size; }
 int gxo_create(const gxo_config* cfg, gxo_env** out)
 {
     if (!cfg || !out || cfg->struct_size != (int32_t)sizeof(gxo_config)) return GXO_ERR_ARG;
-    if (cfg->robot < 0 || cfg->robot > 3) return GXO_ERR_UNSUPPORTED;
+    if (cfg->robot < 0 || cfg->robot > GXO_ROBOT_POINT_BARE) return GXO_ERR_UNSUPPORTED;
     if (cfg->env_num < 1 || cfg->hazards_num < 1 || cfg->hazards_num > 64) return GXO_ERR_ARG;
     if (cfg->lidar_num_bins < 3 || cfg->lidar_num_bins > 64) return GXO_ERR_ARG;
     if (cfg->env_offset < 0 || cfg->env_offset + cfg->env_num > cfg->env_total) return GXO_ERR_ARG;
@@ -308,7 +317,7 @@ int gxo_create(const gxo_config* cfg, gxo_env** out)
     e->H = cfg->hazards_num;
     e->NOBJ = 1 + e->H;
     e->bins = cfg->lidar_num_bins;
-    if (cfg->robot == 0) { e->nq = 3; e->nv = 3; e->nu = 3; e->na = 2; e->h = PT_H; }   /* point.xml */
+    if (cfg->robot == 0 || cfg->robot == GXO_ROBOT_POINT_BARE) { e->nq = 3; e->nv = 3; e->nu = 3; e->na = 2; e->h = PT_H; } /* point.xml */
     else if (cfg->robot == 1) { e->nq = 5; e->nv = 5; e->nu = 2; e->na = 2; e->h = 0.03f; } /* swimmer.xml */
     else if (cfg->robot == 2) { e->nq = 11; e->nv = 11; e->nu = 8; e->na = 8; e->h = 0.09f; } /* ant.xml */
     else { e->nq = 13; e->nv = 13; e->nu = 10; e->na = 10; e->h = 0.02f; }                 /* walker.xml */
@@ -444,7 +453,19 @@ typedef struct {
 
 /* One mjx.step for the Point robot [derived, SURVEY Appendix B]:
  * forward(qpos,qvel,ctrl) -> pose, qacc ; Euler with implicit joint damping. */
-static void point_substep_s(ptstate* s, const float ctrl[3], float pose[4], float qacc[3])
+static float pt_clip(float x, float lim) { return x < -lim ? -lim : (x > lim ? lim : x); } /* jp.clip: NaN stays */
+
+/* actuator force on one DOF [derived: mjx fwd_actuation]: ctrl clamped to ctrlrange, force = gain*ctrl +
+ * biasprm[2]*velocity with actuator velocity = gear*qvel, clamped to forcerange; qfrc = gear*force */
+static float point_act(float ctrl, float vel, int bare)
+{
+    if (bare) return PT_GEAR * ctrl;
+    const float u = pt_clip(ctrl, PT_CTRLLIM);
+    const float force = pt_clip(u - PT_KV * (PT_GEAR * vel), PT_FORCELIM);
+    return PT_GEAR * force;
+}
+
+static void point_substep_s(ptstate* s, const float ctrl[3], float pose[4], float qacc[3], int bare)
 {
     /* kinematics: hinge quaternion (cos th/2, 0,0, sin th/2) -> xmat */
     float sh, ch;
@@ -456,9 +477,9 @@ static void point_substep_s(ptstate* s, const float ctrl[3], float pose[4], floa
     float b = -(PT_MXC * sn), d = PT_MXC * c;
     float w2 = s->om * s->om;
     /* qfrc_smooth = passive - bias + actuator */
-    float fx = (-(PT_DXY * s->vx) - (-(d * w2))) + PT_GEAR * ctrl[0];
-    float fy = (-(PT_DXY * s->vy) - (b * w2)) + PT_GEAR * ctrl[1];
-    float ft = (-(PT_DT * s->om) - 0.0f) + PT_GEAR * ctrl[2];
+    float fx = (-(PT_DXY * s->vx) - (-(d * w2))) + point_act(ctrl[0], s->vx, bare);
+    float fy = (-(PT_DXY * s->vy) - (b * w2)) + point_act(ctrl[1], s->vy, bare);
+    float ft = (-(PT_DT * s->om) - 0.0f) + point_act(ctrl[2], s->om, bare);
     float t = b * fx + d * fy;
     float s2 = b * b + d * d;
     /* data.qacc = M^-1 f (no damping in M) */
@@ -487,10 +508,10 @@ static void point_substep_s(ptstate* s, const float ctrl[3], float pose[4], floa
     s->th = s->th + PT_H * s->om;
 }
 
-static void point_substep(float q[3], float v[3], const float ctrl[3], float pose[4], float qacc[3])
+static void point_substep(float q[3], float v[3], const float ctrl[3], float pose[4], float qacc[3], int bare)
 {
     ptstate s = {q[0], q[1], q[2], v[0], v[1], v[2]};
-    point_substep_s(&s, ctrl, pose, qacc);
+    point_substep_s(&s, ctrl, pose, qacc, bare);
     q[0] = s.x; q[1] = s.y; q[2] = s.th; v[0] = s.vx; v[1] = s.vy; v[2] = s.om;
 }
 
@@ -698,7 +719,8 @@ void gxo_ant_probe(const float* q, const float* v, const float* ctrl, float* q2,
 /* one mjx.step of the configured robot */
 static void robot_substep(const gxo_env* e, float* q, float* v, const float* ctrl, float pose[4], float* qacc)
 {
-    if (e->cfg.robot == 0) point_substep(q, v, ctrl, pose, qacc);
+    if (e->cfg.robot == 0) point_substep(q, v, ctrl, pose, qacc, 0);
+    else if (e->cfg.robot == GXO_ROBOT_POINT_BARE) point_substep(q, v, ctrl, pose, qacc, 1);
     else if (e->cfg.robot == 1) swimmer_substep(q, v, ctrl, pose, qacc);
     else if (e->cfg.robot == 2) ant_substep(q, v, ctrl, pose, qacc);
     else legs_substep(&LG_WALKER, q, v, ctrl, pose, qacc);
@@ -707,14 +729,14 @@ static void robot_substep(const gxo_env* e, float* q, float* v, const float* ctr
 /* convert_action engine.py:672-685: Point rotates (a0,0,0) by the PRE-step xmat; others pass through */
 static void convert_action(const gxo_env* e, const float pose0[4], const float* a, float* ctrl)
 {
-    if (e->cfg.robot == 0) { ctrl[0] = pose0[2] * a[0]; ctrl[1] = pose0[3] * a[0]; ctrl[2] = a[1]; }
+    if (e->cfg.robot == 0 || e->cfg.robot == GXO_ROBOT_POINT_BARE) { ctrl[0] = pose0[2] * a[0]; ctrl[1] = pose0[3] * a[0]; ctrl[2] = a[1]; }
     else { for (int k = 0; k < e->nu; ++k) ctrl[k] = a[k]; }
 }
 
 /* pose of the robot body from qpos (mjx.forward kinematics), qpos with zero angles */
 static void pose_of_rest(const gxo_env* e, const float* q, float pose[4])
 {
-    if (e->cfg.robot >= 2) { ant_pose(q, pose); return; } /* ant, walker: x slide, z hinge, body-y slide */
+    if (e->cfg.robot == 2 || e->cfg.robot == 3) { ant_pose(q, pose); return; } /* ant, walker: x slide, z hinge, body-y slide */
     float sh, ch;
     gx_sincos(0.5f * q[2], &sh, &ch);
     pose[0] = q[0]; pose[1] = q[1]; pose[2] = ch * ch - sh * sh; pose[3] = 2.0f * (ch * sh);
@@ -791,7 +813,7 @@ static void load_layout(gxo_env* e, int i, const float* lay)
     for (int k = 0; k < e->nv; ++k) v[k] = 0.0f;
     /* robot_x / robot_y joints by NAME (:635-638): qpos 0,1 for point and swimmer, 0,2 for the ant and the walker */
     q[0] = lay[2 * e->NOBJ];
-    q[e->cfg.robot >= 2 ? 2 : 1] = lay[2 * e->NOBJ + 1];
+    q[(e->cfg.robot == 2 || e->cfg.robot == 3) ? 2 : 1] = lay[2 * e->NOBJ + 1];
 }
 
 /* get_layout engine.py:446-452: idx = randint(key, (env_num,), 0, layout_size) */

@@ -27,7 +27,8 @@ extern "C" {
  * checker does not include product headers). */
 typedef struct gxo_config {
     int32_t struct_size;        /* sizeof(gxo_config), ABI check */
-    int32_t robot;              /* 0 = xmls/point.xml, 1 = xmls/swimmer.xml, 2 = xmls/ant.xml, 3 = xmls/walker.xml */
+    int32_t robot;              /* 0 = xmls/point.xml, 1 = xmls/swimmer.xml, 2 = xmls/ant.xml, 3 = xmls/walker.xml,
+                                 * 4 = xmls/point.xml with the round-1 actuator reading (no class defaults) */
     int32_t env_num;            /* envs owned by this instance */
     int32_t env_total;          /* env_num of the whole (possibly sharded) batch */
     int32_t env_offset;         /* global index of local env 0 */

@@ -111,7 +111,21 @@ M, MXC, IO = 0.005188790204786391, 1.0e-4, 2.842182748581224e-05
 H_, DXY, DTH, GEAR = f32(0.02), f32(0.01), f32(0.005), f32(0.3)
 
 
-def point_substep(q, v, ctrl):
+CTRL_LIM, FORCE_LIM, KV = 1.0, 0.05, 1.0      # point.xml:7-8 defaults inherited by the <general> actuators
+
+
+def point_actuation(ctrl, v, bare=False):
+    """qfrc_actuator [derived: one actuator default per class, <motor> then <velocity> write it;
+    mjx fwd_actuation]: gear * clip(clip(ctrl, +-1) - kv * gear * qvel, +-0.05).  bare=True is the
+    round-1 reading (general actuators without the class defaults): gear * ctrl."""
+    g = float(GEAR)
+    if bare:
+        return g * ctrl
+    u = np.clip(ctrl.astype(np.float64), -CTRL_LIM, CTRL_LIM)
+    return g * np.clip(u - KV * (g * v.astype(np.float64)), -FORCE_LIM, FORCE_LIM)
+
+
+def point_substep(q, v, ctrl, bare=False):
     """q,v (N,3) f32; returns pose (N,4), qacc (N,3), q', v'.  [derived] MuJoCo Euler step."""
     th = q[:, 2]
     c, s = np.cos(th, dtype=f32), np.sin(th, dtype=f32)
@@ -125,7 +139,7 @@ def point_substep(q, v, ctrl):
     w2 = v[:, 2].astype(np.float64) ** 2
     bias = np.stack([-MXC * c * w2, -MXC * s * w2, np.zeros(N)], 1)
     damp = np.array([DXY, DXY, DTH], np.float64)
-    f = -damp * v - bias + float(GEAR) * ctrl
+    f = -damp * v - bias + point_actuation(ctrl, v, bare)
     qacc = np.linalg.solve(Mm, f[..., None])[..., 0]
     Mi = Mm + np.eye(3) * (float(H_) * damp)
     qa = np.linalg.solve(Mi, f[..., None])[..., 0]
@@ -173,7 +187,7 @@ def step(state, action, cfg):
     a = action.astype(f32)
     ctrl = np.stack([p0[:, 2] * a[:, 0], p0[:, 3] * a[:, 0], a[:, 1]], 1).astype(f32)
     for _ in range(cfg.get('physics_steps_per_control_step', 1)):
-        pose, qacc, q, v = point_substep(q, v, ctrl)
+        pose, qacc, q, v = point_substep(q, v, ctrl, cfg.get('_point_bare', False))
     bins = cfg.get('lidar_num_bins', 16)
     gl, pos_g = lidar(pose, objs[:, :1], bins)
     hl, pos_h = lidar(pose, objs[:, 1:], bins)

@@ -111,13 +111,15 @@ def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
 
 
-def make_config(config, n_candidates=1_000_000, env_total=None, env_offset=0):
+def make_config(config, n_candidates=1_000_000, env_total=None, env_offset=0, point_actuators='mjcf'):
     cfg = dict(DEFAULTS)
     cfg.update({k: v for k, v in config.items() if k in DEFAULTS})
     c = Config()
     c.struct_size = C.sizeof(Config)
     base = cfg['robot_base']
     c.robot = {'xmls/point.xml': 0, 'xmls/swimmer.xml': 1, 'xmls/ant.xml': 2, 'xmls/walker.xml': 3}.get(base, 99)
+    if c.robot == 0 and point_actuators == 'bare':
+        c.robot = 4          # round-1 reading of point.xml:37-39 (no class defaults), kept selectable
     c.env_num = int(cfg['env_num'])
     c.env_total = int(env_total if env_total is not None else cfg['env_num'])
     c.env_offset = int(env_offset)
@@ -169,9 +171,9 @@ def make_config(config, n_candidates=1_000_000, env_total=None, env_offset=0):
 class OracleEngine:
     """numpy-facing mirror of Engine.reset/step/reset_done backed by the C restatement."""
 
-    def __init__(self, config, n_candidates=1_000_000, env_total=None, env_offset=0):
+    def __init__(self, config, n_candidates=1_000_000, env_total=None, env_offset=0, point_actuators='mjcf'):
         self.L = lib()
-        self.cfg = make_config(config, n_candidates, env_total, env_offset)
+        self.cfg = make_config(config, n_candidates, env_total, env_offset, point_actuators)
         h = C.c_void_p()
         rc = self.L.gxo_create(C.byref(self.cfg), C.byref(h))
         if rc != 0:

@@ -29,8 +29,8 @@ def _engines(cfg, oracle, n_candidates=20000, path=None, **kw):
     E = Engine(cfg, n_candidates=n_candidates, **kw)
     if path is not None:
         E.set_path(PATHS[path])
-    O = oracle.OracleEngine(cfg, n_candidates=n_candidates,
-                            env_total=E._cfg.env_total, env_offset=E._cfg.env_offset)
+    O = oracle.OracleEngine(cfg, n_candidates=n_candidates, env_total=E._cfg.env_total,
+                            env_offset=E._cfg.env_offset, point_actuators=kw.get('point_actuators', 'mjcf'))
     return E, O
 
 
@@ -97,17 +97,51 @@ def test_device_split_matches_oracle(torch_cuda, oracle):
 def test_step_parity_random_states(torch_cuda, oracle, N, path):
     torch = torch_cuda
     E, O = _engines(task_config(N, seed=3), oracle, path=path)
+    assert float(E.action_space.low[0]) == -1.0 and float(E.action_space.high[1]) == 1.0   # ctrllimited, engine.py:291-297
     rng = np.random.default_rng(N)
     for trial in range(3):
         s = random_state(N, 8, rng)
         s['hist'] = [2, 1, 0][trial]
+        # actions beyond the ctrl range (clamped for the force only) and, for a third of the envs, small
+        # speeds and actions so that the actuator force is NOT saturated at +-.05 (velocity-servo regime)
+        act = rng.uniform(-1.6, 1.6, (N, 2)).astype(np.float32)
+        s['qvel'][::3] *= np.float32(0.03)
+        act[::3] *= np.float32(0.03)
         E.set_state(s)
         O.set_state(s)
-        act = rng.uniform(-1, 1, (N, 2)).astype(np.float32)
         out_g = E.step(torch.from_numpy(act).cuda())
         out_o = O.step(act)
         _cmp_step(out_g, out_o)
         assert_state_equal(E.get_state(), O.get_state())
+
+
+@pytest.mark.parametrize("path", ["thread", "group"])
+def test_point_bare_actuator_model_parity(torch_cuda, oracle, path):
+    """the round-1 reading of point.xml's actuators (no class defaults) stays selectable and bit exact"""
+    torch = torch_cuda
+    N, T = 300, 40
+    E, O = _engines(task_config(N, seed=4, num_steps=30, goal_size=0.9), oracle, path=path, point_actuators='bare')
+    assert np.isinf(E.action_space.low).all() and np.isinf(E.action_space.high).all()
+    np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
+    rng = np.random.default_rng(2)
+    for t in range(10):
+        act = rng.uniform(-1.6, 1.6, (N, 2)).astype(np.float32)
+        _cmp_step(E.step(torch.from_numpy(act).cuda()), O.step(act))
+        np.testing.assert_array_equal(E.reset_done().cpu().numpy(), O.reset_done())
+    acts = rng.uniform(-1, 1, (T, N, 2)).astype(np.float32)
+    obs, rew, cost, done = E.rollout(torch.from_numpy(acts).cuda())
+    for t in range(T):
+        o, r, d, info = O.step(acts[t])
+        np.testing.assert_array_equal(obs[t].cpu().numpy(), O.reset_done())
+        np.testing.assert_array_equal(rew[t].cpu().numpy(), r)
+        np.testing.assert_array_equal(done[t].cpu().numpy(), d)
+    assert_state_equal(E.get_state(), O.get_state())
+    # and it is a different model: the default engine disagrees after one unclamped push
+    E2, _ = _engines(task_config(N, seed=4, num_steps=30, goal_size=0.9), oracle, path=path)
+    E2.reset()
+    E.reset()
+    a = torch.ones(N, 2, device='cuda')
+    assert not torch.equal(E.step(a)[0], E2.step(a)[0])
 
 
 @pytest.mark.parametrize("path", ["thread", "group"])

@@ -45,7 +45,8 @@ ANT_NAMES = {'H': 'kH', 'A': 'kA', 'A2': 'kA2', 'L': 'kL', 'RF': 'kRf', 'Z0': 'k
 SWIM_NAMES = {'H': 'kH', 'M': 'kM', 'IC': 'kIc', 'ARM': 'kArm', 'GEAR': 'kGear', 'LIM': 'kLim', 'INVW2': 'kInvW2',
               'INVW3': 'kInvW3', 'K': 'kK', 'B': 'kB', 'A11': 'A11', 'A21': 'A21', 'A22': 'A22', 'A31': 'A31',
               'A32': 'A32', 'A33': 'A33'}
-POINT_NAMES = {'H': 'kH', 'MXC': 'kMxc', 'IO': 'kIo', 'DXY': 'kDxy', 'DT': 'kDt', 'GEAR': 'kGear'}
+POINT_NAMES = {'H': 'kH', 'MXC': 'kMxc', 'IO': 'kIo', 'DXY': 'kDxy', 'DT': 'kDt', 'GEAR': 'kGear', 'CTRLLIM': 'kCtrlLim',
+               'FORCELIM': 'kForceLim', 'KV': 'kKv'}
 
 
 def _same_f32(a, b):
@@ -85,7 +86,7 @@ def test_headers_match_the_mjcf_files():
             if name in hip:
                 assert abs(hip[name] - val) <= 2e-7 * abs(val) + 1e-30, (robot, name, hip[name], val)
                 checked += 1
-        assert checked >= {"point": 5, "swimmer": 14, "ant": 27}[robot], (robot, checked)
+        assert checked >= {"point": 8, "swimmer": 14, "ant": 27}[robot], (robot, checked)
     # Point: the mass enters through literal expressions
     txt = _struct_text(os.path.join(ROOT, "guardx_amd/csrc/gx_robot.h"), "PointRobot")
     assert "0.005188790204786391" in txt and abs(0.005188790204786391 - derived['point']['kM']) < 1e-17
@@ -125,3 +126,73 @@ def test_walker_tables_match_the_mjcf_file():
     np.testing.assert_allclose(pm.dof_invweight0, hm.dof_invweight0, rtol=1e-10)
     q = np.random.default_rng(0).uniform(-0.5, 0.5, 13)
     np.testing.assert_allclose(pm.mass_matrix(q), hm.mass_matrix(q), rtol=1e-10, atol=1e-16)
+
+
+SYNTH_MJCF = """<mujoco>
+  <default>
+    <joint damping="0.5"/>
+    <motor ctrlrange="-2 2" ctrllimited="true" forcerange="-3 3" forcelimited="true" gear="7"/>
+    <position kp="4" ctrlrange="-1 1"/>
+  </default>
+  <worldbody>
+    <body name="b" pos="0 0 1">
+      <joint name="j0" type="slide" axis="1 0 0"/>
+      <joint name="j1" type="hinge" axis="0 0 1"/>
+      <geom type="sphere" size="0.1"/>
+    </body>
+  </worldbody>
+  <actuator>
+    <general joint="j0" gear="0.5"/>
+    <motor joint="j1"/>
+    <velocity joint="j1" kv="9" forcelimited="false"/>
+    <general joint="j0" biastype="none" gainprm="2"/>
+  </actuator>
+</mujoco>"""
+
+
+def test_actuator_default_class_resolution(tmp_path):
+    """MuJoCo keeps ONE actuator default per class; the shortcut children of <default> write it in
+    document order and <general> inherits whatever it does not set (XML reference, default/motor ..
+    default/velocity) -- the rule that decides point.xml's actuators.  Synthetic file, written here."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from mjcf_model import Model
+    f = tmp_path / "synth.xml"
+    f.write_text(SYNTH_MJCF)
+    m = Model(str(f))
+    d = m.actuator_default          # <motor> wrote the limits and gear, <position> then gain/bias and ctrlrange
+    assert d['gear'] == 7 and d['ctrllimited'] is True and list(d['ctrlrange']) == [-1, 1]
+    assert d['forcelimited'] is True and list(d['forcerange']) == [-3, 3]
+    assert d['biastype'] == 'affine' and list(d['biasprm']) == [0, -4, 0] and d['gainprm'][0] == 4
+    g, mo, ve, g2 = m.actuators
+    assert g['gear'] == 0.5 and g['biastype'] == 'affine' and list(g['biasprm']) == [0, -4, 0] and g['gainprm'][0] == 4
+    assert g['ctrllimited'] is True and g['forcelimited'] is True and list(g['forcerange']) == [-3, 3]
+    assert mo['gear'] == 7 and mo['biastype'] == 'none' and mo['gainprm'][0] == 1 and list(mo['biasprm']) == [0, 0, 0]
+    assert ve['biastype'] == 'affine' and list(ve['biasprm']) == [0, 0, -9] and ve['gainprm'][0] == 9
+    assert ve['forcelimited'] is False and ve['ctrllimited'] is True
+    assert g2['biastype'] == 'none' and g2['gainprm'][0] == 2 and list(g2['biasprm']) == [0, -4, 0]
+
+
+@pytest.mark.skipif(not os.path.isdir(XML_DIR), reason="robot MJCF files (reference checkout) not present")
+def test_point_actuators_resolve_to_the_limited_velocity_servo():
+    """point.xml:4-10,37-39: the <general gear=.3> actuators inherit ctrlrange +-1, forcerange +-.05 and
+    the affine bias (0, 0, -1) of <velocity>; Engine.action_space follows actuator_ctrllimited
+    (engine.py:291-297).  The other robots' <motor> actuators carry no bias and no force limit."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from mjcf_model import Model
+    m = Model(os.path.join(XML_DIR, "point.xml"))
+    assert len(m.actuators) == 3
+    for a in m.actuators:
+        assert a['kind'] == 'general' and a['gear'] == 0.3
+        assert a['ctrllimited'] is True and list(a['ctrlrange']) == [-1, 1]
+        assert a['forcelimited'] is True and list(a['forcerange']) == [-0.05, 0.05]
+        assert a['gaintype'] == 'fixed' and a['gainprm'][0] == 1
+        assert a['biastype'] == 'affine' and list(a['biasprm']) == [0, 0, -1]
+    from guardx_amd.engine import _ROBOTS
+    for xml, nu in (("point.xml", 2), ("swimmer.xml", 2), ("ant.xml", 8), ("walker.xml", 10)):
+        mm = Model(os.path.join(XML_DIR, xml))
+        lo, hi, dim = _ROBOTS['xmls/' + xml][6]
+        assert dim == nu
+        for a in mm.actuators[:nu]:
+            assert a['ctrllimited'] is True and (lo, hi) == tuple(a['ctrlrange'])
+        if xml != "point.xml":
+            assert all(a['biastype'] == 'none' and a['forcelimited'] is False for a in mm.actuators)

@@ -117,7 +117,7 @@ def test_action_rotated_by_prestep_heading(oracle):
     E.set_state(s)
     obs, *_ = E.step(np.tile(np.array([1.0, 0.0], f32), (4, 1)))
     np.testing.assert_allclose(obs[0, 0:3], [0.0, 1.0, 0.0], atol=1e-7)
-    assert abs(obs[0, 40]) < 1e-3 and obs[0, 41] > 0.5        # pushed along world y
+    assert abs(obs[0, 40]) < 1e-3 and obs[0, 41] > 0.05       # pushed along world y (force-limited: .3*.05 N)
 
 
 def test_cost_dense_sum(oracle):
@@ -205,11 +205,91 @@ def test_nan_guard(oracle):
     assert np.isnan(obs[1]).any() and not np.isfinite(obs[2]).all()
 
 
-def test_point_dynamics_limits(oracle):
-    """terminal velocity = gear*ctrl/damping = 0.3/0.01 = 30 m/s; per-step decay m/(m+h d)."""
+def _bare_engine(oracle, N=4):
+    E = oracle.OracleEngine(task_config(N), n_candidates=6000, point_actuators='bare')
+    E.reset(check=False)
+    return E
+
+
+M_PT = 0.005188790204786391        # point.xml:5,19-20 (sphere + box, density 1)
+I_C = 2.842182748581224e-05 - 1e-4 ** 2 / M_PT
+
+
+def test_point_actuators_inherit_the_class_defaults(oracle):
+    """point.xml:7-8,37-39 [derived, DESIGN section 0]: qfrc = gear*clip(clip(ctrl,+-1) - gear*qvel, +-.05),
+    data.qacc = M^-1 f has no implicit damping."""
     E = _engine(oracle)
+    # (a) force saturation from rest: any |ctrl| > .05 gives the same first-step acceleration .3*.05/m
+    for a0 in (0.06, 0.5, 1.0, 7.0):
+        E.set_state(_still_state(4))
+        _, _, _, info = E.step(np.tile(np.array([a0, 0.0], f32), (4, 1)))
+        assert info['qacc'][0, 0] == pytest.approx(0.3 * 0.05 / M_PT, rel=1e-5)
+    # (b) below saturation the force is gear*ctrl: ctrl = .04 -> qacc = .3*.04/m ; hinge: .3*.04/I_c
+    E.set_state(_still_state(4))
+    _, _, _, info = E.step(np.tile(np.array([0.04, 0.04], f32), (4, 1)))
+    assert info['qacc'][0, 0] == pytest.approx(0.3 * 0.04 / M_PT, rel=1e-5)
+    assert info['qacc'][0, 2] == pytest.approx(0.3 * 0.04 / I_C, rel=1e-5)
+    # (c) velocity-servo bias: moving at v with ctrl = gear*v the actuator force vanishes and only the
+    #     joint damping acts: qacc = -d*v/m
     s = _still_state(4)
+    s['qvel'][:, 0] = 0.1
     E.set_state(s)
+    _, _, _, info = E.step(np.tile(np.array([0.03, 0.0], f32), (4, 1)))
+    assert info['qacc'][0, 0] == pytest.approx(-0.01 * 0.1 / M_PT, rel=1e-4)
+    #     and with ctrl = 0 the servo brakes: force = clip(-.3*v, +-.05) -> qacc = (-.3*.03 - .01*.1)/m
+    E.set_state(s)
+    _, _, _, info = E.step(np.zeros((4, 2), f32))
+    assert info['qacc'][0, 0] == pytest.approx((-0.3 * 0.03 - 0.01 * 0.1) / M_PT, rel=1e-4)
+    # (d) ctrl is clamped for the force only; the observation carries the raw converted ctrl
+    E.set_state(_still_state(4))
+    obs, *_ = E.step(np.tile(np.array([7.0, -9.0], f32), (4, 1)))
+    np.testing.assert_array_equal(obs[0, 0:3], [7.0, 0.0, -9.0])
+
+
+def test_point_terminal_speed(oracle):
+    """terminal speed = gear*forcerange/damping = .3*.05/.01 = 1.5 m/s (3 rad/s on the hinge:
+    .3*.05/.005); per-step decay of a coasting robot m/(m+h d) needs ctrl = gear*v (servo off)."""
+    E = _engine(oracle)
+    E.set_state(_still_state(4))
+    for _ in range(400):
+        obs, *_ = E.step(np.tile(np.array([1.0, 0.0], f32), (4, 1)))
+    assert obs[0, 40] == pytest.approx(1.5, rel=2e-3)
+    E.set_state(_still_state(4))
+    for _ in range(400):
+        obs, *_ = E.step(np.tile(np.array([0.0, 1.0], f32), (4, 1)))
+    assert obs[0, 42] == pytest.approx(3.0, rel=2e-3)
+    s = _still_state(4)
+    s['qvel'][:, 0] = 0.1
+    E.set_state(s)
+    obs, *_ = E.step(np.tile(np.array([0.03, 0.0], f32), (4, 1)))
+    assert obs[0, 40] == pytest.approx(0.1 * M_PT / (M_PT + 0.02 * 0.01), rel=1e-5)
+
+
+def test_point_stays_in_the_arena_under_random_actions(oracle):
+    """plausibility: under U(-1,1) actions the robot must not leave the 4 m arena
+    as a matter of course; with the inherited limits the speed never exceeds 1.5*sqrt(2)."""
+    N = 500
+    E = oracle.OracleEngine(task_config(N, num_steps=200), n_candidates=40000)
+    E.reset()
+    rng = np.random.default_rng(0)
+    outside = total = 0
+    vmax = 0.0
+    for _ in range(200):
+        obs, _, d, _ = E.step(rng.uniform(-1, 1, (N, 2)).astype(f32))
+        outside += int((np.abs(obs[:, 37:39]) > 2.0).any(axis=1).sum())
+        total += N
+        vmax = max(vmax, float(np.linalg.norm(obs[:, 40:42], axis=1).max()))
+        if d.any():
+            E.reset_done()
+    assert outside / total < 0.03
+    assert vmax <= 1.5 * np.sqrt(2) + 1e-3
+
+
+def test_point_bare_model_is_still_selectable(oracle):
+    """the round-1 reading (no class defaults): terminal velocity gear*ctrl/damping = 30 m/s, first-step
+    angular acceleration .3/I_c."""
+    E = _bare_engine(oracle)
+    E.set_state(_still_state(4))
     for _ in range(400):
         obs, *_ = E.step(np.tile(np.array([1.0, 0.0], f32), (4, 1)))
     assert obs[0, 40] == pytest.approx(30.0, rel=2e-3)
@@ -217,14 +297,10 @@ def test_point_dynamics_limits(oracle):
     s['qvel'][:, 0] = 1.0
     E.set_state(s)
     obs, *_ = E.step(np.zeros((4, 2), f32))
-    m = 0.005188790204786391
-    assert obs[0, 40] == pytest.approx(m / (m + 0.02 * 0.01), rel=1e-5)
-    # first-step angular acceleration: qacc_z = 0.3 / Izz' (data.qacc has no implicit damping)
-    s = _still_state(4)
-    E.set_state(s)
+    assert obs[0, 40] == pytest.approx(M_PT / (M_PT + 0.02 * 0.01), rel=1e-5)
+    E.set_state(_still_state(4))
     _, _, _, info = E.step(np.tile(np.array([0.0, 1.0], f32), (4, 1)))
-    I_c = 2.842182748581224e-05 - 1e-4 ** 2 / m
-    assert info['qacc'][0, 2] == pytest.approx(0.3 / I_c, rel=1e-5)
+    assert info['qacc'][0, 2] == pytest.approx(0.3 / I_C, rel=1e-5)
 
 
 def test_reset_layout_constraints_and_key_use(oracle):

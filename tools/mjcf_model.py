@@ -9,7 +9,13 @@ without `mujoco`, the quantities MuJoCo's compiler and mj_setConst would hand to
   * joint tables: axis, damping, armature, stiffness, range (degrees -> radians), limited
   * M(qpos0) by summing m Jp'Jp + Jr' I Jr over bodies (+ armature), dof_invweight0 = diag(M^-1),
     body_invweight0 = (tr(Jp M^-1 Jp')/3, tr(Jr M^-1 Jr')/3) at each body's centre of mass
-  * option timestep, actuator gear / ctrlrange, geom margin / friction, contact-capable geoms
+  * option timestep, geom margin / friction, contact-capable geoms
+  * actuators with MuJoCo's default-class resolution: a class holds ONE actuator default; the
+    <general>/<motor>/<position>/<velocity> children of <default> all write it, in document order
+    (XML reference, default/motor .. default/velocity: "set the attributes of the general element
+    using Actuator shortcuts"); an actuator element starts from that default and applies its own tag
+    the same way.  Result per actuator: gear, ctrllimited/ctrlrange, forcelimited/forcerange,
+    gaintype/gainprm, biastype/biasprm -- what mjx fwd_actuation reads
 
 [derived]: MuJoCo XML reference + computation chapter (kinematics: the joints of one body are applied
 in order, each in the frame left by the previous one).  Used at development time only:
@@ -23,6 +29,7 @@ import xml.etree.ElementTree as ET
 import numpy as np
 
 DEG = np.pi / 180.0
+ACTUATOR_TAGS = ('general', 'motor', 'position', 'velocity')
 
 
 def _vec(s, n=None, default=None):
@@ -54,14 +61,63 @@ class Model:
             self.bodies[0]['geoms'].append(self._geom(g))
         for b in wb.findall('body'):
             self._body(b, 0)
+        # ---- actuators: one default per class, shortcuts overwrite it in document order ----------
+        act_default = self._new_actuator()
+        for el in (list(dflt) if dflt is not None else []):
+            if el.tag in ACTUATOR_TAGS:
+                self._apply_actuator(act_default, el)
+        self.actuator_default = act_default
         self.actuators = []
         act = root.find('actuator')
         for a in (list(act) if act is not None else []):
-            at = dict(self.dflt.get(a.tag, {})); at.update(a.attrib)
-            self.actuators.append(dict(kind=a.tag, joint=at.get('joint'), gear=_vec(at.get('gear'), default=[1.0])[0],
-                                       ctrllimited=at.get('ctrllimited', 'false') == 'true',
-                                       ctrlrange=_vec(at.get('ctrlrange'), 2, default=[0, 0])))
+            d = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in act_default.items()}
+            self._apply_actuator(d, a)
+            d.update(kind=a.tag, joint=a.get('joint'), name=a.get('name'))
+            # autolimits (MuJoCo >= 2.3 default): "auto" means limited iff a range was given
+            for lim, rng in (('ctrllimited', 'ctrlrange'), ('forcelimited', 'forcerange')):
+                if d[lim] == 'auto':
+                    d[lim] = bool(d[rng][0] != 0 or d[rng][1] != 0)
+            self.actuators.append(d)
         self._compile()
+
+    @staticmethod
+    def _new_actuator():
+        """mjs_defaultActuator: fixed gain 1, no bias, gear 1, limits "auto" with empty ranges"""
+        return dict(gear=1.0, ctrllimited='auto', forcelimited='auto', ctrlrange=np.zeros(2), forcerange=np.zeros(2),
+                    gaintype='fixed', biastype='none', gainprm=np.array([1.0, 0, 0]), biasprm=np.zeros(3))
+
+    @staticmethod
+    def _apply_actuator(d, el):
+        """mjXReader::OneActuator: common attributes, then the tag's own rule"""
+        at = el.attrib
+        for lim in ('ctrllimited', 'forcelimited'):
+            if lim in at:
+                d[lim] = {'true': True, 'false': False, 'auto': 'auto'}[at[lim]]
+        for rng in ('ctrlrange', 'forcerange'):
+            if rng in at:
+                d[rng] = _vec(at[rng], 2)
+        if 'gear' in at:
+            d['gear'] = _vec(at['gear'])[0]
+        if el.tag == 'general':                        # explicit attributes only
+            for k in ('gaintype', 'biastype'):
+                if k in at:
+                    d[k] = at[k]
+            for k in ('gainprm', 'biasprm'):
+                if k in at:
+                    v = _vec(at[k]); d[k] = np.concatenate([v, np.zeros(3)])[:3]
+        elif el.tag == 'motor':                        # direct drive: fixed gain 1, no bias
+            d.update(gaintype='fixed', biastype='none', biasprm=np.zeros(3))
+            d['gainprm'] = d['gainprm'].copy(); d['gainprm'][0] = 1.0
+        elif el.tag == 'position':                     # kp (default: the gain already there)
+            kp = float(at['kp']) if 'kp' in at else d['gainprm'][0]
+            d.update(gaintype='fixed', biastype='affine', biasprm=np.array([0.0, -kp, 0.0]))
+            d['gainprm'] = d['gainprm'].copy(); d['gainprm'][0] = kp
+        elif el.tag == 'velocity':                     # kv (default: the gain already there)
+            kv = float(at['kv']) if 'kv' in at else d['gainprm'][0]
+            d.update(gaintype='fixed', biastype='affine', biasprm=np.array([0.0, 0.0, -kv]))
+            d['gainprm'] = d['gainprm'].copy(); d['gainprm'][0] = kv
+        else:
+            raise NotImplementedError("actuator shortcut <%s>" % el.tag)
 
     # ---- parsing -------------------------------------------------------------------------
     def _attr(self, kind, el):
@@ -213,8 +269,11 @@ class Model:
                     None if j['range'] is None else ["%.17g" % x for x in j['range']]))
         out.append("dof_invweight0 " + " ".join("%.17g" % x for x in self.dof_invweight0))
         for a in self.actuators:
-            out.append("actuator %-8s joint %-12s gear %g ctrllimited %s ctrlrange %s" % (
-                a['kind'], a['joint'], a['gear'], a['ctrllimited'], a['ctrlrange'].tolist()))
+            out.append("actuator %-8s joint %-12s gear %g ctrllimited %s ctrlrange %s forcelimited %s forcerange %s "
+                       "gain %s %s bias %s %s" % (
+                           a['kind'], a['joint'], a['gear'], a['ctrllimited'], a['ctrlrange'].tolist(), a['forcelimited'],
+                           a['forcerange'].tolist(), a['gaintype'], a['gainprm'].tolist(), a['biastype'],
+                           a['biasprm'].tolist()))
         return "\n".join(out)
 
 

@@ -33,13 +33,31 @@ def point(m):
     io = m.inertia[r][2, 2] + mass * (m.ipos[r][0] ** 2 + m.ipos[r][1] ** 2)
     d = [j['damping'] for j in m.dof_joint]
     h = m.timestep
-    return dict(kH=h, kM=mass, kMxc=mass * m.ipos[r][0], kIo=io, kDxy=d[0], kDt=d[2], kGear=m.actuators[0]['gear'],
-                kInvM=1 / mass, kInvA=1 / (mass + h * d[0]), kEi=io + h * d[2])
+    a = m.actuators[0]
+    # the three <general> actuators resolve identically (same class default, same attributes)
+    assert all(_same_actuator(a, b) for b in m.actuators[1:])
+    assert a['ctrllimited'] is True and a['forcelimited'] is True and a['gaintype'] == 'fixed' and a['biastype'] == 'affine'
+    assert a['gainprm'][0] == 1.0 and a['biasprm'][0] == 0.0 and a['biasprm'][1] == 0.0
+    return dict(kH=h, kM=mass, kMxc=mass * m.ipos[r][0], kIo=io, kDxy=d[0], kDt=d[2], kGear=a['gear'],
+                kInvM=1 / mass, kInvA=1 / (mass + h * d[0]), kEi=io + h * d[2],
+                kCtrlLim=a['ctrlrange'][1], kForceLim=a['forcerange'][1], kKv=-a['biasprm'][2])
+
+
+def _same_actuator(a, b):
+    return all(np.array_equal(a[k], b[k]) for k in ('gear', 'ctrllimited', 'forcelimited', 'ctrlrange', 'forcerange',
+                                                    'gaintype', 'biastype', 'gainprm', 'biasprm'))
+
+
+def _plain_motor(a):
+    """<motor ctrllimited ctrlrange=+-1>: fixed gain 1, no bias, no force limit"""
+    return (a['gaintype'] == 'fixed' and a['biastype'] == 'none' and a['gainprm'][0] == 1.0 and a['ctrllimited'] is True
+            and list(a['ctrlrange']) == [-1.0, 1.0] and a['forcelimited'] is False)
 
 
 def swimmer(m):
     links = [m.body('robot'), m.body('mid'), m.body('back')]
     k, b = _kb(m.timestep)
+    assert all(_plain_motor(a) for a in m.actuators)
     out = dict(kH=m.timestep, kM=m.mass[links[0]], kIc=m.inertia[links[0]][2, 2], kArm=m.dof_joint[0]['armature'],
                kGear=m.actuators[0]['gear'], kLim=m.dof_joint[3]['range'][1],
                kInvW2=m.dof_invweight0[3], kInvW3=m.dof_invweight0[4], kK=k, kB=b)
@@ -66,6 +84,7 @@ def ant(m):
     mu = max(foot['friction'][0], m.bodies[0]['geoms'][0]['friction'][0])
     t = m.body_invweight0[ank, 0]
     hip, ankle = m.dof_joint[3], m.dof_joint[4]
+    assert all(_plain_motor(x) for x in m.actuators)
     return dict(kH=m.timestep, kA=a, kA2=a / 2, kL=length, kRf=foot['size'][0], kZ0=m.bodies[robot]['pos'][2],
                 kMargin=max(foot['margin'], m.bodies[0]['geoms'][0]['margin']), kMu=mu,
                 kMB=mb, kIB=ib, kMA=m.mass[aux], kITA=m.inertia[aux][2, 2], kMK=m.mass[ank], kLC=lc,
