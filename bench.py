@@ -2,19 +2,26 @@
 """Headline benchmark: env-steps/sec of the GUARD batched environment step,
 Goal_Point_8Hazards, env_num=2000 per GPU, random-policy rollout (BASELINE.json).
 
-A "step" is one pass of the hot path over the batch: Engine.step for all envs plus
-reset_done for the envs that finished (device-side done test; identical results to
-the learner's `if done.any(): reset_done()`), with reset() every `max_ep_len`=200
-steps.  Inputs (the action tape) are resident in HBM before the
-timed region.  Prints ONE JSON line on rank 0.
+One bench "step" (--steps K, --warmup W) is ONE EPOCH of the hot path over the batch: reset()
+(the reference's 1e6-candidate layout resampling, engine.py:433-467) followed by max_ep_len = 200
+passes of Engine.step for all envs + reset_done for the envs that finished (device-side done test;
+identical results to the learner's `if done.any(): reset_done()`), SURVEY.md section 8d.  So
+`--steps 20 --warmup 5` times 20 epochs = 4000 step passes = 8 M env-steps per GPU after 5 warm-up
+epochs.  `value` = env_num * 200 * K * n_gpus / wall.  Inputs (the action tapes) are resident in HBM
+before the timed region.  Prints ONE JSON line on rank 0.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+`python bench.py --gpus N` with no WORLD_SIZE in the environment starts the N rank processes itself
+(fresh children, spawned before this process touches the GPU) and fails if fewer than N join.
 """
 import argparse
 import json
 import os
 import sys
+import socket
+import subprocess
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -52,28 +59,41 @@ def action_tape(T, N, seed, device, act_dim=2):
 class RolloutHandoff:
     """Per-epoch hand-off of the rollout shard to the learner: ONE all-gather of the packed
     (T, N, obs+act+3) shard per epoch (RCCL over xGMI), issued asynchronously so that it overlaps
-    the next epoch's stepping; two packed/gathered buffer pairs are kept in flight."""
+    the next epochs' stepping.  The rollout kernel writes the packed layout itself (gx_rollout_packed),
+    so there is no pack pass; `depth` gathered buffers are in flight.  On the gloo rehearsal backend
+    (several ranks on one GPU, no RCCL) the shard is staged through pinned host memory."""
 
-    def __init__(self, world, depth=2):
+    def __init__(self, world, depth=3):
+        import torch.distributed as dist
         self.world = world
         self.depth = depth
-        self.slots = [None] * depth
+        self.slots = [None] * depth        # (work, packed, gathered)
         self.k = 0
         self.bytes = 0
+        self.host = dist.get_backend() != "nccl"
 
-    def submit(self, obs, acts, rew, cost, done):
-        import torch.distributed as dist
-        from guardx_amd import dist as gxd
+    def out_buffer(self, shape, device):
+        """the gathered buffer of the slot about to be used (waits for its previous collective)"""
         i = self.k % self.depth
+        s = self.slots[i]
+        if s is not None:
+            s[0].wait()
+            if tuple(s[2].shape[1:]) == tuple(shape):
+                return s[2]
+        dev = "cpu" if self.host else device
+        return torch.empty((self.world,) + tuple(shape), dtype=torch.float32, device=dev,
+                           pin_memory=self.host)
+
+    def submit(self, packed):
+        import torch.distributed as dist
+        i = self.k % self.depth
+        out = self.out_buffer(packed.shape, packed.device)
         self.k += 1
-        if self.slots[i] is not None:           # buffer pair about to be reused
-            self.slots[i][0].wait()
-        packed = gxd.pack_rollout(obs, acts, rew, cost, done)
         T = packed.shape[0]
-        prev = self.slots[i]
-        out = prev[2] if prev is not None and prev[2].shape[1] == T else \
-            torch.empty((self.world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
-        work = dist.all_gather_into_tensor(out.view((self.world * T,) + tuple(packed.shape[1:])), packed,
+        src = packed
+        if self.host:
+            src = packed.to("cpu")          # rehearsal only
+        work = dist.all_gather_into_tensor(out.view((self.world * T,) + tuple(packed.shape[1:])), src,
                                            async_op=True)
         self.slots[i] = (work, packed, out)
         self.bytes += packed.numel() * 4 * self.world
@@ -84,19 +104,15 @@ class RolloutHandoff:
                 s[0].wait()
 
 
-def run_epochs(env, tapes, steps, handoff):
-    """`steps` hot-path passes = steps/EP_LEN epochs of reset() + fused rollout (+ hand-off)."""
-    done_steps = 0
-    ep = 0
-    while done_steps < steps:
-        T = min(EP_LEN, steps - done_steps)
+def run_epochs(env, tapes, epochs, handoff):
+    """`epochs` bench steps: reset() + one fused 200-pass rollout each (+ the async hand-off)."""
+    for ep in range(epochs):
         env.reset(check=False)           # the layout_size assert is checked once after the loop
-        acts = tapes[ep % len(tapes)][:T]
-        obs, rew, cost, done = env.rollout(acts)
+        acts = tapes[ep % len(tapes)]
         if handoff is not None:
-            handoff.submit(obs, acts, rew, cost, done)
-        done_steps += T
-        ep += 1
+            handoff.submit(env.rollout(acts, packed=True)[4])
+        else:
+            env.rollout(acts)
     if handoff is not None:
         handoff.drain()
     env.check_layouts()                  # engine.py:444 for every reset above (one sync)
@@ -164,8 +180,9 @@ def roofline_rollout(env_num, T, nlaunch, device):
     return {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 6),
             "traffic": round((2 * 6612.375 + 78236.094) * 1024 / 1e9 * (env_num * T) / (2000 * 200), 4),
-            "traffic_note": "GB per launch from rocprofv3 PMC at env_num=2000, T=200: 2*FETCH_SIZE + WRITE_SIZE = "
-                            "13.5 MB + 80.1 MB (profiles/r01_rollout_N2000_T200_pmc_*.csv); below the 148.8 MB "
+            "traffic_note": "NOT measured in this run: GB per launch from the committed rocprofv3 PMC passes at "
+                            "env_num=2000, T=200: 2*FETCH_SIZE + WRITE_SIZE = 13.5 MB + 80.1 MB "
+                            "(profiles/r01_rollout_N2000_T200_pmc_*.csv); below the 148.8 MB "
                             "algorithmic figure because state and layout stay in registers across the 200 steps",
             "kernel": "gx::group_rollout_kernel<1,1,false,true>", "env_num": env_num, "steps_per_launch": T,
             "avg_launch_us": round(t * 1e6, 3), "event_pair_us": round(per * 1e6, 3),
@@ -198,8 +215,8 @@ def roofline_step(env_num, nlaunch, device):
     return {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 6),
             "traffic": round(380 * env_num / 1e9, 4),
-            "traffic_note": "GB per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE = 380 B/env, "
-                            "profiles/r01_step_N4194304_pmc_*.csv)",
+            "traffic_note": "NOT measured in this run: GB per launch from the committed rocprofv3 PMC passes "
+                            "(2*FETCH_SIZE + WRITE_SIZE = 380 B/env, profiles/r01_step_N4194304_pmc_*.csv)",
             "kernel": "gx::step_kernel<256,5,true>", "env_num": env_num,
             "avg_launch_us": round(t * 1e6, 3), "event_pair_us": round(per * 1e6, 3),
             "back_to_back_us": round(cadence * 1e6, 3),
@@ -233,29 +250,49 @@ def large_batch_fused(env_num, K, device, reps=4):
             "note": "includes the in-kernel reset_done; VALU/occupancy bound (133 VGPRs), not HBM bound"}
 
 
-def cpu_baseline(epochs=8):
-    """The CPU restatement (oracle/, 'port') timed on the host cores on a bounded sample."""
+def cpu_baseline(epochs_all=8, epochs_1t=1):
+    """The CPU restatement (oracle/, 'port') timed on the host cores on a bounded sample: the same epoch
+    (reset over 1e6 layout candidates + 200 x (step, reset_done if any done)) with one thread and with all
+    cores.  Both phases are OpenMP-parallel in the checker (candidates in reset, envs in step)."""
     from oracle import gxo
     cfg = dict(TASK)
     cfg.update(env_num=ENV_NUM, _seed=0, num_steps=EP_LEN)
-    ref = gxo.OracleEngine(cfg, n_candidates=1_000_000)
     rng = np.random.RandomState(0)
     acts = rng.uniform(-1, 1, (EP_LEN, ENV_NUM, 2)).astype(np.float32)
-    t0 = time.perf_counter()
-    n = 0
-    for _ in range(epochs):
-        ref.reset()
-        for t in range(EP_LEN):
-            _, _, d, _ = ref.step(acts[t])
-            if d.any():
-                ref.reset_done()
-            n += ENV_NUM
-    dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 1), "unit": "env-steps/s", "cores": int(gxo.lib().gxo_get_threads()),
-            "kind": "port",
-            "sample": f"{epochs} epochs x {EP_LEN} steps x {ENV_NUM} envs incl. reset() over 1e6 layout "
-                      f"candidates (OpenMP) and reset_done(); {dt:.1f} s wall",
-            "note": "CPU restatement (oracle/), not the reference's XLA:CPU program"}
+    L = gxo.lib()
+    ncores = int(L.gxo_get_threads())
+
+    def run(threads, epochs):
+        L.gxo_set_threads(threads)
+        ref = gxo.OracleEngine(cfg, n_candidates=1_000_000)
+        t_reset = t_step = 0.0
+        for _ in range(epochs):
+            t0 = time.perf_counter()
+            ref.reset()
+            t1 = time.perf_counter()
+            for t in range(EP_LEN):
+                _, _, d, _ = ref.step(acts[t])
+                if d.any():
+                    ref.reset_done()
+            t2 = time.perf_counter()
+            t_reset += t1 - t0
+            t_step += t2 - t1
+        n = epochs * EP_LEN * ENV_NUM
+        return n / (t_reset + t_step), n / t_step, t_reset / epochs, t_reset + t_step
+
+    v1, s1, r1, w1 = run(1, epochs_1t)
+    va, sa, ra, wa = run(ncores, epochs_all)
+    L.gxo_set_threads(0)
+    return {"value": round(va, 1), "unit": "env-steps/s", "cores": ncores, "kind": "port",
+            "value_all_cores": round(va, 1), "value_1thread": round(v1, 1),
+            "stepping_only_all_cores": round(sa, 1), "stepping_only_1thread": round(s1, 1),
+            "reset_s_all_cores": round(ra, 3), "reset_s_1thread": round(r1, 3),
+            "threads": {"reset_phase": ncores, "step_phase": ncores},
+            "sample": f"{epochs_all} epochs on {ncores} threads ({wa:.1f} s) and {epochs_1t} epoch on 1 thread "
+                      f"({w1:.1f} s): {EP_LEN} steps x {ENV_NUM} envs incl. reset() over 1e6 layout candidates "
+                      "and reset_done()",
+            "note": "CPU restatement (oracle/, gcc -O2 -fopenmp), not the reference's XLA:CPU program; "
+                    "a reported baseline, not the optimisation target"}
 
 
 def epoch_breakdown(device):
@@ -357,24 +394,71 @@ def api_loop_rate(env, tape, steps):
     return env.env_num * steps / (time.perf_counter() - t0)
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this process has not
+    touched the GPU), one per GPU, rendezvous on 127.0.0.1, relay rank 0's line, fail if any rank fails."""
+    n = args.gpus
+    have = torch.cuda.device_count()          # does not initialise the GPU
+    if have < n and not os.environ.get("GX_BENCH_FORCE_DEVICE"):
+        print(f"bench.py: --gpus {n} but only {have} HIP device(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GX_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    deadline = time.time() + float(os.environ.get("GX_BENCH_SPAWN_TIMEOUT", "1500"))
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is not None:
+                alive.remove(p)
+                if code != 0:
+                    rc = rc or code
+        if rc or time.time() > deadline:
+            for p in alive:                    # exactly the children started above
+                p.terminate()
+            for p in alive:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            return rc or 3
+        time.sleep(0.2)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40000)    # 200 epochs of 200 steps
-    ap.add_argument("--warmup", type=int, default=2000)    # 10 epochs
+    ap.add_argument("--steps", type=int, default=200)     # bench steps = 200-pass epochs
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
+    if args.steps < 1 or args.warmup < 0:
+        ap.error("--steps >= 1, --warmup >= 0")
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     from guardx_amd import dist as gxd
     rank, local, world = gxd.init_from_env()
-    assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    if world != args.gpus:
+        print(f"bench.py: {world} rank(s) joined the process group but --gpus is {args.gpus}", file=sys.stderr)
+        sys.exit(2)
     if os.environ.get("GX_BENCH_FORCE_DEVICE"):      # rehearsal: several ranks share one GPU
         local = int(os.environ["GX_BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
     env = make_engine(ENV_NUM, rank, world)
+    env.set_prefetch(EP_LEN)
     tapes = [action_tape(EP_LEN, ENV_NUM, 1000 * rank + k, device) for k in range(4)]
     gather = world > 1
     handoff = RolloutHandoff(world) if gather else None
@@ -388,10 +472,11 @@ def main():
     gxd.barrier()
     dt = gxd.max_over_ranks(time.perf_counter() - t0, device)
 
-    value = ENV_NUM * world * args.steps / dt
+    env_steps = ENV_NUM * world * EP_LEN * args.steps
+    value = env_steps / dt
     stepping_only = None
     if gather:
-        # the same loop without the hand-off: what the sharded stepping alone sustains (no collective on the
+        # the same epochs without the hand-off: what the sharded stepping alone sustains (no collective on the
         # data path), so the cost of the mandated all-gather can be read off the two numbers
         gxd.barrier()
         torch.cuda.synchronize()
@@ -400,24 +485,33 @@ def main():
         torch.cuda.synchronize()
         gxd.barrier()
         dt1 = gxd.max_over_ranks(time.perf_counter() - t1, device)
-        stepping_only = {"value": round(ENV_NUM * world * args.steps / dt1, 1), "unit": "env-steps/s",
+        W = env.obs_flat_size + 2 + 3
+        stepping_only = {"value": round(env_steps / dt1, 1), "unit": "env-steps/s",
                          "ms_per_step": round(dt1 / args.steps * 1e3, 6),
-                         "handoff_bytes_received_per_rank_per_epoch": int((world - 1) * EP_LEN * ENV_NUM *
-                                                                          (env.obs_flat_size + 2 + 3) * 4),
-                         "note": "same epochs with the rollout hand-off switched off; `value` above includes it"}
+                         "handoff_ms_per_epoch_exposed": round((dt - dt1) / args.steps * 1e3, 6),
+                         "handoff_bytes_received_per_rank_per_epoch": int((world - 1) * EP_LEN * ENV_NUM * W * 4),
+                         "note": "same epochs with the rollout hand-off switched off; `value` above includes it "
+                                 "(asynchronous all-gather, 3 gathered buffers in flight)"}
     line = {
         "metric": "env-steps/sec", "value": round(value, 1), "unit": "env-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 6), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "Goal_Point_8Hazards env_num=2000/GPU, random-policy rollout "
-                               "(U(-1,1) action tape), 200-step epochs: reset() + 200 x (step + reset_done)"
+        "timed_region_s": round(dt, 6), "env_steps_timed": env_steps,
+        "config": {"workload": "Goal_Point_8Hazards env_num=2000/GPU, random-policy rollout (U(-1,1) action "
+                               "tape resident in HBM); ONE BENCH STEP = ONE 200-PASS EPOCH: reset() over 1e6 layout "
+                               "candidates + 200 x (step + reset_done)"
                                + (", one async RCCL all-gather of the packed rollout shard per epoch, "
-                                  "overlapped with the next epoch" if gather else ""),
-                   "env_num_per_gpu": ENV_NUM, "max_ep_len": EP_LEN, "obs_dim": env.obs_flat_size,
-                   "driver": "gx_rollout: one persistent lane-group kernel launch per 200-step epoch, layout pool of the next epoch prefetched on a side stream",
-                   "layout_candidates_per_reset": 1_000_000},
+                                  "overlapped with the following epochs" if gather else ""),
+                   "env_num_per_gpu": ENV_NUM, "max_ep_len": EP_LEN, "step_passes_per_bench_step": EP_LEN,
+                   "obs_dim": env.obs_flat_size,
+                   "driver": "gx_rollout: one persistent lane-group kernel launch per 200-pass epoch, layout pool of "
+                             "the next epoch prefetched on a side stream",
+                   "layout_candidates_per_reset": 1_000_000,
+                   "point_actuators": "mjcf defaults inherited (DESIGN.md 0.1)"},
     }
+    if dt < 0.010:
+        line["warning"] = f"timed region {dt*1e3:.2f} ms < 10 ms: use more --steps for a meaningful rate"
     if stepping_only is not None:
         line["stepping_only"] = stepping_only
     if rank == 0:
@@ -435,8 +529,8 @@ def main():
                     torch.cuda.empty_cache()
             # bandwidth regime: the thread-per-env step kernel at 2^22 envs
             extra("roofline_large_batch", lambda: roofline_step(1 << 22, 30, device))
-            extra("large_batch_fused", lambda: large_batch_fused(1 << 22, 16, device))
-            extra("api_step_loop_env_steps_per_s", lambda: round(api_loop_rate(env, tapes[0], 1000), 1))
+            extra("large_batch_fused", lambda: large_batch_fused(1 << 22, 32, device))
+            extra("api_step_loop_env_steps_per_s", lambda: round(api_loop_rate(env, tapes[0], 2000), 1))
             extra("epoch_breakdown", lambda: epoch_breakdown(device))
             extra("closed_loop_policy_env_steps_per_s", lambda: round(closed_loop_rate(device), 1))
             extra("other_robots", lambda: other_robots(device))

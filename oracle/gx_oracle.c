@@ -865,7 +865,7 @@ int gxo_step(gxo_env* e, const float* action, float* obs, float* reward, float* 
     const int have_last = e->hist >= 1, have_last_last = e->hist >= 2;
     const float dt = e->h * (float)e->cfg.physics_steps; /* :235 */
     const int nq = e->nq, nv = e->nv, na = e->na;
-#pragma omp parallel for schedule(static) num_threads(gxo_get_threads()) if (N >= 4096)
+#pragma omp parallel for schedule(static) num_threads(gxo_get_threads())
     for (int i = 0; i < N; ++i) {
         float* p0 = &e->pose0[4 * i];
         float* p1 = &e->pose1[2 * i];
