@@ -57,7 +57,11 @@ SYMBOLS = {
     "gx_layout_size": (C.c_int, [C.c_void_p, _I32P]),
     "gx_layout_size_min": (C.c_int, [C.c_void_p, _I32P]),
     "gx_step": (C.c_int, [C.c_void_p, _FP, _FP, _FP, _FP, _FP, _FP, C.c_void_p]),
+    "gx_step_rd": (C.c_int, [C.c_void_p, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _I32P, C.c_void_p]),
+    "gx_reset_done_commit": (C.c_int, [C.c_void_p]),
     "gx_reset_done": (C.c_int, [C.c_void_p, _FP, _FP, C.c_void_p]),
+    "gx_rollout_packed": (C.c_int, [C.c_void_p, C.c_int32, _FP, _FP, C.c_void_p]),
+    "gx_packed_width": (C.c_int32, [C.c_void_p]),
     "gx_rollout": (C.c_int, [C.c_void_p, C.c_int32, _FP, _FP, _FP, _FP, _FP, C.c_void_p]),
     "gx_rollout_policy": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(GxPolicy)] + [_FP] * 12 + [C.c_void_p]),
     "gx_set_policy_impl": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -66,6 +70,7 @@ SYMBOLS = {
     "gx_set_state": (C.c_int, [C.c_void_p] + [_HFP] * 8 + [_U32P, _I32P]),
     "gx_get_pool": (C.c_int, [C.c_void_p, _HFP, C.c_int32, _I32P]),
     "gx_set_prefetch": (C.c_int, [C.c_void_p, C.c_int32]),
+    "gx_prefetch_stats": (C.c_int, [C.c_void_p, _I32P, _I32P, _I32P]),
     "gx_set_path": (C.c_int, [C.c_void_p, C.c_int32]),
     "gx_buffer_store": (C.c_int, [C.c_int32] * 5 + [_FP] * 14 + [C.c_void_p]),
     "gx_gae_finish_path": (C.c_int, [C.c_int32] * 3 + [_FP] * 5 + [C.c_double, C.c_double, _FP, _FP, C.c_int32, C.c_void_p]),

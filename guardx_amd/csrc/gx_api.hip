@@ -61,8 +61,17 @@ struct gx_engine {
     hipEvent_t pool_free[2];  // recorded on the caller's stream when pool i is no longer read
     bool pf_valid;            // pools[1-cur] holds (or will hold) the pool for key pf_key
     uint32_t pf_key[2];
-    int prefetch_steps;       // predicted step() calls between resets; < 0 disables prefetch
+    int prefetch_steps;       // predicted step() calls between resets; -1 disables prefetch; -2 = learn it:
+                              // the number of steps between the last two resets (cfg.num_steps before that) --
+                              // the learners reset every max_ep_len steps, whatever num_steps says
+    int steps_since_reset;    // key advances since the last gx_reset
+    int last_interval;        // ... between the last two gx_reset calls (0: unknown)
+    int pf_hits, pf_misses;
     bool last_policy = false; // the last hot-path call was gx_rollout_policy
+    // speculated reset_done (gx_step_rd): b.rd_j holds the layout rows reset_done would install for the envs the
+    // last step finished; gx_reset_done_commit() only sets pending_commit, the next launch installs them
+    bool spec_valid = false;
+    bool pending_commit = false;
     // per-step layout keys for the fused rollout: ring of pinned staging + device buffers
     static const int kKeyRing = 4;
     uint4* h_keys[kKeyRing];
@@ -70,6 +79,15 @@ struct gx_engine {
     hipEvent_t keys_ev[kKeyRing];
     int keys_next;
 };
+
+// the pending reset_done (if any) is consumed by the launch about to be made / dropped by reset()
+static int take_commit(gx_engine* e)
+{
+    const int c = e->pending_commit ? 1 : 0;
+    e->pending_commit = false;
+    e->spec_valid = false;
+    return c;
+}
 
 static bool use_group_path(const gx_engine* e)
 {
@@ -240,7 +258,8 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     e->haz_bounds = nullptr;
     e->cfg.placements = nullptr; // not retained (folded into SampleParams above)
     e->pf_valid = false;
-    e->prefetch_steps = cfg->num_steps;
+    e->prefetch_steps = -2;
+    e->steps_since_reset = 0; e->last_interval = 0; e->pf_hits = 0; e->pf_misses = 0;
     e->side = nullptr;
     memset(e->pools, 0, sizeof(e->pools));
     for (int i = 0; i < 2; ++i) { e->pool_ready[i] = nullptr; e->pool_free[i] = nullptr; }
@@ -257,6 +276,8 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     alloc((void**)&e->b.dyn, sizeof(float4) * e->ndyn * p.Npad);
     alloc((void**)&e->b.obj, sizeof(float4) * (size_t)p.P * p.Npad);
     alloc((void**)&e->b.hist, sizeof(float4) * p.Npad);
+    alloc((void**)&e->b.rd_j, sizeof(int) * p.Npad);
+    if (err == hipSuccess) err = hipMemset(e->b.rd_j, 0xFF, sizeof(int) * p.Npad); // -1: nothing speculated
     if (!hb.empty()) {
         alloc((void**)&e->haz_bounds, sizeof(float4) * hb.size());
         if (err == hipSuccess) err = hipMemcpy(e->haz_bounds, hb.data(), sizeof(float4) * hb.size(), hipMemcpyHostToDevice);
@@ -310,7 +331,7 @@ extern "C" gx_status gx_destroy(gx_engine* e)
     if (!e) return GX_OK;
     DeviceGuard guard(e->device);
     (void)hipDeviceSynchronize();
-    void* bufs[] = {e->b.dyn, e->b.obj, e->b.hist, e->haz_bounds};
+    void* bufs[] = {e->b.dyn, e->b.obj, e->b.hist, e->b.rd_j, e->haz_bounds};
     for (void* q : bufs)
         if (q) (void)hipFree(q);
     for (int i = 0; i < 2; ++i) {
@@ -332,6 +353,16 @@ extern "C" gx_status gx_destroy(gx_engine* e)
     return GX_OK;
 }
 
+// install a requested-but-not-yet-installed reset_done before a consumer that does not apply it on load
+static gx_status flush_pending(gx_engine* e, hipStream_t s)
+{
+    if (take_commit(e)) {
+        launch_commit_pending(e->p, e->b, e->nobj_total, s);
+        GX_HIP(hipGetLastError());
+    }
+    return GX_OK;
+}
+
 static void layout_keys(const gx_engine* e, uint32_t (&k)[4])
 {
     // get_layout: randint(key, ...) splits the key once  engine.py:447
@@ -343,8 +374,12 @@ extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
     if (!e || !d_obs) return fail(GX_ERR_ARG, "null argument");
     DeviceGuard guard(e->device);
     hipStream_t s = (hipStream_t)stream;
+    (void)take_commit(e); // reset() re-initialises every env: a pending reset_done is moot (engine.py:460-465)
     const int other = 1 - e->cur;
     const bool hit = e->pf_valid && e->pf_key[0] == e->key[0] && e->pf_key[1] == e->key[1];
+    if (e->pf_valid) { if (hit) e->pf_hits++; else e->pf_misses++; }
+    if (e->have_reset) e->last_interval = e->steps_since_reset;
+    e->steps_since_reset = 0;
     const bool swap = hit || e->have_reset;
     // the old pool is free once everything ALREADY queued on `s` has run: recorded before `s` starts to wait
     // for the side stream, so the next prefetch (which reuses the old pool) follows the current one
@@ -371,9 +406,11 @@ extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
 
     // prefetch the pool of the next reset(): the key then is this key advanced by one split per
     // step() (engine.py:431) -- independent of the data, so it can be computed now
-    if (e->prefetch_steps >= 0) {
+    const int horizon = e->prefetch_steps == -2 ? (e->last_interval > 0 ? e->last_interval : e->cfg.num_steps)
+                                                 : e->prefetch_steps;
+    if (horizon >= 0) {
         uint32_t k0 = e->key[0], k1 = e->key[1];
-        for (int t = 0; t < e->prefetch_steps; ++t) {
+        for (int t = 0; t < horizon; ++t) {
             uint32_t a0, a1, b0, b1;
             split2(k0, k1, a0, a1, b0, b1);
             k0 = a0; k1 = a1;
@@ -398,7 +435,15 @@ extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
 extern "C" gx_status gx_set_prefetch(gx_engine* e, int32_t steps)
 {
     if (!e) return fail(GX_ERR_ARG, "null engine");
-    e->prefetch_steps = steps;
+    e->prefetch_steps = steps < -2 ? -1 : steps;
+    return GX_OK;
+}
+
+extern "C" gx_status gx_prefetch_stats(const gx_engine* e, int32_t* hits, int32_t* misses, int32_t* horizon)
+{
+    if (!e || !hits || !misses || !horizon) return fail(GX_ERR_ARG, "null argument");
+    *hits = e->pf_hits; *misses = e->pf_misses;
+    *horizon = e->prefetch_steps == -2 ? (e->last_interval > 0 ? e->last_interval : e->cfg.num_steps) : e->prefetch_steps;
     return GX_OK;
 }
 
@@ -440,34 +485,73 @@ extern "C" gx_status gx_layout_size_min(gx_engine* e, int32_t* out)
     return GX_OK;
 }
 
-extern "C" gx_status gx_step(gx_engine* e, const float* d_action, float* d_obs, float* d_reward,
-                             float* d_cost, float* d_done, float* d_qacc, void* stream)
+static gx_status step_impl(gx_engine* e, const float* d_action, float* d_obs, float* d_reward, float* d_cost,
+                           float* d_done, float* d_qacc, float* d_obs_rd, int32_t* speculated, void* stream)
 {
     if (!e || !d_action || !d_obs || !d_reward || !d_cost || !d_done) return fail(GX_ERR_ARG, "null argument");
     if (!e->have_reset) return fail(GX_ERR_STATE, "gx_step before gx_reset (engine.py: _data is None)");
     if ((reinterpret_cast<uintptr_t>(d_action) & 7u) || (reinterpret_cast<uintptr_t>(d_obs) & 3u))
         return fail(GX_ERR_ARG, "d_action must be 8-byte aligned (float2 rows), d_obs 4-byte");
     DeviceGuard guard(e->device);
+    hipStream_t s = (hipStream_t)stream;
     // update_data: key, _ = split(key, 2)  engine.py:431
     uint32_t a0, a1, b0, b1;
     split2(e->key[0], e->key[1], a0, a1, b0, b1);
     e->key[0] = a0;
     e->key[1] = a1;
+    e->steps_since_reset++;
     e->p.have_last = e->hist >= 1;
     e->p.have_last_last = e->hist >= 2;
     e->last_policy = false;
+    if (speculated) *speculated = 0;
     if (use_group_path(e)) {
         RolloutArgs r;
         memset(&r, 0, sizeof r);
         r.T = 1; r.do_reset = 0; r.nobj_total = e->nobj_total; r.hist0 = e->hist;
+        r.commit = take_commit(e);
+        r.obs_stride = e->p.D; r.sc_stride = 1;
         r.act = static_cast<const float*>(d_action);
         r.obs = d_obs; r.rew = d_reward; r.cost = d_cost; r.done = d_done; r.qacc = d_qacc;
-        launch_group_rollout(e->p, r, e->b, (hipStream_t)stream);
+        r.rd_j = e->b.rd_j;
+        r.layout_size = e->b.pool.layout_size; r.cand_of = e->b.pool.cand_of; r.cand_xy = e->b.pool.cand_xy;
+        if (d_obs_rd) { // also what reset_done() would return and install, with the key it would use (:447,500)
+            uint32_t k[4];
+            layout_keys(e, k);
+            r.do_reset = 2; r.obs_rd = d_obs_rd; r.keys = nullptr; r.key0 = make_uint4(k[0], k[1], k[2], k[3]);
+            e->spec_valid = true;
+            if (speculated) *speculated = 1;
+        }
+        launch_group_rollout(e->p, r, e->b, s);
     } else {
-        launch_step(e->p, e->b, d_action, d_obs, d_reward, d_cost, d_done, d_qacc, (hipStream_t)stream);
+        gx_status st = flush_pending(e, s);
+        if (st != GX_OK) return st;
+        launch_step(e->p, e->b, d_action, d_obs, d_reward, d_cost, d_done, d_qacc, s);
     }
     if (e->hist < 2) e->hist++;
     GX_HIP(hipGetLastError());
+    return GX_OK;
+}
+
+extern "C" gx_status gx_step(gx_engine* e, const float* d_action, float* d_obs, float* d_reward,
+                             float* d_cost, float* d_done, float* d_qacc, void* stream)
+{
+    return step_impl(e, d_action, d_obs, d_reward, d_cost, d_done, d_qacc, nullptr, nullptr, stream);
+}
+
+extern "C" gx_status gx_step_rd(gx_engine* e, const float* d_action, float* d_obs, float* d_reward,
+                                float* d_cost, float* d_done, float* d_qacc, float* d_obs_rd,
+                                int32_t* speculated, void* stream)
+{
+    if (!d_obs_rd || !speculated) return fail(GX_ERR_ARG, "gx_step_rd: null d_obs_rd / speculated");
+    return step_impl(e, d_action, d_obs, d_reward, d_cost, d_done, d_qacc, d_obs_rd, speculated, stream);
+}
+
+extern "C" gx_status gx_reset_done_commit(gx_engine* e)
+{
+    if (!e) return fail(GX_ERR_ARG, "null engine");
+    if (!e->spec_valid && !e->pending_commit)
+        return fail(GX_ERR_STATE, "gx_reset_done_commit: the last hot-path call was not a speculating gx_step_rd");
+    e->pending_commit = true; // installed by the next launch; idempotent like Engine.reset_done
     return GX_OK;
 }
 
@@ -485,6 +569,7 @@ extern "C" gx_status gx_reset_done(gx_engine* e, const float* d_obs_in, float* d
     }
     uint32_t k[4];
     layout_keys(e, k);
+    { gx_status st = flush_pending(e, s); if (st != GX_OK) return st; }
     launch_reset_done(e->p, e->b, e->nobj_total, k[0], k[1], k[2], k[3], d_obs_in, d_obs_out, s);
     GX_HIP(hipGetLastError());
     return GX_OK;
@@ -525,18 +610,19 @@ static void fill_rollout_args(gx_engine* e, RolloutArgs& r, int32_t T, int slot)
 {
     memset(&r, 0, sizeof r);
     r.T = T; r.do_reset = 1; r.nobj_total = e->nobj_total; r.hist0 = e->hist;
+    r.obs_stride = e->p.D; r.sc_stride = 1; r.rd_j = e->b.rd_j;
     r.keys = e->h_keys[slot]; // pinned + device-visible: read over the host link only on a reset
     r.layout_size = e->b.pool.layout_size; r.cand_of = e->b.pool.cand_of; r.cand_xy = e->b.pool.cand_xy;
     e->p.have_last = e->hist >= 1;
     e->p.have_last_last = e->hist >= 2;
 }
 
-extern "C" gx_status gx_rollout(gx_engine* e, int32_t T, const float* d_actions, float* d_obs,
-                                float* d_reward, float* d_cost, float* d_done, void* stream)
+static gx_status rollout_impl(gx_engine* e, int32_t T, const float* d_actions, float* d_obs, float* d_reward,
+                              float* d_cost, float* d_done, float* d_act_out, int obs_stride, int sc_stride,
+                              void* stream)
 {
-    if (!e || !d_actions || !d_obs || !d_reward || !d_cost || !d_done || T < 1)
-        return fail(GX_ERR_ARG, "bad argument");
     if (!e->have_reset) return fail(GX_ERR_STATE, "gx_rollout before gx_reset");
+    if (reinterpret_cast<uintptr_t>(d_actions) & 7u) return fail(GX_ERR_ARG, "d_actions must be 8-byte aligned");
     DeviceGuard guard(e->device);
     hipStream_t s = (hipStream_t)stream;
     int slot; uint32_t k0, k1;
@@ -546,15 +632,42 @@ extern "C" gx_status gx_rollout(gx_engine* e, int32_t T, const float* d_actions,
     fill_rollout_args(e, r, T, slot);
     r.act = static_cast<const float*>(d_actions);
     r.obs = d_obs; r.rew = d_reward; r.cost = d_cost; r.done = d_done; r.qacc = nullptr;
+    r.act_out = d_act_out; r.obs_stride = obs_stride; r.sc_stride = sc_stride;
     e->last_policy = false;
-    if (use_group_path(e)) launch_group_rollout(e->p, r, e->b, s);   // latency regime: 16 lanes per env
-    else launch_thread_rollout(e->p, r, e->b, s);                     // bandwidth regime: one thread per env
+    if (use_group_path(e)) {   // latency regime: 16 lanes per env
+        r.commit = take_commit(e);
+        launch_group_rollout(e->p, r, e->b, s);
+    } else {                    // bandwidth regime: one thread per env
+        st = flush_pending(e, s);
+        if (st != GX_OK) return st;
+        launch_thread_rollout(e->p, r, e->b, s);
+    }
     GX_HIP(hipEventRecord(e->keys_ev[slot], s)); // staging reusable once this launch is done
     GX_HIP(hipGetLastError());
     e->key[0] = k0; e->key[1] = k1;
+    e->steps_since_reset += T;
     e->hist = (e->hist + T) >= 2 ? 2 : e->hist + T;
     return GX_OK;
 }
+
+extern "C" gx_status gx_rollout(gx_engine* e, int32_t T, const float* d_actions, float* d_obs,
+                                float* d_reward, float* d_cost, float* d_done, void* stream)
+{
+    if (!e || !d_actions || !d_obs || !d_reward || !d_cost || !d_done || T < 1)
+        return fail(GX_ERR_ARG, "bad argument");
+    return rollout_impl(e, T, d_actions, d_obs, d_reward, d_cost, d_done, nullptr, e->p.D, 1, stream);
+}
+
+extern "C" gx_status gx_rollout_packed(gx_engine* e, int32_t T, const float* d_actions, float* d_packed,
+                                       void* stream)
+{
+    if (!e || !d_actions || !d_packed || T < 1) return fail(GX_ERR_ARG, "bad argument");
+    const int W = e->p.D + e->na + 3;
+    return rollout_impl(e, T, d_actions, d_packed, d_packed + e->p.D + e->na, d_packed + e->p.D + e->na + 1,
+                        d_packed + e->p.D + e->na + 2, d_packed + e->p.D, W, W, stream);
+}
+
+extern "C" int32_t gx_packed_width(const gx_engine* e) { return e ? e->p.D + e->na + 3 : -1; }
 
 extern "C" gx_status gx_rollout_policy(gx_engine* e, int32_t T, const gx_policy* pol, const float* d_obs0,
                                        float* d_obs_in, float* d_act, float* d_logp, float* d_val,
@@ -587,11 +700,13 @@ extern "C" gx_status gx_rollout_policy(gx_engine* e, int32_t T, const gx_policy*
     pa.params = pol->d_params; pa.seed0 = pol->seed[0]; pa.seed1 = pol->seed[1]; pa.t0 = e->policy_steps;
     pa.obs0 = d_obs0; pa.obs_in = d_obs_in; pa.act = d_act; pa.logp = d_logp; pa.val = d_val; pa.mu = d_mu;
     pa.obs_last = d_obs_last; pa.val_last = d_val_last; pa.logstd = d_logstd;
+    r.commit = take_commit(e);
     launch_policy_rollout(e->p, r, pa, e->b, impl, s);
     e->last_policy = true;
     GX_HIP(hipEventRecord(e->keys_ev[slot], s));
     GX_HIP(hipGetLastError());
     e->key[0] = k0; e->key[1] = k1;
+    e->steps_since_reset += T;
     e->hist = (e->hist + T) >= 2 ? 2 : e->hist + T;
     e->policy_steps += (uint32_t)T;
     return GX_OK;
@@ -629,6 +744,11 @@ extern "C" gx_status gx_get_state(gx_engine* e, float* qpos, float* qvel, float*
     if (!e) return fail(GX_ERR_ARG, "null engine");
     DeviceGuard guard(e->device);
     GX_HIP(hipDeviceSynchronize());
+    if (e->pending_commit) { // a requested reset_done is part of the state
+        gx_status st = flush_pending(e, nullptr);
+        if (st != GX_OK) return st;
+        GX_HIP(hipDeviceSynchronize());
+    }
     const Params& p = e->p;
     const size_t Np = p.Npad;
     const int nq = e->nq, nv = e->nv;
@@ -664,6 +784,11 @@ extern "C" gx_status gx_set_state(gx_engine* e, const float* qpos, const float* 
     if (!e) return fail(GX_ERR_ARG, "null engine");
     DeviceGuard guard(e->device);
     GX_HIP(hipDeviceSynchronize());
+    if (e->pending_commit) { // a requested reset_done is part of the state
+        gx_status st = flush_pending(e, nullptr);
+        if (st != GX_OK) return st;
+        GX_HIP(hipDeviceSynchronize());
+    }
     const Params& p = e->p;
     const size_t Np = p.Npad;
     const int nq = e->nq, nv = e->nv;
@@ -692,6 +817,7 @@ extern "C" gx_status gx_set_state(gx_engine* e, const float* qpos, const float* 
     if (key) { e->key[0] = key[0]; e->key[1] = key[1]; }
     if (hist) e->hist = *hist;
     e->have_reset = true;
+    e->spec_valid = false;
     return GX_OK;
 }
 

@@ -40,6 +40,7 @@ struct DevBuffers {
     float4* dyn;   // [NDYN][Npad] planes of (qpos, qvel, pose0 = (px,py,cos,sin), done0, steps); Point: 3 planes
     float4* obj;   // [P][Npad]: object pairs (goal,h0) (h1,h2) ...
     float4* hist;  // [Npad]: (p1x,p1y,done1,0)   (only when hist_on)
+    int* rd_j;     // [Npad]: layout row of a speculated reset_done (see RolloutArgs::do_reset == 2)
     Pool pool;     // the pool the envs are currently drawn from
 };
 
@@ -54,14 +55,24 @@ void launch_reset_done(const Params& p, const DevBuffers& b, int nobj_total, uin
                        float* obs_out, hipStream_t s);
 // lane-group persistent rollout (small batches): arguments of one launch
 struct RolloutArgs {
-    int T, do_reset, nobj_total, hist0;
+    int T, nobj_total, hist0;
+    int do_reset;      // 0: step only; 1: step + reset_done folded in (rollouts); 2: step, plus the reset_done
+                       //    observation of the finished envs SPECULATIVELY into obs_rd and the layout row that
+                       //    reset_done would install into rd_j -- the state is not touched (Engine.step)
+    int commit;        // apply the pending reset_done recorded in rd_j by the previous (do_reset == 2) launch
+    int obs_stride;    // floats between consecutive obs rows (D, or the packed row width D + A + 3)
+    int sc_stride;     // floats between consecutive reward / cost / done entries (1, or the packed row width)
     const float* act;
     float* obs;
     float* rew;
     float* cost;
     float* done;
     float* qacc;
-    const uint4* keys;
+    float* act_out;    // null, or where the action of (t, env) is copied: act_out + (t*N + env) * obs_stride
+    float* obs_rd;     // do_reset == 2: [N][D] post-reset_done observation
+    int* rd_j;         // [Npad] layout row a pending reset_done installs (-1: none)
+    const uint4* keys; // per-step (k1, k2) = split(key_t) of the reset_done draw; null: key0 for every step (T == 1)
+    uint4 key0;
     const int* layout_size;
     const int* cand_of;
     const float2* cand_xy;
@@ -71,6 +82,8 @@ void launch_group_rollout(const Params& p, const RolloutArgs& r, const DevBuffer
 void launch_thread_rollout(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s);
 void launch_policy_rollout(const Params& p, const RolloutArgs& r, const PolicyArgs& pol, const DevBuffers& b,
                            int impl, hipStream_t s);
+// install the reset_done recorded in b.rd_j (pending commit) for consumers other than the lane-group kernels
+void launch_commit_pending(const Params& p, const DevBuffers& b, int nobj_total, hipStream_t s);
 // per-robot launchers: defined in gx_robot_kernels.inl, instantiated once per robot in gx_kernels_<robot>.hip
 template <class R>
 struct RobotLaunch {
@@ -84,6 +97,7 @@ struct RobotLaunch {
     static void thread_rollout(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s);
     static void policy(const Params& p, const RolloutArgs& r, const PolicyArgs& pol, const DevBuffers& b, int impl,
                        hipStream_t s);
+    static void commit_pending(const Params& p, const DevBuffers& b, int nobj_total, hipStream_t s);
 };
 bool policy_rollout_supported(const Params& p);
 size_t policy_lds_bytes(const Params& p, int impl);

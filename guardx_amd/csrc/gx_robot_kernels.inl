@@ -449,7 +449,11 @@ void thread_rollout_kernel(Params p_in, RolloutArgs r,
     float P1x = 0.f, P1y = 0.f, done1 = 0.f;   // last_last_data.xpos, last_last_done
     if (p.hist_on) { const float4 h = hist[i]; P1x = h.x; P1y = h.y; done1 = h.z; }
     bool touched_layout = false;
-    float* row = tile + tid * p.D;
+    const int L = r.do_reset ? *r.layout_size : 0; // constant for the whole launch
+    // rows of the LDS tile are obs_stride wide: D, or the packed hand-off row (obs | action | reward cost done)
+    const int RS = r.obs_stride;
+    const bool packed = r.act_out != nullptr;
+    float* row = tile + tid * RS;
 
     for (int t = 0; t < r.T; ++t) {
         float a[R::NA];
@@ -500,7 +504,11 @@ void thread_rollout_kernel(Params p_in, RolloutArgs r,
         if (steps > p.num_steps_f) dn = 1.0f;         // :492
         steps = dn > 0.0f ? 0.0f : steps + 1.0f;      // :493
 
-        if (live) {
+        if (packed) {
+#pragma unroll
+            for (int k = 0; k < R::NA; ++k) row[p.D + k] = a[k];
+            row[p.D + R::NA] = rw; row[p.D + R::NA + 1] = cs; row[p.D + R::NA + 2] = dn;
+        } else if (live) {
             const size_t te = (size_t)t * p.N + i;
             r.rew[te] = rw; r.cost[te] = cs; r.done[te] = dn;
         }
@@ -513,9 +521,8 @@ void thread_rollout_kernel(Params p_in, RolloutArgs r,
 
         // reset_done :497-505 for the envs that just finished
         if (r.do_reset) {
-            const int L = *r.layout_size;
             if (live && dn > 0.0f && L > 0) {
-                const uint4 kk = r.keys[t];
+                const uint4 kk = r.keys ? r.keys[t] : r.key0;
                 const uint32_t idx = randint_at(kk.x, kk.y, kk.z, kk.w, (uint32_t)p.env_total, (uint32_t)L,
                                                 (uint32_t)(p.env_offset + i));
                 float rx, ry;
@@ -544,7 +551,7 @@ void thread_rollout_kernel(Params p_in, RolloutArgs r,
             }
         }
         __syncthreads();
-        flush_tile<BLOCK>(tile, r.obs + ((size_t)t * p.N + env0) * p.D, nenv * p.D);
+        flush_tile<BLOCK>(tile, r.obs + ((size_t)t * p.N + env0) * RS, nenv * RS);
         __syncthreads(); // the tile is rewritten by the next step
     }
 
@@ -557,6 +564,35 @@ void thread_rollout_kernel(Params p_in, RolloutArgs r,
                 if (k < p.P) obj[(size_t)k * p.Npad + i] = ob[k];
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// Install a speculated reset_done (rd_j, written by the lane-group step with do_reset == 2) for the consumers
+// that do not apply it on load: qpos/qvel/layout of the finished envs, stale pose / done / steps kept (:715-731).
+// ---------------------------------------------------------------------------
+template <class R, int BLOCK, int PMAX>
+__global__ __launch_bounds__(BLOCK) void commit_pending_kernel(Params p, int nobj_total, const int* __restrict__ rd_j,
+                                                               const float2* __restrict__ cand_xy,
+                                                               float4* __restrict__ dyn, float4* __restrict__ obj)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= p.N) return;
+    const int j = rd_j[i];
+    if (j < 0) return;
+    float4 ob[PMAX];
+    float rx, ry;
+    load_layout<PMAX>(p, cand_xy, nobj_total, j, ob, rx, ry);
+    float q[R::NQ], v[R::NV], pose0[4], done0, steps;
+    R::load(dyn, p.Npad, i, q, v, pose0, done0, steps);
+#pragma unroll
+    for (int k = 0; k < R::NQ; ++k) q[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < R::NV; ++k) v[k] = 0.f;
+    R::place(q, rx, ry);
+    R::store(dyn, p.Npad, i, q, v, pose0, done0, steps);
+#pragma unroll
+    for (int k = 0; k < PMAX; ++k)
+        if (k < p.P) obj[(size_t)k * p.Npad + i] = ob[k];
 }
 
 // ---------------------------------------------------------------------------
@@ -580,6 +616,29 @@ void thread_rollout_kernel(Params p_in, RolloutArgs r,
 // ---------------------------------------------------------------------------
 
 constexpr int kGL = 16; // lanes per environment
+
+// Workgroup synchronisation of the lane-group kernels.  With ONE wave per workgroup (BT == 64) the LDS
+// operations of the wave execute in program order, so the exchange through LDS only needs the compiler
+// to keep that order: wave-scope fences cost no instruction.  __syncthreads() would also wait for every
+// outstanding global store (s_waitcnt vmcnt(0) of the workgroup-scope release fence), i.e. for the
+// observation rows of the previous step to be acknowledged by L2 -- on the critical path of every step.
+template <int BT>
+GX_D void group_sync()
+{
+    if (BT == 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+template <int BT>
+GX_D bool group_any(bool v)
+{
+    if (BT == 64) return __ballot(v) != 0ull;
+    return __syncthreads_or(v ? 1 : 0) != 0;
+}
 
 template <int OPL, int BPL>
 struct GroupObs { float gl[BPL], hl[BPL], comp0, comp1, cost; bool bad; };
@@ -613,7 +672,7 @@ GX_D GroupObs<OPL, BPL> group_observe(const Params& p, float4 (*rec)[BT], float 
         rec[j][lane] = make_float4(__int_as_float(t.bin), t.sensor, t.a1, t.a2);
         term[j][lane] = tc;
     }
-    __syncthreads();
+    group_sync<BT>();
 #pragma unroll
     for (int jb = 0; jb < BPL; ++jb) {
         const int b = l + kGL * jb;
@@ -643,7 +702,7 @@ GX_D GroupObs<OPL, BPL> group_observe(const Params& p, float4 (*rec)[BT], float 
     // any lane of this env's group
     const unsigned long long m = __ballot(bad);
     out.bad = ((m >> (gbase & 63)) & 0xFFFFull) != 0ull;
-    __syncthreads();
+    group_sync<BT>();
     return out;
 }
 
@@ -736,6 +795,26 @@ __global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Par
     float gx, gy;
     { const float2 g = obj2[(size_t)e * 2]; gx = g.x; gy = g.y; }
     bool touched_layout = false;
+    if (r.commit) { // the reset_done the previous launch speculated was requested: install it (engine.py:715-718)
+        const int jj = r.rd_j[e];
+        if (live && jj >= 0) {
+            const float2* rowp = r.cand_xy + (size_t)jj * r.nobj_total;
+#pragma unroll
+            for (int j = 0; j < OPL; ++j) {
+                const int o = l + kGL * j;
+                if (o < p.nobj) { const float2 t2 = rowp[o]; ox[j] = t2.x; oy[j] = t2.y; }
+            }
+            const float2 g = rowp[0], rb = rowp[r.nobj_total - 1];
+            gx = g.x; gy = g.y;
+#pragma unroll
+            for (int k = 0; k < R::NQ; ++k) q[k] = 0.f;
+#pragma unroll
+            for (int k = 0; k < R::NV; ++k) v[k] = 0.f;
+            R::place(q, rb.x, rb.y);
+            touched_layout = true;
+        }
+    }
+    const int L = r.do_reset ? *r.layout_size : 0; // constant for the whole launch
 
     float a_next[R::NA];
 #pragma unroll
@@ -853,19 +932,52 @@ __global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Par
         for (int k = 0; k < R::NV; ++k) o_v[k] = v[k];
         float o_v0 = vel0, o_v1 = vel1, o_a0 = acc0, o_a1 = acc1;
 
-        // reset_done :497-505 folded in (wave-uniform gate)
+        // one observation row (engine.py:773-777 order), 16 lanes of the env's group writing side by side
+        auto write_row = [&](float* row, const GroupObs<OPL, BPL>& gob) {
+#pragma unroll
+            for (int jb = 0; jb < BPL; ++jb) {
+                const int b = l + kGL * jb;
+                if (b < p.bins) {
+                    if (p.off_gl >= 0) row[p.off_gl + b] = gob.gl[jb];
+                    if (p.off_hl >= 0) row[p.off_hl + b] = gob.hl[jb];
+                }
+            }
+            if (l < R::NU && p.off_ctrl >= 0) row[p.off_ctrl + l] = pick(o_ctrl, l);
+            if (l < R::NQ && p.off_qpos >= 0) row[p.off_qpos + l] = pick(o_q, l);
+            if (l < R::NV && p.off_qvel >= 0) row[p.off_qvel + l] = pick(o_v, l);
+            if (l < 2) {
+                if (p.off_comp >= 0) row[p.off_comp + l] = (l == 0) ? gob.comp0 : gob.comp1;
+                if (p.off_vel >= 0) row[p.off_vel + l] = (l == 0) ? o_v0 : o_v1;
+                if (p.off_acc >= 0) row[p.off_acc + l] = (l == 0) ? o_a0 : o_a1;
+            }
+        };
+        const size_t te = (size_t)t * p.N + env;
+        if (live) {
+            if (kQacc && l < R::NV) r.qacc[te * R::NV + l] = pick(qacc, l);
+            if (r.act_out && l < R::NA) r.act_out[te * r.obs_stride + l] = pick(a, l);
+            if (l == 0) {
+                r.rew[te * r.sc_stride] = rw; r.cost[te * r.sc_stride] = ob.cost; r.done[te * r.sc_stride] = dn;
+            }
+            // Engine.step's own observation (the learner's next_o); the row after reset_done goes to obs_rd
+            if (r.do_reset == 2) write_row(r.obs + te * r.obs_stride, ob);
+        }
+
+        // reset_done :497-505 folded in (workgroup-uniform gate).  do_reset == 1: installed at once (the
+        // learner loop calls it whenever an env is done); do_reset == 2: only its observation and the layout
+        // row it draws are recorded, the state changes when reset_done() is actually called (r.commit).
         if (r.do_reset) {
-            const int L = *r.layout_size;
             const bool rs = live && dn > 0.0f && L > 0;
-            if (__syncthreads_or(rs ? 1 : 0)) { // workgroup-uniform gate
+            int jrow = -1;
+            if (group_any<BT>(rs)) {
                 float nox[OPL], noy[OPL], ngx = gx, ngy = gy, rx = 0.f, ry = 0.f;
 #pragma unroll
                 for (int j = 0; j < OPL; ++j) { nox[j] = ox[j]; noy[j] = oy[j]; }
                 if (rs) {
-                    const uint4 kk = r.keys[t];
+                    const uint4 kk = r.keys ? r.keys[t] : r.key0;
                     const uint32_t idx = randint_at(kk.x, kk.y, kk.z, kk.w, (uint32_t)p.env_total, (uint32_t)L,
                                                     (uint32_t)(p.env_offset + env));
-                    const float2* rowp = r.cand_xy + (size_t)r.cand_of[idx] * r.nobj_total;
+                    jrow = r.cand_of[idx];
+                    const float2* rowp = r.cand_xy + (size_t)jrow * r.nobj_total;
 #pragma unroll
                     for (int j = 0; j < OPL; ++j) {
                         const int o = l + kGL * j;
@@ -889,49 +1001,36 @@ __global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Par
                 }
                 const GroupObs<OPL, BPL> rob = group_observe<OPL, BPL, BT>(p, rec, term, lane, rpose, ngx, ngy, nox, noy);
                 if (rs) {
+                    if (r.do_reset == 1) {
 #pragma unroll
-                    for (int j = 0; j < OPL; ++j) { ox[j] = nox[j]; oy[j] = noy[j]; }
-                    gx = ngx; gy = ngy;
+                        for (int j = 0; j < OPL; ++j) { ox[j] = nox[j]; oy[j] = noy[j]; }
+                        gx = ngx; gy = ngy;
 #pragma unroll
-                    for (int k = 0; k < R::NQ; ++k) { q[k] = 0.f; o_q[k] = fq[k]; }
+                        for (int k = 0; k < R::NQ; ++k) q[k] = 0.f;
 #pragma unroll
-                    for (int k = 0; k < R::NV; ++k) { v[k] = 0.f; o_v[k] = fv[k]; }
+                        for (int k = 0; k < R::NV; ++k) v[k] = 0.f;
+                        R::place(q, rx, ry);
+                        touched_layout = true;
+                    }
+#pragma unroll
+                    for (int k = 0; k < R::NQ; ++k) o_q[k] = fq[k];
+#pragma unroll
+                    for (int k = 0; k < R::NV; ++k) o_v[k] = fv[k];
 #pragma unroll
                     for (int k = 0; k < R::NU; ++k) o_ctrl[k] = 0.f;
-                    R::place(q, rx, ry);
 #pragma unroll
                     for (int jb = 0; jb < BPL; ++jb) { ob.gl[jb] = rob.gl[jb]; ob.hl[jb] = rob.hl[jb]; }
                     ob.comp0 = rob.comp0; ob.comp1 = rob.comp1;
                     o_v0 = o_v1 = o_a0 = o_a1 = 0.f;
-                    touched_layout = true;
                 }
             }
+            if (r.do_reset == 2 && live && l == 0) r.rd_j[env] = jrow;
         }
 
         if (live || kPolicy) {
-            const size_t te = (size_t)t * p.N + env;
             // closed loop: the post-reset row is the policy's next input (LDS); open loop: global
-            float* row = kPolicy ? xrow : r.obs + te * p.D;
-#pragma unroll
-            for (int jb = 0; jb < BPL; ++jb) {
-                const int b = l + kGL * jb;
-                if (b < p.bins) {
-                    if (p.off_gl >= 0) row[p.off_gl + b] = ob.gl[jb];
-                    if (p.off_hl >= 0) row[p.off_hl + b] = ob.hl[jb];
-                }
-            }
-            if (l < R::NU && p.off_ctrl >= 0) row[p.off_ctrl + l] = pick(o_ctrl, l);
-            if (l < R::NQ && p.off_qpos >= 0) row[p.off_qpos + l] = pick(o_q, l);
-            if (l < R::NV) {
-                if (p.off_qvel >= 0) row[p.off_qvel + l] = pick(o_v, l);
-                if (kQacc && live) r.qacc[te * R::NV + l] = pick(qacc, l);
-            }
-            if (l < 2) {
-                if (p.off_comp >= 0) row[p.off_comp + l] = (l == 0) ? ob.comp0 : ob.comp1;
-                if (p.off_vel >= 0) row[p.off_vel + l] = (l == 0) ? o_v0 : o_v1;
-                if (p.off_acc >= 0) row[p.off_acc + l] = (l == 0) ? o_a0 : o_a1;
-            }
-            if (l == 0 && live) { r.rew[te] = rw; r.cost[te] = ob.cost; r.done[te] = dn; }
+            float* row = kPolicy ? xrow : (r.do_reset == 2 ? r.obs_rd + (size_t)env * p.D : r.obs + te * r.obs_stride);
+            write_row(row, ob);
         }
         if (kPolicy) __syncthreads();
     }
@@ -1067,11 +1166,24 @@ template <class R, int BLOCK, int PMAX>
 static void launch_thread_rollout_bp(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s)
 {
     const dim3 grid((p.N + BLOCK - 1) / BLOCK), blk(BLOCK);
-    const size_t lds = step_lds_bytes(p, BLOCK);
+    const size_t lds = sizeof(float) * (size_t)BLOCK * r.obs_stride;
     if (PMAX == 5 && is_default_layout<R>(p))
         hipLaunchKernelGGL((thread_rollout_kernel<R, BLOCK, 5, true>), grid, blk, lds, s, p, r, b.dyn, b.obj, b.hist);
     else
         hipLaunchKernelGGL((thread_rollout_kernel<R, BLOCK, PMAX, false>), grid, blk, lds, s, p, r, b.dyn, b.obj, b.hist);
+}
+
+template <class R, int BLOCK, int PMAX>
+static void launch_commit_bp(const Params& p, const DevBuffers& b, int nobj_total, hipStream_t s)
+{
+    hipLaunchKernelGGL((commit_pending_kernel<R, BLOCK, PMAX>), dim3((p.N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p,
+                       nobj_total, b.rd_j, b.pool.cand_xy, b.dyn, b.obj);
+}
+
+template <class R>
+void RobotLaunch<R>::commit_pending(const Params& p, const DevBuffers& b, int nobj_total, hipStream_t s)
+{
+    GX_DISPATCH_P(R, launch_commit_bp, 64, p, b, nobj_total, s);
 }
 
 template <class R>

@@ -104,6 +104,10 @@ class Engine:
                     of a global batch of `env_num * world` envs and reproduces exactly
                     the rows an unsharded Engine(env_num*world) would produce
       emit_qacc     fill info['obs']['qacc'] (engine.py:763-764); costs one more output array
+      out_ring      step() returns tensors from a ring of `out_ring` preallocated output sets (default 8: a tensor
+                    is reused 8 step() calls after it was returned; the learners copy what they keep,
+                    trpo.py:58-64).  0 = a fresh allocation per call, the reference's "never mutated later"
+                    behaviour (engine.py:495), ~15 us more host time per step
       point_actuators  'mjcf' (default): point.xml's <general> actuators inherit the class defaults the way
                     MuJoCo compiles them (ctrl clamp +-1, velocity-servo bias, force clamp +-.05, action
                     space Box(-1, 1)); 'bare': the round-1 reading without the defaults (force = 0.3*ctrl,
@@ -147,10 +151,11 @@ class Engine:
         '_seed': 0,
     }
 
-    def __init__(self, config={}, *, n_candidates=1_000_000, shard=None, emit_qacc=True, point_actuators='mjcf'):
+    def __init__(self, config={}, *, n_candidates=1_000_000, shard=None, emit_qacc=True, point_actuators='mjcf',
+                 out_ring=8):
         self._ctor_config = deepcopy(config)
         self._ctor_kwargs = dict(n_candidates=n_candidates, shard=shard, emit_qacc=emit_qacc,
-                                 point_actuators=point_actuators)
+                                 point_actuators=point_actuators, out_ring=out_ring)
         if point_actuators not in ('mjcf', 'bare'):
             raise ValueError("point_actuators must be 'mjcf' or 'bare'")
         self.parse(config)
@@ -203,6 +208,11 @@ class Engine:
         assert self.obs_flat_size == self._lib.gx_obs_dim(self._h)
 
         self._act_shape = torch.Size((int(self.env_num), act_dim))
+        self._ring = [None] * max(0, int(out_ring))
+        self._ring_i = 0
+        self._spec = C.c_int32(0)
+        self._spec_ref = C.byref(self._spec)
+        self._rd_obs = None          # what reset_done() returns for the step just made (speculated in-kernel)
         self._obs = None
         self._reward = None
         self._done = None
@@ -355,6 +365,7 @@ class Engine:
         check_layouts() call, so that no host round trip separates consecutive epochs."""
         obs = self._new(self.env_num, self.obs_flat_size)
         _native.check(self._lib.gx_reset(self._h, obs.data_ptr(), self._stream()))
+        self._rd_obs = None
         if not check:
             self._obs = obs
             return obs
@@ -379,17 +390,46 @@ class Engine:
         self.layout_size = int(n.value)
         return self.layout_size
 
+    def _out_slot(self):
+        """One set of step() outputs carved out of a single allocation: (obs, obs_rd, reward, cost, done, qacc)
+        and their device addresses."""
+        N, D, nv = self.env_num, self.obs_flat_size, self.robot.nv
+        Dp = (D + 3) // 4 * 4                      # keep every piece 16-byte aligned
+        flat = torch.empty(N * (2 * Dp + 3 + nv) + 16, dtype=torch.float32, device=self.device)
+        o = 0
+        obs = flat[o:o + N * D].view(N, D); o += N * Dp
+        obs_rd = flat[o:o + N * D].view(N, D); o += N * Dp
+        rew = flat[o:o + N]; o += N
+        cost = flat[o:o + N]; o += N
+        done = flat[o:o + N]; o += N
+        o = (o + 3) // 4 * 4
+        qacc = flat[o:o + N * nv].view(N, nv) if self.emit_qacc else None
+        ptrs = (obs.data_ptr(), rew.data_ptr(), cost.data_ptr(), done.data_ptr(),
+                qacc.data_ptr() if qacc is not None else None, obs_rd.data_ptr())
+        return (obs, obs_rd, rew, cost, done, qacc, ptrs)
+
     def step(self, action):
-        """One control step for every env (engine.py:469-495).  No auto-reset."""
-        a = self._as_action(action)
-        N = self.env_num
-        obs = self._new(N, self.obs_flat_size)
-        reward, cost, done = self._new(N), self._new(N), self._new(N)
-        qacc = self._new(N, self.robot.nv) if self.emit_qacc else None
-        _native.check(self._lib.gx_step(self._h, a.data_ptr(), obs.data_ptr(), reward.data_ptr(),
-                                        cost.data_ptr(), done.data_ptr(),
-                                        qacc.data_ptr() if qacc is not None else None,
-                                        self._stream()))
+        """One control step for every env (engine.py:469-495).  No auto-reset.  The same launch also
+        evaluates what reset_done() would return for the envs this step finished (gx_step_rd); nothing is
+        re-initialised unless reset_done() is called."""
+        a = action
+        if not (type(a) is torch.Tensor and a.dtype is torch.float32 and a.shape == self._act_shape
+                and a.device == self.device and a.is_contiguous() and not a.requires_grad):
+            a = self._as_action(action)
+        if self._ring:
+            i = self._ring_i
+            slot = self._ring[i]
+            if slot is None:
+                slot = self._ring[i] = self._out_slot()
+            self._ring_i = i + 1 if i + 1 < len(self._ring) else 0
+        else:
+            slot = self._out_slot()
+        obs, obs_rd, reward, cost, done, qacc, p = slot
+        st = self._lib.gx_step_rd(self._h, a.data_ptr(), p[0], p[1], p[2], p[3], p[4], p[5], self._spec_ref,
+                                  self._stream())
+        if st:
+            _native.check(st)
+        self._rd_obs = obs_rd if self._spec.value else None
         info = {'cost': cost,
                 'obs': _LazyObsDict(obs, self._obs_slices, qacc if self.observe_qacc else None)}
         self._obs, self._reward, self._done, self._info = obs, reward, done, info
@@ -400,31 +440,48 @@ class Engine:
         step's observation (engine.py:497-505)."""
         if self._obs is None:
             raise RuntimeError("reset_done() before reset()")
+        if self._rd_obs is not None:
+            # already evaluated by the step() launch: request the re-initialisation (installed by the next
+            # launch on this engine) and hand out the observation -- no kernel of its own
+            _native.check(self._lib.gx_reset_done_commit(self._h))
+            return self._rd_obs
         out = self._new(self.env_num, self.obs_flat_size)
         _native.check(self._lib.gx_reset_done(self._h, self._obs.data_ptr(), out.data_ptr(),
                                               self._stream()))
         return out
 
-    def rollout(self, actions):
+    def rollout(self, actions, packed=False):
         """Open-loop rollout: T x (step -> reset_done) driven by `actions` (T, env_num, act_dim).
 
         Returns time-major tensors obs (T, N, D) [post-reset_done, i.e. what the learner stores
         as the next observation], reward, cost, done (T, N).  Equivalent to the learner loop of
-        safe_rl_libX/trpo/trpo.py:466-547 with a fixed action tape."""
+        safe_rl_libX/trpo/trpo.py:466-547 with a fixed action tape.
+
+        packed=True: the kernel writes ONE (T, N, D + A + 3) tensor, rows (obs | action | reward, cost, done)
+        -- the per-rank shard of the learner hand-off, ready for a single all-gather; the four results are
+        views of it and it is returned as a fifth value."""
         a = actions
         if a.dtype != torch.float32 or not a.is_contiguous() or a.device != self.device:
             a = a.to(device=self.device, dtype=torch.float32).contiguous()
         T = int(a.shape[0])
-        assert tuple(a.shape[1:]) == (self.env_num, self.action_space.shape[0])
+        A = self.action_space.shape[0]
+        assert tuple(a.shape[1:]) == (self.env_num, A)
         N, D = self.env_num, self.obs_flat_size
-        obs = self._new(T, N, D)
-        reward, cost, done = self._new(T, N), self._new(T, N), self._new(T, N)
-        _native.check(self._lib.gx_rollout(self._h, T, a.data_ptr(), obs.data_ptr(),
-                                           reward.data_ptr(), cost.data_ptr(), done.data_ptr(),
-                                           self._stream()))
+        self._rd_obs = None
+        if packed:
+            W = D + A + 3
+            pk = self._new(T, N, W)
+            _native.check(self._lib.gx_rollout_packed(self._h, T, a.data_ptr(), pk.data_ptr(), self._stream()))
+            obs, reward, cost, done = pk[..., :D], pk[..., D + A], pk[..., D + A + 1], pk[..., D + A + 2]
+        else:
+            obs = self._new(T, N, D)
+            reward, cost, done = self._new(T, N), self._new(T, N), self._new(T, N)
+            _native.check(self._lib.gx_rollout(self._h, T, a.data_ptr(), obs.data_ptr(),
+                                               reward.data_ptr(), cost.data_ptr(), done.data_ptr(),
+                                               self._stream()))
         self._obs, self._reward, self._done = obs[-1], reward[-1], done[-1]
         self._info = {'cost': cost[-1]}
-        return obs, reward, cost, done
+        return (obs, reward, cost, done, pk) if packed else (obs, reward, cost, done)
 
     # ------------------------------------------------------------------
     # closed-loop fused rollout (policy evaluated inside the kernel)
@@ -460,6 +517,7 @@ class Engine:
         params = params.to(device=self.device, dtype=torch.float32).contiguous()
         obs0 = obs0.to(device=self.device, dtype=torch.float32).contiguous()
         assert tuple(obs0.shape) == (N, D)
+        self._rd_obs = None
         out = dict(obs=self._new(T, N, D), act=self._new(T, N, A), logp=self._new(T, N), val=self._new(T, N),
                    mu=self._new(T, N, A), rew=self._new(T, N), cost=self._new(T, N), done=self._new(T, N),
                    obs_last=self._new(N, D), val_last=self._new(N), logstd=self._new(A))
@@ -485,9 +543,16 @@ class Engine:
         _native.check(self._lib.gx_set_policy_impl(self._h, int(impl)))
 
     def set_prefetch(self, steps):
-        """Predicted number of step() calls between reset()s for the layout-pool prefetch
-        (default num_steps); negative disables.  Never changes results."""
+        """Predicted number of step() calls between reset()s for the layout-pool prefetch: >= 0 fixed,
+        -1 off, -2 (default) = the interval between the last two reset() calls (num_steps before the
+        second reset) -- the learners reset every max_ep_len steps.  Never changes results."""
         _native.check(self._lib.gx_set_prefetch(self._h, int(steps)))
+
+    def prefetch_stats(self):
+        """(prefetched pools used, prefetched pools discarded, current prediction in steps)"""
+        h, m, z = C.c_int32(), C.c_int32(), C.c_int32()
+        _native.check(self._lib.gx_prefetch_stats(self._h, C.byref(h), C.byref(m), C.byref(z)))
+        return int(h.value), int(m.value), int(z.value)
 
     def set_path(self, mode):
         """0 auto, 1 thread-per-env kernels, 2 lane-group kernels (bit-identical results)."""
@@ -544,6 +609,7 @@ class Engine:
             key = (C.c_uint32 * 2)(int(s['key'][0]), int(s['key'][1]))
         hist = C.byref(C.c_int32(int(s['hist']))) if s.get('hist') is not None else None
         _native.check(self._lib.gx_set_state(self._h, *ptrs, key, hist))
+        self._rd_obs = None
 
     def get_pool(self, max_rows=4096):
         H = int(self.hazards_num)

@@ -109,6 +109,18 @@ gx_status gx_layout_size_min(gx_engine* e, int32_t* out);
 gx_status gx_step(gx_engine* e, const float* d_action, float* d_obs, float* d_reward,
                   float* d_cost, float* d_done, float* d_qacc, void* stream);
 
+/* Engine.step plus, in the same launch, what a reset_done() right after it returns: d_obs_rd (env_num x obs_dim)
+ * = d_obs with the rows of the envs this step finished replaced by their re-initialised observation
+ * (engine.py:497-505, same key).  The state is NOT re-initialised by this call: gx_reset_done_commit() requests
+ * that, and the next launch on this handle installs it (no launch of its own, so the learner's
+ * `step(); if done.any(): reset_done()` pair costs one kernel).  *speculated = 0 when the handle runs the
+ * thread-per-env kernels (env_num > 16384): d_obs_rd is then left unwritten and the caller uses gx_reset_done. */
+gx_status gx_step_rd(gx_engine* e, const float* d_action, float* d_obs, float* d_reward, float* d_cost,
+                     float* d_done, float* d_qacc, float* d_obs_rd, int32_t* speculated, void* stream);
+/* Engine.reset_done for the step just made through gx_step_rd (speculated == 1): host-only, idempotent.
+ * GX_ERR_STATE if the last hot-path call was anything else. */
+gx_status gx_reset_done_commit(gx_engine* e);
+
 /* Engine.reset_done: rows of envs whose last done was > 0 are re-initialised
  * and their obs rows replaced; other rows are copied from d_obs_in (which may
  * alias d_obs_out). */
@@ -120,6 +132,12 @@ gx_status gx_reset_done(gx_engine* e, const float* d_obs_in, float* d_obs_out, v
  * d_cost / d_done [T][env_num]. */
 gx_status gx_rollout(gx_engine* e, int32_t T, const float* d_actions, float* d_obs,
                      float* d_reward, float* d_cost, float* d_done, void* stream);
+
+/* gx_rollout writing the learner hand-off layout directly: d_packed[T][env_num][W], W = gx_packed_width() =
+ * obs_dim + act_dim + 3, row = (obs | action | reward, cost, done) -- what TRPOBufferX stores per step
+ * (safe_rl_libX/trpo/trpo.py:34-42,49-64), ready for ONE all-gather per epoch with no pack pass. */
+gx_status gx_rollout_packed(gx_engine* e, int32_t T, const float* d_actions, float* d_packed, void* stream);
+int32_t gx_packed_width(const gx_engine* e);
 
 /* ---- closed-loop fused rollout with an on-device policy ------------------
  * `ac.step(o)` of MLPActorCritic(hidden_sizes=(64,64), tanh) (safe_rl_libX/trpo/trpo_core.py:110-173)
@@ -161,8 +179,12 @@ gx_status gx_get_pool(gx_engine* e, float* pool, int32_t max_rows, int32_t* got)
 /* Layout-pool prefetch: after each gx_reset the pool for the NEXT reset (the key advanced
  * by `steps` step() calls, engine.py:431) is sampled on a low-priority side stream while the
  * epoch runs; a reset whose key matches uses it, otherwise it samples inline.  Results are
- * identical either way.  steps < 0 disables; the default is cfg.num_steps. */
+ * identical either way.  steps >= 0: fixed prediction; -1: no prefetch; -2 (default): predict the
+ * number of steps made between the last two resets (cfg.num_steps before the second reset) -- the
+ * learners reset every max_ep_len steps (trpo.py:453,517), which need not equal num_steps. */
 gx_status gx_set_prefetch(gx_engine* e, int32_t steps);
+/* prefetched pools used / discarded so far, and the current prediction */
+gx_status gx_prefetch_stats(const gx_engine* e, int32_t* hits, int32_t* misses, int32_t* horizon);
 
 /* Kernel family used by step / rollout: 0 = auto (lane-group kernels up to 16384 envs,
  * thread-per-env kernels above), 1 = force thread-per-env, 2 = force lane-group.

@@ -27,6 +27,7 @@ PATHS = {"thread": 1, "group": 2}
 def _engines(cfg, oracle, n_candidates=20000, path=None, **kw):
     from guardx_amd import Engine
     E = Engine(cfg, n_candidates=n_candidates, **kw)
+    assert E.action_space.shape[0] == E._lib.gx_act_dim(E._h)
     if path is not None:
         E.set_path(PATHS[path])
     O = oracle.OracleEngine(cfg, n_candidates=n_candidates, env_total=E._cfg.env_total,
@@ -266,6 +267,114 @@ def test_variant_configs(torch_cuda, oracle, path, robot):
         assert_state_equal(E.get_state(), O.get_state(),
                            fields=('qpos', 'qvel', 'pose0', 'pose1', 'objs', 'done0', 'done1', 'steps')
                            if v.get('observe_vel') else ('qpos', 'qvel', 'pose0', 'objs', 'done0', 'steps'))
+
+
+@pytest.mark.parametrize("robot", ["point", "ant"])
+def test_step_speculates_reset_done_without_installing_it(torch_cuda, oracle, robot):
+    """Engine.step() evaluates reset_done() in the same launch (gx_step_rd) but must not re-initialise
+    anything unless reset_done() is called (the *_one_episode learners never call it): every mix of
+    step / step+reset_done / get_state / rollout must follow the checker, on fresh and ring buffers."""
+    torch = torch_cuda
+    extra = ANT if robot == "ant" else {}
+    A = 8 if robot == "ant" else 2
+    N = 257
+    for ring in (8, 0):
+        cfg = task_config(N, seed=17, num_steps=12, goal_size=2.6, **extra)
+        E, O = _engines(cfg, oracle, n_candidates=30000, out_ring=ring)
+        np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
+        rng = np.random.default_rng(4)
+        called = skipped = 0
+        for t in range(70):
+            act = rng.uniform(-1, 1, (N, A)).astype(np.float32)
+            out_g, out_o = E.step(torch.from_numpy(act).cuda()), O.step(act)
+            _cmp_step(out_g, out_o)
+            mode = t % 5
+            if mode in (0, 1):                       # reset_done right after the step (trpo.py:547)
+                rg = E.reset_done()
+                np.testing.assert_array_equal(rg.cpu().numpy(), O.reset_done())
+                if mode == 1:                        # idempotent (same key, _done unchanged)
+                    np.testing.assert_array_equal(E.reset_done().cpu().numpy(), O.reset_done())
+                called += int(out_o[2].sum())
+            elif mode == 2:                          # state read-back installs a requested reset first
+                np.testing.assert_array_equal(E.reset_done().cpu().numpy(), O.reset_done())
+                assert_state_equal(E.get_state(), O.get_state())
+            else:                                    # no reset_done: finished envs stay where they are
+                skipped += int(out_o[2].sum())
+                if mode == 4:
+                    assert_state_equal(E.get_state(), O.get_state())
+        assert called > 0 and skipped > 0
+        acts = rng.uniform(-1, 1, (5, N, A)).astype(np.float32)   # a rollout right after a requested reset_done
+        o, r, d, info = E.step(torch.from_numpy(acts[0]).cuda()); O.step(acts[0])
+        np.testing.assert_array_equal(E.reset_done().cpu().numpy(), O.reset_done())
+        obs, rew, cost, done = E.rollout(torch.from_numpy(acts).cuda())
+        for t in range(5):
+            oo, ro, do, io = O.step(acts[t])
+            np.testing.assert_array_equal(obs[t].cpu().numpy(), O.reset_done())
+            np.testing.assert_array_equal(rew[t].cpu().numpy(), ro)
+        assert_state_equal(E.get_state(), O.get_state())
+        # reset() right after a requested reset_done: the request is moot
+        E.step(torch.from_numpy(acts[1]).cuda()); O.step(acts[1])
+        E.reset_done(); O.reset_done()
+        np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
+        assert_state_equal(E.get_state(), O.get_state())
+
+
+def test_step_reset_done_above_the_group_limit(torch_cuda, oracle):
+    """env_num > 16384 runs the thread-per-env kernels: step() does not speculate, reset_done() launches"""
+    torch = torch_cuda
+    N = 16384 + 640
+    E, O = _engines(task_config(N, seed=3, num_steps=6, goal_size=2.7), oracle, n_candidates=120000)
+    np.testing.assert_array_equal(E.reset(check=False).cpu().numpy(), O.reset(check=False))
+    rng = np.random.default_rng(0)
+    for t in range(9):
+        act = rng.uniform(-1, 1, (N, 2)).astype(np.float32)
+        _cmp_step(E.step(torch.from_numpy(act).cuda()), O.step(act))
+        assert E._rd_obs is None
+        if t % 2:
+            np.testing.assert_array_equal(E.reset_done().cpu().numpy(), O.reset_done())
+    assert_state_equal(E.get_state(), O.get_state())
+
+
+@pytest.mark.parametrize("path", ["thread", "group"])
+@pytest.mark.parametrize("robot", ["point", "walker"])
+def test_packed_rollout_equals_plain(torch_cuda, oracle, path, robot):
+    """gx_rollout_packed: rows (obs | action | reward, cost, done) written by the kernel == gx_rollout's arrays"""
+    torch = torch_cuda
+    from guardx_amd import Engine
+    extra = WALKER if robot == "walker" else {}
+    A = 10 if robot == "walker" else 2
+    N, T = 203, 31
+    cfg = task_config(N, seed=5, num_steps=10, goal_size=2.6, **extra)
+    acts = torch.from_numpy(np.random.default_rng(1).uniform(-1, 1, (T, N, A)).astype(np.float32)).cuda()
+    outs = []
+    for packed in (False, True):
+        E = Engine(cfg, n_candidates=30000)
+        E.set_path(PATHS[path])
+        E.reset()
+        outs.append(E.rollout(acts, packed=packed))
+        st = E.get_state()
+    (o0, r0, c0, d0), (o1, r1, c1, d1, pk) = outs
+    D = o0.shape[-1]
+    assert pk.shape == (T, N, D + A + 3) and d0.sum().item() > 0
+    for a, b in ((o0, o1), (r0, r1), (c0, c1), (d0, d1)):
+        assert torch.equal(a, b)
+    assert torch.equal(pk[..., D:D + A], acts)
+    assert torch.equal(pk[..., :D], o0) and torch.equal(pk[..., D + A + 2], d0)
+
+
+def test_prefetch_horizon_follows_the_learner(torch_cuda, oracle):
+    """the prefetch predicts the interval between the last two reset() calls, not num_steps"""
+    torch = torch_cuda
+    N = 64
+    E, O = _engines(task_config(N, seed=2, num_steps=1000), oracle, n_candidates=30000)   # DEFAULT num_steps
+    tape = torch.zeros(25, N, 2, device='cuda')
+    for ep in range(5):                                  # the learner resets every max_ep_len = 25 steps
+        np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
+        E.rollout(tape)
+        for t in range(25):
+            O.step(np.zeros((N, 2), np.float32)); O.reset_done()
+    hits, misses, horizon = E.prefetch_stats()
+    assert horizon == 25 and hits == 3 and misses == 1   # epoch 1 mispredicts (1000), 2.. hit
 
 
 def test_sharded_equals_unsharded(torch_cuda, oracle):
