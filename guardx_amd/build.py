@@ -22,6 +22,22 @@ SOURCES = ["gx_api.hip", "gx_kernels.hip", "gx_gae.hip", "gx_kernels_point.hip",
 HEADERS = ["gx_device.h", "gx_robot.h", "gx_robot_ant.h", "gx_robot_ant_group.h", "gx_robot_legs.h", "gx_robot_legs_group.h", "gx_policy.h", "gx_kernels.h", "gx_robot_kernels.inl",
            os.path.join("..", "..", "include", "guardx.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# The Ant / Walker steps are real (noinline) device functions called from the lane-group kernels.  With LLVM's
+# inter-procedural register allocation (on by default for amdgcn at -O3) hipcc 7.2 lets such a callee use, without
+# saving them, the VGPRs in whose lanes the CALLER parks spilled SGPRs (exec masks, v254/v255 in the failing
+# kernel): after the call the masks are garbage and masked-off lanes execute stores with garbage addresses
+# (found with rocgdb on group_rollout_kernel<WalkerRobot,5,4,...>: HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION in
+# the observation-row stores right after the second substep_call; gone with IPRA off).  So those two translation
+# units are compiled without IPRA: the callee then saves and restores the callee-saved registers it uses.
+PER_SOURCE_FLAGS = {
+    "gx_kernels_ant.hip": ["-mllvm", "-enable-ipra=0"],
+    "gx_kernels_walker.hip": ["-mllvm", "-enable-ipra=0"],
+}
+
+
+def _extra(src):
+    # GX_EXTRA_FLAGS_<source stem>="...": experiments
+    return PER_SOURCE_FLAGS.get(src, []) + os.environ.get("GX_EXTRA_FLAGS_" + os.path.splitext(src)[0], "").split()
 
 
 def _deps_mtime():
@@ -52,7 +68,7 @@ def build(force=False, verbose=False, jobs=None):
         path, obj = os.path.join(CSRC, src), _obj(src)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_t):
             return
-        cmd = [hipcc] + FLAGS + ["-c", path, "-o", obj]
+        cmd = [hipcc] + FLAGS + _extra(src) + ["-c", path, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

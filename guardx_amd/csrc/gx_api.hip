@@ -357,7 +357,7 @@ extern "C" gx_status gx_destroy(gx_engine* e)
 static gx_status flush_pending(gx_engine* e, hipStream_t s)
 {
     if (take_commit(e)) {
-        launch_commit_pending(e->p, e->b, e->nobj_total, s);
+        launch_commit_pending(e->p, e->b, e->nobj_total, e->sp.M, s);
         GX_HIP(hipGetLastError());
     }
     return GX_OK;
@@ -514,6 +514,7 @@ static gx_status step_impl(gx_engine* e, const float* d_action, float* d_obs, fl
         r.obs = d_obs; r.rew = d_reward; r.cost = d_cost; r.done = d_done; r.qacc = d_qacc;
         r.rd_j = e->b.rd_j;
         r.layout_size = e->b.pool.layout_size; r.cand_of = e->b.pool.cand_of; r.cand_xy = e->b.pool.cand_xy;
+        r.n_rows = e->sp.M;
         if (d_obs_rd) { // also what reset_done() would return and install, with the key it would use (:447,500)
             uint32_t k[4];
             layout_keys(e, k);
@@ -613,6 +614,7 @@ static void fill_rollout_args(gx_engine* e, RolloutArgs& r, int32_t T, int slot)
     r.obs_stride = e->p.D; r.sc_stride = 1; r.rd_j = e->b.rd_j;
     r.keys = e->h_keys[slot]; // pinned + device-visible: read over the host link only on a reset
     r.layout_size = e->b.pool.layout_size; r.cand_of = e->b.pool.cand_of; r.cand_xy = e->b.pool.cand_xy;
+    r.n_rows = e->sp.M;
     e->p.have_last = e->hist >= 1;
     e->p.have_last_last = e->hist >= 2;
 }

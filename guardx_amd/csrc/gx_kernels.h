@@ -76,6 +76,7 @@ struct RolloutArgs {
     const int* layout_size;
     const int* cand_of;
     const float2* cand_xy;
+    int n_rows;        // rows of cand_xy (layout candidates): bound for every row index read back from memory
 };
 void launch_group_rollout(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s);
 // thread-per-env persistent rollout (large batches)
@@ -83,7 +84,7 @@ void launch_thread_rollout(const Params& p, const RolloutArgs& r, const DevBuffe
 void launch_policy_rollout(const Params& p, const RolloutArgs& r, const PolicyArgs& pol, const DevBuffers& b,
                            int impl, hipStream_t s);
 // install the reset_done recorded in b.rd_j (pending commit) for consumers other than the lane-group kernels
-void launch_commit_pending(const Params& p, const DevBuffers& b, int nobj_total, hipStream_t s);
+void launch_commit_pending(const Params& p, const DevBuffers& b, int nobj_total, int n_rows, hipStream_t s);
 // per-robot launchers: defined in gx_robot_kernels.inl, instantiated once per robot in gx_kernels_<robot>.hip
 template <class R>
 struct RobotLaunch {
@@ -97,7 +98,7 @@ struct RobotLaunch {
     static void thread_rollout(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s);
     static void policy(const Params& p, const RolloutArgs& r, const PolicyArgs& pol, const DevBuffers& b, int impl,
                        hipStream_t s);
-    static void commit_pending(const Params& p, const DevBuffers& b, int nobj_total, hipStream_t s);
+    static void commit_pending(const Params& p, const DevBuffers& b, int nobj_total, int n_rows, hipStream_t s);
 };
 bool policy_rollout_supported(const Params& p);
 size_t policy_lds_bytes(const Params& p, int impl);

@@ -384,9 +384,9 @@ void launch_thread_rollout(const Params& p, const RolloutArgs& r, const DevBuffe
     GX_ROBOT_DISPATCH(thread_rollout(p, r, b, s));
 }
 
-void launch_commit_pending(const Params& p, const DevBuffers& b, int nobj_total, hipStream_t s)
+void launch_commit_pending(const Params& p, const DevBuffers& b, int nobj_total, int n_rows, hipStream_t s)
 {
-    GX_ROBOT_DISPATCH(commit_pending(p, b, nobj_total, s));
+    GX_ROBOT_DISPATCH(commit_pending(p, b, nobj_total, n_rows, s));
 }
 
 bool policy_rollout_supported(const Params& p) { return p.nobj <= 16 && p.bins <= 16; }

@@ -571,14 +571,14 @@ void thread_rollout_kernel(Params p_in, RolloutArgs r,
 // that do not apply it on load: qpos/qvel/layout of the finished envs, stale pose / done / steps kept (:715-731).
 // ---------------------------------------------------------------------------
 template <class R, int BLOCK, int PMAX>
-__global__ __launch_bounds__(BLOCK) void commit_pending_kernel(Params p, int nobj_total, const int* __restrict__ rd_j,
+__global__ __launch_bounds__(BLOCK) void commit_pending_kernel(Params p, int nobj_total, int n_rows, const int* __restrict__ rd_j,
                                                                const float2* __restrict__ cand_xy,
                                                                float4* __restrict__ dyn, float4* __restrict__ obj)
 {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= p.N) return;
     const int j = rd_j[i];
-    if (j < 0) return;
+    if (j < 0 || j >= n_rows) return;
     float4 ob[PMAX];
     float rx, ry;
     load_layout<PMAX>(p, cand_xy, nobj_total, j, ob, rx, ry);
@@ -622,10 +622,12 @@ constexpr int kGL = 16; // lanes per environment
 // to keep that order: wave-scope fences cost no instruction.  __syncthreads() would also wait for every
 // outstanding global store (s_waitcnt vmcnt(0) of the workgroup-scope release fence), i.e. for the
 // observation rows of the previous step to be acknowledged by L2 -- on the critical path of every step.
-template <int BT>
+// kWave: only for the robots whose step is inline register code (Point, Swimmer).  The Ant / Walker kernels call
+// their step as a real function with stack arrays in scratch and keep the full barrier.
+template <int BT, bool kWave>
 GX_D void group_sync()
 {
-    if (BT == 64) {
+    if (BT == 64 && kWave) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -633,10 +635,10 @@ GX_D void group_sync()
         __syncthreads();
     }
 }
-template <int BT>
+template <int BT, bool kWave>
 GX_D bool group_any(bool v)
 {
-    if (BT == 64) return __ballot(v) != 0ull;
+    if (BT == 64 && kWave) return __ballot(v) != 0ull;
     return __syncthreads_or(v ? 1 : 0) != 0;
 }
 
@@ -646,7 +648,7 @@ struct GroupObs { float gl[BPL], hl[BPL], comp0, comp1, cost; bool bad; };
 // object phase + LDS exchange + bin phase for one pose
 // `lane` = thread index in the workgroup (BT threads = BT/16 environments); must be reached by the
 // whole workgroup.
-template <int OPL, int BPL, int BT>
+template <int OPL, int BPL, int BT, bool kWave>
 GX_D GroupObs<OPL, BPL> group_observe(const Params& p, float4 (*rec)[BT], float (*term)[BT], int lane,
                                       const float (&pose)[4], float gx, float gy,
                                       const float (&ox)[OPL], const float (&oy)[OPL])
@@ -672,7 +674,7 @@ GX_D GroupObs<OPL, BPL> group_observe(const Params& p, float4 (*rec)[BT], float 
         rec[j][lane] = make_float4(__int_as_float(t.bin), t.sensor, t.a1, t.a2);
         term[j][lane] = tc;
     }
-    group_sync<BT>();
+    group_sync<BT, kWave>();
 #pragma unroll
     for (int jb = 0; jb < BPL; ++jb) {
         const int b = l + kGL * jb;
@@ -702,7 +704,7 @@ GX_D GroupObs<OPL, BPL> group_observe(const Params& p, float4 (*rec)[BT], float 
     // any lane of this env's group
     const unsigned long long m = __ballot(bad);
     out.bad = ((m >> (gbase & 63)) & 0xFFFFull) != 0ull;
-    group_sync<BT>();
+    group_sync<BT, kWave>();
     return out;
 }
 
@@ -797,7 +799,7 @@ __global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Par
     bool touched_layout = false;
     if (r.commit) { // the reset_done the previous launch speculated was requested: install it (engine.py:715-718)
         const int jj = r.rd_j[e];
-        if (live && jj >= 0) {
+        if (live && jj >= 0 && jj < r.n_rows) {
             const float2* rowp = r.cand_xy + (size_t)jj * r.nobj_total;
 #pragma unroll
             for (int j = 0; j < OPL; ++j) {
@@ -887,7 +889,7 @@ __global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Par
             ego_vel_acc(p, pose, L1x, L1y, P2x, P2y, last_done, done2, have_last, have_last_last, vel0, vel1,
                         acc0, acc1);
 
-        GroupObs<OPL, BPL> ob = group_observe<OPL, BPL, BT>(p, rec, term, lane, pose, gx, gy, ox, oy);
+        GroupObs<OPL, BPL> ob = group_observe<OPL, BPL, BT, R::kRestFixed>(p, rec, term, lane, pose, gx, gy, ox, oy);
         bool bad = ob.bad;
         if (p.off_acc >= 0) bad = bad || notfinite(acc0) || notfinite(acc1);
         if (p.off_ctrl >= 0) {
@@ -968,7 +970,7 @@ __global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Par
         if (r.do_reset) {
             const bool rs = live && dn > 0.0f && L > 0;
             int jrow = -1;
-            if (group_any<BT>(rs)) {
+            if (group_any<BT, R::kRestFixed>(rs)) {
                 float nox[OPL], noy[OPL], ngx = gx, ngy = gy, rx = 0.f, ry = 0.f;
 #pragma unroll
                 for (int j = 0; j < OPL; ++j) { nox[j] = ox[j]; noy[j] = oy[j]; }
@@ -999,7 +1001,7 @@ __global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Par
                     for (int k = 0; k < R::NU; ++k) zc[k] = 0.f;
                     for (int k = 0; k < p.physics_steps; ++k) group_substep<R, false>(fq, fv, zc, rpose, fa, l);
                 }
-                const GroupObs<OPL, BPL> rob = group_observe<OPL, BPL, BT>(p, rec, term, lane, rpose, ngx, ngy, nox, noy);
+                const GroupObs<OPL, BPL> rob = group_observe<OPL, BPL, BT, R::kRestFixed>(p, rec, term, lane, rpose, ngx, ngy, nox, noy);
                 if (rs) {
                     if (r.do_reset == 1) {
 #pragma unroll
@@ -1174,16 +1176,16 @@ static void launch_thread_rollout_bp(const Params& p, const RolloutArgs& r, cons
 }
 
 template <class R, int BLOCK, int PMAX>
-static void launch_commit_bp(const Params& p, const DevBuffers& b, int nobj_total, hipStream_t s)
+static void launch_commit_bp(const Params& p, const DevBuffers& b, int nobj_total, int n_rows, hipStream_t s)
 {
     hipLaunchKernelGGL((commit_pending_kernel<R, BLOCK, PMAX>), dim3((p.N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p,
-                       nobj_total, b.rd_j, b.pool.cand_xy, b.dyn, b.obj);
+                       nobj_total, n_rows, b.rd_j, b.pool.cand_xy, b.dyn, b.obj);
 }
 
 template <class R>
-void RobotLaunch<R>::commit_pending(const Params& p, const DevBuffers& b, int nobj_total, hipStream_t s)
+void RobotLaunch<R>::commit_pending(const Params& p, const DevBuffers& b, int nobj_total, int n_rows, hipStream_t s)
 {
-    GX_DISPATCH_P(R, launch_commit_bp, 64, p, b, nobj_total, s);
+    GX_DISPATCH_P(R, launch_commit_bp, 64, p, b, nobj_total, n_rows, s);
 }
 
 template <class R>

@@ -14,6 +14,7 @@ the current stream.  There is no CPU fallback.
 from collections import OrderedDict
 from copy import deepcopy
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -210,6 +211,7 @@ class Engine:
         self._act_shape = torch.Size((int(self.env_num), act_dim))
         self._ring = [None] * max(0, int(out_ring))
         self._ring_i = 0
+        self._speculate = os.environ.get("GX_NO_SPECULATE", "0") != "1"
         self._spec = C.c_int32(0)
         self._spec_ref = C.byref(self._spec)
         self._rd_obs = None          # what reset_done() returns for the step just made (speculated in-kernel)
@@ -425,8 +427,12 @@ class Engine:
         else:
             slot = self._out_slot()
         obs, obs_rd, reward, cost, done, qacc, p = slot
-        st = self._lib.gx_step_rd(self._h, a.data_ptr(), p[0], p[1], p[2], p[3], p[4], p[5], self._spec_ref,
-                                  self._stream())
+        if self._speculate:
+            st = self._lib.gx_step_rd(self._h, a.data_ptr(), p[0], p[1], p[2], p[3], p[4], p[5], self._spec_ref,
+                                      self._stream())
+        else:   # two-launch form (step, then reset_done on demand): debugging / A-B timing only
+            self._spec.value = 0
+            st = self._lib.gx_step(self._h, a.data_ptr(), p[0], p[1], p[2], p[3], p[4], self._stream())
         if st:
             _native.check(st)
         self._rd_obs = obs_rd if self._spec.value else None

@@ -268,10 +268,10 @@ void gxo_randint(const uint32_t* key, int32_t n, uint32_t span, int32_t* out_n)
 
 struct gxo_env {
     gxo_config cfg;
-    int N, H, NOBJ, D, bins;
+    int N, H, PL, NOBJ, D, bins; /* hazards, pillars (synthetic extension), goal + hazards + pillars */
     int nq, nv, nu, na; /* robot.nq/nv/nu (world.py:435-438) and action width */
     float h;            /* opt.timestep */
-    int off_acc, off_ctrl, off_comp, off_glidar, off_hlidar, off_qpos, off_qvel, off_vel;
+    int off_acc, off_ctrl, off_comp, off_glidar, off_hlidar, off_plidar, off_qpos, off_qvel, off_vel;
     float *qpos, *qvel, *pose0, *pose1, *objs; /* env-major */
     float *done0, *done1, *done2, *steps, *obs;
     float* pool; /* valid layouts, rows of (H+2)*2 */
@@ -303,19 +303,21 @@ int gxo_create(const gxo_config* cfg, gxo_env** out)
     if (!cfg || !out || cfg->struct_size != (int32_t)sizeof(gxo_config)) return GXO_ERR_ARG;
     if (cfg->robot < 0 || cfg->robot > GXO_ROBOT_POINT_BARE) return GXO_ERR_UNSUPPORTED;
     if (cfg->env_num < 1 || cfg->hazards_num < 1 || cfg->hazards_num > 64) return GXO_ERR_ARG;
+    if (cfg->pillars_num < 0 || cfg->hazards_num + cfg->pillars_num > 64) return GXO_ERR_ARG;
     if (cfg->lidar_num_bins < 3 || cfg->lidar_num_bins > 64) return GXO_ERR_ARG;
     if (cfg->env_offset < 0 || cfg->env_offset + cfg->env_num > cfg->env_total) return GXO_ERR_ARG;
     gxo_env* e = (gxo_env*)calloc(1, sizeof(gxo_env));
     e->cfg = *cfg;
     if (cfg->placements) { /* own copy: the caller's array need not outlive the call */
-        const size_t n = (size_t)(cfg->hazards_num + 2) * 4;
+        const size_t n = (size_t)(cfg->hazards_num + cfg->pillars_num + 2) * 4;
         double* pc = (double*)malloc(n * sizeof(double));
         memcpy(pc, cfg->placements, n * sizeof(double));
         e->cfg.placements = pc;
     }
     e->N = cfg->env_num;
     e->H = cfg->hazards_num;
-    e->NOBJ = 1 + e->H;
+    e->PL = cfg->pillars_num;
+    e->NOBJ = 1 + e->H + e->PL;
     e->bins = cfg->lidar_num_bins;
     if (cfg->robot == 0 || cfg->robot == GXO_ROBOT_POINT_BARE) { e->nq = 3; e->nv = 3; e->nu = 3; e->na = 2; e->h = PT_H; } /* point.xml */
     else if (cfg->robot == 1) { e->nq = 5; e->nv = 5; e->nu = 2; e->na = 2; e->h = 0.03f; } /* swimmer.xml */
@@ -323,13 +325,14 @@ int gxo_create(const gxo_config* cfg, gxo_env** out)
     else { e->nq = 13; e->nv = 13; e->nu = 10; e->na = 10; e->h = 0.02f; }                 /* walker.xml */
     /* flat obs = concat over sorted(obs_space_dict keys)  engine.py:386-409,773-777 */
     int o = 0;
-    e->off_acc = e->off_ctrl = e->off_comp = e->off_glidar = e->off_hlidar = -1;
+    e->off_acc = e->off_ctrl = e->off_comp = e->off_glidar = e->off_hlidar = e->off_plidar = -1;
     e->off_qpos = e->off_qvel = e->off_vel = -1;
     if (cfg->observe_acc) { e->off_acc = o; o += 2; }
     if (cfg->observe_ctrl) { e->off_ctrl = o; o += e->nu; }
     if (cfg->observe_goal_comp) { e->off_comp = o; o += 2; }
     if (cfg->observe_goal_lidar) { e->off_glidar = o; o += e->bins; }
     if (cfg->observe_hazards) { e->off_hlidar = o; o += e->bins; }
+    if (cfg->observe_pillars && e->PL > 0) { e->off_plidar = o; o += e->bins; } /* 'pillars_lidar' sorts here */
     if (cfg->observe_qpos) { e->off_qpos = o; o += e->nq; }
     if (cfg->observe_qvel) { e->off_qvel = o; o += e->nv; }
     if (cfg->observe_vel) { e->off_vel = o; o += 2; }
@@ -369,16 +372,17 @@ void gxo_destroy(gxo_env* e)
 /* ------------------------------------------------------------------ */
 static double obj_keepout(const gxo_config* c, int obj, int nobj_total)
 {
-    /* placements order: goal, hazard0.., robot  engine.py:533-544 */
+    /* placements order: goal, hazard0.., [pillar0..,] robot  engine.py:533-544 */
     if (obj == 0) return c->goal_keepout;
     if (obj == nobj_total - 1) return c->robot_keepout;
-    return c->hazards_keepout;
+    if (obj <= c->hazards_num) return c->hazards_keepout;
+    return c->pillars_keepout;
 }
 
-/* engine.py:546-572 for one candidate key; xy holds (H+2)*2 floats. */
+/* engine.py:546-572 for one candidate key; xy holds (H+PL+2)*2 floats. */
 static int sample_layout(const gxo_config* c, const uint32_t key[2], float* xy)
 {
-    const int nobj = c->hazards_num + 2;
+    const int nobj = c->hazards_num + c->pillars_num + 2;
     uint32_t rng[2] = {key[0], key[1]};
     int success = 1;
     for (int o = 0; o < nobj; ++o) {
@@ -420,7 +424,7 @@ static int sample_layout(const gxo_config* c, const uint32_t key[2], float* xy)
 /* reset_layout  engine.py:433-444 */
 static int reset_layout(gxo_env* e)
 {
-    const int M = e->cfg.n_candidates, row = (e->H + 2) * 2;
+    const int M = e->cfg.n_candidates, row = (e->NOBJ + 1) * 2;
     unsigned char* ok = (unsigned char*)malloc((size_t)M);
     float* all = (float*)malloc((size_t)M * row * 4);
     const uint32_t* key = e->key;
@@ -792,6 +796,7 @@ static void build_obs(const gxo_env* e, const float pose[4], const float* objs,
     }
     if (e->off_glidar >= 0) obs_lidar(e, pose, objs, 1, &row[e->off_glidar]);
     if (e->off_hlidar >= 0) obs_lidar(e, pose, objs + 2, e->H, &row[e->off_hlidar]);
+    if (e->off_plidar >= 0) obs_lidar(e, pose, objs + 2 * (1 + e->H), e->PL, &row[e->off_plidar]);
     if (e->off_qpos >= 0) { for (int i = 0; i < e->nq; ++i) row[e->off_qpos + i] = q[i]; }
     if (e->off_qvel >= 0) { for (int i = 0; i < e->nv; ++i) row[e->off_qvel + i] = v[i]; }
     if (e->off_vel >= 0) { row[e->off_vel] = vel[0]; row[e->off_vel + 1] = vel[1]; }
@@ -834,7 +839,7 @@ int gxo_reset(gxo_env* e, float* obs)
     if (rc != GXO_OK && e->layout_size < 1) return rc;
     uint32_t* idx = (uint32_t*)malloc((size_t)e->N * 4);
     layout_indices(e, idx); /* :458 */
-    const int row = (e->H + 2) * 2;
+    const int row = (e->NOBJ + 1) * 2;
     const float zero5[GX_MAXQ] = {0, 0, 0, 0, 0}, zero2[2] = {0, 0};
     for (int i = 0; i < e->N; ++i) {
         load_layout(e, i, &e->pool[(size_t)idx[i] * row]);
@@ -853,7 +858,7 @@ int gxo_reset(gxo_env* e, float* obs)
 int gxo_step(gxo_env* e, const float* action, float* obs, float* reward, float* cost,
              float* done, float* qacc_out)
 {
-    const int N = e->N, D = e->D, H = e->H;
+    const int N = e->N, D = e->D, H = e->H, PL = e->PL;
     /* update_data :426-431 */
     memcpy(e->done2, e->done1, (size_t)N * 4);
     memcpy(e->done1, e->done0, (size_t)N * 4);
@@ -922,6 +927,13 @@ int gxo_step(gxo_env* e, const float* action, float* obs, float* reward, float* 
             if (dh != dh) below = dh;
             cs = cs + (e->cfg.hazards_size - below);
         }
+        for (int h = 0; h < PL; ++h) { /* synthetic pillars: the same dense form with pillars_size */
+            float dx = objs[2 * (1 + H + h)] - pose[0], dy = objs[2 * (1 + H + h) + 1] - pose[1];
+            float dh = sqrtf(dx * dx + dy * dy);
+            float below = dh < e->cfg.pillars_size ? dh : e->cfg.pillars_size;
+            if (dh != dh) below = dh;
+            cs = cs + (e->cfg.pillars_size - below);
+        }
         /* NaN/Inf guard :696-699 */
         int bad = 0;
         for (int k = 0; k < D; ++k) if (!(fabsf(row[k]) <= 3.4028234663852886e38f)) bad = 1;
@@ -945,7 +957,7 @@ int gxo_step(gxo_env* e, const float* action, float* obs, float* reward, float* 
 
 int gxo_reset_done(gxo_env* e, float* obs)
 {
-    const int N = e->N, D = e->D, row = (e->H + 2) * 2;
+    const int N = e->N, D = e->D, row = (e->NOBJ + 1) * 2;
     if (e->hist == 0) { /* self._done is None: :713 falls through */
         memcpy(obs, e->obs, (size_t)N * D * 4);
         return GXO_OK;
@@ -1011,7 +1023,7 @@ int gxo_set_state(gxo_env* e, const float* qpos, const float* qvel, const float*
 int gxo_get_pool(const gxo_env* e, float* pool, int32_t max_rows)
 {
     int n = e->layout_size < max_rows ? e->layout_size : max_rows;
-    if (n > 0) memcpy(pool, e->pool, (size_t)n * (e->H + 2) * 2 * 4);
+    if (n > 0) memcpy(pool, e->pool, (size_t)n * (e->NOBJ + 1) * 2 * 4);
     return n;
 }
 

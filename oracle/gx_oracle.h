@@ -60,7 +60,17 @@ typedef struct gxo_config {
     int32_t physics_steps;      /* engine.py:202 */
     float robot_goal_min_dist;  /* engine.py:571  3.0 */
     int32_t reserved;
-    const double* placements;   /* NULL or (H+2) x 4 doubles, engine.py:507-531 */
+    const double* placements;   /* NULL or (H+PL+2) x 4 doubles (goal, hazards, pillars, robot), engine.py:507-531 */
+    /* ---- synthetic extension, NO reference counterpart (BASELINE config 5): a second class
+     * of static circles, "pillars", in the hazard style -- placed by the sampler after the hazards (own
+     * keepout), seen by a lidar of their own ('pillars_lidar', sorted between 'hazards_lidar' and 'qpos'),
+     * and adding sum(pillars_size - min(dist, pillars_size)) to the cost after the hazard terms.  The
+     * reference only carries the colour / lidar group constants (engine.py:38,56). */
+    int32_t pillars_num;        /* 0 = the reference's task */
+    int32_t observe_pillars;
+    float pillars_size;
+    float pad_;
+    double pillars_keepout;
 } gxo_config;
 
 typedef struct gxo_env gxo_env;

@@ -76,9 +76,12 @@ def randint(key, n, span):
 # --------------------------------------------------------------------------
 # layout sampling  engine.py:546-621 (one candidate, scalar python: small cases only)
 # --------------------------------------------------------------------------
-def sample_layout(key, hazards_num=8, keepouts=(0.5, 0.4, 0.4), extents=(-2, -2, 2, 2), margin=0.0):
-    names = ['goal'] + [f'hazard{i}' for i in range(hazards_num)] + ['robot']
-    ko = {n: (keepouts[0] if n == 'goal' else keepouts[2] if n == 'robot' else keepouts[1]) for n in names}
+def sample_layout(key, hazards_num=8, keepouts=(0.5, 0.4, 0.4), extents=(-2, -2, 2, 2), margin=0.0,
+                  pillars_num=0, pillars_keepout=0.3):
+    """pillars (synthetic extension, no reference counterpart) are placed after the hazards"""
+    names = ['goal'] + [f'hazard{i}' for i in range(hazards_num)] + [f'pillar{i}' for i in range(pillars_num)] + ['robot']
+    ko = {n: (keepouts[0] if n == 'goal' else keepouts[2] if n == 'robot' else
+              pillars_keepout if n.startswith('pillar') else keepouts[1]) for n in names}
     rng = np.asarray(key, U32)
     layout, success = {}, True
     for name in names:

@@ -26,6 +26,9 @@ DEFAULTS = {
     'physics_steps_per_control_step': 1,
     'robot_placements': None, 'robot_locations': [], 'goal_placements': None, 'goal_locations': [],
     'hazards_placements': None, 'hazards_locations': [],
+    # synthetic extension (BASELINE config 5; no reference counterpart, see gx_oracle.h)
+    'pillars_num': 0, 'pillars_keepout': 0.3, 'pillars_size': 0.2, 'observe_pillars': False,
+    'pillars_placements': None, 'pillars_locations': [],
 }
 
 
@@ -47,6 +50,8 @@ class Config(C.Structure):
         ("n_candidates", C.c_int32), ("physics_steps", C.c_int32),
         ("robot_goal_min_dist", C.c_float), ("reserved", C.c_int32),
         ("placements", C.POINTER(C.c_double)),
+        ("pillars_num", C.c_int32), ("observe_pillars", C.c_int32), ("pillars_size", C.c_float),
+        ("pad_", C.c_float), ("pillars_keepout", C.c_double),
     ]
 
 
@@ -146,10 +151,14 @@ def make_config(config, n_candidates=1_000_000, env_total=None, env_offset=0, po
     c.n_candidates = int(n_candidates)
     c.physics_steps = int(cfg['physics_steps_per_control_step'])
     c.robot_goal_min_dist = 3.0
+    c.pillars_num = int(cfg['pillars_num'])
+    c.observe_pillars = int(bool(cfg['observe_pillars']))
+    c.pillars_size = float(cfg['pillars_size'])
+    c.pillars_keepout = float(cfg['pillars_keepout'])
     # engine.py:507-531: per-object rectangle from *_locations (a +-keepout box around the point,
     # which the keepout shrink collapses back onto the point) or a single *_placements rectangle
     rows, custom = [], False
-    for kind, count in (('goal', 1), ('hazards', c.hazards_num), ('robot', 1)):
+    for kind, count in (('goal', 1), ('hazards', c.hazards_num), ('pillars', c.pillars_num), ('robot', 1)):
         locs, rects, ko = cfg[kind + '_locations'], cfg[kind + '_placements'], cfg[kind + '_keepout']
         for i in range(count):
             if i < len(locs):
@@ -181,6 +190,7 @@ class OracleEngine:
         self.h = h
         self.N = self.cfg.env_num
         self.H = self.cfg.hazards_num
+        self.PL = self.cfg.pillars_num
         self.D = self.L.gxo_obs_dim(self.h)
         d = [C.c_int32() for _ in range(4)]
         self.L.gxo_dims(self.h, *[C.byref(x) for x in d])
@@ -241,7 +251,7 @@ class OracleEngine:
         s = {
             'qpos': np.empty((N, self.nq), np.float32), 'qvel': np.empty((N, self.nv), np.float32),
             'pose0': np.empty((N, 4), np.float32), 'pose1': np.empty((N, 2), np.float32),
-            'objs': np.empty((N, 1 + H, 2), np.float32), 'done0': np.empty(N, np.float32),
+            'objs': np.empty((N, 1 + H + self.PL, 2), np.float32), 'done0': np.empty(N, np.float32),
             'done1': np.empty(N, np.float32), 'steps': np.empty(N, np.float32),
         }
         key = (C.c_uint32 * 2)()
@@ -268,7 +278,7 @@ class OracleEngine:
 
     def get_pool(self, max_rows=None):
         n = self.layout_size if max_rows is None else min(max_rows, self.layout_size)
-        pool = np.empty((max(n, 1), self.H + 2, 2), np.float32)
+        pool = np.empty((max(n, 1), self.H + self.PL + 2, 2), np.float32)
         got = self.L.gxo_get_pool(self.h, _fp(pool), n)
         return pool[:got]
 

@@ -69,6 +69,27 @@ def test_sample_layout_c_vs_numpy(oracle):
     np.testing.assert_array_equal(np.stack(got), pool_c[:len(got)])
 
 
+def test_sample_layout_with_pillars_c_vs_numpy(oracle):
+    """synthetic config-5 objects: the pillars are drawn after the hazards with their own keepout"""
+    M = 1500
+    ext = [-3, -3, 3, 3]
+    E = oracle.OracleEngine(task_config(4, seed=9, pillars_num=5, hazards_num=4, placements_extents=ext),
+                            n_candidates=M)
+    E.reset(check=False)
+    pool_c = E.get_pool()
+    assert pool_c.shape[1:] == (1 + 4 + 5 + 1, 2)
+    keys = onp.split(np.array([0, 9], np.uint32), M)
+    got = []
+    for j in range(M):
+        lay, ok = onp.sample_layout(keys[j], hazards_num=4, extents=ext, pillars_num=5)
+        if ok:
+            got.append(lay)
+        if len(got) == 5:
+            break
+    assert len(got) >= 3
+    np.testing.assert_array_equal(np.stack(got), pool_c[:len(got)])
+
+
 def test_get_layout_indices_c_vs_numpy(oracle):
     N = 37
     E = oracle.OracleEngine(task_config(N, seed=11), n_candidates=8000)
