@@ -31,6 +31,8 @@ class GxConfig(C.Structure):
         ("n_candidates", C.c_int32), ("physics_steps", C.c_int32),
         ("robot_goal_min_dist", C.c_float), ("device", C.c_int32),
         ("placements", C.POINTER(C.c_double)),
+        ("pillars_num", C.c_int32), ("observe_pillars", C.c_int32), ("pillars_size", C.c_float),
+        ("pad_", C.c_float), ("pillars_keepout", C.c_double),
     ]
 
 
@@ -72,6 +74,7 @@ SYMBOLS = {
     "gx_set_prefetch": (C.c_int, [C.c_void_p, C.c_int32]),
     "gx_prefetch_stats": (C.c_int, [C.c_void_p, _I32P, _I32P, _I32P]),
     "gx_set_path": (C.c_int, [C.c_void_p, C.c_int32]),
+    "gx_debug_stamps": (C.c_int, [C.c_void_p, _FP]),
     "gx_buffer_store": (C.c_int, [C.c_int32] * 5 + [_FP] * 14 + [C.c_void_p]),
     "gx_gae_finish_path": (C.c_int, [C.c_int32] * 3 + [_FP] * 5 + [C.c_double, C.c_double, _FP, _FP, C.c_int32, C.c_void_p]),
     "gx_gae_rollout": (C.c_int, [C.c_int32, C.c_int32, _FP, _FP, _FP, _FP, C.c_double, C.c_double, _FP, _FP, C.c_void_p]),

@@ -70,6 +70,7 @@ struct gx_engine {
     bool last_policy = false; // the last hot-path call was gx_rollout_policy
     // speculated reset_done (gx_step_rd): b.rd_j holds the layout rows reset_done would install for the envs the
     // last step finished; gx_reset_done_commit() only sets pending_commit, the next launch installs them
+    unsigned long long* stamps = nullptr; // gx_debug_stamps
     bool spec_valid = false;
     bool pending_commit = false;
     // per-step layout keys for the fused rollout: ring of pinned staging + device buffers
@@ -148,6 +149,8 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
         return fail(GX_ERR_ARG, "bad env_num/env_total/env_offset");
     if (cfg->hazards_num < 1 || cfg->hazards_num > 64)
         return fail(GX_ERR_ARG, "hazards_num must be in [1,64]");
+    if (cfg->pillars_num < 0 || cfg->hazards_num + cfg->pillars_num > 64)
+        return fail(GX_ERR_ARG, "pillars_num must be >= 0 and hazards_num + pillars_num <= 64");
     if (cfg->lidar_num_bins < 3 || cfg->lidar_num_bins > 64)
         return fail(GX_ERR_ARG, "lidar_num_bins must be in [3,64]");
     if (cfg->n_candidates < 1 || cfg->physics_steps < 1) return fail(GX_ERR_ARG, "bad n_candidates/physics_steps");
@@ -179,17 +182,19 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     p.N = cfg->env_num;
     p.Npad = (p.N + 255) / 256 * 256;
     p.H = cfg->hazards_num;
-    p.nobj = 1 + p.H;
+    p.PL = cfg->pillars_num;
+    p.nobj = 1 + p.H + p.PL;
     p.P = (p.nobj + 1) / 2;
     p.bins = cfg->lidar_num_bins;
     // flat obs = concat over sorted(obs_space_dict keys)  engine.py:386-409,773-777
     int o = 0;
-    p.off_acc = p.off_ctrl = p.off_comp = p.off_gl = p.off_hl = p.off_qpos = p.off_qvel = p.off_vel = -1;
+    p.off_acc = p.off_ctrl = p.off_comp = p.off_gl = p.off_hl = p.off_pl = p.off_qpos = p.off_qvel = p.off_vel = -1;
     if (cfg->observe_acc) { p.off_acc = o; o += 2; }
     if (cfg->observe_ctrl) { p.off_ctrl = o; o += e->nu; }
     if (cfg->observe_goal_comp) { p.off_comp = o; o += 2; }
     if (cfg->observe_goal_lidar) { p.off_gl = o; o += p.bins; }
     if (cfg->observe_hazards) { p.off_hl = o; o += p.bins; }
+    if (cfg->observe_pillars && p.PL > 0) { p.off_pl = o; o += p.bins; } // 'pillars_lidar' sorts between hazards_lidar and qpos
     if (cfg->observe_qpos) { p.off_qpos = o; o += e->nq; }
     if (cfg->observe_qvel) { p.off_qvel = o; o += e->nv; }
     if (cfg->observe_vel) { p.off_vel = o; o += 2; }
@@ -202,6 +207,7 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     p.bin_size = (float)((3.14159265358979323846 * 2) / p.bins); // engine.py:880
     p.goal_size = cfg->goal_size;
     p.hazards_size = cfg->hazards_size;
+    p.pillars_size = cfg->pillars_size;
     p.reward_distance = cfg->reward_distance;
     p.num_steps_f = (float)cfg->num_steps;
     p.physics_steps = cfg->physics_steps;
@@ -217,32 +223,33 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
 
     // layout sampler constants (python-float arithmetic, then f32: engine.py:554,574-577)
     SampleParams& sp = e->sp;
-    e->nobj_total = p.H + 2;
+    e->nobj_total = p.H + p.PL + 2;
     sp.M = cfg->n_candidates;
     sp.nobj_total = e->nobj_total;
-    const double ko[3] = {cfg->goal_keepout, cfg->hazards_keepout, cfg->robot_keepout};
-    std::vector<float4> hb; // per-hazard rectangles when explicit placements are given
-    for (int t = 0; t < 3; ++t) {
+    sp.H = p.H;
+    const double ko[4] = {cfg->goal_keepout, cfg->hazards_keepout, cfg->robot_keepout, cfg->pillars_keepout};
+    std::vector<float4> hb; // per-hazard / per-pillar rectangles when explicit placements are given
+    for (int t = 0; t < 4; ++t) {
         // object of this type whose rectangle seeds the per-type bounds: goal = 0, robot = last
         const double* rc = cfg->extents;
         if (cfg->placements && t == 0) rc = &cfg->placements[0];
-        if (cfg->placements && t == 2) rc = &cfg->placements[4 * (p.H + 1)];
+        if (cfg->placements && t == 2) rc = &cfg->placements[4 * (p.H + p.PL + 1)];
         sp.lo_x[t] = (float)(rc[0] + ko[t]);
         sp.lo_y[t] = (float)(rc[1] + ko[t]);
         sp.hi_x[t] = (float)(rc[2] - ko[t]);
         sp.hi_y[t] = (float)(rc[3] - ko[t]);
-        for (int q = 0; q < 3; ++q) sp.thr[q][t] = (float)(ko[q] + cfg->placements_margin + ko[t]);
+        for (int q = 0; q < 4; ++q) sp.thr[q][t] = (float)(ko[q] + cfg->placements_margin + ko[t]);
     }
     sp.haz_bounds = nullptr;
     if (cfg->placements)
-        for (int hz = 0; hz < p.H; ++hz) {
+        for (int hz = 0; hz < p.H + p.PL; ++hz) {
             const double* rc = &cfg->placements[4 * (1 + hz)];
-            hb.push_back(make_float4((float)(rc[0] + ko[1]), (float)(rc[2] - ko[1]), (float)(rc[1] + ko[1]),
-                                     (float)(rc[3] - ko[1])));
+            const double k = hz < p.H ? ko[1] : ko[3];
+            hb.push_back(make_float4((float)(rc[0] + k), (float)(rc[2] - k), (float)(rc[1] + k), (float)(rc[3] - k)));
         }
     sp.min_rg = cfg->robot_goal_min_dist;
-    for (int q = 0; q < 3; ++q)
-        for (int t = 0; t < 3; ++t) sp.thr_sq[q][t] = sqrt_cutoff(sp.thr[q][t]);
+    for (int q = 0; q < 4; ++q)
+        for (int t = 0; t < 4; ++t) sp.thr_sq[q][t] = sqrt_cutoff(sp.thr[q][t]);
     sp.min_rg_sq = sqrt_cutoff(sp.min_rg);
 
     // PRNGKey(seed)  engine.py:216
@@ -514,7 +521,7 @@ static gx_status step_impl(gx_engine* e, const float* d_action, float* d_obs, fl
         r.obs = d_obs; r.rew = d_reward; r.cost = d_cost; r.done = d_done; r.qacc = d_qacc;
         r.rd_j = e->b.rd_j;
         r.layout_size = e->b.pool.layout_size; r.cand_of = e->b.pool.cand_of; r.cand_xy = e->b.pool.cand_xy;
-        r.n_rows = e->sp.M;
+        r.n_rows = e->sp.M; r.stamps = e->stamps;
         if (d_obs_rd) { // also what reset_done() would return and install, with the key it would use (:447,500)
             uint32_t k[4];
             layout_keys(e, k);
@@ -614,7 +621,7 @@ static void fill_rollout_args(gx_engine* e, RolloutArgs& r, int32_t T, int slot)
     r.obs_stride = e->p.D; r.sc_stride = 1; r.rd_j = e->b.rd_j;
     r.keys = e->h_keys[slot]; // pinned + device-visible: read over the host link only on a reset
     r.layout_size = e->b.pool.layout_size; r.cand_of = e->b.pool.cand_of; r.cand_xy = e->b.pool.cand_xy;
-    r.n_rows = e->sp.M;
+    r.n_rows = e->sp.M; r.stamps = e->stamps;
     e->p.have_last = e->hist >= 1;
     e->p.have_last_last = e->hist >= 2;
 }
@@ -839,6 +846,13 @@ extern "C" gx_status gx_get_pool(gx_engine* e, float* pool, int32_t max_rows, in
         GX_HIP(hipMemcpy(pool + r * row, e->b.pool.cand_xy + (size_t)idx[r] * e->nobj_total, sizeof(float) * row,
                          hipMemcpyDeviceToHost));
     *got = n;
+    return GX_OK;
+}
+
+extern "C" gx_status gx_debug_stamps(gx_engine* e, uint64_t* d_stamps)
+{
+    if (!e) return fail(GX_ERR_ARG, "null engine");
+    e->stamps = reinterpret_cast<unsigned long long*>(d_stamps);
     return GX_OK;
 }
 

@@ -22,14 +22,15 @@ struct Params {
     int N;        // local envs
     int Npad;     // N rounded up to 256: stride of every SoA array
     int H;        // hazards
-    int nobj;     // 1 + H   (goal, hazards)
+    int PL;       // pillars (synthetic extension, include/guardx.h): objects H+1 .. H+PL
+    int nobj;     // 1 + H + PL   (goal, hazards, pillars)
     int P;        // float4 object-pair arrays = ceil(nobj / 2)
     int bins;     // lidar bins
     int D;        // flat obs width
-    int off_acc, off_ctrl, off_comp, off_gl, off_hl, off_qpos, off_qvel, off_vel;
+    int off_acc, off_ctrl, off_comp, off_gl, off_hl, off_pl, off_qpos, off_qvel, off_vel;
     int lidar_alias, lidar_max_dist_set;
     float lidar_max_dist, neg_gain, bin_size;
-    float goal_size, hazards_size, reward_distance, num_steps_f, dt;
+    float goal_size, hazards_size, pillars_size, reward_distance, num_steps_f, dt;
     int physics_steps;
     int env_total, env_offset;
     int have_last, have_last_last; // None-ness of _last_done / _last_last_done
@@ -257,6 +258,17 @@ GX_D LidarTerms lidar_terms(const Params& p, float ox, float oy, const float (&p
     t.a1 = alias * t.sensor;
     t.a2 = (1.0f - alias) * t.sensor;
     return t;
+}
+
+// cost term of object o >= 1 (engine.py:804-811; pillars: the same dense form with pillars_size)
+GX_D float cost_term(const Params& p, int o, float ox, float oy, const float (&pose)[4])
+{
+    const float size = (o <= p.H) ? p.hazards_size : p.pillars_size;
+    const float dx = ox - pose[0], dy = oy - pose[1];
+    const float dh = sqrtf(dx * dx + dy * dy);
+    float below = dh < size ? dh : size;
+    if (dh != dh) below = dh;
+    return size - below;
 }
 
 GX_D int bin_plus(int bin, int B) { return (bin + 1 >= B) ? bin + 1 - B : bin + 1; }

@@ -7,15 +7,17 @@
 
 namespace gx {
 
-// layout-sampler parameters (engine.py:546-621); object types: 0 goal, 1 hazard, 2 robot
+// layout-sampler parameters (engine.py:546-621); object types: 0 goal, 1 hazard, 2 robot, 3 pillar (synthetic
+// extension); placement order goal, hazards, pillars, robot
 struct SampleParams {
     int M;          // candidates (engine.py:263)
-    int nobj_total; // goal + hazards + robot
-    float lo_x[3], hi_x[3], lo_y[3], hi_y[3]; // by type (hazards: default rectangle)
-    const float4* haz_bounds;                  // null, or per-hazard (lox, hix, loy, hiy)
-    float thr[3][3]; // thr[placed type][new type] = f32(keepout_p + margin + keepout_new)
+    int nobj_total; // goal + hazards + pillars + robot
+    int H;          // hazards: objects 1..H; pillars: H+1 .. nobj_total-2
+    float lo_x[4], hi_x[4], lo_y[4], hi_y[4]; // by type (hazards / pillars: default rectangle)
+    const float4* haz_bounds;                  // null, or per hazard-or-pillar (lox, hix, loy, hiy), index o-1
+    float thr[4][4]; // thr[placed type][new type] = f32(keepout_p + margin + keepout_new)
     float min_rg;    // engine.py:571
-    float thr_sq[3][3]; // exact cutoffs: sqrtf(d2) < thr  <=>  d2 < thr_sq
+    float thr_sq[4][4]; // exact cutoffs: sqrtf(d2) < thr  <=>  d2 < thr_sq
     float min_rg_sq;
     uint32_t k0, k1; // engine key at reset time
 };
@@ -76,6 +78,7 @@ struct RolloutArgs {
     const int* layout_size;
     const int* cand_of;
     const float2* cand_xy;
+    unsigned long long* stamps; // null, or [grid][8] s_memtime stamps of wave 0 of every workgroup (profiling aid)
     int n_rows;        // rows of cand_xy (layout candidates): bound for every row index read back from memory
 };
 void launch_group_rollout(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s);

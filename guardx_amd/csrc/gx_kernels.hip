@@ -159,9 +159,10 @@ __global__ __launch_bounds__(kSampleBlock) void sample_phase2_kernel(SampleParam
         const float gx = u2f(rec[3]), gy = u2f(rec[4]);
         placed[tid] = make_float2(gx, gy);
         bool success = true;
-        for (int o = 1; o < nobj - 1; ++o) { // hazards
+        for (int o = 1; o < nobj - 1; ++o) { // hazards, then pillars
+            const int tn = o <= sp.H ? 1 : 3;
             const float4 hb = sp.haz_bounds ? sp.haz_bounds[o - 1]
-                                            : make_float4(sp.lo_x[1], sp.hi_x[1], sp.lo_y[1], sp.hi_y[1]);
+                                            : make_float4(sp.lo_x[tn], sp.hi_x[tn], sp.lo_y[tn], sp.hi_y[tn]);
             // draw_placement :579-621 keeps the LAST valid of the 10 tries.  The `rng, rng1 = split(rng)` chain has
             // to be walked in order (20 blocks), but the draws (4 blocks each) are evaluated from the last try
             // backwards and stop at the first valid one -- the same winner, ~3 draws per wave instead of 10.
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(kSampleBlock) void sample_phase2_kernel(SampleParam
                     bool flag = true;
                     for (int q = 0; q < o; ++q) { // placement_is_valid :549-555
                         const float2 pq = placed[q * kSampleBlock + tid];
-                        if (dsq(cx, cy, pq.x, pq.y) < sp.thr_sq[q == 0 ? 0 : 1][1]) flag = false;
+                        if (dsq(cx, cy, pq.x, pq.y) < sp.thr_sq[q == 0 ? 0 : (q <= sp.H ? 1 : 3)][tn]) flag = false;
                     }
                     if (flag) { px = cx; py = cy; conflicted = false; }
                 }
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(kSampleBlock) void sample_phase2_kernel(SampleParam
                 bool flag = true;
                 for (int q = 0; q < nobj - 1; ++q) {
                     const float2 pq = placed[q * kSampleBlock + tid];
-                    if (dsq(cx, cy, pq.x, pq.y) < sp.thr_sq[q == 0 ? 0 : 1][2]) flag = false;
+                    if (dsq(cx, cy, pq.x, pq.y) < sp.thr_sq[q == 0 ? 0 : (q <= sp.H ? 1 : 3)][2]) flag = false;
                 }
                 if (flag) { px = cx; py = cy; conflicted = false; }
             }

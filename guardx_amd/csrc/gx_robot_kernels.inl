@@ -47,14 +47,23 @@ GX_D bool build_obs_row(const Params& p, float* row, const float (&pose)[4],
         for (int b = 0; b < p.bins; ++b) r[b] = 0.0f;
         bad = lidar_one(p, r, ob[0].x, ob[0].y, pose) || bad;
     }
-    if (p.off_hl >= 0) {
-        float* r = row + p.off_hl;
-        for (int b = 0; b < p.bins; ++b) r[b] = 0.0f;
+    if (p.off_hl >= 0 || p.off_pl >= 0) {
+        float* rh = row + (p.off_hl >= 0 ? p.off_hl : 0);
+        float* rp = row + (p.off_pl >= 0 ? p.off_pl : 0);
+        if (p.off_hl >= 0) for (int b = 0; b < p.bins; ++b) rh[b] = 0.0f;
+        if (p.off_pl >= 0) for (int b = 0; b < p.bins; ++b) rp[b] = 0.0f;
 #pragma unroll
         for (int k = 0; k < PMAX; ++k) {
-            // objects 2k and 2k+1; object 0 is the goal
-            if (k > 0 && 2 * k < p.nobj) bad = lidar_one(p, r, ob[k].x, ob[k].y, pose) || bad;
-            if (2 * k + 1 < p.nobj) bad = lidar_one(p, r, ob[k].z, ob[k].w, pose) || bad;
+            // objects 2k and 2k+1; object 0 is the goal, 1..H hazards, H+1.. pillars
+            const int oa = 2 * k, ob_ = 2 * k + 1;
+            if (k > 0 && oa < p.nobj) {
+                if (oa <= p.H) { if (p.off_hl >= 0) bad = lidar_one(p, rh, ob[k].x, ob[k].y, pose) || bad; }
+                else if (p.off_pl >= 0) bad = lidar_one(p, rp, ob[k].x, ob[k].y, pose) || bad;
+            }
+            if (ob_ < p.nobj) {
+                if (ob_ <= p.H) { if (p.off_hl >= 0) bad = lidar_one(p, rh, ob[k].z, ob[k].w, pose) || bad; }
+                else if (p.off_pl >= 0) bad = lidar_one(p, rp, ob[k].z, ob[k].w, pose) || bad;
+            }
         }
     }
     if (p.off_qpos >= 0) {
@@ -115,7 +124,7 @@ GX_D float dist2(float ax, float ay, float bx, float by)
 template <class R>
 static bool is_default_layout(const Params& p)
 {
-    return p.nobj == 9 && p.bins == 16 && p.D == R::kD && p.off_acc == -1 && p.off_ctrl == R::kOffCtrl &&
+    return p.nobj == 9 && p.PL == 0 && p.off_pl == -1 && p.bins == 16 && p.D == R::kD && p.off_acc == -1 && p.off_ctrl == R::kOffCtrl &&
            p.off_comp == R::kOffComp && p.off_gl == R::kOffGl && p.off_hl == R::kOffHl &&
            p.off_qpos == R::kOffQpos && p.off_qvel == R::kOffQvel && p.off_vel == -1 && p.lidar_alias == 1 &&
            p.lidar_max_dist_set == 0 && p.physics_steps == 1 && p.hist_on == 0;
@@ -125,7 +134,7 @@ template <class R, bool kDef>
 GX_D Params fold_params(Params p)
 {
     if (kDef) {
-        p.H = 8; p.nobj = 9; p.P = 5; p.bins = 16; p.D = R::kD;
+        p.H = 8; p.PL = 0; p.off_pl = -1; p.nobj = 9; p.P = 5; p.bins = 16; p.D = R::kD;
         p.off_acc = -1; p.off_ctrl = R::kOffCtrl; p.off_comp = R::kOffComp; p.off_gl = R::kOffGl;
         p.off_hl = R::kOffHl; p.off_qpos = R::kOffQpos; p.off_qvel = R::kOffQvel; p.off_vel = -1;
         p.lidar_alias = 1; p.lidar_max_dist_set = 0; p.physics_steps = 1; p.hist_on = 0;
@@ -238,18 +247,8 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p_in, const float* _
     float cs = 0.0f;
 #pragma unroll
     for (int k = 0; k < PMAX; ++k) {
-        if (k > 0 && 2 * k < p.nobj) {
-            const float dh = dist2(ob[k].x, ob[k].y, pose[0], pose[1]);
-            float below = dh < p.hazards_size ? dh : p.hazards_size;
-            if (dh != dh) below = dh;
-            cs = cs + (p.hazards_size - below);
-        }
-        if (2 * k + 1 < p.nobj) {
-            const float dh = dist2(ob[k].z, ob[k].w, pose[0], pose[1]);
-            float below = dh < p.hazards_size ? dh : p.hazards_size;
-            if (dh != dh) below = dh;
-            cs = cs + (p.hazards_size - below);
-        }
+        if (k > 0 && 2 * k < p.nobj) cs = cs + cost_term(p, 2 * k, ob[k].x, ob[k].y, pose);
+        if (2 * k + 1 < p.nobj) cs = cs + cost_term(p, 2 * k + 1, ob[k].z, ob[k].w, pose);
     }
 
     // NaN/Inf guard :696-699, timeout + step counter :492-493
@@ -487,18 +486,8 @@ void thread_rollout_kernel(Params p_in, RolloutArgs r,
         float cs = 0.0f;
 #pragma unroll
         for (int k = 0; k < PMAX; ++k) {
-            if (k > 0 && 2 * k < p.nobj) {
-                const float dh = dist2(ob[k].x, ob[k].y, pose[0], pose[1]);
-                float below = dh < p.hazards_size ? dh : p.hazards_size;
-                if (dh != dh) below = dh;
-                cs = cs + (p.hazards_size - below);
-            }
-            if (2 * k + 1 < p.nobj) {
-                const float dh = dist2(ob[k].z, ob[k].w, pose[0], pose[1]);
-                float below = dh < p.hazards_size ? dh : p.hazards_size;
-                if (dh != dh) below = dh;
-                cs = cs + (p.hazards_size - below);
-            }
+            if (k > 0 && 2 * k < p.nobj) cs = cs + cost_term(p, 2 * k, ob[k].x, ob[k].y, pose);
+            if (2 * k + 1 < p.nobj) cs = cs + cost_term(p, 2 * k + 1, ob[k].z, ob[k].w, pose);
         }
         if (bad) { rw = 0.0f; dn = 1.0f; }           // :696-699
         if (steps > p.num_steps_f) dn = 1.0f;         // :492
@@ -617,6 +606,12 @@ __global__ __launch_bounds__(BLOCK) void commit_pending_kernel(Params p, int nob
 
 constexpr int kGL = 16; // lanes per environment
 
+// profiling aid: shader-clock stamp k of this workgroup (RolloutArgs::stamps, normally null)
+GX_D void stamp(const RolloutArgs& r, int k)
+{
+    if (r.stamps && threadIdx.x == 0) r.stamps[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
+}
+
 // Workgroup synchronisation of the lane-group kernels.  With ONE wave per workgroup (BT == 64) the LDS
 // operations of the wave execute in program order, so the exchange through LDS only needs the compiler
 // to keep that order: wave-scope fences cost no instruction.  __syncthreads() would also wait for every
@@ -643,57 +638,106 @@ GX_D bool group_any(bool v)
 }
 
 template <int OPL, int BPL>
-struct GroupObs { float gl[BPL], hl[BPL], comp0, comp1, cost; bool bad; };
+struct GroupObs { float gl[BPL], hl[BPL], pl[BPL], comp0, comp1, cost; bool bad; };
+
+// LDS of the lane-group kernels: per-object records (exact path), hazard cost terms, and the lidar bins of
+// the (goal, hazards, pillars) rows of every env of the workgroup (scatter-max path)
+template <int OPL, int BPL, int BT>
+struct GroupLds {
+    float4 rec[OPL][BT];
+    float term[OPL][BT];
+    int bins[3][BT / kGL][kGL * BPL];
+};
 
 // object phase + LDS exchange + bin phase for one pose
 // `lane` = thread index in the workgroup (BT threads = BT/16 environments); must be reached by the
 // whole workgroup.
+//
+// Lidar bins: the reference scatter-maxes every object's (sensor, alias) values into its row one object after
+// the other (engine.py:872-899).  All contributions are >= +0 or negative numbers that lose against the
+// initial 0, and the maximum of such values does not depend on the order, so the normal case is an LDS
+// scatter-max on the BIT PATTERNS (ds_max_i32: signed integer order == float order for non-negative floats,
+// every negative float is a negative integer): 3 atomics per object instead of a 3-compare / 3-select chain per
+// (object, bin) pair.  If any value that would land in an observation is NaN or Inf (wave-uniform test; the
+// NaN guard of engine.py:696-699 then ends the episode) the workgroup takes the exact path, which replays the
+// reference's NaN-propagating sequential maxima through per-object records.
 template <int OPL, int BPL, int BT, bool kWave>
-GX_D GroupObs<OPL, BPL> group_observe(const Params& p, float4 (*rec)[BT], float (*term)[BT], int lane,
+GX_D GroupObs<OPL, BPL> group_observe(const Params& p, GroupLds<OPL, BPL, BT>& S, int lane,
                                       const float (&pose)[4], float gx, float gy,
                                       const float (&ox)[OPL], const float (&oy)[OPL])
 {
-    const int l = lane & (kGL - 1), gbase = lane & ~(kGL - 1);
+    const int l = lane & (kGL - 1), gbase = lane & ~(kGL - 1), g = lane >> 4;
+    const int B = p.bins;
     GroupObs<OPL, BPL> out;
     bool bad = false;
+    LidarTerms tt[OPL];
+    int rowof[OPL];
 #pragma unroll
     for (int j = 0; j < OPL; ++j) {
         const int o = l + kGL * j;
         const bool valid = o < p.nobj;
-        LidarTerms t = lidar_terms(p, ox[j], oy[j], pose);
-        const bool enabled = (o == 0) ? (p.off_gl >= 0) : (p.off_hl >= 0);
-        if (valid && enabled) bad = bad || lidar_bad(p, t);
-        float tc = 0.0f;
-        if (valid && o >= 1) { // cost term :804-811
-            const float dh = dist2(ox[j], oy[j], pose[0], pose[1]);
-            float below = dh < p.hazards_size ? dh : p.hazards_size;
-            if (dh != dh) below = dh;
-            tc = p.hazards_size - below;
-        }
-        if (!valid) { t.bin = -1000; t.sensor = 0.f; t.a1 = 0.f; t.a2 = 0.f; }
-        rec[j][lane] = make_float4(__int_as_float(t.bin), t.sensor, t.a1, t.a2);
-        term[j][lane] = tc;
+        tt[j] = lidar_terms(p, ox[j], oy[j], pose);
+        const int cls = (o == 0) ? 0 : (o <= p.H ? 1 : 2);
+        const bool enabled = (cls == 0) ? (p.off_gl >= 0) : (cls == 1 ? p.off_hl >= 0 : p.off_pl >= 0);
+        rowof[j] = (valid && enabled) ? cls : -1;
+        if (valid && enabled) bad = bad || lidar_bad(p, tt[j]);
+        S.term[j][lane] = (valid && o >= 1) ? cost_term(p, o, ox[j], oy[j], pose) : 0.0f;
     }
-    group_sync<BT, kWave>();
 #pragma unroll
     for (int jb = 0; jb < BPL; ++jb) {
         const int b = l + kGL * jb;
-        float gl = 0.0f, hl = 0.0f;
-#pragma unroll 9
-        for (int o = 0; o < p.nobj; ++o) {
-            const float4 rc = rec[o >> 4][gbase + (o & 15)];
-            LidarTerms t;
-            t.bin = __float_as_int(rc.x); t.sensor = rc.y; t.a1 = rc.z; t.a2 = rc.w;
-            const float c = lidar_contrib(p, t, b);
-            if (o == 0) gl = nmax(gl, c);
-            else hl = nmax(hl, c);
+        S.bins[0][g][b] = 0; S.bins[1][g][b] = 0; S.bins[2][g][b] = 0;
+    }
+    const bool exact = group_any<BT, kWave>(bad); // includes the synchronisation of the zeroed bins
+    if (!exact) {
+        group_sync<BT, kWave>();
+#pragma unroll
+        for (int j = 0; j < OPL; ++j) {
+            if (rowof[j] >= 0) {
+                int* rowp = S.bins[rowof[j]][g];
+                const LidarTerms& t = tt[j];
+                if (t.bin < B) atomicMax(&rowp[t.bin], __float_as_int(t.sensor));
+                if (p.lidar_alias) {
+                    atomicMax(&rowp[bin_plus(t.bin, B)], __float_as_int(t.a1));
+                    atomicMax(&rowp[bin_minus(t.bin, B)], __float_as_int(t.a2));
+                }
+            }
         }
-        out.gl[jb] = gl;
-        out.hl[jb] = hl;
+        group_sync<BT, kWave>();
+#pragma unroll
+        for (int jb = 0; jb < BPL; ++jb) {
+            const int b = l + kGL * jb;
+            out.gl[jb] = __int_as_float(S.bins[0][g][b]);
+            out.hl[jb] = __int_as_float(S.bins[1][g][b]);
+            out.pl[jb] = __int_as_float(S.bins[2][g][b]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < OPL; ++j) {
+            LidarTerms t = tt[j];
+            if (rowof[j] < 0) { t.bin = -1000; t.sensor = 0.f; t.a1 = 0.f; t.a2 = 0.f; }
+            S.rec[j][lane] = make_float4(__int_as_float(t.bin), t.sensor, t.a1, t.a2);
+        }
+        group_sync<BT, kWave>();
+#pragma unroll
+        for (int jb = 0; jb < BPL; ++jb) {
+            const int b = l + kGL * jb;
+            float gl = 0.0f, hl = 0.0f, pl = 0.0f;
+            for (int o = 0; o < p.nobj; ++o) {
+                const float4 rc = S.rec[o >> 4][gbase + (o & 15)];
+                LidarTerms t;
+                t.bin = __float_as_int(rc.x); t.sensor = rc.y; t.a1 = rc.z; t.a2 = rc.w;
+                const float c = lidar_contrib(p, t, b);
+                if (o == 0) gl = nmax(gl, c);
+                else if (o <= p.H) hl = nmax(hl, c);
+                else pl = nmax(pl, c);
+            }
+            out.gl[jb] = gl; out.hl[jb] = hl; out.pl[jb] = pl;
+        }
     }
     float cs = 0.0f;
 #pragma unroll 8
-    for (int o = 1; o < p.nobj; ++o) cs = cs + term[o >> 4][gbase + (o & 15)];
+    for (int o = 1; o < p.nobj; ++o) cs = cs + S.term[o >> 4][gbase + (o & 15)];
     out.cost = cs;
     { // obs_compass :834-844 (same expression as ego_xy of the goal)
         const float dx = gx - pose[0], dy = gy - pose[1];
@@ -730,8 +774,8 @@ __global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Par
     constexpr int BT = (kPol == 2) ? 256 : 64;
     constexpr bool kPolicy = kPol != 0;
     const Params p = fold_params<R, kDef>(p_in);
-    __shared__ float4 rec[OPL][BT];
-    __shared__ float term[OPL][BT];
+    stamp(r, 0);
+    __shared__ GroupLds<OPL, BPL, BT> S;
     extern __shared__ float4 pol_lds4[];
     const int lane = threadIdx.x;           // thread in the workgroup
     const int l = lane & (kGL - 1);         // lane within the env's 16-lane group
@@ -822,7 +866,14 @@ __global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Par
 #pragma unroll
     for (int d = 0; d < R::NA; ++d) a_next[d] = 0.f;
     if (!kPolicy) load_action<R>(r.act, (size_t)e, a_next);
+    if (r.stamps) { // profiling: when have the state and the first action arrived?
+        stamp(r, 1);
+        float s_ = q[0] + v[0] + pose0[0] + ox[0] + a_next[0] + gx;
+        asm volatile("" ::"v"(s_));
+        stamp(r, 2);
+    }
     for (int t = 0; t < r.T; ++t) {
+        if (t == 1) stamp(r, 4);
         float a[R::NA];
 #pragma unroll
         for (int d = 0; d < R::NA; ++d) a[d] = a_next[d];
@@ -889,7 +940,7 @@ __global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Par
             ego_vel_acc(p, pose, L1x, L1y, P2x, P2y, last_done, done2, have_last, have_last_last, vel0, vel1,
                         acc0, acc1);
 
-        GroupObs<OPL, BPL> ob = group_observe<OPL, BPL, BT, R::kRestFixed>(p, rec, term, lane, pose, gx, gy, ox, oy);
+        GroupObs<OPL, BPL> ob = group_observe<OPL, BPL, BT, R::kRestFixed>(p, S, lane, pose, gx, gy, ox, oy);
         bool bad = ob.bad;
         if (p.off_acc >= 0) bad = bad || notfinite(acc0) || notfinite(acc1);
         if (p.off_ctrl >= 0) {
@@ -942,6 +993,7 @@ __global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Par
                 if (b < p.bins) {
                     if (p.off_gl >= 0) row[p.off_gl + b] = gob.gl[jb];
                     if (p.off_hl >= 0) row[p.off_hl + b] = gob.hl[jb];
+                    if (p.off_pl >= 0) row[p.off_pl + b] = gob.pl[jb];
                 }
             }
             if (l < R::NU && p.off_ctrl >= 0) row[p.off_ctrl + l] = pick(o_ctrl, l);
@@ -1001,7 +1053,7 @@ __global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Par
                     for (int k = 0; k < R::NU; ++k) zc[k] = 0.f;
                     for (int k = 0; k < p.physics_steps; ++k) group_substep<R, false>(fq, fv, zc, rpose, fa, l);
                 }
-                const GroupObs<OPL, BPL> rob = group_observe<OPL, BPL, BT, R::kRestFixed>(p, rec, term, lane, rpose, ngx, ngy, nox, noy);
+                const GroupObs<OPL, BPL> rob = group_observe<OPL, BPL, BT, R::kRestFixed>(p, S, lane, rpose, ngx, ngy, nox, noy);
                 if (rs) {
                     if (r.do_reset == 1) {
 #pragma unroll
@@ -1021,7 +1073,7 @@ __global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Par
 #pragma unroll
                     for (int k = 0; k < R::NU; ++k) o_ctrl[k] = 0.f;
 #pragma unroll
-                    for (int jb = 0; jb < BPL; ++jb) { ob.gl[jb] = rob.gl[jb]; ob.hl[jb] = rob.hl[jb]; }
+                    for (int jb = 0; jb < BPL; ++jb) { ob.gl[jb] = rob.gl[jb]; ob.hl[jb] = rob.hl[jb]; ob.pl[jb] = rob.pl[jb]; }
                     ob.comp0 = rob.comp0; ob.comp1 = rob.comp1;
                     o_v0 = o_v1 = o_a0 = o_a1 = 0.f;
                 }
@@ -1035,7 +1087,9 @@ __global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Par
             write_row(row, ob);
         }
         if (kPolicy) __syncthreads();
+        if (t == 0) stamp(r, 3);
     }
+    stamp(r, 5);
 
     if (kPolicy) { // bootstrap inputs: o_T and V(o_T)   trpo.py:523-529
         const float vlast = critic_forward(wv, xrow, hbuf, p.D, l);
@@ -1059,6 +1113,7 @@ __global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Par
             }
         }
     }
+    stamp(r, 6);
 }
 
 // ---------------------------------------------------------------------------

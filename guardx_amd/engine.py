@@ -152,6 +152,16 @@ class Engine:
         '_seed': 0,
     }
 
+    # Synthetic extension -- NOT part of the reference (which asserts "Bad key" on every one of these):
+    # BASELINE.json config 5 asks for "8 pillars" next to the hazards; the reference only has the colour /
+    # lidar-group constants (engine.py:38,56).  Pillars are static circles in the hazard style: placed by the
+    # layout sampler after the hazards, observed through 'pillars_lidar', costed like hazards with
+    # pillars_size.  With pillars_num == 0 (default) the Engine is exactly the reference's task.
+    EXTENSIONS = {
+        'pillars_num': 0, 'pillars_placements': None, 'pillars_locations': [], 'pillars_keepout': 0.3,
+        'pillars_size': 0.2, 'observe_pillars': False,
+    }
+
     def __init__(self, config={}, *, n_candidates=1_000_000, shard=None, emit_qacc=True, point_actuators='mjcf',
                  out_ring=8):
         self._ctor_config = deepcopy(config)
@@ -228,9 +238,10 @@ class Engine:
     def parse(self, config):
         """engine.py:322-328"""
         self.config = deepcopy(self.DEFAULT)
+        self.config.update(deepcopy(self.EXTENSIONS))
         self.config.update(deepcopy(config))
         for key, value in self.config.items():
-            assert key in self.DEFAULT, f'Bad key {key}'
+            assert key in self.DEFAULT or key in self.EXTENSIONS, f'Bad key {key}'
             setattr(self, key, value)
 
     def placements_dict_from_object(self, object_name):
@@ -264,6 +275,8 @@ class Engine:
         placements = OrderedDict()
         placements.update(self.placements_dict_from_object('goal'))
         placements.update(self.placements_dict_from_object('hazard'))
+        if self.pillars_num:                       # synthetic extension
+            placements.update(self.placements_dict_from_object('pillar'))
         placements.update(self.placements_dict_from_object('robot'))
         self.placements = placements
 
@@ -317,6 +330,10 @@ class Engine:
         c.n_candidates = n_candidates
         c.physics_steps = int(self.physics_steps_per_control_step)
         c.robot_goal_min_dist = 3.0  # engine.py:571
+        c.pillars_num = int(self.pillars_num)
+        c.observe_pillars = int(bool(self.observe_pillars))
+        c.pillars_size = float(self.pillars_size)
+        c.pillars_keepout = float(self.pillars_keepout)
         c.device = int(self.device_id)
         return c
 
@@ -330,6 +347,8 @@ class Engine:
             d['goal_compass'] = Box(-inf, inf, (2,), dtype=np.float32)
         if self.observe_hazards:
             d['hazards_lidar'] = Box(0.0, 1.0, (self.lidar_num_bins,), dtype=np.float32)
+        if self.observe_pillars and self.pillars_num:
+            d['pillars_lidar'] = Box(0.0, 1.0, (self.lidar_num_bins,), dtype=np.float32)
         if self.observe_qpos:
             d['qpos'] = Box(-inf, inf, (self.robot.nq,), dtype=np.float32)
         if self.observe_qvel:
@@ -585,7 +604,7 @@ class Engine:
                 ('done0', 1), ('done1', 1), ('steps', 1))
 
     def get_state(self):
-        N, H = self.env_num, int(self.hazards_num)
+        N, H = self.env_num, int(self.hazards_num) + int(self.pillars_num)
         s = OrderedDict()
         for name, w in self._STATE_FIELDS:
             shape = (N, 1 + H, 2) if name == 'objs' else ((N,) if w == 1 else (N, w))
@@ -618,7 +637,7 @@ class Engine:
         self._rd_obs = None
 
     def get_pool(self, max_rows=4096):
-        H = int(self.hazards_num)
+        H = int(self.hazards_num) + int(self.pillars_num)
         pool = np.empty((max_rows, H + 2, 2), np.float32)
         got = C.c_int32()
         _native.check(self._lib.gx_get_pool(self._h, pool.ctypes.data_as(C.POINTER(C.c_float)),

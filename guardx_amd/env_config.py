@@ -47,6 +47,16 @@ def configuration_list(task):
             'sensors_obs': ['accelerometer', 'velocimeter', 'gyro', 'magnetometer',
                             'touch_ankle_1a', 'touch_ankle_2a', 'touch_ankle_3a', 'touch_ankle_4a',
                             'touch_ankle_1b', 'touch_ankle_2b', 'touch_ankle_3b', 'touch_ankle_4b']})
+    if task == "Ant_8Hazards_8Pillars_synthetic":
+        # BASELINE.json config 5 ("Push_Ant_8Hazards+8Pillars").  NO REFERENCE COUNTERPART: the reference's
+        # Push_Ant_8Hazards (:768-796) carries 'observe_box_comp', which Engine.parse rejects (engine.py:326-328),
+        # the push task places no goal (engine.py:538) and pillars exist only as two constants (engine.py:38,56).
+        # Synthetic stand-in per SURVEY.md section 8d: ant.xml (foot-floor contacts), the goal task, 8 hazards and 8
+        # static pillar circles in the hazard style (own lidar, keepout .3, size .2; guardx_amd.Engine.EXTENSIONS).
+        # The arena is 6 m x 6 m: 18 objects with their keepouts do not fit the reference's 4 m x 4 m in 10 tries.
+        return _goal_task('xmls/ant.xml', {
+            'pillars_num': 8, 'observe_pillars': True, 'pillars_keepout': 0.3, 'pillars_size': 0.2,
+            'placements_extents': [-3, -3, 3, 3]})
     return {}  # unknown names fall through to Engine defaults, as in the reference
 
 

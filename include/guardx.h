@@ -74,9 +74,20 @@ typedef struct gx_config {
     int32_t physics_steps;      /* engine.py:202 */
     float robot_goal_min_dist;  /* engine.py:571, 3.0 */
     int32_t device;             /* HIP device ordinal ('device_id' engine.py:100) */
-    const double* placements;   /* NULL, or (hazards_num+2) x 4 doubles: the placement rectangle
-                                 * (xmin,ymin,xmax,ymax) of goal, hazard0.., robot BEFORE the keepout
+    const double* placements;   /* NULL, or (hazards_num+pillars_num+2) x 4 doubles: the placement rectangle
+                                 * (xmin,ymin,xmax,ymax) of goal, hazard0.., pillar0.., robot BEFORE the keepout
                                  * shrink -- *_placements / *_locations, engine.py:507-531 */
+    /* ---- synthetic extension with NO reference counterpart (BASELINE.json config 5):
+     * "pillars", a second class of static circles in the hazard style.  The reference only carries their colour /
+     * lidar-group constants (engine.py:38,56) and rejects every config that names them (Bad key).  Here: placed by
+     * the layout sampler after the hazards with pillars_keepout; observed by a pseudo-lidar of their own
+     * ('pillars_lidar', sorted between 'hazards_lidar' and 'qpos'); cost += sum(pillars_size - min(dist,
+     * pillars_size)) after the hazard terms.  pillars_num = 0 is the reference's task. */
+    int32_t pillars_num;
+    int32_t observe_pillars;
+    float pillars_size;
+    float pad_;
+    double pillars_keepout;
 } gx_config;
 
 typedef struct gx_engine gx_engine;
@@ -222,6 +233,11 @@ gx_status gx_gae_rollout(int32_t env_num, int32_t T, const float* d_rew, const f
  * safe_rl_libX/cpo/cpo.py:158-162) */
 gx_status gx_adv_normalize(int32_t env_num, int32_t max_ep_len, float* d_adv_buf, int32_t scale,
                            void* stream);
+
+/* Profiling aid: while d_stamps (device, ceil(env_num/4) x 8 uint64) is set, the lane-group kernels record the
+ * shader clock (s_memtime) of each workgroup at: 0 entry, 1 state+action loads issued, 2 loads arrived, 3 end of
+ * step 0, 4 start of step 1, 5 end of the last step, 6 state stored.  NULL switches it off (the default). */
+gx_status gx_debug_stamps(gx_engine* e, uint64_t* d_stamps);
 
 /* Device-math probe (tests): s,c = sincos(x); at2 = atan2(y,x); ex = exp(x). */
 gx_status gx_math_probe(int32_t n, const float* d_x, const float* d_y, float* d_s,

@@ -59,6 +59,16 @@ def test_task_configs():
     assert configuration("no_such_task") == {}
 
 
+def test_pillars_are_an_extension_not_a_reference_key():
+    """BASELINE config 5 objects: accepted by this Engine, absent from the reference's DEFAULT"""
+    assert not (set(Engine.EXTENSIONS) & set(Engine.DEFAULT))
+    c = configuration("Ant_8Hazards_8Pillars_synthetic")
+    assert c['robot_base'] == 'xmls/ant.xml' and c['pillars_num'] == 8 and c['hazards_num'] == 8
+    assert set(c) <= set(Engine.DEFAULT) | set(Engine.EXTENSIONS)
+    with pytest.raises(AssertionError, match="Bad key pillars_cost"):
+        Engine({'pillars_cost': 1.0})
+
+
 def test_box_stand_in():
     b = Box(-np.inf, np.inf, (43,), dtype=np.float32)
     assert b.shape == (43,) and b.dtype == np.float32

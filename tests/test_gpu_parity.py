@@ -377,6 +377,53 @@ def test_prefetch_horizon_follows_the_learner(torch_cuda, oracle):
     assert horizon == 25 and hits == 3 and misses == 1   # epoch 1 mispredicts (1000), 2.. hit
 
 
+# ---------------------------------------------------------------------------
+# BASELINE config 5 (synthetic, no reference counterpart): Ant + 8 hazards + 8 pillars
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("path", ["thread", "group"])
+@pytest.mark.parametrize("robot", ["ant", "point"])
+def test_pillars_config5_parity(torch_cuda, oracle, path, robot):
+    torch = torch_cuda
+    from guardx_amd import configuration
+    cfg = dict(configuration("Ant_8Hazards_8Pillars_synthetic"))
+    A = 8
+    if robot == "point":
+        cfg['robot_base'] = 'xmls/point.xml'; A = 2
+    N, T = 260, 50
+    cfg.update(env_num=N, _seed=12, num_steps=35, goal_size=2.4)
+    E, O = _engines(cfg, oracle, n_candidates=60000, path=path)
+    assert E.obs_flat_size == O.D == (64 if robot == "ant" else 43) + 16
+    assert 'pillars_lidar' in E.obs_space_dict
+    np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
+    assert E.layout_size == O.layout_size
+    np.testing.assert_array_equal(E.get_pool(256), O.get_pool(256))
+    rng = np.random.default_rng(5)
+    s = O.get_state()                      # some robots right next to a pillar / a hazard: both cost terms fire
+    base = s['qpos'][:, [0, 2]] if robot == "ant" else s['qpos'][:, :2]
+    s['objs'][::3, 9] = base[::3] + rng.uniform(-0.15, 0.15, (len(base[::3]), 2)).astype(np.float32)
+    s['objs'][1::3, 1] = base[1::3] + rng.uniform(-0.2, 0.2, (len(base[1::3]), 2)).astype(np.float32)
+    E.set_state(s); O.set_state(s)
+    pcost = 0
+    for t in range(20):                       # step()/reset_done() API
+        act = rng.uniform(-1, 1, (N, A)).astype(np.float32)
+        out_g, out_o = E.step(torch.from_numpy(act).cuda()), O.step(act)
+        _cmp_step(out_g, out_o)
+        pcost += int((out_o[3]['cost'] > 0).sum())
+        np.testing.assert_array_equal(E.reset_done().cpu().numpy(), O.reset_done())
+    assert pcost > 0
+    acts = rng.uniform(-1, 1, (T, N, A)).astype(np.float32)   # fused rollout, scattered dones + timeouts
+    obs, rew, cost, done = E.rollout(torch.from_numpy(acts).cuda())
+    for t in range(T):
+        o, r, d, info = O.step(acts[t])
+        np.testing.assert_array_equal(obs[t].cpu().numpy(), O.reset_done())
+        np.testing.assert_array_equal(rew[t].cpu().numpy(), r)
+        np.testing.assert_array_equal(done[t].cpu().numpy(), d)
+        np.testing.assert_array_equal(cost[t].cpu().numpy(), info['cost'])
+    assert done.sum().item() > 0
+    assert_state_equal(E.get_state(), O.get_state())
+    np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
+
+
 def test_sharded_equals_unsharded(torch_cuda, oracle):
     """rank r of a world-of-4 engine reproduces rows [r*N, (r+1)*N) of one 4N-env engine."""
     torch = torch_cuda

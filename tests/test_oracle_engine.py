@@ -369,3 +369,36 @@ def test_layout_assert(oracle):
     E = oracle.OracleEngine(task_config(500, seed=0), n_candidates=2000)
     with pytest.raises(AssertionError):
         E.reset()
+
+
+def test_pillars_extension_closed_forms(oracle):
+    """synthetic config-5 objects (no reference counterpart): own lidar row sorted between hazards_lidar and
+    qpos, dense cost with pillars_size after the hazard terms, own keepout in the sampler"""
+    N = 4
+    cfg = task_config(N, pillars_num=3, observe_pillars=True, placements_extents=[-3, -3, 3, 3])
+    E = oracle.OracleEngine(cfg, n_candidates=8000)
+    E.reset(check=False)
+    assert E.D == 43 + 16
+    s = _still_state(N, H=8 + 3)
+    s['objs'][:, 9] = [1.0, 0.0]            # pillar 0 one metre ahead  -> bin 0 of pillars_lidar
+    s['objs'][:, 10] = [0.0, 0.1]           # pillar 1 at 0.1 m: inside pillars_size = 0.2
+    s['objs'][:, 1] = [0.25, 0.0]           # hazard 0 at 0.25 m: inside hazards_size = 0.3
+    E.set_state(s)
+    obs, r, d, info = E.step(np.zeros((N, 2), f32))
+    pl = obs[0, 37:53]
+    assert pl[0] == pytest.approx(np.exp(-1.0), abs=2e-7) and pl[4] == pytest.approx(np.exp(-0.1), abs=2e-7)
+    assert (obs[0, 53:56] == 0).all() and obs.shape[1] == 59          # qpos follows the pillars lidar
+    assert info['cost'][0] == pytest.approx((0.3 - 0.25) + (0.2 - 0.1), abs=1e-6)
+    # layout: pillar keepouts .3 (pillar-pillar .6, pillar-hazard .7, pillar-goal .8, pillar-robot .7)
+    E = oracle.OracleEngine(task_config(32, seed=3, pillars_num=8, observe_pillars=True,
+                                        placements_extents=[-3, -3, 3, 3]), n_candidates=40000)
+    E.reset()
+    st = E.get_state()
+    objs, robot = st['objs'], st['qpos'][:, :2]
+    P = objs[:, 9:]
+    for i in range(8):
+        for j in range(i + 1, 8):
+            assert (np.linalg.norm(P[:, i] - P[:, j], axis=1) >= 0.6 - 1e-6).all()
+    assert (np.linalg.norm(P[:, :, None] - objs[:, None, 1:9], axis=3) >= 0.7 - 1e-6).all()
+    assert (np.linalg.norm(P - objs[:, :1], axis=2) >= 0.8 - 1e-6).all()
+    assert (np.linalg.norm(P - robot[:, None], axis=2) >= 0.7 - 1e-6).all()
