@@ -235,8 +235,9 @@ gx_status gx_adv_normalize(int32_t env_num, int32_t max_ep_len, float* d_adv_buf
                            void* stream);
 
 /* Profiling aid: while d_stamps (device, ceil(env_num/4) x 8 uint64) is set, the lane-group kernels record the
- * shader clock (s_memtime) of each workgroup at: 0 entry, 1 state+action loads issued, 2 loads arrived, 3 end of
- * step 0, 4 start of step 1, 5 end of the last step, 6 state stored.  NULL switches it off (the default). */
+ * shader clock (s_memtime) of each workgroup at: 0 entry, 1 state+action loads issued, 2 loads arrived; for step
+ * t* = min(T-1, 100): 3 start, 4 dynamics done, 5 lidar/cost exchange done, 6 end of step; 7 state stored.
+ * NULL switches it off (the default). */
 gx_status gx_debug_stamps(gx_engine* e, uint64_t* d_stamps);
 
 /* Device-math probe (tests): s,c = sincos(x); at2 = atan2(y,x); ex = exp(x). */

@@ -87,3 +87,24 @@ def test_integration_stub_matches_the_header():
     for f in stub._fields_:
         flat.append(f[0])
     assert names == flat, (names, flat)
+
+
+def test_no_kernel_reads_the_aql_packet():
+    """A kernel whose descriptor enables the dispatch / queue pointer reads workgroup sizes from the AQL packet
+    (host memory) at run time -- what AMDGPUPromoteAlloca makes of a private array it moves to LDS.  That scalar
+    load cost every launch of the round-1 lane-group kernels ~12 us (profiles/r02_stamps_*.log)."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import kernel_descriptors as kd
+    from guardx_amd import _native
+    _native.load()
+    ks = kd.library_kernels(_native.LIB_PATH)
+    assert len(ks) > 150 and any("group_rollout_kernel" in k for k in ks)
+    bad = [k for k, v in ks.items() if v["dispatch_ptr"] or v["queue_ptr"]]
+    assert not bad, bad[:3]
+    # the Point / Swimmer lane-group kernels keep their state in registers: no scratch
+    for k, v in ks.items():
+        if "group_rollout_kernel" in k and ("PointRobot" in k or "SwimmerRobot" in k) and k.endswith("ELi0EEEvNS_6ParamsENS_11RolloutArgsENS_10PolicyArgsEP15HIP_vector_typeIfLj4EES8_S8_"):
+            assert v["scratch"] == 0, (k, v)

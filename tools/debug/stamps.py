@@ -18,11 +18,11 @@ def report(tag):
     torch.cuda.synchronize()
     s = st.cpu().numpy().astype(np.int64)
     t0 = s[:, 0].min()
-    d = np.diff(s[:, [0, 1, 2, 3, 5, 6]], axis=1)
-    print(tag, "per-workgroup deltas in shader cycles (median / p90):")
-    for k, n in enumerate(["loads issued", "loads arrived", "step 0", "steps 1..T-1", "state stored"]):
-        print(f"   {n:16s} {np.median(d[:, k]):9.0f} {np.percentile(d[:, k], 90):9.0f}")
-    print(f"   wave lifetime median {np.median(s[:, 6] - s[:, 0]):.0f}; first entry -> last exit {s[:, 6].max() - t0} cycles; entry spread {s[:, 0].max() - t0}")
+    d = np.diff(s[:, [0, 1, 2, 3, 4, 5, 6, 7]], axis=1)
+    print(tag, "per-workgroup deltas in s_memtime ticks (median / p90):")
+    for k, n in enumerate(["loads issued", "loads arrived", "-> step t* start", "t*: dynamics", "t*: lidar+exchange", "t*: reward/rows/reset", "-> state stored"]):
+        print(f"   {n:22s} {np.median(d[:, k]):9.0f} {np.percentile(d[:, k], 90):9.0f}")
+    print(f"   wave lifetime median {np.median(s[:, 7] - s[:, 0]):.0f}")
 for rep in range(3):
     env.step(act); report(f"T=1 step #{rep}")
 tape = bench.action_tape(200, 2000, 0, dev)
