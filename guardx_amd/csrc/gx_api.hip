@@ -71,6 +71,10 @@ struct gx_engine {
     // speculated reset_done (gx_step_rd): b.rd_j holds the layout rows reset_done would install for the envs the
     // last step finished; gx_reset_done_commit() only sets pending_commit, the next launch installs them
     unsigned long long* stamps = nullptr; // gx_debug_stamps
+    // two-kernel rollout (gx_split_rollout.inl): dynamics tape [T][N][W] and the layout snapshot of its launch
+    float* tape = nullptr;
+    size_t tape_cap = 0;      // floats
+    float4* obj0 = nullptr;
     bool spec_valid = false;
     bool pending_commit = false;
     // per-step layout keys for the fused rollout: ring of pinned staging + device buffers
@@ -90,11 +94,20 @@ static int take_commit(gx_engine* e)
     return c;
 }
 
+// fused rollouts of the light robots at small env_num: two kernels (a serial dynamics tape, then one thread per
+// (step, env) row) instead of the persistent lane-group kernel, from 8 steps up
+static bool use_split_rollout(const gx_engine* e, int T)
+{
+    if (e->path_mode == 1 || e->path_mode == 2) return false;
+    if (!split_rollout_supported(e->p) || e->p.N > 16384) return false;
+    return e->path_mode == 3 || T >= 8;
+}
+
 static bool use_group_path(const gx_engine* e)
 {
     if (e->path_mode == 1) return false;
     if (e->path_mode == 2) return true;
-    return e->p.N <= 16384; // <= 4096 single-wave workgroups: latency regime
+    return e->p.N <= 16384; // <= 4096 single-wave workgroups: latency regime (path_mode 3: rollouts split, steps here)
 }
 
 struct DeviceGuard {
@@ -338,7 +351,7 @@ extern "C" gx_status gx_destroy(gx_engine* e)
     if (!e) return GX_OK;
     DeviceGuard guard(e->device);
     (void)hipDeviceSynchronize();
-    void* bufs[] = {e->b.dyn, e->b.obj, e->b.hist, e->b.rd_j, e->haz_bounds};
+    void* bufs[] = {e->b.dyn, e->b.obj, e->b.hist, e->b.rd_j, e->haz_bounds, e->tape, e->obj0};
     for (void* q : bufs)
         if (q) (void)hipFree(q);
     for (int i = 0; i < 2; ++i) {
@@ -643,7 +656,20 @@ static gx_status rollout_impl(gx_engine* e, int32_t T, const float* d_actions, f
     r.obs = d_obs; r.rew = d_reward; r.cost = d_cost; r.done = d_done; r.qacc = nullptr;
     r.act_out = d_act_out; r.obs_stride = obs_stride; r.sc_stride = sc_stride;
     e->last_policy = false;
-    if (use_group_path(e)) {   // latency regime: 16 lanes per env
+    if (use_split_rollout(e, T)) { // light robots, small env_num: dynamics tape + one thread per (step, env) row
+        const size_t need = (size_t)T * e->p.N * split_tape_width(e->p);
+        if (need > e->tape_cap) {
+            GX_HIP(hipStreamSynchronize(s));            // an earlier launch may still read the old tape
+            if (e->tape) (void)hipFree(e->tape);
+            e->tape = nullptr; e->tape_cap = 0;
+            GX_HIP(hipMalloc((void**)&e->tape, sizeof(float) * need));
+            e->tape_cap = need;
+        }
+        if (!e->obj0) GX_HIP(hipMalloc((void**)&e->obj0, sizeof(float4) * (size_t)e->p.P * e->p.Npad));
+        st = flush_pending(e, s);
+        if (st != GX_OK) return st;
+        launch_split_rollout(e->p, r, e->tape, e->obj0, e->b, s);
+    } else if (use_group_path(e)) {   // latency regime: 16 lanes per env
         r.commit = take_commit(e);
         launch_group_rollout(e->p, r, e->b, s);
     } else {                    // bandwidth regime: one thread per env
@@ -858,7 +884,9 @@ extern "C" gx_status gx_debug_stamps(gx_engine* e, uint64_t* d_stamps)
 
 extern "C" gx_status gx_set_path(gx_engine* e, int32_t mode)
 {
-    if (!e || mode < 0 || mode > 2) return fail(GX_ERR_ARG, "gx_set_path: mode must be 0 (auto), 1 (thread-per-env) or 2 (lane-group)");
+    if (!e || mode < 0 || mode > 3)
+        return fail(GX_ERR_ARG, "gx_set_path: mode must be 0 (auto), 1 (thread-per-env), 2 (lane-group) or 3 (two-kernel "
+                                "rollouts where supported, lane-group otherwise)");
     e->path_mode = mode;
     return GX_OK;
 }

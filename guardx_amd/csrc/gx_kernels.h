@@ -86,6 +86,12 @@ void launch_group_rollout(const Params& p, const RolloutArgs& r, const DevBuffer
 void launch_thread_rollout(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s);
 void launch_policy_rollout(const Params& p, const RolloutArgs& r, const PolicyArgs& pol, const DevBuffers& b,
                            int impl, hipStream_t s);
+// two-kernel rollout of the light robots (gx_split_rollout.inl): dynamics tape, then one thread per (step, env) row
+struct SplitArgs;
+bool split_rollout_supported(const Params& p);
+int split_tape_width(const Params& p);
+void launch_split_rollout(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b,
+                          hipStream_t s);
 // install the reset_done recorded in b.rd_j (pending commit) for consumers other than the lane-group kernels
 void launch_commit_pending(const Params& p, const DevBuffers& b, int nobj_total, int n_rows, hipStream_t s);
 // per-robot launchers: defined in gx_robot_kernels.inl, instantiated once per robot in gx_kernels_<robot>.hip
@@ -102,6 +108,8 @@ struct RobotLaunch {
     static void policy(const Params& p, const RolloutArgs& r, const PolicyArgs& pol, const DevBuffers& b, int impl,
                        hipStream_t s);
     static void commit_pending(const Params& p, const DevBuffers& b, int nobj_total, int n_rows, hipStream_t s);
+    static void split(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b, hipStream_t s);
+    static int split_width();
 };
 bool policy_rollout_supported(const Params& p);
 size_t policy_lds_bytes(const Params& p, int impl);

@@ -385,6 +385,25 @@ void launch_thread_rollout(const Params& p, const RolloutArgs& r, const DevBuffe
     GX_ROBOT_DISPATCH(thread_rollout(p, r, b, s));
 }
 
+bool split_rollout_supported(const Params& p)
+{
+    // robots whose reset_done observation needs no physics step, no pose history in the observation
+    return (p.robot == PointRobot::kId || p.robot == PointBareRobot::kId || p.robot == SwimmerRobot::kId) && !p.hist_on;
+}
+int split_tape_width(const Params& p)
+{
+    int w = 0;
+    if (p.robot == SwimmerRobot::kId) w = RobotLaunch<SwimmerRobot>::split_width();
+    else if (p.robot == PointBareRobot::kId) w = RobotLaunch<PointBareRobot>::split_width();
+    else if (p.robot == PointRobot::kId) w = RobotLaunch<PointRobot>::split_width();
+    return w;
+}
+void launch_split_rollout(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b,
+                          hipStream_t s)
+{
+    GX_ROBOT_DISPATCH(split(p, r, tape, obj0, b, s));
+}
+
 void launch_commit_pending(const Params& p, const DevBuffers& b, int nobj_total, int n_rows, hipStream_t s)
 {
     GX_ROBOT_DISPATCH(commit_pending(p, b, nobj_total, n_rows, s));

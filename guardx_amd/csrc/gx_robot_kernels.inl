@@ -1128,6 +1128,10 @@ __global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Par
     stamp(r, 7);
 }
 
+} // namespace gx
+#include "gx_split_rollout.inl"
+namespace gx {
+
 // ---------------------------------------------------------------------------
 // launchers (per robot)
 // ---------------------------------------------------------------------------
@@ -1253,6 +1257,25 @@ template <class R>
 void RobotLaunch<R>::commit_pending(const Params& p, const DevBuffers& b, int nobj_total, int n_rows, hipStream_t s)
 {
     GX_DISPATCH_P(R, launch_commit_bp, 64, p, b, nobj_total, n_rows, s);
+}
+
+template <class R>
+void RobotLaunch<R>::split(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b,
+                           hipStream_t s)
+{
+    if constexpr (R::kRestFixed) {
+        SplitArgs sa;
+        sa.tape = tape; sa.obj0 = obj0;
+        if (p.P <= 5) launch_split_p<R, 5>(p, r, sa, b, s);
+        else if (p.P <= 9) launch_split_p<R, 9>(p, r, sa, b, s);
+        else launch_split_p<R, 33>(p, r, sa, b, s);
+    }
+}
+template <class R>
+int RobotLaunch<R>::split_width()
+{
+    if constexpr (R::kRestFixed) return SplitTape<R>::kW;
+    return 0;
 }
 
 template <class R>

@@ -1,0 +1,268 @@
+// gx_split_rollout.inl -- the fused T-step rollout of the light robots (Point, Swimmer) at small env_num as TWO
+// kernels instead of one persistent lane-group kernel (included by gx_robot_kernels.inl):
+//
+//   pass 1  dyn_tape_kernel   one thread per env, T steps: convert_action, mjx.step, reward / done / NaN guard /
+//           timeout, reset_done (layout index draw + re-placement) -- everything the NEXT step depends on -- and one
+//           80-byte tape row per (step, env): stepped pose, qpos, qvel, ctrl, reward, done, the layout row in effect
+//           and the layout row a reset_done installed.  ~200 instructions per step on the serial chain.
+//   pass 2  obs_tape_kernel   one thread per (step, env) tape row: lidars, compass, cost, the observation row (of the
+//           re-initialised env where reset_done fired) and the reward / cost / done outputs -- 400 000 independent
+//           rows at env_num = 2000, T = 200, i.e. the bandwidth regime of the thread-per-env kernels.
+//
+// Same functions, same operation order as step_kernel / reset_done_kernel, hence the same bits
+// (tests/test_gpu_parity.py runs every rollout test on this path too).  Not used when observe_vel / observe_acc
+// need the pose history in the row, for robots whose reset_done observation needs a physics step (Ant, Walker: their
+// dynamics dominate anyway), for the closed-loop policy rollout, or for Engine.step.
+//
+// The NaN guard (engine.py:696-699) needs "any observation entry non-finite" in pass 1.  With finite qpos / qvel /
+// ctrl / pose, |position| < 1e18 and finite objects of that size every entry is finite (exp <= 1, alias in [0,1],
+// compass a sum of two products < 1e37), so that test decides almost every step; whenever it does not hold, pass 1
+// evaluates the observation exactly (build_obs_row into an LDS row) like the one-kernel paths.
+#pragma once
+
+namespace gx {
+
+template <class R>
+struct SplitTape {
+    static constexpr int kPose = 0, kQ = 4, kV = kQ + R::NQ, kCtrl = kV + R::NV, kRew = kCtrl + R::NU, kDone = kRew + 1,
+                         kJcur = kDone + 1, kJaft = kJcur + 1, kUsed = kJaft + 1, kW = (kUsed + 3) / 4 * 4;
+};
+
+struct SplitArgs {
+    float* tape;        // [T][N][kW]
+    float4* obj0;       // [P][Npad] snapshot of the layouts at entry (pass 2 reads it for rows with jcur < 0)
+};
+
+GX_D bool moderate(float x) { return fabsf(x) < 1e18f; } // false for NaN / Inf too
+
+template <class R, int BLOCK, int PMAX, bool kDef>
+__global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArgs r, SplitArgs sa,
+                                                         float4* __restrict__ dyn, float4* __restrict__ obj)
+{
+    using TP = SplitTape<R>;
+    const Params p = fold_params<R, kDef>(p_in);
+    extern __shared__ float4 tile4[];
+    float* tile = reinterpret_cast<float*>(tile4); // one obs row per thread: exact NaN-guard evaluation only
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * BLOCK + tid;
+    if (i >= p.N) return;
+    float q[R::NQ], v[R::NV], pose0[4], done0, steps;
+    R::load(dyn, p.Npad, i, q, v, pose0, done0, steps);
+    // layout at entry: snapshot for pass 2, goal for reward / done, magnitude check for the NaN-guard shortcut
+    float gx = 0.f, gy = 0.f;
+    // the shortcut also needs a closeness that cannot overflow: exp(-gain*dist) with gain >= 0, or a positive max_dist
+    const bool cfg_ok = p.lidar_max_dist_set ? (p.lidar_max_dist > 0.0f) : (p.neg_gain <= 0.0f);
+    bool objs_ok = cfg_ok;
+#pragma unroll
+    for (int k = 0; k < PMAX; ++k) {
+        if (k < p.P) {
+            const float4 o4 = obj[(size_t)k * p.Npad + i];
+            sa.obj0[(size_t)k * p.Npad + i] = o4;
+            if (k == 0) { gx = o4.x; gy = o4.y; }
+            objs_ok = objs_ok && moderate(o4.x) && moderate(o4.y);
+            if (2 * k + 1 < p.nobj) objs_ok = objs_ok && moderate(o4.z) && moderate(o4.w);
+        }
+    }
+    const int L = r.do_reset ? *r.layout_size : 0;
+    int jcur = -1;
+    float* row = tile + tid * p.D;
+    float an[R::NA];
+    load_action<R>(r.act, (size_t)i, an);
+    for (int t = 0; t < r.T; ++t) {
+        float a[R::NA];
+#pragma unroll
+        for (int d = 0; d < R::NA; ++d) a[d] = an[d];
+        if (t + 1 < r.T) load_action<R>(r.act, (size_t)(t + 1) * p.N + i, an);
+        const bool have_last = (r.hist0 + t) >= 1;
+        const float last_done = done0;
+        const float L1x = pose0[0], L1y = pose0[1];
+
+        float ctrl[R::NU];
+        R::convert_action(pose0, a, ctrl); // :672-685, PRE-step xmat
+        float pose[4], qacc[R::NV];
+        for (int k = 0; k < p.physics_steps; ++k) R::template substep<false>(q, v, ctrl, pose, qacc);
+
+        // NaN / Inf guard :696-699
+        bool fin = objs_ok && moderate(pose[0]) && moderate(pose[1]) && moderate(pose[2]) && moderate(pose[3]);
+#pragma unroll
+        for (int k = 0; k < R::NQ; ++k) fin = fin && moderate(q[k]);
+#pragma unroll
+        for (int k = 0; k < R::NV; ++k) fin = fin && moderate(v[k]);
+#pragma unroll
+        for (int k = 0; k < R::NU; ++k) fin = fin && moderate(ctrl[k]);
+        bool bad = false;
+        if (!fin) { // rare: evaluate the observation exactly
+            float4 ob[PMAX];
+            if (jcur >= 0) { float rx_, ry_; load_layout<PMAX>(p, r.cand_xy, r.nobj_total, jcur, ob, rx_, ry_); }
+            else {
+#pragma unroll
+                for (int k = 0; k < PMAX; ++k)
+                    ob[k] = (k < p.P) ? sa.obj0[(size_t)k * p.Npad + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            bad = build_obs_row<R, PMAX>(p, row, pose, ob, ctrl, q, v, 0.f, 0.f, 0.f, 0.f);
+        }
+
+        // reward_done :787-802
+        const float dg = dist2(gx, gy, pose[0], pose[1]);
+        float last = dg;
+        if (have_last && !(last_done > 0.0f)) last = dist2(gx, gy, L1x, L1y);
+        const float dd = last - dg;
+        float rw = dd * p.reward_distance;
+        float dn = dg < p.goal_size ? 1.0f : 0.0f;
+        if (fabsf(dd) > 1.0f) { dn = 1.0f; rw = 0.0f; }
+        if (bad) { rw = 0.0f; dn = 1.0f; }        // :696-699
+        if (steps > p.num_steps_f) dn = 1.0f;      // :492
+        steps = dn > 0.0f ? 0.0f : steps + 1.0f;   // :493
+
+        // reset_done :497-505 for the env that just finished: the draw and the re-placement
+        int jaft = -1;
+        float nq0 = 0.f, nq1 = 0.f;
+        if (r.do_reset && dn > 0.0f && L > 0) {
+            const uint4 kk = r.keys ? r.keys[t] : r.key0;
+            const uint32_t idx = randint_at(kk.x, kk.y, kk.z, kk.w, (uint32_t)p.env_total, (uint32_t)L,
+                                            (uint32_t)(p.env_offset + i));
+            jaft = r.cand_of[idx];
+            const float2* rowp = r.cand_xy + (size_t)jaft * r.nobj_total;
+            const float2 g = rowp[0], rb = rowp[r.nobj_total - 1];
+            nq0 = rb.x; nq1 = rb.y;
+            gx = g.x; gy = g.y;
+        }
+
+        // tape row
+        float* tp = sa.tape + ((size_t)t * p.N + i) * TP::kW;
+        float rowv[TP::kW];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rowv[TP::kPose + k] = pose[k];
+#pragma unroll
+        for (int k = 0; k < R::NQ; ++k) rowv[TP::kQ + k] = q[k];
+#pragma unroll
+        for (int k = 0; k < R::NV; ++k) rowv[TP::kV + k] = v[k];
+#pragma unroll
+        for (int k = 0; k < R::NU; ++k) rowv[TP::kCtrl + k] = ctrl[k];
+        rowv[TP::kRew] = rw; rowv[TP::kDone] = dn;
+        rowv[TP::kJcur] = __int_as_float(jcur); rowv[TP::kJaft] = __int_as_float(jaft);
+#pragma unroll
+        for (int k = TP::kUsed; k < TP::kW; ++k) rowv[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < TP::kW / 4; ++k)
+            reinterpret_cast<float4*>(tp)[k] = make_float4(rowv[4 * k], rowv[4 * k + 1], rowv[4 * k + 2], rowv[4 * k + 3]);
+
+        // commit the history, then the re-initialisation (the stale pose stays, :731)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pose0[k] = pose[k];
+        done0 = dn;
+        if (jaft >= 0) {
+#pragma unroll
+            for (int k = 0; k < R::NQ; ++k) q[k] = 0.f;
+#pragma unroll
+            for (int k = 0; k < R::NV; ++k) v[k] = 0.f;
+            R::place(q, nq0, nq1);
+            jcur = jaft;
+            objs_ok = cfg_ok; // pool rows lie inside the placement extents
+        }
+    }
+    R::store(dyn, p.Npad, i, q, v, pose0, done0, steps);
+    if (jcur >= 0) { // the layout a reset_done installed becomes the env's layout
+        float4 ob[PMAX];
+        float rx_, ry_;
+        load_layout<PMAX>(p, r.cand_xy, r.nobj_total, jcur, ob, rx_, ry_);
+#pragma unroll
+        for (int k = 0; k < PMAX; ++k)
+            if (k < p.P) obj[(size_t)k * p.Npad + i] = ob[k];
+    }
+}
+
+template <class R, int BLOCK, int PMAX, bool kDef>
+__global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArgs r, SplitArgs sa)
+{
+    using TP = SplitTape<R>;
+    const Params p = fold_params<R, kDef>(p_in);
+    extern __shared__ float4 tile4[];
+    float* tile = reinterpret_cast<float*>(tile4);
+    const int tid = threadIdx.x;
+    const size_t G = (size_t)r.T * p.N;
+    const size_t g0 = (size_t)blockIdx.x * BLOCK, g = g0 + tid;
+    const bool live = g < G;
+    const size_t gg = live ? g : 0;
+    const int i = (int)(gg % (size_t)p.N);
+    const int RS = r.obs_stride;
+    const bool packed = r.act_out != nullptr;
+    float* row = tile + tid * RS;
+
+    const float* tp = sa.tape + gg * TP::kW;
+    float rowv[TP::kW];
+#pragma unroll
+    for (int k = 0; k < TP::kW / 4; ++k) {
+        const float4 t4 = reinterpret_cast<const float4*>(tp)[k];
+        rowv[4 * k] = t4.x; rowv[4 * k + 1] = t4.y; rowv[4 * k + 2] = t4.z; rowv[4 * k + 3] = t4.w;
+    }
+    float pose[4], q[R::NQ], v[R::NV], ctrl[R::NU];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pose[k] = rowv[TP::kPose + k];
+#pragma unroll
+    for (int k = 0; k < R::NQ; ++k) q[k] = rowv[TP::kQ + k];
+#pragma unroll
+    for (int k = 0; k < R::NV; ++k) v[k] = rowv[TP::kV + k];
+#pragma unroll
+    for (int k = 0; k < R::NU; ++k) ctrl[k] = rowv[TP::kCtrl + k];
+    const float rw = rowv[TP::kRew], dn = rowv[TP::kDone];
+    const int jcur = __float_as_int(rowv[TP::kJcur]), jaft = __float_as_int(rowv[TP::kJaft]);
+
+    float4 ob[PMAX];
+    if (jcur >= 0 && jcur < r.n_rows) { float rx_, ry_; load_layout<PMAX>(p, r.cand_xy, r.nobj_total, jcur, ob, rx_, ry_); }
+    else {
+#pragma unroll
+        for (int k = 0; k < PMAX; ++k)
+            ob[k] = (k < p.P) ? sa.obj0[(size_t)k * p.Npad + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // cost :804-811 (the layout the step was made in)
+    float cs = 0.0f;
+#pragma unroll
+    for (int k = 0; k < PMAX; ++k) {
+        if (k > 0 && 2 * k < p.nobj) cs = cs + cost_term(p, 2 * k, ob[k].x, ob[k].y, pose);
+        if (2 * k + 1 < p.nobj) cs = cs + cost_term(p, 2 * k + 1, ob[k].z, ob[k].w, pose);
+    }
+    if (jaft >= 0 && jaft < r.n_rows) { // reset_done fired: the row the learner sees is the re-initialised env's
+        float rx, ry;
+        load_layout<PMAX>(p, r.cand_xy, r.nobj_total, jaft, ob, rx, ry);
+#pragma unroll
+        for (int k = 0; k < R::NQ; ++k) q[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < R::NV; ++k) v[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < R::NU; ++k) ctrl[k] = 0.f;
+        R::place(q, rx, ry);
+        pose[0] = rx; pose[1] = ry; pose[2] = 1.0f; pose[3] = 0.0f;
+    }
+    build_obs_row<R, PMAX>(p, row, pose, ob, ctrl, q, v, 0.f, 0.f, 0.f, 0.f);
+    if (packed) {
+        float a[R::NA];
+        load_action<R>(r.act, gg, a);
+#pragma unroll
+        for (int k = 0; k < R::NA; ++k) row[p.D + k] = a[k];
+        row[p.D + R::NA] = rw; row[p.D + R::NA + 1] = cs; row[p.D + R::NA + 2] = dn;
+    } else if (live) {
+        r.rew[g] = rw; r.cost[g] = cs; r.done[g] = dn;
+    }
+    __syncthreads();
+    const size_t left = G - g0;
+    const int nrow = left < (size_t)BLOCK ? (int)left : BLOCK;
+    flush_tile<BLOCK>(tile, r.obs + g0 * RS, nrow * RS);
+}
+
+template <class R, int PMAX>
+static void launch_split_p(const Params& p, const RolloutArgs& r, const SplitArgs& sa, const DevBuffers& b, hipStream_t s)
+{
+    constexpr int B1 = 64, B2 = 64;
+    const dim3 g1((p.N + B1 - 1) / B1), g2((unsigned)(((size_t)r.T * p.N + B2 - 1) / B2));
+    const size_t lds1 = sizeof(float) * (size_t)B1 * p.D, lds2 = sizeof(float) * (size_t)B2 * r.obs_stride;
+    if (PMAX == 5 && is_default_layout<R>(p)) {
+        hipLaunchKernelGGL((dyn_tape_kernel<R, B1, 5, true>), g1, dim3(B1), lds1, s, p, r, sa, b.dyn, b.obj);
+        hipLaunchKernelGGL((obs_tape_kernel<R, B2, 5, true>), g2, dim3(B2), lds2, s, p, r, sa);
+    } else {
+        hipLaunchKernelGGL((dyn_tape_kernel<R, B1, PMAX, false>), g1, dim3(B1), lds1, s, p, r, sa, b.dyn, b.obj);
+        hipLaunchKernelGGL((obs_tape_kernel<R, B2, PMAX, false>), g2, dim3(B2), lds2, s, p, r, sa);
+    }
+}
+
+} // namespace gx

@@ -197,8 +197,10 @@ gx_status gx_set_prefetch(gx_engine* e, int32_t steps);
 /* prefetched pools used / discarded so far, and the current prediction */
 gx_status gx_prefetch_stats(const gx_engine* e, int32_t* hits, int32_t* misses, int32_t* horizon);
 
-/* Kernel family used by step / rollout: 0 = auto (lane-group kernels up to 16384 envs,
- * thread-per-env kernels above), 1 = force thread-per-env, 2 = force lane-group.
+/* Kernel family used by step / rollout: 0 = auto (up to 16384 envs: lane-group kernels, and for rollouts of 8+
+ * steps of the Point / Swimmer the two-kernel form -- serial dynamics tape, then one thread per (step, env)
+ * observation row; thread-per-env kernels above 16384 envs), 1 = force thread-per-env, 2 = force lane-group,
+ * 3 = two-kernel rollouts at any T where supported (lane-group otherwise).
  * Results are bit-identical either way (tests/test_gpu_parity.py). */
 gx_status gx_set_path(gx_engine* e, int32_t mode);
 

@@ -21,7 +21,7 @@ def torch_cuda():
     return torch
 
 
-PATHS = {"thread": 1, "group": 2}
+PATHS = {"thread": 1, "group": 2, "split": 3}   # split: two-kernel rollouts (Point / Swimmer), lane-group steps
 
 
 def _engines(cfg, oracle, n_candidates=20000, path=None, **kw):
@@ -116,7 +116,7 @@ def test_step_parity_random_states(torch_cuda, oracle, N, path):
         assert_state_equal(E.get_state(), O.get_state())
 
 
-@pytest.mark.parametrize("path", ["thread", "group"])
+@pytest.mark.parametrize("path", ["thread", "group", "split"])
 def test_point_bare_actuator_model_parity(torch_cuda, oracle, path):
     """the round-1 reading of point.xml's actuators (no class defaults) stays selectable and bit exact"""
     torch = torch_cuda
@@ -166,6 +166,31 @@ def test_step_parity_nan_inf_actions(torch_cuda, oracle, path):
     assert d[::7].all() and (out_g[1].cpu().numpy()[::7] == 0).all()  # guard engine.py:696-699
 
 
+@pytest.mark.parametrize("path", ["thread", "group", "split"])
+def test_rollout_nan_guard_parity(torch_cuda, oracle, path):
+    """NaN / Inf actions inside a fused rollout: the guard (engine.py:696-699) ends the episode, reset_done
+    re-initialises the env, the NaN row is replaced by the reset observation -- same on every path"""
+    torch = torch_cuda
+    N, T = 150, 24
+    E, O = _engines(task_config(N, seed=6, num_steps=50), oracle, n_candidates=30000, path=path)
+    np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
+    rng = np.random.default_rng(9)
+    acts = rng.uniform(-1, 1, (T, N, 2)).astype(np.float32)
+    acts[3, ::7, 0] = np.nan
+    acts[5, 1::11, 1] = np.inf
+    acts[9, 2::13, 0] = -np.inf
+    acts[9, 4::17, 0] = 3e38            # finite but huge: the exact evaluation decides
+    obs, rew, cost, done = E.rollout(torch.from_numpy(acts).cuda())
+    for t in range(T):
+        o, r, d, info = O.step(acts[t])
+        np.testing.assert_array_equal(obs[t].cpu().numpy(), O.reset_done())
+        np.testing.assert_array_equal(rew[t].cpu().numpy(), r)
+        np.testing.assert_array_equal(done[t].cpu().numpy(), d)
+        np.testing.assert_array_equal(cost[t].cpu().numpy(), info['cost'])
+    assert done[3, ::7].all().item() and done.sum().item() >= 20
+    assert_state_equal(E.get_state(), O.get_state())
+
+
 @pytest.mark.parametrize("N,cand", [(4, 20000), (2000, 200000)])
 def test_reset_parity(torch_cuda, oracle, N, cand):
     E, O = _engines(task_config(N, seed=0), oracle, n_candidates=cand)
@@ -177,7 +202,7 @@ def test_reset_parity(torch_cuda, oracle, N, cand):
     assert_state_equal(E.get_state(), O.get_state())
 
 
-@pytest.mark.parametrize("path", ["thread", "group"])
+@pytest.mark.parametrize("path", ["thread", "group", "split"])
 def test_rollout_parity_with_reset_done(torch_cuda, oracle, path):
     """200-step random-policy episode with reset_done() whenever any env is done."""
     torch = torch_cuda
@@ -206,7 +231,7 @@ def test_rollout_parity_with_reset_done(torch_cuda, oracle, path):
     _cmp_step(E.step(torch.from_numpy(act).cuda()), O.step(act))
 
 
-@pytest.mark.parametrize("path", ["thread", "group"])
+@pytest.mark.parametrize("path", ["thread", "group", "split"])
 def test_fused_rollout_equals_stepwise(torch_cuda, oracle, path):
     torch = torch_cuda
     N, T = 301, 64
@@ -228,7 +253,7 @@ def test_fused_rollout_equals_stepwise(torch_cuda, oracle, path):
 
 
 @pytest.mark.parametrize("robot", ["point", "swimmer", "ant", "walker"])
-@pytest.mark.parametrize("path", ["thread", "group"])
+@pytest.mark.parametrize("path", ["thread", "group", "split"])
 def test_variant_configs(torch_cuda, oracle, path, robot):
     torch = torch_cuda
     extra = {"point": {}, "swimmer": SWIMMER, "ant": ANT, "walker": WALKER}[robot]
@@ -335,7 +360,7 @@ def test_step_reset_done_above_the_group_limit(torch_cuda, oracle):
     assert_state_equal(E.get_state(), O.get_state())
 
 
-@pytest.mark.parametrize("path", ["thread", "group"])
+@pytest.mark.parametrize("path", ["thread", "group", "split"])
 @pytest.mark.parametrize("robot", ["point", "walker"])
 def test_packed_rollout_equals_plain(torch_cuda, oracle, path, robot):
     """gx_rollout_packed: rows (obs | action | reward, cost, done) written by the kernel == gx_rollout's arrays"""
@@ -380,7 +405,7 @@ def test_prefetch_horizon_follows_the_learner(torch_cuda, oracle):
 # ---------------------------------------------------------------------------
 # BASELINE config 5 (synthetic, no reference counterpart): Ant + 8 hazards + 8 pillars
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("path", ["thread", "group"])
+@pytest.mark.parametrize("path", ["thread", "group", "split"])
 @pytest.mark.parametrize("robot", ["ant", "point"])
 def test_pillars_config5_parity(torch_cuda, oracle, path, robot):
     torch = torch_cuda
@@ -555,7 +580,7 @@ def test_swimmer_step_parity_random_states(torch_cuda, oracle, N, path):
         assert_state_equal(E.get_state(), O.get_state())
 
 
-@pytest.mark.parametrize("path", ["thread", "group"])
+@pytest.mark.parametrize("path", ["thread", "group", "split"])
 def test_swimmer_rollout_parity(torch_cuda, oracle, path):
     torch = torch_cuda
     N, T = 300, 120
