@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -75,6 +76,8 @@ struct gx_engine {
     float* tape = nullptr;
     size_t tape_cap = 0;      // floats
     float4* obj0 = nullptr;
+    hipEvent_t pf_phase1 = nullptr;  // prefetch sampler: phases 0 and 1 done (the observation pass is held until then)
+    bool pf_phase1_pending = false;
     bool spec_valid = false;
     bool pending_commit = false;
     // per-step layout keys for the fused rollout: ring of pinned staging + device buffers
@@ -322,7 +325,9 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     if (err == hipSuccess) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi); // lo = least urgent
-        err = hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, lo);
+        int prio = lo;
+        if (const char* ev = getenv("GX_SIDE_PRIORITY")) prio = (atoi(ev) > 0) ? hi : (atoi(ev) == 0 ? (lo + hi) / 2 : lo); // experiments
+        err = hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio);
     }
     e->cur = 0;
     e->b.pool = e->pools[0];
@@ -369,6 +374,7 @@ extern "C" gx_status gx_destroy(gx_engine* e)
     }
     if (e->h_layout_size) (void)hipHostFree(e->h_layout_size);
     if (e->layout_ev) (void)hipEventDestroy(e->layout_ev);
+    if (e->pf_phase1) (void)hipEventDestroy(e->pf_phase1);
     delete e;
     return GX_OK;
 }
@@ -443,7 +449,9 @@ extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
         if (e->last_policy) GX_HIP(hipStreamWaitEvent(e->side, e->layout_ev, 0));
         SampleParams sp = e->sp;
         sp.k0 = k0; sp.k1 = k1;
-        launch_sample(sp, e->pools[tgt], e->side);
+        if (!e->pf_phase1) GX_HIP(hipEventCreateWithFlags(&e->pf_phase1, hipEventDisableTiming));
+        launch_sample(sp, e->pools[tgt], e->side, e->pf_phase1);
+        e->pf_phase1_pending = true;
         GX_HIP(hipEventRecord(e->pool_ready[tgt], e->side));
         GX_HIP(hipGetLastError());
         e->pf_valid = true;
@@ -668,7 +676,9 @@ static gx_status rollout_impl(gx_engine* e, int32_t T, const float* d_actions, f
         if (!e->obj0) GX_HIP(hipMalloc((void**)&e->obj0, sizeof(float4) * (size_t)e->p.P * e->p.Npad));
         st = flush_pending(e, s);
         if (st != GX_OK) return st;
-        launch_split_rollout(e->p, r, e->tape, e->obj0, e->b, s);
+        hipEvent_t hold = nullptr;
+        if (e->pf_phase1_pending && getenv("GX_NO_OBS_HOLD") == nullptr) { hold = e->pf_phase1; e->pf_phase1_pending = false; }
+        launch_split_rollout(e->p, r, e->tape, e->obj0, e->b, s, hold);
     } else if (use_group_path(e)) {   // latency regime: 16 lanes per env
         r.commit = take_commit(e);
         launch_group_rollout(e->p, r, e->b, s);

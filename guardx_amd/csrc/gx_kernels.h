@@ -48,7 +48,8 @@ struct DevBuffers {
 
 void launch_step(const Params& p, const DevBuffers& b, const float* act, float* obs, float* rew,
                  float* cost, float* done, float* qacc, hipStream_t s);
-void launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s);
+// `after_phase1`: null, or an event recorded on `s` once the fully VALU-bound phases 0 and 1 are done
+void launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s, hipEvent_t after_phase1 = nullptr);
 void launch_reset_apply(const Params& p, const DevBuffers& b, int nobj_total, uint32_t k10,
                         uint32_t k11, uint32_t k20, uint32_t k21, float* obs, int* host_layout_size,
                         hipStream_t s);
@@ -90,8 +91,9 @@ void launch_policy_rollout(const Params& p, const RolloutArgs& r, const PolicyAr
 struct SplitArgs;
 bool split_rollout_supported(const Params& p);
 int split_tape_width(const Params& p);
+// `hold`: null, or an event the observation pass (not the dynamics pass) waits for
 void launch_split_rollout(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b,
-                          hipStream_t s);
+                          hipStream_t s, hipEvent_t hold = nullptr);
 // install the reset_done recorded in b.rd_j (pending commit) for consumers other than the lane-group kernels
 void launch_commit_pending(const Params& p, const DevBuffers& b, int nobj_total, int n_rows, hipStream_t s);
 // per-robot launchers: defined in gx_robot_kernels.inl, instantiated once per robot in gx_kernels_<robot>.hip
@@ -108,7 +110,8 @@ struct RobotLaunch {
     static void policy(const Params& p, const RolloutArgs& r, const PolicyArgs& pol, const DevBuffers& b, int impl,
                        hipStream_t s);
     static void commit_pending(const Params& p, const DevBuffers& b, int nobj_total, int n_rows, hipStream_t s);
-    static void split(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b, hipStream_t s);
+    static void split(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b, hipStream_t s,
+                      hipEvent_t hold);
     static int split_width();
 };
 bool policy_rollout_supported(const Params& p);

@@ -325,7 +325,7 @@ int pick_block(const Params& p)
     return 64;
 }
 
-void launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s)
+void launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s, hipEvent_t after_phase1)
 {
     const int M = sp.M, W = (M + 63) / 64;
     const int grid = (M + kSampleBlock - 1) / kSampleBlock;
@@ -336,6 +336,7 @@ void launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s)
     const int grid1 = grid < 3072 ? grid : 3072;
     hipLaunchKernelGGL(sample_phase1_kernel, dim3(grid1), dim3(kSampleBlock), 0, s, sp, pl.n_surv + 1, pl.surv0,
                        pl.n_surv, pl.surv);
+    if (after_phase1) (void)hipEventRecord(after_phase1, s);
     const int grid2 = grid < 1024 ? grid : 1024;
     hipLaunchKernelGGL(sample_phase2_kernel, dim3(grid2), dim3(kSampleBlock), lds, s, sp, pl.n_surv, pl.surv,
                        pl.cand_ok, pl.cand_xy);
@@ -399,9 +400,9 @@ int split_tape_width(const Params& p)
     return w;
 }
 void launch_split_rollout(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b,
-                          hipStream_t s)
+                          hipStream_t s, hipEvent_t hold)
 {
-    GX_ROBOT_DISPATCH(split(p, r, tape, obj0, b, s));
+    GX_ROBOT_DISPATCH(split(p, r, tape, obj0, b, s, hold));
 }
 
 void launch_commit_pending(const Params& p, const DevBuffers& b, int nobj_total, int n_rows, hipStream_t s)

@@ -83,13 +83,15 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
         for (int k = 0; k < p.physics_steps; ++k) R::template substep<false>(q, v, ctrl, pose, qacc);
 
         // NaN / Inf guard :696-699
-        bool fin = objs_ok && moderate(pose[0]) && moderate(pose[1]) && moderate(pose[2]) && moderate(pose[3]);
+        // sum of magnitudes < 1e18  =>  every term finite and < 1e18 (NaN / Inf make the comparison false)
+        float mag = (fabsf(pose[0]) + fabsf(pose[1])) + (fabsf(pose[2]) + fabsf(pose[3]));
 #pragma unroll
-        for (int k = 0; k < R::NQ; ++k) fin = fin && moderate(q[k]);
+        for (int k = 0; k < R::NQ; ++k) mag = mag + fabsf(q[k]);
 #pragma unroll
-        for (int k = 0; k < R::NV; ++k) fin = fin && moderate(v[k]);
+        for (int k = 0; k < R::NV; ++k) mag = mag + fabsf(v[k]);
 #pragma unroll
-        for (int k = 0; k < R::NU; ++k) fin = fin && moderate(ctrl[k]);
+        for (int k = 0; k < R::NU; ++k) mag = mag + fabsf(ctrl[k]);
+        const bool fin = objs_ok && moderate(mag);
         bool bad = false;
         if (!fin) { // rare: evaluate the observation exactly
             float4 ob[PMAX];
@@ -251,16 +253,19 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
 }
 
 template <class R, int PMAX>
-static void launch_split_p(const Params& p, const RolloutArgs& r, const SplitArgs& sa, const DevBuffers& b, hipStream_t s)
+static void launch_split_p(const Params& p, const RolloutArgs& r, const SplitArgs& sa, const DevBuffers& b, hipStream_t s,
+                           hipEvent_t hold)
 {
     constexpr int B1 = 64, B2 = 64;
     const dim3 g1((p.N + B1 - 1) / B1), g2((unsigned)(((size_t)r.T * p.N + B2 - 1) / B2));
     const size_t lds1 = sizeof(float) * (size_t)B1 * p.D, lds2 = sizeof(float) * (size_t)B2 * r.obs_stride;
     if (PMAX == 5 && is_default_layout<R>(p)) {
         hipLaunchKernelGGL((dyn_tape_kernel<R, B1, 5, true>), g1, dim3(B1), lds1, s, p, r, sa, b.dyn, b.obj);
+        if (hold) (void)hipStreamWaitEvent(s, hold, 0);
         hipLaunchKernelGGL((obs_tape_kernel<R, B2, 5, true>), g2, dim3(B2), lds2, s, p, r, sa);
     } else {
         hipLaunchKernelGGL((dyn_tape_kernel<R, B1, PMAX, false>), g1, dim3(B1), lds1, s, p, r, sa, b.dyn, b.obj);
+        if (hold) (void)hipStreamWaitEvent(s, hold, 0);
         hipLaunchKernelGGL((obs_tape_kernel<R, B2, PMAX, false>), g2, dim3(B2), lds2, s, p, r, sa);
     }
 }
