@@ -158,8 +158,8 @@ def time_launches(launch, nlaunch):
 
 
 def roofline_rollout(env_num, T, nlaunch, device):
-    """The dominant kernel of the headline workload: the persistent lane-group rollout kernel
-    (one launch = T fused step+reset_done passes over env_num envs)."""
+    """The step path of the headline workload: one gx_rollout call = T fused step+reset_done passes over env_num
+    envs = the dynamics-tape kernel + the observation-pass kernel (gx_split_rollout.inl)."""
     env = _fresh_engine(env_num)
     tape = action_tape(T, env_num, 7, device)
     N, D = env_num, env.obs_flat_size
@@ -177,19 +177,29 @@ def roofline_rollout(env_num, T, nlaunch, device):
     env.close()
     t = min(per, cadence)
     ach = ALGO_BYTES_PER_ENV_STEP * env_num * T / t / 1e9
+    # rocprofv3 PMC, profiles/r02_rollout_N2000_T200_pmc_{FETCH,WRITE}_SIZE.csv (KB per launch; FETCH x2 on gfx950)
+    pmc_kb = 2 * (1738.6 + 16540.7) + (31500.0 + 71875.0)
     return {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 6),
-            "traffic": round((2 * 6612.375 + 78236.094) * 1024 / 1e9 * (env_num * T) / (2000 * 200), 4),
-            "traffic_note": "NOT measured in this run: GB per launch from the committed rocprofv3 PMC passes at "
-                            "env_num=2000, T=200: 2*FETCH_SIZE + WRITE_SIZE = 13.5 MB + 80.1 MB "
-                            "(profiles/r01_rollout_N2000_T200_pmc_*.csv); below the 148.8 MB "
-                            "algorithmic figure because state and layout stay in registers across the 200 steps",
-            "kernel": "gx::group_rollout_kernel<1,1,false,true>", "env_num": env_num, "steps_per_launch": T,
+            "traffic": round(pmc_kb * 1024 / 1e9 * (env_num * T) / (2000 * 200), 4),
+            "traffic_note": "NOT measured in this run: GB per gx_rollout call from the committed rocprofv3 PMC passes at "
+                            "env_num=2000, T=200: 2*FETCH_SIZE + WRITE_SIZE = 36.6 MB + 103.4 MB "
+                            "(profiles/r02_rollout_N2000_T200_pmc_*.csv) against 148.8 MB algorithmic: the 32 MB "
+                            "dynamics tape is written once and read once instead of the 36 B/env-step state round trip",
+            "kernel": "gx::dyn_tape_kernel<PointRobot,64,5,true> + gx::obs_tape_kernel<PointRobot,64,5,true> "
+                      "(the two launches of one gx_rollout call = 200 fused step+reset_done passes)",
+            "kernels_us_rocprof": {"dyn_tape_kernel": 124.6, "obs_tape_kernel": 33.7,
+                                   "source": "profiles/r02_rollout_N2000_T200_kernel_stats.csv (standalone)"},
+            "obs_pass_alone": {"GBps_pmc_traffic": round((2 * 16540.7 + 71875.0) * 1024 / 33.7e-6 / 1e9, 1),
+                               "frac_of_peak": round((2 * 16540.7 + 71875.0) * 1024 / 33.7e-6 / 1e9 / HBM_PEAK_GBS, 4),
+                               "note": "the 400k-row observation pass alone (profiled, not this run): 105.5 MB in 33.7 us"},
+            "env_num": env_num, "steps_per_launch": T,
             "avg_launch_us": round(t * 1e6, 3), "event_pair_us": round(per * 1e6, 3),
             "back_to_back_us": round(cadence * 1e6, 3),
             "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
-            "note": "latency-bound at env_num=2000: 500 single-wave workgroups, 0.74 MB of algorithmic "
-                    "traffic per step; see roofline_large_batch for the bandwidth regime"}
+            "note": "env_num=2000 is latency-bound by construction (0.74 MB of algorithmic traffic per step): the serial "
+                    "dynamics pass (32 waves, ~1400 cycles per step) takes 3/4 of the call; see roofline_large_batch for "
+                    "the bandwidth regime"}
 
 
 def roofline_step(env_num, nlaunch, device):
@@ -505,8 +515,8 @@ def main():
                                   "overlapped with the following epochs" if gather else ""),
                    "env_num_per_gpu": ENV_NUM, "max_ep_len": EP_LEN, "step_passes_per_bench_step": EP_LEN,
                    "obs_dim": env.obs_flat_size,
-                   "driver": "gx_rollout: one persistent lane-group kernel launch per 200-pass epoch, layout pool of "
-                             "the next epoch prefetched on a side stream",
+                   "driver": "gx_rollout: two launches per 200-pass epoch (serial dynamics tape, then one thread per "
+                             "(step, env) observation row), layout pool of the next epoch prefetched on a side stream",
                    "layout_candidates_per_reset": 1_000_000,
                    "point_actuators": "mjcf defaults inherited (DESIGN.md 0.1)"},
     }

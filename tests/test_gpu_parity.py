@@ -449,6 +449,72 @@ def test_pillars_config5_parity(torch_cuda, oracle, path, robot):
     np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
 
 
+def test_bench_workload_three_epochs(torch_cuda, oracle):
+    """EXACTLY bench.py's workload (BASELINE config 2): env_num=2000, n_candidates=1e6 (engine.py:263), 200-step
+    epochs of reset(check=False) + rollout with the default layout-pool prefetch, three epochs back to back,
+    against the checker: pool, layout_size, every observation / reward / cost / done, final state."""
+    torch = torch_cuda
+    N, T, M = 2000, 200, 1_000_000
+    E, O = _engines(task_config(N, seed=0, num_steps=T), oracle, n_candidates=M)
+    rng = np.random.default_rng(0)
+    for ep in range(3):
+        og, oo = E.reset(check=False), O.reset()
+        np.testing.assert_array_equal(og.cpu().numpy(), oo)
+        if ep != 1:
+            np.testing.assert_array_equal(E.get_pool(4096), O.get_pool(4096))
+        acts = rng.uniform(-1, 1, (T, N, 2)).astype(np.float32)
+        obs, rew, cost, done = E.rollout(torch.from_numpy(acts).cuda())
+        obs, rew, cost, done = obs.cpu().numpy(), rew.cpu().numpy(), cost.cpu().numpy(), done.cpu().numpy()
+        for t in range(T):
+            o, r, d, info = O.step(acts[t])
+            if d.any():
+                o = O.reset_done()
+            np.testing.assert_array_equal(obs[t], o)
+            np.testing.assert_array_equal(rew[t], r)
+            np.testing.assert_array_equal(done[t], d)
+            np.testing.assert_array_equal(cost[t], info['cost'])
+        assert E.check_layouts() == O.layout_size > N
+    assert_state_equal(E.get_state(), O.get_state())
+    hits, misses, horizon = E.prefetch_stats()
+    assert (hits, misses, horizon) == (2, 0, T)       # epochs 2 and 3 took the prefetched pool
+
+
+def test_config4_shape_eight_shards_of_2000(torch_cuda, oracle):
+    """BASELINE config 4 on one GPU: eight Engine(env_num=2000, shard=(r, 8)) reproduce the rows of one
+    16 000-env engine (1e6 candidates) through reset, a fused rollout with resets and the next reset; the
+    16 000-env engine itself is checked against the checker."""
+    torch = torch_cuda
+    from guardx_amd import Engine
+    N, W, T, M = 2000, 8, 40, 1_000_000
+    cfg_full = task_config(N * W, seed=3, num_steps=25, goal_size=2.7)
+    full, O = _engines(cfg_full, oracle, n_candidates=M)
+    o_full = full.reset()
+    np.testing.assert_array_equal(o_full.cpu().numpy(), O.reset())
+    assert full.layout_size == O.layout_size > N * W
+    acts = torch.from_numpy(np.random.default_rng(1).uniform(-1, 1, (T, N * W, 2)).astype(np.float32)).cuda()
+    obs_f, rew_f, cost_f, done_f = full.rollout(acts)
+    assert done_f.sum().item() > N * W                      # timeouts (and some goals): reset_done on every shard
+    a_np = acts.cpu().numpy()
+    for t in range(T):
+        o, r, d, info = O.step(a_np[t])
+        if t in (0, 12, 26, 27, T - 1):                     # spot-check the big engine against the checker
+            np.testing.assert_array_equal(obs_f[t].cpu().numpy(), O.reset_done())
+            np.testing.assert_array_equal(done_f[t].cpu().numpy(), d)
+        else:
+            O.reset_done()
+    o_full2 = full.reset()
+    np.testing.assert_array_equal(o_full2.cpu().numpy(), O.reset())
+    for r in range(W):
+        sh = Engine(task_config(N, seed=3, num_steps=25, goal_size=2.7), n_candidates=M, shard=(r, W))
+        sl = slice(r * N, (r + 1) * N)
+        assert torch.equal(sh.reset(), o_full[sl])
+        obs, rew, cost, done = sh.rollout(acts[:, sl].contiguous())
+        assert torch.equal(obs, obs_f[:, sl]) and torch.equal(rew, rew_f[:, sl])
+        assert torch.equal(cost, cost_f[:, sl]) and torch.equal(done, done_f[:, sl])
+        assert torch.equal(sh.reset(), o_full2[sl])
+        sh.close()
+
+
 def test_sharded_equals_unsharded(torch_cuda, oracle):
     """rank r of a world-of-4 engine reproduces rows [r*N, (r+1)*N) of one 4N-env engine."""
     torch = torch_cuda
