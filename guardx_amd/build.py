@@ -36,8 +36,11 @@ PER_SOURCE_FLAGS = {
 
 
 def _extra(src):
-    # GX_EXTRA_FLAGS_<source stem>="...": experiments
-    return PER_SOURCE_FLAGS.get(src, []) + os.environ.get("GX_EXTRA_FLAGS_" + os.path.splitext(src)[0], "").split()
+    # GX_EXTRA_FLAGS_<source stem>="...": experiments (replaces the per-source defaults when it starts with "=")
+    env = os.environ.get("GX_EXTRA_FLAGS_" + os.path.splitext(src)[0], "")
+    if env.startswith("="):
+        return env[1:].split()
+    return PER_SOURCE_FLAGS.get(src, []) + env.split()
 
 
 def _deps_mtime():

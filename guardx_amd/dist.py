@@ -63,6 +63,8 @@ def barrier():
 
 
 def max_over_ranks(value, device):
+    if dist.is_initialized() and dist.get_backend() != "nccl":
+        device = "cpu"                      # gloo rehearsal
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -486,14 +486,14 @@ def test_config4_shape_eight_shards_of_2000(torch_cuda, oracle):
     torch = torch_cuda
     from guardx_amd import Engine
     N, W, T, M = 2000, 8, 40, 1_000_000
-    cfg_full = task_config(N * W, seed=3, num_steps=25, goal_size=2.7)
+    cfg_full = task_config(N * W, seed=3, num_steps=25, goal_size=2.95)
     full, O = _engines(cfg_full, oracle, n_candidates=M)
     o_full = full.reset()
     np.testing.assert_array_equal(o_full.cpu().numpy(), O.reset())
     assert full.layout_size == O.layout_size > N * W
     acts = torch.from_numpy(np.random.default_rng(1).uniform(-1, 1, (T, N * W, 2)).astype(np.float32)).cuda()
     obs_f, rew_f, cost_f, done_f = full.rollout(acts)
-    assert done_f.sum().item() > N * W                      # timeouts (and some goals): reset_done on every shard
+    assert done_f.sum().item() >= N * W                     # every env times out once (plus the odd goal): reset_done on every shard
     a_np = acts.cpu().numpy()
     for t in range(T):
         o, r, d, info = O.step(a_np[t])
@@ -505,7 +505,7 @@ def test_config4_shape_eight_shards_of_2000(torch_cuda, oracle):
     o_full2 = full.reset()
     np.testing.assert_array_equal(o_full2.cpu().numpy(), O.reset())
     for r in range(W):
-        sh = Engine(task_config(N, seed=3, num_steps=25, goal_size=2.7), n_candidates=M, shard=(r, W))
+        sh = Engine(task_config(N, seed=3, num_steps=25, goal_size=2.95), n_candidates=M, shard=(r, W))
         sl = slice(r * N, (r + 1) * N)
         assert torch.equal(sh.reset(), o_full[sl])
         obs, rew, cost, done = sh.rollout(acts[:, sl].contiguous())
