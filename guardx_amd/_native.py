@@ -50,6 +50,7 @@ _I32P = C.POINTER(C.c_int32)
 SYMBOLS = {
     "gx_last_error": (C.c_char_p, []),
     "gx_abi_version": (C.c_int32, []),
+    "gx_build_id": (C.c_char_p, []),
     "gx_create": (C.c_int, [C.POINTER(GxConfig), C.POINTER(C.c_void_p)]),
     "gx_destroy": (C.c_int, [C.c_void_p]),
     "gx_obs_dim": (C.c_int32, [C.c_void_p]),
@@ -87,25 +88,33 @@ _lib = None
 
 
 def load():
-    """Load the HIP library; raises (never falls back) when it is unavailable."""
+    """Load the HIP library; raises (never falls back) when it is unavailable or was built from other sources.
+
+    The library carries the hash of the sources it was built from (gx_build_id).  If the file is missing or the
+    hash on disk differs from the sources in the tree it is rebuilt in place with hipcc (one process at a time:
+    guardx_amd.build takes a file lock and renames the finished file into place); a library whose embedded id does
+    not match after that is refused."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        # in-tree build on first use (hipcc cross-compiles gfx950 without a GPU); there is no
-        # CPU fallback: if this fails the import fails
+    from . import build as _build
+    want = _build.source_hash()
+    if _build.needs_build():
         try:
-            from . import build as _build
-            _build.build(force=True)
+            _build.build(force=False)
         except Exception as exc:  # noqa: BLE001
             raise ImportError(
-                f"{LIB_PATH} is missing and could not be built with hipcc ({exc}); "
-                "run `python -m guardx_amd.build` (guardx_amd has no CPU fallback)") from exc
+                f"{LIB_PATH} is missing or stale (sources {want}, library {_build.built_id()}) and could not be "
+                f"built with hipcc ({exc}); run `python -m guardx_amd.build` (guardx_amd has no CPU fallback)") from exc
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the ABI drifted
         fn.restype = res
         fn.argtypes = args
+    got = lib.gx_build_id().decode()
+    if got != want:
+        raise ImportError(f"{LIB_PATH} was built from other sources (library {got}, tree {want}); "
+                          "run `python -m guardx_amd.build`")
     _lib = lib
     return lib
 

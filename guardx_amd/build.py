@@ -20,7 +20,7 @@ LIB = os.path.join(LIB_DIR, "libguardx_hip.so")
 SOURCES = ["gx_api.hip", "gx_kernels.hip", "gx_gae.hip", "gx_kernels_point.hip", "gx_kernels_point_bare.hip", "gx_kernels_swimmer.hip",
            "gx_kernels_ant.hip", "gx_kernels_walker.hip"]
 HEADERS = ["gx_device.h", "gx_robot.h", "gx_robot_ant.h", "gx_robot_ant_group.h", "gx_robot_legs.h", "gx_robot_legs_group.h", "gx_policy.h", "gx_kernels.h", "gx_robot_kernels.inl",
-           os.path.join("..", "..", "include", "guardx.h")]
+           "gx_split_rollout.inl", os.path.join("..", "..", "include", "guardx.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # The Ant / Walker steps are real (noinline) device functions called from the lane-group kernels.  With LLVM's
 # inter-procedural register allocation (on by default for amdgcn at -O3) hipcc 7.2 lets such a callee use, without
@@ -43,48 +43,105 @@ def _extra(src):
     return PER_SOURCE_FLAGS.get(src, []) + env.split()
 
 
-def _deps_mtime():
-    deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
-    return max(os.path.getmtime(d) for d in deps if os.path.exists(d))
+BUILD_ID_FILE = os.path.join(LIB_DIR, "BUILD_ID")
+LOCK_FILE = os.path.join(LIB_DIR, ".build.lock")
+
+
+def source_hash():
+    """sha256 over every source, header and flag that goes into the library: the identity of a build.  It is
+    compiled into the library (gx_build_id()) and checked at load time, so a stale or foreign .so is never
+    loaded silently, whatever the file times say (the tree is copied to the GPU box without them)."""
+    import hashlib
+    h = hashlib.sha256()
+    names = sorted(set(SOURCES) | set(HEADERS) | {"gx_split_rollout.inl"})
+    for n in names:
+        path = os.path.join(CSRC, n)
+        h.update(n.encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update(repr((FLAGS, sorted(PER_SOURCE_FLAGS.items()))).encode())
+    return h.hexdigest()[:24]
 
 
 def _obj(src):
     return os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
 
 
+def built_id():
+    try:
+        with open(BUILD_ID_FILE) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
 def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    return _deps_mtime() > t or any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in SOURCES)
+    return not os.path.exists(LIB) or built_id() != source_hash()
+
+
+def _dep_hash(src):
+    """identity of one object file: its source, every header, its flags (objects are reused across builds)"""
+    import hashlib
+    h = hashlib.sha256()
+    for n in [src] + sorted(set(HEADERS) | {"gx_split_rollout.inl"}):
+        with open(os.path.join(CSRC, n), "rb") as f:
+            h.update(n.encode() + b"\0" + f.read())
+    h.update(repr((FLAGS, _extra(src))).encode())
+    return h.hexdigest()[:24]
 
 
 def build(force=False, verbose=False, jobs=None):
-    if not force and not needs_build():
-        return LIB
-    from concurrent.futures import ThreadPoolExecutor
+    """Build under an inter-process lock (several ranks importing at once build once), link to a temporary name
+    and rename into place (nobody can dlopen a half-written file)."""
+    import fcntl
     os.makedirs(OBJ_DIR, exist_ok=True)
+    with open(LOCK_FILE, "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():
+                return LIB
+            return _build_locked(force, verbose, jobs)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose, jobs):
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "hipcc")
-    hdr_t = _deps_mtime()
+    bid = source_hash()
 
     def compile_one(src):
-        path, obj = os.path.join(CSRC, src), _obj(src)
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_t):
+        path, obj, tag = os.path.join(CSRC, src), _obj(src), _obj(src) + ".id"
+        want = _dep_hash(src) + (":" + bid if src == "gx_api.hip" else "")   # gx_api.hip carries the build id
+        try:
+            have = open(tag).read().strip()
+        except OSError:
+            have = None
+        if not force and os.path.exists(obj) and have == want:
             return
-        cmd = [hipcc] + FLAGS + _extra(src) + ["-c", path, "-o", obj]
+        cmd = [hipcc] + FLAGS + _extra(src) + (['-DGX_BUILD_ID="%s"' % bid] if src == "gx_api.hip" else []) + \
+              ["-c", path, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        with open(tag, "w") as f:
+            f.write(want)
 
     jobs = jobs or int(os.environ.get("GX_BUILD_JOBS", "0")) or min(len(SOURCES), os.cpu_count() or 1)
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + [_obj(s) for s in SOURCES]
+    tmp = LIB + ".tmp.%d" % os.getpid()
+    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", tmp] + [_obj(s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB)
+    with open(BUILD_ID_FILE + ".tmp", "w") as f:
+        f.write(bid + "\n")
+    os.replace(BUILD_ID_FILE + ".tmp", BUILD_ID_FILE)
     return LIB
 
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print("build id", built_id())

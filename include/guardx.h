@@ -94,6 +94,8 @@ typedef struct gx_engine gx_engine;
 
 const char* gx_last_error(void);
 int32_t gx_abi_version(void);
+/* identity of the sources and flags this library was built from (guardx_amd/build.py:source_hash) */
+const char* gx_build_id(void);
 
 gx_status gx_create(const gx_config* cfg, gx_engine** out);
 gx_status gx_destroy(gx_engine* e);

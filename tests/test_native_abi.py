@@ -34,7 +34,9 @@ def test_every_declared_symbol_is_exported_and_bound(native):
 
 def test_abi_version_and_struct_size(native):
     lib = native.load()
-    assert lib.gx_abi_version() == 1
+    assert lib.gx_abi_version() == 2
+    from guardx_amd import build as gx_build
+    assert lib.gx_build_id().decode() == gx_build.source_hash() == gx_build.built_id()   # the library is this tree's
     cfg = native.GxConfig()
     h = C.c_void_p()
     cfg.struct_size = 4                       # wrong size is rejected before any HIP call
