@@ -364,12 +364,20 @@ def closed_loop_rate(device, epochs=50):
 
 
 def other_robots(device, epochs=50):
-    """the same epoch (reset + one 200-step rollout launch, env_num=2000) for the articulated robots:
-    BASELINE config 3 (Goal_Swimmer_8Hazards) and Goal_Ant_8Hazards (contact + joint-limit solver)"""
+    """the same epoch (reset + one 200-step rollout, env_num=2000) for the articulated robots: BASELINE config 3
+    (Goal_Swimmer_8Hazards), Goal_Ant_8Hazards / Goal_Walker_8Hazards (contact + joint-limit solver), and BASELINE
+    config 5 as a SYNTHETIC task (the reference has no runnable counterpart): Ant + 8 hazards + 8 pillars"""
+    from guardx_amd import Engine, configuration
     out = {}
-    for name, xml in (("Goal_Swimmer_8Hazards", "xmls/swimmer.xml"), ("Goal_Ant_8Hazards", "xmls/ant.xml"),
-                      ("Goal_Walker_8Hazards", "xmls/walker.xml")):
-        env = make_engine(ENV_NUM, 0, 1, robot_base=xml)
+    cases = [("Goal_Swimmer_8Hazards", dict(TASK, robot_base="xmls/swimmer.xml"), None),
+             ("Goal_Ant_8Hazards", dict(TASK, robot_base="xmls/ant.xml"), None),
+             ("Goal_Walker_8Hazards", dict(TASK, robot_base="xmls/walker.xml"), None),
+             ("Ant_8Hazards_8Pillars_synthetic", dict(configuration("Ant_8Hazards_8Pillars_synthetic")),
+              "synthetic -- no reference counterpart (BASELINE config 5): ant.xml, goal task, 8 hazards + 8 static "
+              "pillar circles with their own lidar and keepout, 6 m x 6 m arena")]
+    for name, cfg, label in cases:
+        cfg.update(env_num=ENV_NUM, _seed=0, num_steps=EP_LEN, device_id=torch.cuda.current_device())
+        env = Engine(cfg)
         tape = action_tape(EP_LEN, ENV_NUM, 0, device, env.action_space.shape[0])
 
         def epoch():
@@ -386,6 +394,8 @@ def other_robots(device, epochs=50):
         env.close()
         out[name] = {"env_steps_per_s": round(ENV_NUM * EP_LEN * epochs / dt, 1), "obs_dim": env.obs_flat_size,
                      "ms_per_epoch": round(dt / epochs * 1e3, 4)}
+        if label:
+            out[name]["label"] = label
     return out
 
 

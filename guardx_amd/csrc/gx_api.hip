@@ -102,7 +102,7 @@ static int take_commit(gx_engine* e)
 static bool use_split_rollout(const gx_engine* e, int T)
 {
     if (e->path_mode == 1 || e->path_mode == 2) return false;
-    if (!split_rollout_supported(e->p) || e->p.N > 16384) return false;
+    if (!split_rollout_supported(e->p) || e->p.N > 16384) return false; // (light robots: limit 16384 either way)
     return e->path_mode == 3 || T >= 8;
 }
 
@@ -110,7 +110,11 @@ static bool use_group_path(const gx_engine* e)
 {
     if (e->path_mode == 1) return false;
     if (e->path_mode == 2) return true;
-    return e->p.N <= 16384; // <= 4096 single-wave workgroups: latency regime (path_mode 3: rollouts split, steps here)
+    // latency regime (path_mode 3: rollouts split, steps here).  Measured crossovers of the two families (fused
+    // step incl. reset_done): Point / Swimmer 16384 envs; Ant ~11 k (lane-group 36 us at 8192 and 73 us at 16384
+    // against a flat ~50 us of the serial thread-per-env step); Walker ~8.5 k (62 us at 8192 against ~64 us)
+    const int limit = e->cfg.robot == AntRobot::kId ? 11000 : (e->cfg.robot == WalkerRobot::kId ? 8192 : 16384);
+    return e->p.N <= limit;
 }
 
 struct DeviceGuard {

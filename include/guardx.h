@@ -199,7 +199,8 @@ gx_status gx_set_prefetch(gx_engine* e, int32_t steps);
 /* prefetched pools used / discarded so far, and the current prediction */
 gx_status gx_prefetch_stats(const gx_engine* e, int32_t* hits, int32_t* misses, int32_t* horizon);
 
-/* Kernel family used by step / rollout: 0 = auto (up to 16384 envs: lane-group kernels, and for rollouts of 8+
+/* Kernel family used by step / rollout: 0 = auto (up to 16384 envs -- Ant 11000, Walker 8192, the measured
+ * crossovers -- lane-group kernels, and for rollouts of 8+
  * steps of the Point / Swimmer the two-kernel form -- serial dynamics tape, then one thread per (step, env)
  * observation row; thread-per-env kernels above 16384 envs), 1 = force thread-per-env, 2 = force lane-group,
  * 3 = two-kernel rollouts at any T where supported (lane-group otherwise).
