@@ -82,7 +82,7 @@ class RolloutHandoff:
                 return s[2]
         dev = "cpu" if self.host else device
         return torch.empty((self.world,) + tuple(shape), dtype=torch.float32, device=dev,
-                           pin_memory=self.host)
+                           pin_memory=self.host and torch.cuda.is_available())
 
     def submit(self, packed):
         import torch.distributed as dist

@@ -53,6 +53,18 @@ def _worker_body(rank, world, port, N, T, q):
     packed = gxd.pack_rollout(*[torch.from_numpy(np.stack(x)) for x in (obs, acts, rew, cost, done)])
     full = gxd.all_gather_rollout(packed)            # (world, T, N, D+2+3)
     assert gxd.max_over_ranks(rank, torch.device("cpu")) == world - 1
+    # bench.py's asynchronous hand-off ring (three gathered buffers in flight) on the same shards
+    sys.path.insert(0, ROOT)
+    import bench
+    ring = bench.RolloutHandoff(world)
+    shards = [packed * float(k + 1) for k in range(5)]          # five "epochs"
+    for sh in shards:
+        ring.submit(sh)
+    ring.drain()
+    assert ring.bytes == 5 * packed.numel() * 4 * world
+    for k in (2, 3, 4):                                         # the three buffers still held
+        got = ring.slots[k % ring.depth][2]
+        assert torch.equal(got, full * float(k + 1))
     gxd.barrier()
     if rank == 0:
         q.put(("ok", full.numpy()))

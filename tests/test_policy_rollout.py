@@ -109,3 +109,12 @@ def test_policy_rollout_parity(oracle, robot, impl):
     oo3, _, do3, _ = O.step(act)
     np.testing.assert_array_equal(og3.cpu().numpy(), oo3)
     np.testing.assert_array_equal(dg3.cpu().numpy(), do3)
+    # ... including reset_done() requested right before the next policy rollout: the re-initialisation the
+    # step speculated is installed by the policy kernel itself on load (gx_step_rd / gx_reset_done_commit)
+    rd_g, rd_o = E.reset_done(), O.reset_done()
+    np.testing.assert_array_equal(rd_g.cpu().numpy(), rd_o)
+    g3 = E.rollout_policy(params.cuda(), 5, obs0=rd_g, noise_seed=(11, 13))
+    o3 = O.rollout_policy(params.numpy(), 5, rd_o, noise_seed=(11, 13), t0=T + 7)
+    for k in ('obs', 'act', 'rew', 'done', 'obs_last'):
+        np.testing.assert_array_equal(g3[k].cpu().numpy(), o3[k], err_msg=k)
+    assert_state_equal(E.get_state(), O.get_state())
