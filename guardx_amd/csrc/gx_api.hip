@@ -249,6 +249,7 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     SampleParams& sp = e->sp;
     e->nobj_total = p.H + p.PL + 2;
     sp.M = cfg->n_candidates;
+    sp.dbg = nullptr;
     sp.nobj_total = e->nobj_total;
     sp.H = p.H;
     const double ko[4] = {cfg->goal_keepout, cfg->hazards_keepout, cfg->robot_keepout, cfg->pillars_keepout};
@@ -425,6 +426,7 @@ extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
     if (!hit) { // reset_layout on the caller's stream  engine.py:433-444
         e->sp.k0 = e->key[0];
         e->sp.k1 = e->key[1];
+        e->sp.dbg = e->stamps ? e->stamps + 65536 : nullptr; // tools/debug/sampler_waves.py
         launch_sample(e->sp, e->pools[e->cur], s);
     }
     e->pf_valid = false;

@@ -20,6 +20,7 @@ struct SampleParams {
     float thr_sq[4][4]; // exact cutoffs: sqrtf(d2) < thr  <=>  d2 < thr_sq
     float min_rg_sq;
     uint32_t k0, k1; // engine key at reset time
+    unsigned long long* dbg; // null, or per phase-2 wave: s_memtime at entry / exit, HW_ID, XCC_ID (gx_debug_stamps)
 };
 
 constexpr int kScanTile = 16 * 1024; // counts per tile of scan_kernel: wave_cnt / wave_off are padded to whole tiles

@@ -141,76 +141,163 @@ __global__ __launch_bounds__(kSampleBlock) void sample_phase1_kernel(SampleParam
     }
 }
 
-__global__ __launch_bounds__(kSampleBlock) void sample_phase2_kernel(SampleParams sp,
-                                                                     const int* __restrict__ n_surv,
-                                                                     const uint32_t* __restrict__ surv,
-                                                                     uint8_t* __restrict__ ok,
-                                                                     float2* __restrict__ cand_xy)
+// phase 2 (survivors): hazards (+ pillars), the saved robot tries, success.  One wave per workgroup, lane = survivor.
+//
+// draw_placement (:579-621) keeps the LAST valid of an object's 10 tries, so a try only has to be drawn when every
+// later one conflicts -- per candidate 1.1 (first hazard) to ~2.2 (last hazard) draws of 4 Threefry blocks each.  Evaluated
+// lane-by-lane that laziness is lost to divergence: a wave keeps drawing while ANY of its 64 candidates is still
+// conflicted, ~9 of the 10 tries for the later hazards (round 2: 36 k instructions per wave, half of them draws
+// for a handful of lanes).  Here the draws are work items handed to whichever lanes are free: in each round the c
+// still-conflicted candidates ("owners") get m = 64/c tries each (a power of two), evaluated by m consecutive lanes
+// from the owner's keys and placed objects in LDS; the highest valid try wins (ds_max on the try index).  A round
+// costs one draw; an object needs ~3 rounds (64 -> ~25 -> ~6 -> 0 owners) instead of ~9.
+// The `rng, rng1 = split(rng)` chain itself (20 blocks per object) is sequential per candidate and stays per lane.
+constexpr int kP2Block = 64;  // survivors per wave (the unit of work)
+constexpr int kP2Waves = 4;   // independent waves per workgroup: one per SIMD of the CU it lands on
+struct P2Lds {
+    uint2 keys[9][kP2Block];   // rng1 of the object's tries 0..8, per owner lane (try 9 is drawn by the owner itself);
+                               // a helper overwrites the key it consumed with its valid draw
+    int best[kP2Block];        // per owner lane: highest valid try of the round (-1: none)
+    int owner[kP2Block];       // compacted list of the owners' lanes
+};
+// 9.5 KB per wave with the default 10 objects: 16 waves per CU, i.e. the ~3900 waves of the default arena (15.2 per
+// CU) are resident at once.  Workgroups of FOUR independent waves, because the waves of a workgroup go to the four
+// SIMDs of its CU: VALU issue is arbitrated oldest-first, a SIMD with n waves finishes after T_alone + (n-1) T_issue
+// (stamps: 160k + (n-1) 85k ticks), and with one-wave workgroups the hardware put 5 waves on 5 % of the SIMDs and 3 on
+// 25 % -- the kernel took the 5-wave time.
+GX_D void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(kP2Block * kP2Waves) void sample_phase2_kernel(SampleParams sp,
+                                                                 const int* __restrict__ n_surv,
+                                                                 const uint32_t* __restrict__ surv,
+                                                                 uint8_t* __restrict__ ok,
+                                                                 float2* __restrict__ cand_xy)
 {
     extern __shared__ float4 smem4[];
-    float2* placed = reinterpret_cast<float2*>(smem4); // [nobj_total][kSampleBlock]
-    const int tid = threadIdx.x;
-    const int S = *n_surv;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nobj = sp.nobj_total;
-    for (int i = blockIdx.x * kSampleBlock + tid; i < S; i += gridDim.x * kSampleBlock) {
-        const uint32_t* rec = surv + (size_t)i * kSurvWords;
+    const size_t per_wave = sizeof(P2Lds) + (size_t)(nobj - 1) * kP2Block * sizeof(float2);
+    char* mine_lds = reinterpret_cast<char*>(smem4) + per_wave * wv; // nothing is shared between the waves
+    P2Lds& S = *reinterpret_cast<P2Lds*>(mine_lds);
+    float2* placed = reinterpret_cast<float2*>(mine_lds + sizeof(P2Lds)); // [nobj_total - 1][64]
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int NS = *n_surv;
+    const int wpb = blockDim.x >> 6; // kP2Waves, or 1 when the objects of four waves do not fit 64 KB of LDS
+    const int wave0 = blockIdx.x * wpb + wv, nwaves = gridDim.x * wpb;
+    if (sp.dbg && lane == 0 && wave0 * kP2Block < NS) {
+        unsigned long long* d = sp.dbg + (size_t)wave0 * 4;
+        d[0] = __builtin_amdgcn_s_memtime();
+        d[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID
+        d[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20); // HW_REG_XCC_ID
+    }
+    for (int base = wave0 * kP2Block; base < NS; base += nwaves * kP2Block) { // wave-uniform
+        const int i = base + lane;
+        const bool live = i < NS;
+        const uint32_t* rec = surv + (size_t)(live ? i : 0) * kSurvWords;
         const int j = (int)rec[0];
         uint32_t r0 = rec[1], r1 = rec[2];
         const float gx = u2f(rec[3]), gy = u2f(rec[4]);
-        placed[tid] = make_float2(gx, gy);
-        bool success = true;
+        wave_sync(); // the previous batch's reads of `placed` are done
+        placed[lane] = make_float2(gx, gy);
+        bool alive = live; // placed everything so far
         for (int o = 1; o < nobj - 1; ++o) { // hazards, then pillars
             const int tn = o <= sp.H ? 1 : 3;
             const float4 hb = sp.haz_bounds ? sp.haz_bounds[o - 1]
                                             : make_float4(sp.lo_x[tn], sp.hi_x[tn], sp.lo_y[tn], sp.hi_y[tn]);
-            // draw_placement :579-621 keeps the LAST valid of the 10 tries.  The `rng, rng1 = split(rng)` chain has
-            // to be walked in order (20 blocks), but the draws (4 blocks each) are evaluated from the last try
-            // backwards and stop at the first valid one -- the same winner, ~3 draws per wave instead of 10.
-            uint32_t gk[10][2];
+            // cutoffs against a placed goal / hazard / pillar (in registers: no scalar loads in the loops below)
+            const float tg = sp.thr_sq[0][tn], th = sp.thr_sq[1][tn], tp = sp.thr_sq[3][tn];
+            uint32_t k9a = 0, k9b = 0;
 #pragma unroll
             for (int t = 0; t < 10; ++t) {
-                uint32_t n0, n1;
-                split2(r0, r1, n0, n1, gk[t][0], gk[t][1]); r0 = n0; r1 = n1;
+                uint32_t n0, n1, g0, g1;
+                split2(r0, r1, n0, n1, g0, g1); r0 = n0; r1 = n1;
+                if (t < 9) S.keys[t][lane] = make_uint2(g0, g1);
+                else { k9a = g0; k9b = g1; }
             }
-            bool conflicted = true;
+            bool conflicted = alive;
             float px = -__builtin_inff(), py = -__builtin_inff();
-#pragma unroll
-            for (int t = 9; t >= 0; --t) {
-                if (conflicted) {
-                    float cx, cy;
-                    draw_xy(gk[t][0], gk[t][1], hb.x, hb.y, hb.z, hb.w, cx, cy);
+            // round 0: every live candidate draws its own try 9; later rounds: m = 1 << sh tries per owner
+            int nt = 9, sh = 0; // nt: the highest try not yet evaluated (the same for every owner)
+            bool first = true;
+            unsigned long long mask = __ballot(conflicted);
+            while (mask != 0ull) {
+                const int c = __popcll(mask);
+                const int rank = __popcll(mask & below);
+                if (!first) {
+                    sh = c > 32 ? 0 : (c > 16 ? 1 : (c > 8 ? 2 : 3));
+                    if (conflicted) { S.owner[rank] = lane; S.best[lane] = -1; }
+                }
+                wave_sync();
+                const int oi = lane >> sh, ht = nt - (lane & ((1 << sh) - 1));
+                const bool work = first ? conflicted : (oi < c && ht >= 0);
+                bool mine = false; // round 0: my own try 9 is valid
+                float cx = 0.f, cy = 0.f;
+                if (work) {
+                    const int ow = first ? lane : S.owner[oi];
+                    uint2 k = make_uint2(k9a, k9b);
+                    if (!first) k = S.keys[ht][ow];
+                    draw_xy(k.x, k.y, hb.x, hb.y, hb.z, hb.w, cx, cy);
                     bool flag = true;
                     for (int q = 0; q < o; ++q) { // placement_is_valid :549-555
-                        const float2 pq = placed[q * kSampleBlock + tid];
-                        if (dsq(cx, cy, pq.x, pq.y) < sp.thr_sq[q == 0 ? 0 : (q <= sp.H ? 1 : 3)][tn]) flag = false;
+                        const float2 pq = placed[q * kP2Block + ow];
+                        if (dsq(cx, cy, pq.x, pq.y) < (q == 0 ? tg : (q <= sp.H ? th : tp))) flag = false;
                     }
-                    if (flag) { px = cx; py = cy; conflicted = false; }
+                    if (flag) {
+                        if (first) mine = true;
+                        else { atomicMax(&S.best[ow], ht); S.keys[ht][ow] = make_uint2(f2u(cx), f2u(cy)); }
+                    }
                 }
+                wave_sync();
+                if (conflicted) {
+                    if (first) {
+                        if (mine) { px = cx; py = cy; conflicted = false; }
+                    } else {
+                        const int b = S.best[lane];
+                        if (b >= 0) {
+                            const uint2 w = S.keys[b][lane];
+                            px = u2f(w.x); py = u2f(w.y); conflicted = false;
+                        } else if (nt - (1 << sh) < 0) { // all ten tries conflict: the candidate fails (:565-566)
+                            conflicted = false; alive = false;
+                        }
+                    }
+                }
+                nt -= 1 << sh;
+                first = false;
+                mask = __ballot(conflicted);
+                wave_sync(); // owner / best are rewritten by the next round
             }
-            placed[o * kSampleBlock + tid] = make_float2(px, py);
-            if (conflicted) success = false;
+            placed[o * kP2Block + lane] = make_float2(px, py);
+            wave_sync();
         }
-        { // robot: tries were drawn in phase 1
+        bool success = alive;
+        float px = -__builtin_inff(), py = -__builtin_inff();
+        if (alive) { // robot: tries were drawn in phase 1
             bool conflicted = true;
-            float px = -__builtin_inff(), py = -__builtin_inff();
+            const float tg = sp.thr_sq[0][2], th = sp.thr_sq[1][2], tp = sp.thr_sq[3][2];
             for (int t = 0; t < 10; ++t) {
                 const float cx = u2f(rec[5 + 2 * t]), cy = u2f(rec[6 + 2 * t]);
                 bool flag = true;
                 for (int q = 0; q < nobj - 1; ++q) {
-                    const float2 pq = placed[q * kSampleBlock + tid];
-                    if (dsq(cx, cy, pq.x, pq.y) < sp.thr_sq[q == 0 ? 0 : (q <= sp.H ? 1 : 3)][2]) flag = false;
+                    const float2 pq = placed[q * kP2Block + lane];
+                    if (dsq(cx, cy, pq.x, pq.y) < (q == 0 ? tg : (q <= sp.H ? th : tp))) flag = false;
                 }
                 if (flag) { px = cx; py = cy; conflicted = false; }
             }
-            placed[(nobj - 1) * kSampleBlock + tid] = make_float2(px, py);
             if (conflicted) success = false;
             if (dsq(px, py, gx, gy) < sp.min_rg_sq) success = false; // :570-571
         }
         if (success) {
             ok[j] = 1;
-            for (int o = 0; o < nobj; ++o) cand_xy[(size_t)j * nobj + o] = placed[o * kSampleBlock + tid];
+            for (int o = 0; o < nobj - 1; ++o) cand_xy[(size_t)j * nobj + o] = placed[o * kP2Block + lane];
+            cand_xy[(size_t)j * nobj + nobj - 1] = make_float2(px, py);
         }
     }
+    if (sp.dbg && lane == 0 && wave0 * kP2Block < NS) sp.dbg[(size_t)wave0 * 4 + 1] = __builtin_amdgcn_s_memtime();
 }
 
 // per-wave count of valid candidates (in candidate order)
@@ -329,7 +416,6 @@ void launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s, hipEve
 {
     const int M = sp.M, W = (M + 63) / 64;
     const int grid = (M + kSampleBlock - 1) / kSampleBlock;
-    const size_t lds = (size_t)sp.nobj_total * kSampleBlock * sizeof(float2);
     (void)hipMemsetAsync(pl.n_surv, 0, 2 * sizeof(int), s); // n_surv, n_surv0
     hipLaunchKernelGGL(sample_phase0_kernel, dim3(grid), dim3(kSampleBlock), 0, s, sp, pl.cand_ok, pl.n_surv + 1,
                        pl.surv0);
@@ -337,8 +423,12 @@ void launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s, hipEve
     hipLaunchKernelGGL(sample_phase1_kernel, dim3(grid1), dim3(kSampleBlock), 0, s, sp, pl.n_surv + 1, pl.surv0,
                        pl.n_surv, pl.surv);
     if (after_phase1) (void)hipEventRecord(after_phase1, s);
-    const int grid2 = grid < 1024 ? grid : 1024;
-    hipLaunchKernelGGL(sample_phase2_kernel, dim3(grid2), dim3(kSampleBlock), lds, s, sp, pl.n_surv, pl.surv,
+    const size_t lds_wave = sizeof(P2Lds) + (size_t)(sp.nobj_total - 1) * kP2Block * sizeof(float2);
+    const int wpb = kP2Waves * lds_wave <= 65536 ? kP2Waves : 1;
+    const int wgs = (M + kP2Block * wpb - 1) / (kP2Block * wpb);
+    const int grid2 = wgs < 8192 / wpb ? wgs : 8192 / wpb;
+    const size_t lds2 = wpb * lds_wave;
+    hipLaunchKernelGGL(sample_phase2_kernel, dim3(grid2), dim3(kP2Block * wpb), lds2, s, sp, pl.n_surv, pl.surv,
                        pl.cand_ok, pl.cand_xy);
     hipLaunchKernelGGL(count_kernel, dim3(grid), dim3(kSampleBlock), 0, s, M, pl.cand_ok, pl.wave_cnt);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kScanBlock), 0, s, pl.wave_cnt, pl.wave_off, W,
