@@ -49,9 +49,10 @@ GX_D void draw_xy(uint32_t g0, uint32_t g1, float lox, float hix, float loy, flo
 // workgroup (a single counter word sustains only ~88 returning atomics/us chip-wide, which at one
 // atomic per wave -- 15,625 of them -- would cost more than phase 0 itself).  Must be reached by
 // every thread of the workgroup.
+template <int BLOCK = kSampleBlock>
 GX_D int alloc_slot(bool want, int* __restrict__ counter)
 {
-    __shared__ int wcnt[kSampleBlock / 64];
+    __shared__ int wcnt[BLOCK / 64];
     __shared__ int bbase;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const unsigned long long m = __ballot(want);
@@ -60,7 +61,7 @@ GX_D int alloc_slot(bool want, int* __restrict__ counter)
     if (threadIdx.x == 0) {
         int tot = 0;
 #pragma unroll
-        for (int k = 0; k < kSampleBlock / 64; ++k) tot += wcnt[k];
+        for (int k = 0; k < BLOCK / 64; ++k) tot += wcnt[k];
         bbase = tot ? atomicAdd(counter, tot) : 0;
     }
     __syncthreads();
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(kSampleBlock) void sample_phase0_kernel(SampleParam
 }
 
 // phase 1 (goal-feasible candidates, 220 blocks): hazard links, the 10 robot tries
-__global__ __launch_bounds__(kSampleBlock) void sample_phase1_kernel(SampleParams sp,
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void sample_phase1_kernel(SampleParams sp,
                                                                      const int* __restrict__ n_surv0,
                                                                      const uint32_t* __restrict__ surv0,
                                                                      int* __restrict__ n_surv,
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(kSampleBlock) void sample_phase1_kernel(SampleParam
     const int S0 = *n_surv0;
     const int nh = 10 * (sp.nobj_total - 2);
     // grid-stride with whole waves active until the last one (ballot-based allocation below)
-    for (int base_i = blockIdx.x * kSampleBlock; base_i < S0; base_i += gridDim.x * kSampleBlock) {
+    for (int base_i = blockIdx.x * BLOCK; base_i < S0; base_i += gridDim.x * BLOCK) {
         const int i = base_i + tid;
         const bool live = i < S0;
         const uint4* rin = reinterpret_cast<const uint4*>(surv0) + (size_t)(live ? i : 0) * 2;
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(kSampleBlock) void sample_phase1_kernel(SampleParam
             draw_xy(g0, g1, sp.lo_x[2], sp.hi_x[2], sp.lo_y[2], sp.hi_y[2], rx[t], ry[t]);
             if (!(dsq(rx[t], ry[t], gx, gy) < sp.min_rg_sq)) any_far = true;
         }
-        const int slot = alloc_slot(live && any_far, n_surv);
+        const int slot = alloc_slot<BLOCK>(live && any_far, n_surv);
         if (slot >= 0) {
             uint32_t* rec = surv + (size_t)slot * kSurvWords;
             rec[0] = (uint32_t)j; rec[1] = s0; rec[2] = s1; rec[3] = f2u(gx); rec[4] = f2u(gy);
@@ -243,9 +245,15 @@ __global__ __launch_bounds__(kP2Block * kP2Waves) void sample_phase2_kernel(Samp
                     if (!first) k = S.keys[ht][ow];
                     draw_xy(k.x, k.y, hb.x, hb.y, hb.z, hb.w, cx, cy);
                     bool flag = true;
-                    for (int q = 0; q < o; ++q) { // placement_is_valid :549-555
-                        const float2 pq = placed[q * kP2Block + ow];
-                        if (dsq(cx, cy, pq.x, pq.y) < (q == 0 ? tg : (q <= sp.H ? th : tp))) flag = false;
+                    for (int q0 = 0; q0 < o; q0 += 4) { // placement_is_valid :549-555, four LDS reads in flight
+                        float2 pq[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) pq[u] = placed[(q0 + u < o ? q0 + u : o - 1) * kP2Block + ow];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int q = q0 + u;
+                            if (q < o && dsq(cx, cy, pq[u].x, pq[u].y) < (q == 0 ? tg : (q <= sp.H ? th : tp))) flag = false;
+                        }
                     }
                     if (flag) {
                         if (first) mine = true;
@@ -277,18 +285,22 @@ __global__ __launch_bounds__(kP2Block * kP2Waves) void sample_phase2_kernel(Samp
         bool success = alive;
         float px = -__builtin_inff(), py = -__builtin_inff();
         if (alive) { // robot: tries were drawn in phase 1
-            bool conflicted = true;
             const float tg = sp.thr_sq[0][2], th = sp.thr_sq[1][2], tp = sp.thr_sq[3][2];
-            for (int t = 0; t < 10; ++t) {
-                const float cx = u2f(rec[5 + 2 * t]), cy = u2f(rec[6 + 2 * t]);
-                bool flag = true;
-                for (int q = 0; q < nobj - 1; ++q) {
-                    const float2 pq = placed[q * kP2Block + lane];
-                    if (dsq(cx, cy, pq.x, pq.y) < (q == 0 ? tg : (q <= sp.H ? th : tp))) flag = false;
-                }
-                if (flag) { px = cx; py = cy; conflicted = false; }
+            float cx[10], cy[10];
+#pragma unroll
+            for (int t = 0; t < 10; ++t) { cx[t] = u2f(rec[5 + 2 * t]); cy[t] = u2f(rec[6 + 2 * t]); }
+            unsigned valid = 0x3ffu; // bit t: try t conflicts with nothing placed
+            for (int q = 0; q < nobj - 1; ++q) {
+                const float2 pq = placed[q * kP2Block + lane];
+                const float thr = q == 0 ? tg : (q <= sp.H ? th : tp);
+#pragma unroll
+                for (int t = 0; t < 10; ++t)
+                    if (dsq(cx[t], cy[t], pq.x, pq.y) < thr) valid &= ~(1u << t);
             }
-            if (conflicted) success = false;
+#pragma unroll
+            for (int t = 0; t < 10; ++t)
+                if (valid & (1u << t)) { px = cx[t]; py = cy[t]; } // the last valid try wins
+            if (!valid) success = false;
             if (dsq(px, py, gx, gy) < sp.min_rg_sq) success = false; // :570-571
         }
         if (success) {
@@ -420,8 +432,8 @@ void launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s, hipEve
     hipLaunchKernelGGL(sample_phase0_kernel, dim3(grid), dim3(kSampleBlock), 0, s, sp, pl.cand_ok, pl.n_surv + 1,
                        pl.surv0);
     const int grid1 = grid < 3072 ? grid : 3072;
-    hipLaunchKernelGGL(sample_phase1_kernel, dim3(grid1), dim3(kSampleBlock), 0, s, sp, pl.n_surv + 1, pl.surv0,
-                       pl.n_surv, pl.surv);
+    hipLaunchKernelGGL(sample_phase1_kernel<kSampleBlock>, dim3(grid1), dim3(kSampleBlock), 0, s, sp, pl.n_surv + 1,
+                       pl.surv0, pl.n_surv, pl.surv);
     if (after_phase1) (void)hipEventRecord(after_phase1, s);
     const size_t lds_wave = sizeof(P2Lds) + (size_t)(sp.nobj_total - 1) * kP2Block * sizeof(float2);
     const int wpb = kP2Waves * lds_wave <= 65536 ? kP2Waves : 1;
