@@ -53,7 +53,13 @@ struct PointRobotT {
     static constexpr bool kRestFixed = true;
     GX_D static void place(float (&q)[NQ], float rx, float ry) { q[0] = rx; q[1] = ry; }
 
-    GX_D static float clip(float x, float lim) { return x < -lim ? -lim : (x > lim ? lim : x); } // jp.clip: NaN stays
+    // jp.clip: NaN stays.  v_med3_f32 is the exact median for ordered operands (and keeps -0); one compare puts the
+    // NaN back -- 3 instructions instead of two compare / select pairs on the serial chain of the dynamics pass
+    GX_D static float clip(float x, float lim)
+    {
+        const float m = __builtin_amdgcn_fmed3f(x, -lim, lim);
+        return x == x ? m : x;
+    }
     // qfrc_actuator of one DOF [derived: mjx fwd_actuation]
     GX_D static float actuate(float ctrl, float vel)
     {

@@ -73,6 +73,10 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
 #pragma unroll
     for (int d = 0; d < R::NA; ++d) an2[d] = 0.f;
     if (r.T > 1) load_action<R>(r.act, (size_t)p.N + i, an2);
+    // distance to the goal after the previous step: reward_done's `last` (:787-802) is dist(goal, previous position),
+    // i.e. the same operands as the previous step's `dg` whenever it is used (a reset_done changes the goal, but then
+    // last_done > 0 and `last` is the new dg) -- one correctly rounded sqrt less on the serial chain
+    float dprev = dist2(gx, gy, pose0[0], pose0[1]);
     for (int t = 0; t < r.T; ++t) {
         float a[R::NA];
 #pragma unroll
@@ -80,7 +84,6 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
         if (t + 2 < r.T) load_action<R>(r.act, (size_t)(t + 2) * p.N + i, an2);
         const bool have_last = (r.hist0 + t) >= 1;
         const float last_done = done0;
-        const float L1x = pose0[0], L1y = pose0[1];
 
         float ctrl[R::NU];
         R::convert_action(pose0, a, ctrl); // :672-685, PRE-step xmat
@@ -112,7 +115,8 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
         // reward_done :787-802
         const float dg = dist2(gx, gy, pose[0], pose[1]);
         float last = dg;
-        if (have_last && !(last_done > 0.0f)) last = dist2(gx, gy, L1x, L1y);
+        if (have_last && !(last_done > 0.0f)) last = dprev;
+        dprev = dg;
         const float dd = last - dg;
         float rw = dd * p.reward_distance;
         float dn = dg < p.goal_size ? 1.0f : 0.0f;
