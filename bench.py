@@ -178,21 +178,21 @@ def roofline_rollout(env_num, T, nlaunch, device):
     t = min(per, cadence)
     ach = ALGO_BYTES_PER_ENV_STEP * env_num * T / t / 1e9
     # rocprofv3 PMC, profiles/r02_rollout_N2000_T200_pmc_{FETCH,WRITE}_SIZE.csv (KB per launch; FETCH x2 on gfx950)
-    pmc_kb = 2 * (1738.6 + 16540.7) + (31500.0 + 71875.0)
+    pmc_kb = 2 * (1742.6 + 16662.1) + (31500.0 + 71875.0)
     return {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 6),
             "traffic": round(pmc_kb * 1024 / 1e9 * (env_num * T) / (2000 * 200), 4),
             "traffic_note": "NOT measured in this run: GB per gx_rollout call from the committed rocprofv3 PMC passes at "
-                            "env_num=2000, T=200: 2*FETCH_SIZE + WRITE_SIZE = 36.6 MB + 103.4 MB "
+                            "env_num=2000, T=200: 2*FETCH_SIZE + WRITE_SIZE = 36.8 MB + 103.4 MB "
                             "(profiles/r02_rollout_N2000_T200_pmc_*.csv) against 148.8 MB algorithmic: the 32 MB "
                             "dynamics tape is written once and read once instead of the 36 B/env-step state round trip",
             "kernel": "gx::dyn_tape_kernel<PointRobot,64,5,true> + gx::obs_tape_kernel<PointRobot,64,5,true> "
                       "(the two launches of one gx_rollout call = 200 fused step+reset_done passes)",
-            "kernels_us_rocprof": {"dyn_tape_kernel": 124.6, "obs_tape_kernel": 33.7,
+            "kernels_us_rocprof": {"dyn_tape_kernel": 118.3, "obs_tape_kernel": 33.8,
                                    "source": "profiles/r02_rollout_N2000_T200_kernel_stats.csv (standalone)"},
-            "obs_pass_alone": {"GBps_pmc_traffic": round((2 * 16540.7 + 71875.0) * 1024 / 33.7e-6 / 1e9, 1),
-                               "frac_of_peak": round((2 * 16540.7 + 71875.0) * 1024 / 33.7e-6 / 1e9 / HBM_PEAK_GBS, 4),
-                               "note": "the 400k-row observation pass alone (profiled, not this run): 105.5 MB in 33.7 us"},
+            "obs_pass_alone": {"GBps_pmc_traffic": round((2 * 16662.1 + 71875.0) * 1024 / 33.8e-6 / 1e9, 1),
+                               "frac_of_peak": round((2 * 16662.1 + 71875.0) * 1024 / 33.8e-6 / 1e9 / HBM_PEAK_GBS, 4),
+                               "note": "the 400k-row observation pass alone (profiled, not this run): 105.8 MB in 33.8 us"},
             "env_num": env_num, "steps_per_launch": T,
             "avg_launch_us": round(t * 1e6, 3), "event_pair_us": round(per * 1e6, 3),
             "back_to_back_us": round(cadence * 1e6, 3),
