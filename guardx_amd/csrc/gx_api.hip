@@ -55,12 +55,19 @@ struct gx_engine {
     int path_mode;       // 0 auto, 1 thread-per-env kernels, 2 lane-group kernels
     // double-buffered layout pools + side stream: the pool of the NEXT reset() is sampled
     // while the current epoch is being stepped (the key chain is data-independent)
-    Pool pools[2];
+    // a ring of THREE: the pool of epoch k is overwritten by the prefetch launched at reset(k+2), so a dynamics tape
+    // handed to other ranks (gx_rollout_tape) can be expanded there (gx_expand_tape, which reads the pool rows its
+    // reset_done events refer to) during the whole of epoch k+1, overlapped with its all-gather
+    static const int kPools = 3;
+    Pool pools[kPools];
     int cur;                 // pool the envs are drawn from
     hipStream_t side;
-    hipEvent_t pool_ready[2]; // recorded on the sampling stream when pool i is complete
-    hipEvent_t pool_free[2];  // recorded on the caller's stream when pool i is no longer read
-    bool pf_valid;            // pools[1-cur] holds (or will hold) the pool for key pf_key
+    hipEvent_t pool_ready[kPools]; // recorded on the sampling stream when pool i is complete
+    hipEvent_t pool_free[kPools];  // recorded on the caller's stream when pool i is no longer read
+    hipEvent_t expand_ev[kPools];  // recorded behind the last gx_expand_tape that read pool i
+    bool expand_pending[kPools];
+    uint32_t pool_gen[kPools];     // bumped whenever a sampler is launched into pool i (tape tokens)
+    bool pf_valid;            // pools[(cur+1)%kPools] holds (or will hold) the pool for key pf_key
     uint32_t pf_key[2];
     int prefetch_steps;       // predicted step() calls between resets; -1 disables prefetch; -2 = learn it:
                               // the number of steps between the last two resets (cfg.num_steps before that) --
@@ -294,7 +301,10 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     e->steps_since_reset = 0; e->last_interval = 0; e->pf_hits = 0; e->pf_misses = 0;
     e->side = nullptr;
     memset(e->pools, 0, sizeof(e->pools));
-    for (int i = 0; i < 2; ++i) { e->pool_ready[i] = nullptr; e->pool_free[i] = nullptr; }
+    for (int i = 0; i < gx_engine::kPools; ++i) {
+        e->pool_ready[i] = nullptr; e->pool_free[i] = nullptr; e->expand_ev[i] = nullptr;
+        e->expand_pending[i] = false; e->pool_gen[i] = 0;
+    }
     e->keys_next = 0;
     for (int i = 0; i < gx_engine::kKeyRing; ++i) { e->h_keys[i] = nullptr; e->keys_cap[i] = 0; e->keys_ev[i] = nullptr; }
     memset(&e->b, 0, sizeof(e->b));
@@ -315,7 +325,7 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
         if (err == hipSuccess) err = hipMemcpy(e->haz_bounds, hb.data(), sizeof(float4) * hb.size(), hipMemcpyHostToDevice);
         sp.haz_bounds = e->haz_bounds;
     }
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < gx_engine::kPools; ++i) {
         Pool& pl = e->pools[i];
         alloc((void**)&pl.cand_ok, M);
         alloc((void**)&pl.cand_xy, sizeof(float2) * M * e->nobj_total);
@@ -330,6 +340,7 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
         alloc((void**)&pl.surv0, sizeof(uint32_t) * 8 * M);
         if (err == hipSuccess) err = hipEventCreateWithFlags(&e->pool_ready[i], hipEventDisableTiming);
         if (err == hipSuccess) err = hipEventCreateWithFlags(&e->pool_free[i], hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&e->expand_ev[i], hipEventDisableTiming);
     }
     if (err == hipSuccess) {
         int lo = 0, hi = 0;
@@ -368,13 +379,14 @@ extern "C" gx_status gx_destroy(gx_engine* e)
     void* bufs[] = {e->b.dyn, e->b.obj, e->b.hist, e->b.rd_j, e->haz_bounds, e->tape, e->obj0};
     for (void* q : bufs)
         if (q) (void)hipFree(q);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < gx_engine::kPools; ++i) {
         Pool& pl = e->pools[i];
         void* pb[] = {pl.cand_ok, pl.cand_xy, pl.wave_cnt, pl.wave_off, pl.cand_of, pl.layout_size, pl.n_surv, pl.surv, pl.surv0};
         for (void* q : pb)
             if (q) (void)hipFree(q);
         if (e->pool_ready[i]) (void)hipEventDestroy(e->pool_ready[i]);
         if (e->pool_free[i]) (void)hipEventDestroy(e->pool_free[i]);
+        if (e->expand_ev[i]) (void)hipEventDestroy(e->expand_ev[i]);
     }
     if (e->side) (void)hipStreamDestroy(e->side);
     for (int i = 0; i < gx_engine::kKeyRing; ++i) {
@@ -398,6 +410,16 @@ static gx_status flush_pending(gx_engine* e, hipStream_t s)
     return GX_OK;
 }
 
+// a sampler is about to overwrite pool i on stream `s`: tape tokens of that pool expire, and the sampler runs
+// behind the last gx_expand_tape that reads the pool
+static hipError_t claim_pool(gx_engine* e, int i, hipStream_t s)
+{
+    e->pool_gen[i]++;
+    if (!e->expand_pending[i]) return hipSuccess;
+    e->expand_pending[i] = false;
+    return hipStreamWaitEvent(s, e->expand_ev[i], 0);
+}
+
 static void layout_keys(const gx_engine* e, uint32_t (&k)[4])
 {
     // get_layout: randint(key, ...) splits the key once  engine.py:447
@@ -410,7 +432,7 @@ extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
     DeviceGuard guard(e->device);
     hipStream_t s = (hipStream_t)stream;
     (void)take_commit(e); // reset() re-initialises every env: a pending reset_done is moot (engine.py:460-465)
-    const int other = 1 - e->cur;
+    const int other = (e->cur + 1) % gx_engine::kPools;
     const bool hit = e->pf_valid && e->pf_key[0] == e->key[0] && e->pf_key[1] == e->key[1];
     if (e->pf_valid) { if (hit) e->pf_hits++; else e->pf_misses++; }
     if (e->have_reset) e->last_interval = e->steps_since_reset;
@@ -424,6 +446,7 @@ extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
         GX_HIP(hipStreamWaitEvent(s, e->pool_ready[other], 0));
     if (swap) e->cur = other;
     if (!hit) { // reset_layout on the caller's stream  engine.py:433-444
+        GX_HIP(claim_pool(e, e->cur, s));
         e->sp.k0 = e->key[0];
         e->sp.k1 = e->key[1];
         e->sp.dbg = e->stamps ? e->stamps + 65536 : nullptr; // tools/debug/sampler_waves.py
@@ -451,8 +474,9 @@ extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
             split2(k0, k1, a0, a1, b0, b1);
             k0 = a0; k1 = a1;
         }
-        const int tgt = 1 - e->cur;
+        const int tgt = (e->cur + 1) % gx_engine::kPools;
         if (!first) GX_HIP(hipStreamWaitEvent(e->side, e->pool_free[tgt], 0));
+        GX_HIP(claim_pool(e, tgt, e->side));
         // The closed-loop policy kernel (256-thread workgroups holding ~150 KB of LDS each) loses ~15 % when the
         // sampler's grids reach the CUs first; after a policy rollout the prefetch therefore starts behind
         // reset_apply.  The open-loop kernels are insensitive and keep the back-to-back sampler chain.
@@ -723,6 +747,89 @@ extern "C" gx_status gx_rollout_packed(gx_engine* e, int32_t T, const float* d_a
 }
 
 extern "C" int32_t gx_packed_width(const gx_engine* e) { return e ? e->p.D + e->na + 3 : -1; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// tape hand-off: the rank that steps the envs runs only the serial dynamics pass and hands out its tape (80 B per
+// env-step for the Point instead of the 192 B packed row); whoever needs the rollout -- every rank, after ONE
+// all-gather of the tapes -- runs the observation pass on it.  Every rank samples the same layout pools (the key is
+// shared, engine.py:263), so the pool rows a tape's reset_done events refer to are local everywhere.
+// Buffer of one shard: [ tape T*N*W | layouts at entry P*Npad*4 | actions T*N*NA ] floats.
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" gx_status gx_tape_floats(const gx_engine* e, int32_t T, int64_t* tape, int64_t* obj0, int64_t* act)
+{
+    if (!e || T < 1 || !tape || !obj0 || !act) return fail(GX_ERR_ARG, "bad argument");
+    if (!split_rollout_supported(e->p))
+        return fail(GX_ERR_UNSUPPORTED, "tape hand-off: Point / Swimmer without observe_vel / observe_acc only");
+    *tape = (int64_t)T * e->p.N * split_tape_width(e->p);
+    *obj0 = (int64_t)e->p.P * e->p.Npad * 4;
+    *act = (int64_t)T * e->p.N * e->na;
+    return GX_OK;
+}
+
+extern "C" gx_status gx_rollout_tape(gx_engine* e, int32_t T, const float* d_actions, float* d_shard,
+                                     int64_t* token, void* stream)
+{
+    if (!e || !d_actions || !d_shard || !token || T < 1) return fail(GX_ERR_ARG, "bad argument");
+    if (!e->have_reset) return fail(GX_ERR_STATE, "gx_rollout_tape before gx_reset");
+    if (!split_rollout_supported(e->p))
+        return fail(GX_ERR_UNSUPPORTED, "tape hand-off: Point / Swimmer without observe_vel / observe_acc only");
+    if ((reinterpret_cast<uintptr_t>(d_actions) & 7u) || (reinterpret_cast<uintptr_t>(d_shard) & 15u))
+        return fail(GX_ERR_ARG, "d_actions must be 8-byte, d_shard 16-byte aligned");
+    DeviceGuard guard(e->device);
+    hipStream_t s = (hipStream_t)stream;
+    int slot; uint32_t k0, k1;
+    gx_status st = stage_rollout_keys(e, T, slot, k0, k1);
+    if (st != GX_OK) return st;
+    RolloutArgs r;
+    fill_rollout_args(e, r, T, slot);
+    r.act = d_actions;
+    e->last_policy = false;
+    st = flush_pending(e, s);
+    if (st != GX_OK) return st;
+    const size_t nt = (size_t)T * e->p.N * split_tape_width(e->p), no = (size_t)e->p.P * e->p.Npad * 4;
+    launch_split_rollout(e->p, r, d_shard, reinterpret_cast<float4*>(d_shard + nt), e->b, s, nullptr, 1,
+                         d_shard + nt + no);
+    GX_HIP(hipEventRecord(e->keys_ev[slot], s));
+    GX_HIP(hipGetLastError());
+    e->key[0] = k0; e->key[1] = k1;
+    e->steps_since_reset += T;
+    e->hist = (e->hist + T) >= 2 ? 2 : e->hist + T;
+    *token = ((int64_t)e->pool_gen[e->cur] << 8) | (int64_t)e->cur;
+    return GX_OK;
+}
+
+extern "C" gx_status gx_expand_tape(gx_engine* e, int32_t T, const float* d_shard, int64_t token, float* d_packed,
+                                    void* stream)
+{
+    if (!e || !d_shard || !d_packed || T < 1) return fail(GX_ERR_ARG, "bad argument");
+    if (!split_rollout_supported(e->p))
+        return fail(GX_ERR_UNSUPPORTED, "tape hand-off: Point / Swimmer without observe_vel / observe_acc only");
+    if (reinterpret_cast<uintptr_t>(d_shard) & 15u) return fail(GX_ERR_ARG, "d_shard must be 16-byte aligned");
+    const int pi = (int)(token & 0xff);
+    if (pi < 0 || pi >= gx_engine::kPools || (uint32_t)(token >> 8) != e->pool_gen[pi])
+        return fail(GX_ERR_STATE, "gx_expand_tape: the layout pool of this tape has been resampled (expand a tape "
+                                  "before the second gx_reset after its rollout)");
+    DeviceGuard guard(e->device);
+    hipStream_t s = (hipStream_t)stream;
+    RolloutArgs r;
+    memset(&r, 0, sizeof r);
+    const int W = e->p.D + e->na + 3;
+    r.T = T; r.do_reset = 1; r.nobj_total = e->nobj_total;
+    r.cand_xy = e->pools[pi].cand_xy; r.n_rows = e->sp.M;
+    const size_t nt = (size_t)T * e->p.N * split_tape_width(e->p), no = (size_t)e->p.P * e->p.Npad * 4;
+    r.act = d_shard + nt + no;
+    r.obs = d_packed; r.act_out = d_packed + e->p.D;
+    r.rew = d_packed + e->p.D + e->na; r.cost = r.rew + 1; r.done = r.rew + 2;
+    r.obs_stride = W; r.sc_stride = W;
+    // the pool must be complete on this stream (it is when the tape's rank has stepped, but this may be another stream)
+    GX_HIP(hipStreamWaitEvent(s, e->pool_ready[pi], 0));
+    launch_split_rollout(e->p, r, const_cast<float*>(d_shard),
+                         reinterpret_cast<float4*>(const_cast<float*>(d_shard) + nt), e->b, s, nullptr, 2, nullptr);
+    GX_HIP(hipEventRecord(e->expand_ev[pi], s));
+    e->expand_pending[pi] = true;
+    GX_HIP(hipGetLastError());
+    return GX_OK;
+}
 
 extern "C" gx_status gx_rollout_policy(gx_engine* e, int32_t T, const gx_policy* pol, const float* d_obs0,
                                        float* d_obs_in, float* d_act, float* d_logp, float* d_val,

@@ -93,8 +93,10 @@ struct SplitArgs;
 bool split_rollout_supported(const Params& p);
 int split_tape_width(const Params& p);
 // `hold`: null, or an event the observation pass (not the dynamics pass) waits for
+// `which`: 3 both passes (gx_rollout), 1 the dynamics pass only (gx_rollout_tape; `act_copy` receives the actions),
+// 2 the observation pass only (gx_expand_tape)
 void launch_split_rollout(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b,
-                          hipStream_t s, hipEvent_t hold = nullptr);
+                          hipStream_t s, hipEvent_t hold = nullptr, int which = 3, float* act_copy = nullptr);
 // install the reset_done recorded in b.rd_j (pending commit) for consumers other than the lane-group kernels
 void launch_commit_pending(const Params& p, const DevBuffers& b, int nobj_total, int n_rows, hipStream_t s);
 // per-robot launchers: defined in gx_robot_kernels.inl, instantiated once per robot in gx_kernels_<robot>.hip
@@ -112,7 +114,7 @@ struct RobotLaunch {
                        hipStream_t s);
     static void commit_pending(const Params& p, const DevBuffers& b, int nobj_total, int n_rows, hipStream_t s);
     static void split(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b, hipStream_t s,
-                      hipEvent_t hold);
+                      hipEvent_t hold, int which, float* act_copy);
     static int split_width();
 };
 bool policy_rollout_supported(const Params& p);

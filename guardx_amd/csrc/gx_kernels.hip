@@ -502,9 +502,9 @@ int split_tape_width(const Params& p)
     return w;
 }
 void launch_split_rollout(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b,
-                          hipStream_t s, hipEvent_t hold)
+                          hipStream_t s, hipEvent_t hold, int which, float* act_copy)
 {
-    GX_ROBOT_DISPATCH(split(p, r, tape, obj0, b, s, hold));
+    GX_ROBOT_DISPATCH(split(p, r, tape, obj0, b, s, hold, which, act_copy));
 }
 
 void launch_commit_pending(const Params& p, const DevBuffers& b, int nobj_total, int n_rows, hipStream_t s)

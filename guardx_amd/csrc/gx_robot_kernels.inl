@@ -1261,14 +1261,14 @@ void RobotLaunch<R>::commit_pending(const Params& p, const DevBuffers& b, int no
 
 template <class R>
 void RobotLaunch<R>::split(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b,
-                           hipStream_t s, hipEvent_t hold)
+                           hipStream_t s, hipEvent_t hold, int which, float* act_copy)
 {
     if constexpr (R::kRestFixed) {
         SplitArgs sa;
-        sa.tape = tape; sa.obj0 = obj0;
-        if (p.P <= 5) launch_split_p<R, 5>(p, r, sa, b, s, hold);
-        else if (p.P <= 9) launch_split_p<R, 9>(p, r, sa, b, s, hold);
-        else launch_split_p<R, 33>(p, r, sa, b, s, hold);
+        sa.tape = tape; sa.obj0 = obj0; sa.act_copy = act_copy;
+        if (p.P <= 5) launch_split_p<R, 5>(p, r, sa, b, s, hold, which);
+        else if (p.P <= 9) launch_split_p<R, 9>(p, r, sa, b, s, hold, which);
+        else launch_split_p<R, 33>(p, r, sa, b, s, hold, which);
     }
 }
 template <class R>

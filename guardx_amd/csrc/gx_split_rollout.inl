@@ -31,6 +31,7 @@ struct SplitTape {
 struct SplitArgs {
     float* tape;        // [T][N][kW]
     float4* obj0;       // [P][Npad] snapshot of the layouts at entry (pass 2 reads it for rows with jcur < 0)
+    float* act_copy;    // null, or [T][N][NA]: pass 1 copies the actions it consumed (tape hand-off, gx_rollout_tape)
 };
 
 GX_D bool moderate(float x) { return fabsf(x) < 1e18f; } // false for NaN / Inf too
@@ -82,6 +83,10 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
 #pragma unroll
         for (int d = 0; d < R::NA; ++d) { a[d] = an[d]; an[d] = an2[d]; }
         if (t + 2 < r.T) load_action<R>(r.act, (size_t)(t + 2) * p.N + i, an2);
+        if (sa.act_copy) {
+#pragma unroll
+            for (int d = 0; d < R::NA; ++d) sa.act_copy[((size_t)t * p.N + i) * R::NA + d] = a[d];
+        }
         const bool have_last = (r.hist0 + t) >= 1;
         const float last_done = done0;
 
@@ -261,21 +266,23 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
     flush_tile<BLOCK>(tile, r.obs + g0 * RS, nrow * RS);
 }
 
+// which: bit 0 = the dynamics pass, bit 1 = the observation pass (gx_rollout: both; the tape hand-off runs them on
+// different ranks: gx_rollout_tape / gx_expand_tape)
 template <class R, int PMAX>
 static void launch_split_p(const Params& p, const RolloutArgs& r, const SplitArgs& sa, const DevBuffers& b, hipStream_t s,
-                           hipEvent_t hold)
+                           hipEvent_t hold, int which)
 {
     constexpr int B1 = 64, B2 = 64;
     const dim3 g1((p.N + B1 - 1) / B1), g2((unsigned)(((size_t)r.T * p.N + B2 - 1) / B2));
     const size_t lds1 = sizeof(float) * (size_t)B1 * p.D, lds2 = sizeof(float) * (size_t)B2 * r.obs_stride;
     if (PMAX == 5 && is_default_layout<R>(p)) {
-        hipLaunchKernelGGL((dyn_tape_kernel<R, B1, 5, true>), g1, dim3(B1), lds1, s, p, r, sa, b.dyn, b.obj);
+        if (which & 1) hipLaunchKernelGGL((dyn_tape_kernel<R, B1, 5, true>), g1, dim3(B1), lds1, s, p, r, sa, b.dyn, b.obj);
         if (hold) (void)hipStreamWaitEvent(s, hold, 0);
-        hipLaunchKernelGGL((obs_tape_kernel<R, B2, 5, true>), g2, dim3(B2), lds2, s, p, r, sa);
+        if (which & 2) hipLaunchKernelGGL((obs_tape_kernel<R, B2, 5, true>), g2, dim3(B2), lds2, s, p, r, sa);
     } else {
-        hipLaunchKernelGGL((dyn_tape_kernel<R, B1, PMAX, false>), g1, dim3(B1), lds1, s, p, r, sa, b.dyn, b.obj);
+        if (which & 1) hipLaunchKernelGGL((dyn_tape_kernel<R, B1, PMAX, false>), g1, dim3(B1), lds1, s, p, r, sa, b.dyn, b.obj);
         if (hold) (void)hipStreamWaitEvent(s, hold, 0);
-        hipLaunchKernelGGL((obs_tape_kernel<R, B2, PMAX, false>), g2, dim3(B2), lds2, s, p, r, sa);
+        if (which & 2) hipLaunchKernelGGL((obs_tape_kernel<R, B2, PMAX, false>), g2, dim3(B2), lds2, s, p, r, sa);
     }
 }
 

@@ -509,6 +509,50 @@ class Engine:
         return (obs, reward, cost, done, pk) if packed else (obs, reward, cost, done)
 
     # ------------------------------------------------------------------
+    # tape hand-off (multi-GPU): step here, build the observations wherever the rollout is needed
+    # ------------------------------------------------------------------
+    def tape_floats(self, T):
+        """(tape, layouts, actions) float counts of one shard buffer of rollout_tape(T)."""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        _native.check(self._lib.gx_tape_floats(self._h, int(T), C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def rollout_tape(self, actions, out=None):
+        """The serial half of rollout(): T x (step -> reset_done) without building observations.  Returns
+        (shard, token): `shard` a flat float32 tensor [tape | layouts at entry | actions] (80 B per env-step for
+        the Point against 192 B of packed rows) to all-gather as is, `token` naming the layout pool in effect.
+        expand_tape(shard, token) -- here or on any rank's engine of the same configuration -- gives the packed
+        (T, N, D + A + 3) rows of rollout(packed=True), bit for bit; call it before the second reset() after
+        this rollout.  step() / reset_done() may follow, but the last observation is only known after expand_tape."""
+        a = actions
+        if a.dtype != torch.float32 or not a.is_contiguous() or a.device != self.device:
+            a = a.to(device=self.device, dtype=torch.float32).contiguous()
+        T = int(a.shape[0])
+        assert tuple(a.shape[1:]) == (self.env_num, self.action_space.shape[0])
+        n = sum(self.tape_floats(T))
+        if out is None:
+            out = torch.empty(n, dtype=torch.float32, device=self.device)
+        assert out.numel() == n and out.is_contiguous() and out.dtype == torch.float32 and out.device == self.device
+        tok = C.c_int64()
+        self._rd_obs = None
+        _native.check(self._lib.gx_rollout_tape(self._h, T, a.data_ptr(), out.data_ptr(), C.byref(tok), self._stream()))
+        self._obs = None
+        return out, tok.value
+
+    def expand_tape(self, shard, token, T, out=None):
+        """Observation pass over one shard of rollout_tape(): (T, N, D + A + 3) packed rows (obs | action |
+        reward, cost, done).  Runs on the current stream; the engine orders its next layout sampler behind it."""
+        N, W = self.env_num, self.obs_flat_size + self.action_space.shape[0] + 3
+        assert shard.is_contiguous() and shard.dtype == torch.float32 and shard.device == self.device
+        assert shard.numel() == sum(self.tape_floats(T))
+        if out is None:
+            out = torch.empty(int(T), N, W, dtype=torch.float32, device=self.device)
+        assert tuple(out.shape) == (int(T), N, W) and out.is_contiguous()
+        _native.check(self._lib.gx_expand_tape(self._h, int(T), shard.data_ptr(), int(token), out.data_ptr(),
+                                               self._stream()))
+        return out
+
+    # ------------------------------------------------------------------
     # closed-loop fused rollout (policy evaluated inside the kernel)
     # ------------------------------------------------------------------
     @staticmethod

@@ -152,6 +152,24 @@ gx_status gx_rollout(gx_engine* e, int32_t T, const float* d_actions, float* d_o
 gx_status gx_rollout_packed(gx_engine* e, int32_t T, const float* d_actions, float* d_packed, void* stream);
 int32_t gx_packed_width(const gx_engine* e);
 
+/* ---- tape hand-off (multi-GPU; Point / Swimmer) ----------------------------------------------------------
+ * The packed row is 4 * (obs_dim + act_dim + 3) bytes per env-step (192 B for Goal_Point_8Hazards); an all-gather of it
+ * over xGMI takes longer than the epoch that produced it.  The observation is a function of 80 B of state, so the
+ * stepping rank runs only the serial dynamics pass of gx_rollout and hands out that tape; every rank that needs the
+ * rollout (safe_rl_libX/trpo/trpo.py:34-42: obs, act, rew, cost, done) runs the observation pass on the gathered
+ * tapes and gets the packed rows of gx_rollout_packed, bit for bit.  All ranks sample identical layout pools (shared
+ * key, engine.py:263), so the pool rows a tape's reset_done events refer to are local on every rank.
+ *   d_shard: gx_tape_floats() floats = [ tape | layouts at entry | actions ], 16-byte aligned; all-gather it as is.
+ *   token:   names the layout pool in effect; gx_expand_tape (on any engine of the same configuration and key
+ *            history, e.g. the other ranks') must be CALLED before the second gx_reset after the rollout --
+ *            the engines keep three pools for that; GX_ERR_STATE afterwards.  The next sampler that reuses the
+ *            pool is ordered behind the expansion by an event, whatever stream it ran on. */
+gx_status gx_tape_floats(const gx_engine* e, int32_t T, int64_t* tape, int64_t* layouts, int64_t* actions);
+gx_status gx_rollout_tape(gx_engine* e, int32_t T, const float* d_actions, float* d_shard, int64_t* token,
+                          void* stream);
+gx_status gx_expand_tape(gx_engine* e, int32_t T, const float* d_shard, int64_t token, float* d_packed,
+                         void* stream);
+
 /* ---- closed-loop fused rollout with an on-device policy ------------------
  * `ac.step(o)` of MLPActorCritic(hidden_sizes=(64,64), tanh) (safe_rl_libX/trpo/trpo_core.py:110-173)
  * evaluated inside the persistent rollout kernel: per step  a ~ N(mu_net(o), exp(log_std)), logp,

@@ -810,3 +810,73 @@ def test_deferred_layout_check(torch_cuda):
         bad.check_layouts()
     with pytest.raises(ResamplingError):
         bad.reset()
+
+
+@pytest.mark.parametrize("robot", ["point", "swimmer"])
+def test_tape_handoff_two_ranks_equal_the_packed_rollout(torch_cuda, robot):
+    """The multi-GPU hand-off on one GPU: two shard engines ("ranks") step with rollout_tape(), exchange the shard
+    buffers, and each expands BOTH tapes with expand_tape() on another stream one epoch later (what the all-gather
+    overlap needs: the pool ring keeps the layouts alive).  Every expansion equals the packed rows of one unsharded
+    engine's rollout(packed=True) bit for bit -- reset_done events, timeouts and the NaN guard included; a tape
+    whose pool has been resampled is refused."""
+    torch = torch_cuda
+    from guardx_amd import Engine
+    N, W, T, M, EPOCHS = 192, 2, 50, 60000, 4
+    kw = dict(seed=9, num_steps=17, goal_size=2.6)
+    if robot == "swimmer":
+        kw.update(SWIMMER)
+    full = Engine(task_config(N * W, **kw), n_candidates=M)
+    ranks = [Engine(task_config(N, **kw), n_candidates=M, shard=(r, W)) for r in range(W)]
+    A = full.action_space.shape[0]
+    rng = np.random.default_rng(5)
+    side = torch.cuda.Stream()
+    pending = None                                             # (epoch, shards, tokens) waiting to be expanded
+    ref = {}
+    done_total = 0
+
+    def expand_and_check(ep, shards, tokens):
+        want = ref.pop(ep)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            outs = [[e.expand_tape(shards[src], tokens[src], T) for src in range(W)] for e in ranks]
+        torch.cuda.current_stream().wait_stream(side)
+        for by in range(W):
+            for src in range(W):
+                w = want[:, src * N:(src + 1) * N].contiguous()
+                assert torch.equal(outs[by][src].view(torch.int32), w.view(torch.int32)), (ep, by, src)   # bits: NaN rows too
+
+    for ep in range(EPOCHS):
+        acts = rng.uniform(-1, 1, (T, N * W, A)).astype(np.float32)
+        if ep == 2:
+            acts[7, 3::11] = np.nan                            # the NaN guard fires in both shards
+        acts = torch.from_numpy(acts).cuda()
+        o_full = full.reset()
+        for r, e in enumerate(ranks):
+            assert torch.equal(e.reset(), o_full[r * N:(r + 1) * N])
+        # the previous epoch's tapes are expanded only now, AFTER the next reset (the pool ring keeps their layouts)
+        if pending is not None:
+            expand_and_check(*pending)
+        *_, pk = full.rollout(acts, packed=True)
+        ref[ep] = pk
+        done_total += int(pk[..., -1].sum().item())
+        shards, tokens = [], []
+        for r, e in enumerate(ranks):
+            sh, tok = e.rollout_tape(acts[:, r * N:(r + 1) * N].contiguous())
+            shards.append(sh); tokens.append(tok)
+        pending = (ep, shards, tokens)
+    stale = pending
+    expand_and_check(*pending)
+    assert done_total > 2 * N * W                              # timeouts every 18 steps plus goals: reset_done on every env
+    # two more resets: the pool of the last tapes is resampled, the token is refused
+    for e in ranks:
+        e.reset(); e.reset()
+    with pytest.raises(RuntimeError, match="resampled"):
+        ranks[0].expand_tape(stale[1][0], stale[2][0], T)
+    # the engines are still in step with the unsharded one
+    full.reset(); full.reset()
+    o_full = full.reset()
+    for r, e in enumerate(ranks):
+        assert torch.equal(e.reset(), o_full[r * N:(r + 1) * N])
+    full.close()
+    for e in ranks:
+        e.close()
