@@ -109,8 +109,10 @@ def run_epochs(env, tapes, epochs, handoff):
     for ep in range(epochs):
         env.reset(check=False)           # the layout_size assert is checked once after the loop
         acts = tapes[ep % len(tapes)]
-        if handoff is not None:
+        if isinstance(handoff, RolloutHandoff):
             handoff.submit(env.rollout(acts, packed=True)[4])
+        elif handoff is not None:
+            handoff.step(acts)           # TapeHandoff: dynamics pass here, observation pass on every rank
         else:
             env.rollout(acts)
     if handoff is not None:
@@ -481,7 +483,12 @@ def main():
     env.set_prefetch(EP_LEN)
     tapes = [action_tape(EP_LEN, ENV_NUM, 1000 * rank + k, device) for k in range(4)]
     gather = world > 1
-    handoff = RolloutHandoff(world) if gather else None
+    # the hand-off: "tape" (default) all-gathers the 80-B dynamics tape and expands it on every rank,
+    # "packed" all-gathers the 192-B packed rows (what round 1 did; GX_HANDOFF=packed to compare)
+    mode = os.environ.get("GX_HANDOFF", "tape")
+    handoff = None
+    if gather:
+        handoff = gxd.TapeHandoff(env, EP_LEN) if mode == "tape" else RolloutHandoff(world)
 
     run_epochs(env, tapes, args.warmup, handoff)
     gxd.barrier()
@@ -509,9 +516,16 @@ def main():
         stepping_only = {"value": round(env_steps / dt1, 1), "unit": "env-steps/s",
                          "ms_per_step": round(dt1 / args.steps * 1e3, 6),
                          "handoff_ms_per_epoch_exposed": round((dt - dt1) / args.steps * 1e3, 6),
-                         "handoff_bytes_received_per_rank_per_epoch": int((world - 1) * EP_LEN * ENV_NUM * W * 4),
-                         "note": "same epochs with the rollout hand-off switched off; `value` above includes it "
-                                 "(asynchronous all-gather, 3 gathered buffers in flight)"}
+                         "handoff": mode,
+                         "handoff_bytes_received_per_rank_per_epoch":
+                             int((world - 1) * (handoff.n if mode == "tape" else EP_LEN * ENV_NUM * W) * 4),
+                         "packed_rows_bytes_per_rank_per_epoch": int(EP_LEN * ENV_NUM * W * 4),
+                         "note": "same epochs with the rollout hand-off switched off (two-kernel gx_rollout); `value` "
+                                 "above includes the hand-off: asynchronous all-gather of the dynamics tape, 3 in "
+                                 "flight, and the observation pass over all ranks' tapes on every rank"
+                                 if mode == "tape" else
+                                 "same epochs with the rollout hand-off switched off; `value` above includes it "
+                                 "(asynchronous all-gather of the packed rows, 3 gathered buffers in flight)"}
     line = {
         "metric": "env-steps/sec", "value": round(value, 1), "unit": "env-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -521,8 +535,11 @@ def main():
         "config": {"workload": "Goal_Point_8Hazards env_num=2000/GPU, random-policy rollout (U(-1,1) action "
                                "tape resident in HBM); ONE BENCH STEP = ONE 200-PASS EPOCH: reset() over 1e6 layout "
                                "candidates + 200 x (step + reset_done)"
-                               + (", one async RCCL all-gather of the packed rollout shard per epoch, "
-                                  "overlapped with the following epochs" if gather else ""),
+                               + ((", one async RCCL all-gather of the dynamics tape per epoch, overlapped with the "
+                                   "following epoch, every rank expanding all tapes into the packed rollout"
+                                   if mode == "tape" else
+                                   ", one async RCCL all-gather of the packed rollout shard per epoch, "
+                                   "overlapped with the following epochs") if gather else ""),
                    "env_num_per_gpu": ENV_NUM, "max_ep_len": EP_LEN, "step_passes_per_bench_step": EP_LEN,
                    "obs_dim": env.obs_flat_size,
                    "driver": "gx_rollout: two launches per 200-pass epoch (serial dynamics tape, then one thread per "

@@ -1,8 +1,11 @@
 """Multi-GPU glue: one process per GPU, environments sharded with no data-path
 collective; the only exchange is the once-per-epoch rollout hand-off to the
-learner -- one all-gather (RCCL over xGMI on GPUs, gloo on CPU) of the packed
-per-rank rollout shard.  The reference has no counterpart:
-it runs on a single device (engine.py:100, trpo.py:21)."""
+learner -- one all-gather (RCCL over xGMI on GPUs, gloo on CPU) per epoch
+(SURVEY.md section 8e): either of the packed per-rank rollout shard
+(all_gather_rollout), or -- 2.4x fewer bytes for the Point -- of the dynamics
+tape, which every rank then expands into the packed rows itself (TapeHandoff).
+The reference has no counterpart: it runs on a single device (engine.py:100,
+trpo.py:21)."""
 import os
 
 import torch
@@ -52,6 +55,77 @@ def all_gather_rollout(packed, out=None):
     # concatenated-along-dim-0 form: accepted by both RCCL and gloo
     dist.all_gather_into_tensor(out.view((world * shape[0],) + shape[1:]), packed.contiguous())
     return out
+
+
+class TapeHandoff:
+    """Once-per-epoch rollout hand-off by dynamics tape.
+
+        h = TapeHandoff(env, T)                    # after init_process_group
+        per epoch:  env.reset(); h.step(actions)   # = env.rollout_tape + async all-gather + expansion of the
+                                                   #   PREVIOUS epoch's gathered tapes on a side stream
+        h.drain(); h.rollout                       # (world, T, N, obs+act+3): the last expanded epoch
+
+    The rank that steps writes 80 B per env-step (Point) instead of the 192-B packed row; ONE
+    all_gather_into_tensor per epoch moves the shards as they are; every rank runs the observation pass
+    (Engine.expand_tape) over all `world` tapes and so holds the same rows rollout(packed=True) + an all-gather of
+    the packed shards would have given it, bit for bit.  The all-gather of epoch k overlaps epoch k+1 entirely:
+    its expansion is enqueued during epoch k+1 behind a stream-level wait for the collective, and the engine orders
+    the layout sampler that recycles epoch k's pool behind that expansion (three pools), so a slow link slows the
+    epochs down instead of corrupting anything.  On the gloo rehearsal backend the shard goes through host memory."""
+
+    def __init__(self, env, T, depth=3):
+        self.env, self.T, self.depth = env, int(T), depth
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.n = sum(env.tape_floats(self.T))
+        self.host = dist.is_initialized() and dist.get_backend() != "nccl"
+        dev = env.device
+        self.send = [torch.empty(self.n, dtype=torch.float32, device=dev) for _ in range(depth)]
+        self.recv = [torch.empty(self.world * self.n, dtype=torch.float32, device="cpu" if self.host else dev,
+                                 pin_memory=self.host and torch.cuda.is_available()) for _ in range(depth)]
+        W = env.obs_flat_size + env.action_space.shape[0] + 3
+        self.out = [torch.empty(self.world, self.T, env.env_num, W, dtype=torch.float32, device=dev) for _ in range(2)]
+        self.stream = torch.cuda.Stream(device=dev)
+        self.pending = None            # (work, slot, token) of the epoch whose tapes are in flight
+        self.k = 0
+        self.rollout = None            # the most recently expanded epoch (valid after drain())
+        self.bytes_received = 0
+
+    def step(self, actions):
+        i = self.k % self.depth
+        shard, token = self.env.rollout_tape(actions, out=self.send[i])
+        self._expand_pending()         # epoch k-1: its collective has had a whole epoch
+        if self.world == 1:
+            work, self.recv[i] = None, shard
+        else:
+            src = shard.to("cpu") if self.host else shard
+            work = dist.all_gather_into_tensor(self.recv[i], src, async_op=True)
+            self.bytes_received += (self.world - 1) * self.n * 4
+        self.pending = (work, i, token)
+        self.k += 1
+
+    def _expand_pending(self):
+        if self.pending is None:
+            return
+        work, i, token = self.pending
+        self.pending = None
+        out = self.out[self.k % 2]
+        # no wait for the caller's stream: the buffers are this object's own, and their reuse three epochs later is
+        # ordered behind this expansion by the engine (sampler of the recycled pool -> reset_apply -> rollout_tape)
+        if work is None:               # single rank: the shard comes straight from the caller's stream
+            self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            if work is not None:
+                work.wait()            # RCCL: this stream waits for the collective; gloo: the host does
+            recv = self.recv[i]
+            if self.host:
+                recv = recv.to(self.env.device, non_blocking=True)
+            for s in range(self.world):
+                self.env.expand_tape(recv[s * self.n:(s + 1) * self.n], token, self.T, out=out[s])
+        self.rollout = out
+
+    def drain(self):
+        self._expand_pending()
+        torch.cuda.current_stream().wait_stream(self.stream)
 
 
 def barrier():

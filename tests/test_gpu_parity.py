@@ -880,3 +880,35 @@ def test_tape_handoff_two_ranks_equal_the_packed_rollout(torch_cuda, robot):
     full.close()
     for e in ranks:
         e.close()
+
+
+def test_tape_handoff_object_pipeline(torch_cuda):
+    """guardx_amd.dist.TapeHandoff as bench.py drives it (world of one: no collective): reset() + step(actions) per
+    epoch, the expansion of epoch k enqueued during epoch k+1 on the hand-off's own stream, default prefetch.  After
+    drain() `rollout` holds the last epoch's packed rows = a twin engine's rollout(packed=True)."""
+    torch = torch_cuda
+    from guardx_amd import Engine
+    from guardx_amd.dist import TapeHandoff
+    N, T, M = 500, 60, 200_000
+    cfg = task_config(N, seed=2, num_steps=T, goal_size=2.9)
+    a, b = Engine(cfg, n_candidates=M), Engine(cfg, n_candidates=M)
+    h = TapeHandoff(a, T)
+    rng = np.random.default_rng(11)
+    dones = 0
+    for ep in range(5):
+        acts = torch.from_numpy(rng.uniform(-1, 1, (T, N, 2)).astype(np.float32)).cuda()
+        oa, ob = a.reset(check=False), b.reset(check=False)
+        assert torch.equal(oa, ob)
+        h.step(acts)
+        *_, pk = b.rollout(acts, packed=True)
+        if ep >= 1:
+            torch.cuda.current_stream().wait_stream(h.stream)
+            assert torch.equal(h.rollout[0], prev)                 # epoch ep-1, expanded during epoch ep
+        prev = pk
+        dones += int(pk[..., -1].sum().item())
+    h.drain()
+    assert torch.equal(h.rollout[0], prev)
+    assert dones > 0                                               # goals were reached: reset_done rows in the tapes
+    a.check_layouts(); b.check_layouts()
+    assert a.prefetch_stats()[0] == 4                               # every later reset took the prefetched pool
+    a.close(); b.close()
