@@ -61,7 +61,8 @@ struct gx_engine {
     static const int kPools = 3;
     Pool pools[kPools];
     int cur;                 // pool the envs are drawn from
-    hipStream_t side;
+    hipStream_t side[kPools]; // prefetch samplers: pool i is sampled on side[i % n_side]
+    int n_side;
     hipEvent_t pool_ready[kPools]; // recorded on the sampling stream when pool i is complete
     hipEvent_t pool_free[kPools];  // recorded on the caller's stream when pool i is no longer read
     hipEvent_t expand_ev[kPools];  // recorded behind the last gx_expand_tape that read pool i
@@ -299,7 +300,8 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     e->pf_valid = false;
     e->prefetch_steps = -2;
     e->steps_since_reset = 0; e->last_interval = 0; e->pf_hits = 0; e->pf_misses = 0;
-    e->side = nullptr;
+    for (int i = 0; i < gx_engine::kPools; ++i) e->side[i] = nullptr;
+    e->n_side = 1;
     memset(e->pools, 0, sizeof(e->pools));
     for (int i = 0; i < gx_engine::kPools; ++i) {
         e->pool_ready[i] = nullptr; e->pool_free[i] = nullptr; e->expand_ev[i] = nullptr;
@@ -347,7 +349,10 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi); // lo = least urgent
         int prio = lo;
         if (const char* ev = getenv("GX_SIDE_PRIORITY")) prio = (atoi(ev) > 0) ? hi : (atoi(ev) == 0 ? (lo + hi) / 2 : lo); // experiments
-        err = hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, prio);
+        e->n_side = gx_engine::kPools;
+        if (const char* ev = getenv("GX_SIDE_STREAMS")) e->n_side = atoi(ev) >= 1 && atoi(ev) <= gx_engine::kPools ? atoi(ev) : e->n_side; // experiments
+        for (int i = 0; i < e->n_side && err == hipSuccess; ++i)
+            err = hipStreamCreateWithPriority(&e->side[i], hipStreamNonBlocking, prio);
     }
     e->cur = 0;
     e->b.pool = e->pools[0];
@@ -388,7 +393,8 @@ extern "C" gx_status gx_destroy(gx_engine* e)
         if (e->pool_free[i]) (void)hipEventDestroy(e->pool_free[i]);
         if (e->expand_ev[i]) (void)hipEventDestroy(e->expand_ev[i]);
     }
-    if (e->side) (void)hipStreamDestroy(e->side);
+    for (int i = 0; i < gx_engine::kPools; ++i)
+        if (e->side[i]) (void)hipStreamDestroy(e->side[i]);
     for (int i = 0; i < gx_engine::kKeyRing; ++i) {
         if (e->h_keys[i]) (void)hipHostFree(e->h_keys[i]);
         if (e->keys_ev[i]) (void)hipEventDestroy(e->keys_ev[i]);
@@ -475,18 +481,19 @@ extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
             k0 = a0; k1 = a1;
         }
         const int tgt = (e->cur + 1) % gx_engine::kPools;
-        if (!first) GX_HIP(hipStreamWaitEvent(e->side, e->pool_free[tgt], 0));
-        GX_HIP(claim_pool(e, tgt, e->side));
+        hipStream_t side = e->side[tgt % e->n_side];
+        if (!first) GX_HIP(hipStreamWaitEvent(side, e->pool_free[tgt], 0));
+        GX_HIP(claim_pool(e, tgt, side));
         // The closed-loop policy kernel (256-thread workgroups holding ~150 KB of LDS each) loses ~15 % when the
         // sampler's grids reach the CUs first; after a policy rollout the prefetch therefore starts behind
         // reset_apply.  The open-loop kernels are insensitive and keep the back-to-back sampler chain.
-        if (e->last_policy) GX_HIP(hipStreamWaitEvent(e->side, e->layout_ev, 0));
+        if (e->last_policy) GX_HIP(hipStreamWaitEvent(side, e->layout_ev, 0));
         SampleParams sp = e->sp;
         sp.k0 = k0; sp.k1 = k1;
         if (!e->pf_phase1) GX_HIP(hipEventCreateWithFlags(&e->pf_phase1, hipEventDisableTiming));
-        launch_sample(sp, e->pools[tgt], e->side, e->pf_phase1);
+        launch_sample(sp, e->pools[tgt], side, e->pf_phase1);
         e->pf_phase1_pending = true;
-        GX_HIP(hipEventRecord(e->pool_ready[tgt], e->side));
+        GX_HIP(hipEventRecord(e->pool_ready[tgt], side));
         GX_HIP(hipGetLastError());
         e->pf_valid = true;
         e->pf_key[0] = k0; e->pf_key[1] = k1;
