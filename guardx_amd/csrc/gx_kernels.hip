@@ -431,14 +431,18 @@ void launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s, hipEve
     (void)hipMemsetAsync(pl.n_surv, 0, 2 * sizeof(int), s); // n_surv, n_surv0
     hipLaunchKernelGGL(sample_phase0_kernel, dim3(grid), dim3(kSampleBlock), 0, s, sp, pl.cand_ok, pl.n_surv + 1,
                        pl.surv0);
-    const int grid1 = grid < 3072 ? grid : 3072;
+    // GX_SAMPLE_GRID_CAP (tests): a small cap makes phases 1 and 2 take many grid-stride iterations at small M
+    int cap = 1 << 30;
+    if (const char* ev = getenv("GX_SAMPLE_GRID_CAP")) cap = atoi(ev) > 0 ? atoi(ev) : cap;
+    const int grid1 = grid < (cap < 3072 ? cap : 3072) ? grid : (cap < 3072 ? cap : 3072);
     hipLaunchKernelGGL(sample_phase1_kernel<kSampleBlock>, dim3(grid1), dim3(kSampleBlock), 0, s, sp, pl.n_surv + 1,
                        pl.surv0, pl.n_surv, pl.surv);
     if (after_phase1) (void)hipEventRecord(after_phase1, s);
     const size_t lds_wave = sizeof(P2Lds) + (size_t)(sp.nobj_total - 1) * kP2Block * sizeof(float2);
     const int wpb = kP2Waves * lds_wave <= 65536 ? kP2Waves : 1;
     const int wgs = (M + kP2Block * wpb - 1) / (kP2Block * wpb);
-    const int grid2 = wgs < 8192 / wpb ? wgs : 8192 / wpb;
+    const int cap2 = cap < 8192 / wpb ? cap : 8192 / wpb;
+    const int grid2 = wgs < cap2 ? wgs : cap2;
     const size_t lds2 = wpb * lds_wave;
     hipLaunchKernelGGL(sample_phase2_kernel, dim3(grid2), dim3(kP2Block * wpb), lds2, s, sp, pl.n_surv, pl.surv,
                        pl.cand_ok, pl.cand_xy);

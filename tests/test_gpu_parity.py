@@ -912,3 +912,26 @@ def test_tape_handoff_object_pipeline(torch_cuda):
     a.check_layouts(); b.check_layouts()
     assert a.prefetch_stats()[0] == 4                               # every later reset took the prefetched pool
     a.close(); b.close()
+
+
+def test_sampler_grid_stride_iterations(torch_cuda, oracle, monkeypatch):
+    """sample_phase1 / sample_phase2 are grid-stride kernels whose grids are capped (3072 / 2048 workgroups); at the
+    production size every workgroup handles about one batch.  With the cap forced down to 6 workgroups the same
+    kernels take ~30 (phase 1) and ~8 (phase 2) iterations per workgroup: pool, layout_size and reset observations
+    still equal the checker's, with pillars too (18 objects: the one-wave-per-workgroup LDS layout of phase 2)."""
+    torch = torch_cuda
+    monkeypatch.setenv("GX_SAMPLE_GRID_CAP", "6")
+    for extra in ({}, {'pillars_num': 8, 'observe_pillars': True, 'pillars_keepout': 0.3, 'pillars_size': 0.2,
+                       'placements_extents': [-3, -3, 3, 3]},
+                  {'pillars_num': 24, 'observe_pillars': True, 'pillars_keepout': 0.15, 'pillars_size': 0.1,
+                   'placements_extents': [-4, -4, 4, 4]}):
+        cfg = task_config(300, seed=21)
+        cfg.update(extra)
+        E, O = _engines(cfg, oracle, n_candidates=60000)
+        E.set_prefetch(-1)
+        for _ in range(2):
+            np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
+            assert E.layout_size == O.layout_size
+            n = min(E.layout_size, 3000)
+            np.testing.assert_array_equal(E.get_pool(n), O.get_pool(n))
+        E.close()
