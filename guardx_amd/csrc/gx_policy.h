@@ -167,24 +167,53 @@ GX_D float critic_forward(const MlpLds& wc, const float* x, float* hbuf, int D, 
 typedef float mfma_f4 __attribute__((ext_vector_type(4)));
 constexpr int kPolHS = 68; // LDS row stride of the hidden activations (16-byte aligned rows)
 
+// One hidden layer, two 16x16 output tiles per wave.  KS > 0: the number of k-steps (K / 4) is a compile-time
+// constant -- every A / B operand of both tiles is fetched from LDS up front and the two accumulator chains are
+// issued alternately, so that neither the LDS latency (two dependent ds_read per MFMA in the round-1 loop: ~170
+// cycles per k-step) nor the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32 sits between two MFMAs.  The
+// order of accumulation within a tile (k ascending) is unchanged, hence the same bits.  KS == 0: run-time K.
+template <int KS>
 GX_D void mfma_layer(const MlpLds& wp, const MlpLds& wc, bool second, const float* in, int in_stride,
                      int in_net_stride, int K, float* out, int wave, int lw)
 {
     const int c16 = lw & 15, kq = lw >> 4;
+    const float* arow[2];
+    const float* bcol[2];
+    float* o[2];
+    mfma_f4 acc[2];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
         const int t = 2 * wave + tt, net = t >> 2, ut = t & 3;
         const MlpLds& w = net ? wc : wp;
         const float* Wt = second ? w.Wt2 : w.Wt1;
         const float bias = (second ? w.b2 : w.b1)[16 * ut + c16];
-        mfma_f4 acc = {bias, bias, bias, bias};
-        const float* arow = in + net * in_net_stride + c16 * in_stride + kq;
-        const float* bcol = Wt + kq * kPolHd + 16 * ut + c16;
-        for (int k0 = 0; k0 < K; k0 += 4)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[k0], bcol[k0 * kPolHd], acc, 0, 0, 0);
-        float* o = out + net * 16 * kPolHS + 16 * ut + c16;
+        acc[tt] = mfma_f4{bias, bias, bias, bias};
+        arow[tt] = in + net * in_net_stride + c16 * in_stride + kq;
+        bcol[tt] = Wt + kq * kPolHd + 16 * ut + c16;
+        o[tt] = out + net * 16 * kPolHS + 16 * ut + c16;
+    }
+    if (KS > 0) {
+        float av[2][KS > 0 ? KS : 1], bv[2][KS > 0 ? KS : 1];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[(4 * kq + r) * kPolHS] = tanh_f(acc[r]);
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) { av[tt][s] = arow[tt][4 * s]; bv[tt][s] = bcol[tt][4 * s * kPolHd]; }
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][s], bv[0][s], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][s], bv[1][s], acc[1], 0, 0, 0);
+        }
+    } else {
+        for (int k0 = 0; k0 < K; k0 += 4) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[0][k0], bcol[0][k0 * kPolHd], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[1][k0], bcol[1][k0 * kPolHd], acc[1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[tt][(4 * kq + r) * kPolHS] = tanh_f(acc[tt][r]);
     }
 }
 
@@ -193,9 +222,14 @@ GX_D void mfma_layer(const MlpLds& wp, const MlpLds& wc, bool second, const floa
 GX_D void mfma_hidden(const MlpLds& wp, const MlpLds& wc, const float* X, int XS, int Kp, float* H1, float* H2,
                       int wave, int lw)
 {
-    mfma_layer(wp, wc, false, X, XS, 0, Kp, H1, wave, lw);
+    // the observation widths of the four robots' default tasks (Point 43, Swimmer 46, Ant 64, Walker 70 -> pad4)
+    if (Kp == 44) mfma_layer<11>(wp, wc, false, X, XS, 0, Kp, H1, wave, lw);
+    else if (Kp == 48) mfma_layer<12>(wp, wc, false, X, XS, 0, Kp, H1, wave, lw);
+    else if (Kp == 64) mfma_layer<16>(wp, wc, false, X, XS, 0, Kp, H1, wave, lw);
+    else if (Kp == 72) mfma_layer<18>(wp, wc, false, X, XS, 0, Kp, H1, wave, lw);
+    else mfma_layer<0>(wp, wc, false, X, XS, 0, Kp, H1, wave, lw);
     __syncthreads();
-    mfma_layer(wp, wc, true, H1, kPolHS, 16 * kPolHS, kPolHd, H2, wave, lw);
+    mfma_layer<kPolHd / 4>(wp, wc, true, H1, kPolHS, 16 * kPolHS, kPolHd, H2, wave, lw);
     __syncthreads();
 }
 
