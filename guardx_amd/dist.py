@@ -6,6 +6,7 @@ learner -- one all-gather (RCCL over xGMI on GPUs, gloo on CPU) per epoch
 tape, which every rank then expands into the packed rows itself (TapeHandoff).
 The reference has no counterpart: it runs on a single device (engine.py:100,
 trpo.py:21)."""
+import contextlib
 import os
 
 import torch
@@ -81,10 +82,11 @@ class TapeHandoff:
         dev = env.device
         self.send = [torch.empty(self.n, dtype=torch.float32, device=dev) for _ in range(depth)]
         self.recv = [torch.empty(self.world * self.n, dtype=torch.float32, device="cpu" if self.host else dev,
-                                 pin_memory=self.host and torch.cuda.is_available()) for _ in range(depth)]
+                                 pin_memory=self.host and dev.type == "cuda") for _ in range(depth)]
         W = env.obs_flat_size + env.action_space.shape[0] + 3
         self.out = [torch.empty(self.world, self.T, env.env_num, W, dtype=torch.float32, device=dev) for _ in range(2)]
-        self.stream = torch.cuda.Stream(device=dev)
+        # the expansion runs on its own stream (a CPU stand-in engine, as in the gloo unit test, has none)
+        self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self.pending = None            # (work, slot, token) of the epoch whose tapes are in flight
         self.k = 0
         self.rollout = None            # the most recently expanded epoch (valid after drain())
@@ -111,9 +113,9 @@ class TapeHandoff:
         out = self.out[self.k % 2]
         # no wait for the caller's stream: the buffers are this object's own, and their reuse three epochs later is
         # ordered behind this expansion by the engine (sampler of the recycled pool -> reset_apply -> rollout_tape)
-        if work is None:               # single rank: the shard comes straight from the caller's stream
+        if work is None and self.stream is not None:   # single rank: the shard comes straight from the caller's stream
             self.stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.stream):
+        with (torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()):
             if work is not None:
                 work.wait()            # RCCL: this stream waits for the collective; gloo: the host does
             recv = self.recv[i]
@@ -125,7 +127,8 @@ class TapeHandoff:
 
     def drain(self):
         self._expand_pending()
-        torch.cuda.current_stream().wait_stream(self.stream)
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
 
 
 def barrier():

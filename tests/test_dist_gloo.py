@@ -104,6 +104,82 @@ def test_two_rank_rollout_allgather_equals_unsharded():
         np.testing.assert_array_equal(parts['done'].numpy(), d)
 
 
+class _StubEngine:
+    """CPU stand-in with the Engine surface TapeHandoff uses: the "tape" of (rank, epoch) is a ramp, the expansion an
+    affine map of it that depends on the token, so slots, ordering and shard indexing all show in the result."""
+
+    def __init__(self, rank, N, D):
+        self.rank, self.env_num, self.obs_flat_size = rank, N, D
+        self.device = torch.device("cpu")
+        self.action_space = type("Box", (), {"shape": (2,)})()
+        self.epoch = 0
+        self.expanded = []
+
+    def tape_floats(self, T):
+        return T * self.env_num * 4, 8, T * self.env_num * 2
+
+    def rollout_tape(self, actions, out=None):
+        n = sum(self.tape_floats(actions.shape[0]))
+        out.copy_(torch.arange(n, dtype=torch.float32) + 1000.0 * self.rank + 10000.0 * self.epoch)
+        self.epoch += 1
+        return out, 77 + self.epoch
+
+    def expand_tape(self, shard, token, T, out=None):
+        W = self.obs_flat_size + 2 + 3
+        self.expanded.append(int(token))
+        out.copy_((shard[:T * self.env_num * 4].reshape(T, self.env_num, 4).sum(-1, keepdim=True) + float(token)).expand(T, self.env_num, W))
+        return out
+
+
+def _tape_worker(rank, world, port, q):
+    try:
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                          MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        from guardx_amd import dist as gxd
+        gxd.init_from_env("gloo")
+        T, N, D = 3, 5, 6
+        env = _StubEngine(rank, N, D)
+        h = gxd.TapeHandoff(env, T)
+        n = sum(env.tape_floats(T))
+        acts = torch.zeros(T, N, 2)
+        for ep in range(5):
+            h.step(acts)
+            if ep >= 1:            # the previous epoch has been expanded by now
+                for src in range(world):
+                    ramp = torch.arange(n, dtype=torch.float32) + 1000.0 * src + 10000.0 * (ep - 1)
+                    want = ramp[:T * N * 4].reshape(T, N, 4).sum(-1, keepdim=True) + float(77 + ep)
+                    assert torch.equal(h.rollout[src], want.expand(T, N, D + 5)), (rank, ep, src)
+        h.drain()
+        assert env.expanded == [78] * world + [79] * world + [80] * world + [81] * world + [82] * world
+        assert h.bytes_received == 5 * (world - 1) * n * 4
+        gxd.barrier()
+        if rank == 0:
+            q.put(("ok", None))
+        torch.distributed.destroy_process_group()
+    except Exception as exc:  # noqa: BLE001
+        q.put(("fail", f"rank {rank}: {type(exc).__name__}: {exc}"))
+        raise
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_tape_handoff_ring_over_gloo():
+    """guardx_amd.dist.TapeHandoff over 2 gloo ranks with a stand-in engine: every rank ends up with every rank's
+    expanded rows, epoch by epoch, one epoch behind the stepping (the GPU engine's own tape / expand parity is
+    tests/test_gpu_parity.py::test_tape_handoff_*)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tape_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    tag, msg = q.get(timeout=240)
+    assert tag == "ok", msg
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+
+
 def test_single_process_passthrough():
     from guardx_amd import dist as gxd
     x = torch.arange(24, dtype=torch.float32).reshape(2, 3, 4)
