@@ -769,7 +769,7 @@ extern "C" gx_status gx_tape_floats(const gx_engine* e, int32_t T, int64_t* tape
         return fail(GX_ERR_UNSUPPORTED, "tape hand-off: Point / Swimmer without observe_vel / observe_acc only");
     *tape = (int64_t)T * e->p.N * split_tape_width(e->p);
     *obj0 = (int64_t)e->p.P * e->p.Npad * 4;
-    *act = (int64_t)T * e->p.N * e->na;
+    *act = split_tape_has_action(e->p) ? 0 : (int64_t)T * e->p.N * e->na; // the Point's tape row carries its action
     return GX_OK;
 }
 
@@ -795,7 +795,7 @@ extern "C" gx_status gx_rollout_tape(gx_engine* e, int32_t T, const float* d_act
     if (st != GX_OK) return st;
     const size_t nt = (size_t)T * e->p.N * split_tape_width(e->p), no = (size_t)e->p.P * e->p.Npad * 4;
     launch_split_rollout(e->p, r, d_shard, reinterpret_cast<float4*>(d_shard + nt), e->b, s, nullptr, 1,
-                         d_shard + nt + no);
+                         split_tape_has_action(e->p) ? nullptr : d_shard + nt + no);
     GX_HIP(hipEventRecord(e->keys_ev[slot], s));
     GX_HIP(hipGetLastError());
     e->key[0] = k0; e->key[1] = k1;
@@ -824,7 +824,7 @@ extern "C" gx_status gx_expand_tape(gx_engine* e, int32_t T, const float* d_shar
     r.T = T; r.do_reset = 1; r.nobj_total = e->nobj_total;
     r.cand_xy = e->pools[pi].cand_xy; r.n_rows = e->sp.M;
     const size_t nt = (size_t)T * e->p.N * split_tape_width(e->p), no = (size_t)e->p.P * e->p.Npad * 4;
-    r.act = d_shard + nt + no;
+    r.act = split_tape_has_action(e->p) ? nullptr : d_shard + nt + no;
     r.obs = d_packed; r.act_out = d_packed + e->p.D;
     r.rew = d_packed + e->p.D + e->na; r.cost = r.rew + 1; r.done = r.rew + 2;
     r.obs_stride = W; r.sc_stride = W;

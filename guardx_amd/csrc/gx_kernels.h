@@ -92,6 +92,7 @@ void launch_policy_rollout(const Params& p, const RolloutArgs& r, const PolicyAr
 struct SplitArgs;
 bool split_rollout_supported(const Params& p);
 int split_tape_width(const Params& p);
+bool split_tape_has_action(const Params& p); // the tape row carries the action (in its padding)
 // `hold`: null, or an event the observation pass (not the dynamics pass) waits for
 // `which`: 3 both passes (gx_rollout), 1 the dynamics pass only (gx_rollout_tape; `act_copy` receives the actions),
 // 2 the observation pass only (gx_expand_tape)
@@ -116,6 +117,7 @@ struct RobotLaunch {
     static void split(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b, hipStream_t s,
                       hipEvent_t hold, int which, float* act_copy);
     static int split_width();
+    static bool split_act_in_row();
 };
 bool policy_rollout_supported(const Params& p);
 size_t policy_lds_bytes(const Params& p, int impl);

@@ -505,6 +505,13 @@ int split_tape_width(const Params& p)
     else if (p.robot == PointRobot::kId) w = RobotLaunch<PointRobot>::split_width();
     return w;
 }
+bool split_tape_has_action(const Params& p)
+{
+    if (p.robot == SwimmerRobot::kId) return RobotLaunch<SwimmerRobot>::split_act_in_row();
+    if (p.robot == PointBareRobot::kId) return RobotLaunch<PointBareRobot>::split_act_in_row();
+    if (p.robot == PointRobot::kId) return RobotLaunch<PointRobot>::split_act_in_row();
+    return false;
+}
 void launch_split_rollout(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b,
                           hipStream_t s, hipEvent_t hold, int which, float* act_copy)
 {

@@ -1277,6 +1277,12 @@ int RobotLaunch<R>::split_width()
     if constexpr (R::kRestFixed) return SplitTape<R>::kW;
     return 0;
 }
+template <class R>
+bool RobotLaunch<R>::split_act_in_row()
+{
+    if constexpr (R::kRestFixed) return SplitTape<R>::kAct >= 0;
+    return false;
+}
 
 template <class R>
 void RobotLaunch<R>::thread_rollout(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s)

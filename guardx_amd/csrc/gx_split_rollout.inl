@@ -25,7 +25,9 @@ namespace gx {
 template <class R>
 struct SplitTape {
     static constexpr int kPose = 0, kQ = 4, kV = kQ + R::NQ, kCtrl = kV + R::NV, kRew = kCtrl + R::NU, kDone = kRew + 1,
-                         kJcur = kDone + 1, kJaft = kJcur + 1, kUsed = kJaft + 1, kW = (kUsed + 3) / 4 * 4;
+                         kJcur = kDone + 1, kJaft = kJcur + 1, kUsed = kJaft + 1, kW = (kUsed + 3) / 4 * 4,
+                         // the action rides in the row's padding where it fits (Point: 17 + 2 of 20 floats)
+                         kAct = (kUsed + R::NA <= kW) ? kUsed : -1;
 };
 
 struct SplitArgs {
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
 #pragma unroll
         for (int d = 0; d < R::NA; ++d) { a[d] = an[d]; an[d] = an2[d]; }
         if (t + 2 < r.T) load_action<R>(r.act, (size_t)(t + 2) * p.N + i, an2);
-        if (sa.act_copy) {
+        if (TP::kAct < 0 && sa.act_copy) {
 #pragma unroll
             for (int d = 0; d < R::NA; ++d) sa.act_copy[((size_t)t * p.N + i) * R::NA + d] = a[d];
         }
@@ -159,6 +161,10 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
         rowv[TP::kJcur] = __int_as_float(jcur); rowv[TP::kJaft] = __int_as_float(jaft);
 #pragma unroll
         for (int k = TP::kUsed; k < TP::kW; ++k) rowv[k] = 0.f;
+        if (TP::kAct >= 0) {
+#pragma unroll
+            for (int d = 0; d < R::NA; ++d) rowv[(TP::kAct >= 0 ? TP::kAct : 0) + d] = a[d];
+        }
 #pragma unroll
         for (int k = 0; k < TP::kW / 4; ++k)
             reinterpret_cast<float4*>(tp)[k] = make_float4(rowv[4 * k], rowv[4 * k + 1], rowv[4 * k + 2], rowv[4 * k + 3]);
@@ -253,7 +259,12 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
     build_obs_row<R, PMAX>(p, row, pose, ob, ctrl, q, v, 0.f, 0.f, 0.f, 0.f);
     if (packed) {
         float a[R::NA];
-        load_action<R>(r.act, gg, a);
+        if (TP::kAct >= 0) {
+#pragma unroll
+            for (int k = 0; k < R::NA; ++k) a[k] = rowv[(TP::kAct >= 0 ? TP::kAct : 0) + k];
+        } else {
+            load_action<R>(r.act, gg, a);
+        }
 #pragma unroll
         for (int k = 0; k < R::NA; ++k) row[p.D + k] = a[k];
         row[p.D + R::NA] = rw; row[p.D + R::NA + 1] = cs; row[p.D + R::NA + 2] = dn;

@@ -159,7 +159,8 @@ int32_t gx_packed_width(const gx_engine* e);
  * rollout (safe_rl_libX/trpo/trpo.py:34-42: obs, act, rew, cost, done) runs the observation pass on the gathered
  * tapes and gets the packed rows of gx_rollout_packed, bit for bit.  All ranks sample identical layout pools (shared
  * key, engine.py:263), so the pool rows a tape's reset_done events refer to are local on every rank.
- *   d_shard: gx_tape_floats() floats = [ tape | layouts at entry | actions ], 16-byte aligned; all-gather it as is.
+ *   d_shard: gx_tape_floats() floats = [ tape | layouts at entry | actions ], 16-byte aligned; all-gather it as is
+ *            (the Point's 20-float tape row has room for the action: its `actions` part is empty).
  *   token:   names the layout pool in effect; gx_expand_tape (on any engine of the same configuration and key
  *            history, e.g. the other ranks') must be CALLED before the second gx_reset after the rollout --
  *            the engines keep three pools for that; GX_ERR_STATE afterwards.  The next sampler that reuses the
