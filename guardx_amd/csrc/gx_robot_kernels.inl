@@ -98,6 +98,22 @@ GX_D void flush_tile(const float* tile, float* gbase, int total)
     }
 }
 
+// The same for a tile whose rows sit `ls` floats apart in LDS while the destination rows are `rs` floats (rs % 4 == 0,
+// 16-byte aligned destination): a row stride that is a multiple of 16 floats (the 48-float packed hand-off row) puts
+// the 64 rows of a wave on 4 LDS banks, 16-way conflicts on every row write; ls = rs + 1 spreads them.
+template <int BLOCK>
+GX_D void flush_tile_padded(const float* tile, int ls, float* gbase, int nrow, int rs)
+{
+    const int q4 = rs >> 2, nvec = nrow * q4;
+    const unsigned inv = (1u << 20) / (unsigned)q4 + 1u; // v / q4 for v < 2^20 / q4 ... exact here (v < 64 * 64)
+    float4* g4 = reinterpret_cast<float4*>(gbase);
+    for (int v = threadIdx.x; v < nvec; v += BLOCK) {
+        const int row = (int)(((unsigned)v * inv) >> 20), c = (v - row * q4) << 2;
+        const float* t = tile + row * ls + c;
+        g4[v] = make_float4(t[0], t[1], t[2], t[3]);
+    }
+}
+
 template <int BLOCK>
 GX_D void stage_tile(float* tile, const float* gbase, int total)
 {

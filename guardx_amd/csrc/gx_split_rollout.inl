@@ -209,7 +209,9 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
     const int i = (int)(gg % (size_t)p.N);
     const int RS = r.obs_stride;
     const bool packed = r.act_out != nullptr;
-    float* row = tile + tid * RS;
+    // LDS row stride: odd, so that the 64 rows of the wave fall on different banks (RS = 48 for the packed rows)
+    const int LS = (RS & 1) ? RS : RS + 1;
+    float* row = tile + tid * LS;
 
     const float* tp = sa.tape + gg * TP::kW;
     float rowv[TP::kW];
@@ -274,7 +276,11 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
     __syncthreads();
     const size_t left = G - g0;
     const int nrow = left < (size_t)BLOCK ? (int)left : BLOCK;
-    flush_tile<BLOCK>(tile, r.obs + g0 * RS, nrow * RS);
+    if (LS == RS) flush_tile<BLOCK>(tile, r.obs + g0 * RS, nrow * RS);
+    else if ((RS & 3) == 0 && (reinterpret_cast<uintptr_t>(r.obs) & 15u) == 0) flush_tile_padded<BLOCK>(tile, LS, r.obs + g0 * RS, nrow, RS);
+    else {
+        for (int k = tid; k < nrow * RS; k += BLOCK) { const int rw = k / RS; r.obs[g0 * RS + k] = tile[rw * LS + (k - rw * RS)]; }
+    }
 }
 
 // which: bit 0 = the dynamics pass, bit 1 = the observation pass (gx_rollout: both; the tape hand-off runs them on
@@ -285,7 +291,7 @@ static void launch_split_p(const Params& p, const RolloutArgs& r, const SplitArg
 {
     constexpr int B1 = 64, B2 = 64;
     const dim3 g1((p.N + B1 - 1) / B1), g2((unsigned)(((size_t)r.T * p.N + B2 - 1) / B2));
-    const size_t lds1 = sizeof(float) * (size_t)B1 * p.D, lds2 = sizeof(float) * (size_t)B2 * r.obs_stride;
+    const size_t lds1 = sizeof(float) * (size_t)B1 * p.D, lds2 = sizeof(float) * (size_t)B2 * (r.obs_stride | 1);
     if (PMAX == 5 && is_default_layout<R>(p)) {
         if (which & 1) hipLaunchKernelGGL((dyn_tape_kernel<R, B1, 5, true>), g1, dim3(B1), lds1, s, p, r, sa, b.dyn, b.obj);
         if (hold) (void)hipStreamWaitEvent(s, hold, 0);
