@@ -337,7 +337,15 @@ def epoch_breakdown(device):
             "epoch_overlapped_us": round(t_epoch * 1e6, 1),
             "note": "reset() = exact restatement of the reference's 1e6-candidate rejection sampler "
                     "(6e8 Threefry-2x32 blocks cut to under 3e8 by exact early rejection and lazy evaluation of the draws); it is integer-VALU "
-                    "bound and bounds the epoch"}
+                    "bound and bounds the epoch",
+            "valu_issue": {
+                "wave_instructions_per_epoch": 301e6,
+                "ns_per_wave_instruction_per_simd": 1.73, "simds": 1024,
+                "issue_floor_us": round(301e6 * 1.73e-9 / 1024 * 1e6, 1),
+                "note": "NOT measured in this run: SQ_INSTS_VALU of every kernel of one epoch (profiles/r02_sampler_pmc_SQ.csv, "
+                        "r02_rollout_N2000_T200_pmc_SQ.csv) x the measured issue cost of the sampler's own Threefry code "
+                        "(profiles/r02_probe_threefry_chain.log: 110 ns per 63.5-instruction block per SIMD) / 1024 SIMDs: the time "
+                        "the vector ALUs need just to issue one epoch's instructions; compare with the headline ms_per_step"}}
 
 
 def closed_loop_rate(device, epochs=50):
