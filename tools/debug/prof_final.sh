@@ -14,3 +14,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_kt -- python3 $
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/reset_kt -- python3 $R/tools/profile_reset.py > $O/reset_kt.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_BUSY_CYCLES --output-format csv -d $O/reset_sq -- python3 $R/tools/profile_reset.py > $O/reset_sq.log 2>&1
 find $O -name "*.csv" | wc -l
+# copy what is judged into profiles/ by hand (gpurun merges into an existing gpurun_out/final: take the newest files)
