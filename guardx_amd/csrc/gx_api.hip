@@ -340,6 +340,8 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
         alloc((void**)&pl.n_surv, 2 * sizeof(int));
         alloc((void**)&pl.surv, sizeof(uint32_t) * 32 * M);
         alloc((void**)&pl.surv0, sizeof(uint32_t) * 8 * M);
+        pl.fake = nullptr;
+        if (fake_table_width(p) > 0) alloc((void**)&pl.fake, sizeof(float) * (size_t)fake_table_width(p) * M);
         if (err == hipSuccess) err = hipEventCreateWithFlags(&e->pool_ready[i], hipEventDisableTiming);
         if (err == hipSuccess) err = hipEventCreateWithFlags(&e->pool_free[i], hipEventDisableTiming);
         if (err == hipSuccess) err = hipEventCreateWithFlags(&e->expand_ev[i], hipEventDisableTiming);
@@ -391,7 +393,7 @@ extern "C" gx_status gx_destroy(gx_engine* e)
         if (q) (void)hipFree(q);
     for (int i = 0; i < gx_engine::kPools; ++i) {
         Pool& pl = e->pools[i];
-        void* pb[] = {pl.cand_ok, pl.cand_xy, pl.wave_cnt, pl.wave_off, pl.cand_of, pl.layout_size, pl.n_surv, pl.surv, pl.surv0};
+        void* pb[] = {pl.cand_ok, pl.cand_xy, pl.wave_cnt, pl.wave_off, pl.cand_of, pl.layout_size, pl.n_surv, pl.surv, pl.surv0, pl.fake};
         for (void* q : pb)
             if (q) (void)hipFree(q);
         if (e->pool_ready[i]) (void)hipEventDestroy(e->pool_ready[i]);
@@ -462,6 +464,7 @@ extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
         e->sp.k1 = e->key[1];
         e->sp.dbg = e->stamps ? e->stamps + 65536 : nullptr; // tools/debug/sampler_waves.py
         launch_sample(e->sp, e->pools[e->cur], s);
+        launch_fake_table(e->p, e->pools[e->cur], e->nobj_total, e->sp.M, s);
     }
     e->pf_valid = false;
     e->b.pool = e->pools[e->cur];
@@ -497,6 +500,7 @@ extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
         sp.k0 = k0; sp.k1 = k1;
         if (!e->pf_phase1) GX_HIP(hipEventCreateWithFlags(&e->pf_phase1, hipEventDisableTiming));
         launch_sample(sp, e->pools[tgt], side, e->pf_phase1);
+        launch_fake_table(e->p, e->pools[tgt], e->nobj_total, sp.M, side);
         e->pf_phase1_pending = true;
         GX_HIP(hipEventRecord(e->pool_ready[tgt], side));
         GX_HIP(hipGetLastError());
@@ -588,7 +592,7 @@ static gx_status step_impl(gx_engine* e, const float* d_action, float* d_obs, fl
         r.obs = d_obs; r.rew = d_reward; r.cost = d_cost; r.done = d_done; r.qacc = d_qacc;
         r.rd_j = e->b.rd_j;
         r.layout_size = e->b.pool.layout_size; r.cand_of = e->b.pool.cand_of; r.cand_xy = e->b.pool.cand_xy;
-        r.n_rows = e->sp.M; r.stamps = e->stamps;
+        r.n_rows = e->sp.M; r.stamps = e->stamps; r.fake = e->b.pool.fake;
         if (d_obs_rd) { // also what reset_done() would return and install, with the key it would use (:447,500)
             uint32_t k[4];
             layout_keys(e, k);
@@ -688,7 +692,7 @@ static void fill_rollout_args(gx_engine* e, RolloutArgs& r, int32_t T, int slot)
     r.obs_stride = e->p.D; r.sc_stride = 1; r.rd_j = e->b.rd_j;
     r.keys = e->h_keys[slot]; // pinned + device-visible: read over the host link only on a reset
     r.layout_size = e->b.pool.layout_size; r.cand_of = e->b.pool.cand_of; r.cand_xy = e->b.pool.cand_xy;
-    r.n_rows = e->sp.M; r.stamps = e->stamps;
+    r.n_rows = e->sp.M; r.stamps = e->stamps; r.fake = e->b.pool.fake;
     e->p.have_last = e->hist >= 1;
     e->p.have_last_last = e->hist >= 2;
 }

@@ -37,6 +37,8 @@ struct Pool {
     int* n_surv;       // [2] phase-1 survivors, phase-0 survivors
     uint32_t* surv;    // [M][32] phase-1 survivor records
     uint32_t* surv0;   // [M][8] phase-0 survivor records
+    float* fake;       // null, or [M][NQ+NV+4]: reset_done's fake step (engine.py:719-724) from rest at the robot
+                       // position of valid layout c (row c of the compacted list): qpos, qvel, pose -- robots that move at rest
 };
 
 struct DevBuffers {
@@ -82,6 +84,7 @@ struct RolloutArgs {
     const float2* cand_xy;
     unsigned long long* stamps; // null, or [grid][8] s_memtime stamps of wave 0 of every workgroup (profiling aid)
     int n_rows;        // rows of cand_xy (layout candidates): bound for every row index read back from memory
+    const float* fake; // Pool::fake of the pool in effect (lane-group kernels of the robots that move at rest)
 };
 void launch_group_rollout(const Params& p, const RolloutArgs& r, const DevBuffers& b, hipStream_t s);
 // thread-per-env persistent rollout (large batches)
@@ -100,6 +103,9 @@ void launch_split_rollout(const Params& p, const RolloutArgs& r, float* tape, fl
                           hipStream_t s, hipEvent_t hold = nullptr, int which = 3, float* act_copy = nullptr);
 // install the reset_done recorded in b.rd_j (pending commit) for consumers other than the lane-group kernels
 void launch_commit_pending(const Params& p, const DevBuffers& b, int nobj_total, int n_rows, hipStream_t s);
+// fill Pool::fake for the valid layouts of a freshly sampled pool (no-op for robots whose rest state is a fixed point)
+void launch_fake_table(const Params& p, const Pool& pl, int nobj_total, int M, hipStream_t s);
+int fake_table_width(const Params& p); // floats per row, 0 when the robot needs none
 // per-robot launchers: defined in gx_robot_kernels.inl, instantiated once per robot in gx_kernels_<robot>.hip
 template <class R>
 struct RobotLaunch {
@@ -114,6 +120,7 @@ struct RobotLaunch {
     static void policy(const Params& p, const RolloutArgs& r, const PolicyArgs& pol, const DevBuffers& b, int impl,
                        hipStream_t s);
     static void commit_pending(const Params& p, const DevBuffers& b, int nobj_total, int n_rows, hipStream_t s);
+    static void fake_table(const Params& p, const Pool& pl, int nobj_total, int M, hipStream_t s);
     static void split(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b, hipStream_t s,
                       hipEvent_t hold, int which, float* act_copy);
     static int split_width();

@@ -523,6 +523,19 @@ void launch_commit_pending(const Params& p, const DevBuffers& b, int nobj_total,
     GX_ROBOT_DISPATCH(commit_pending(p, b, nobj_total, n_rows, s));
 }
 
+void launch_fake_table(const Params& p, const Pool& pl, int nobj_total, int M, hipStream_t s)
+{
+    if (!pl.fake) return;
+    if (p.robot == AntRobot::kId) RobotLaunch<AntRobot>::fake_table(p, pl, nobj_total, M, s);
+    else if (p.robot == WalkerRobot::kId) RobotLaunch<WalkerRobot>::fake_table(p, pl, nobj_total, M, s);
+}
+int fake_table_width(const Params& p)
+{
+    if (p.robot == AntRobot::kId) return AntRobot::NQ + AntRobot::NV + 4;
+    if (p.robot == WalkerRobot::kId) return WalkerRobot::NQ + WalkerRobot::NV + 4;
+    return 0;
+}
+
 bool policy_rollout_supported(const Params& p) { return p.nobj <= 16 && p.bins <= 16; }
 size_t policy_lds_bytes(const Params& p, int impl)
 {

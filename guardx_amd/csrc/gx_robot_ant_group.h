@@ -122,8 +122,8 @@ struct AntGroup {
         xbt = i01 * t0 + i11 * t1;
     }
 
-    // a real call, like the serial form (see AntRobot::substep_impl)
-    __device__ __attribute__((noinline)) static void substep_call(float* q, float* v, const float* ctrl, float* pose,
+    // the lane-group kernels' ONE call site of the step (reset_done's fake step comes from Pool::fake): inlined
+    __device__ __attribute__((always_inline)) static void substep_call(float* q, float* v, const float* ctrl, float* pose,
                                                                   float* qacc, int L)
     {
         substep(*reinterpret_cast<float (*)[11]>(q), *reinterpret_cast<float (*)[11]>(v),

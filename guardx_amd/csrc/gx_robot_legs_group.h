@@ -109,6 +109,11 @@ struct WalkerGroup {
         return (uint32_t)quadi<0>((int)own) | ((uint32_t)quadi<1>((int)own) << 16);
     }
 
+    // A real call (the Ant's copy of this wrapper is inlined): hipcc 7.2 miscompiles the lane-group kernels with the
+    // Walker's 15k-instruction step inlined (dynamics blow up in test_variant_configs[group-walker], at -O3 and -O2,
+    // with or without IPRA).  It is the kernels' only call site -- reset_done's fake step comes from Pool::fake --
+    // and with one call site the build with LLVM's inter-procedural register allocation passes every parity test
+    // and the soak again (build.py), which is worth 18 % here: the callee no longer saves ~100 callee-saved VGPRs.
     __device__ __attribute__((noinline)) static void substep_call(float* q, float* v, const float* ctrl, float* pose,
                                                                   float* qacc, int L)
     {
