@@ -1266,6 +1266,7 @@ static void launch_group_r(const Params& p, const RolloutArgs& r, const DevBuffe
     } while (0)
     if (is_default_layout<R>(p)) GX_GROUP_LAUNCH(1, 1, true);
     else if (p.nobj <= 16 && p.bins <= 16) GX_GROUP_LAUNCH(1, 1, false);
+    else if (p.nobj <= 32 && p.bins <= 16) GX_GROUP_LAUNCH(2, 1, false); // e.g. 8 hazards + 8 pillars (BASELINE config 5)
     else GX_GROUP_LAUNCH(5, 4, false);
 #undef GX_GROUP_LAUNCH
 }
