@@ -209,8 +209,9 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
     const int i = (int)(gg % (size_t)p.N);
     const int RS = r.obs_stride;
     const bool packed = r.act_out != nullptr;
-    // LDS row stride: odd, so that the 64 rows of the wave fall on different banks (RS = 48 for the packed rows)
-    const int LS = (RS & 1) ? RS : RS + 1;
+    // LDS row stride: RS + 1 when RS is a multiple of 4 floats (48 for the Point's packed rows: 64 rows on 4 banks,
+    // 16-way conflicts on every row write); other widths conflict 2-way at worst and keep the contiguous tile
+    const int LS = (RS & 3) ? RS : RS + 1;
     float* row = tile + tid * LS;
 
     const float* tp = sa.tape + gg * TP::kW;
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
     const size_t left = G - g0;
     const int nrow = left < (size_t)BLOCK ? (int)left : BLOCK;
     if (LS == RS) flush_tile<BLOCK>(tile, r.obs + g0 * RS, nrow * RS);
-    else if ((RS & 3) == 0 && (reinterpret_cast<uintptr_t>(r.obs) & 15u) == 0) flush_tile_padded<BLOCK>(tile, LS, r.obs + g0 * RS, nrow, RS);
+    else if ((reinterpret_cast<uintptr_t>(r.obs) & 15u) == 0) flush_tile_padded<BLOCK>(tile, LS, r.obs + g0 * RS, nrow, RS);
     else {
         for (int k = tid; k < nrow * RS; k += BLOCK) { const int rw = k / RS; r.obs[g0 * RS + k] = tile[rw * LS + (k - rw * RS)]; }
     }
