@@ -935,3 +935,31 @@ def test_sampler_grid_stride_iterations(torch_cuda, oracle, monkeypatch):
             n = min(E.layout_size, 3000)
             np.testing.assert_array_equal(E.get_pool(n), O.get_pool(n))
         E.close()
+
+
+def test_bench_two_ranks_on_one_gpu_rehearsal(torch_cuda):
+    """bench.py's N > 1 path end to end on this box: `--gpus 2` with no launcher starts two rank processes itself;
+    both share GPU 0 and talk over gloo (RCCL refuses two ranks on one device), shards staged through host memory.
+    What is checked is the plumbing the 8-GPU run depends on -- spawn, rendezvous, barrier, max-over-ranks timing, the
+    tape hand-off ring with both ranks expanding both tapes, the stepping-only re-run, ONE JSON line from rank 0 --
+    not the rate (gloo through host memory is two orders of magnitude slower than xGMI)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GX_BENCH_FORCE_DEVICE="0", GX_DIST_BACKEND="gloo", GX_BENCH_SPAWN_TIMEOUT="400")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
+    assert line["env_steps_timed"] == 2 * 2000 * 200 * 3 and line["value"] > 0
+    so = line["stepping_only"]
+    assert so["handoff"] == "tape" and so["value"] > line["value"]
+    assert so["handoff_bytes_received_per_rank_per_epoch"] < so["packed_rows_bytes_per_rank_per_epoch"] / 2
+    assert "roofline" in line
