@@ -22,19 +22,17 @@ SOURCES = ["gx_api.hip", "gx_kernels.hip", "gx_gae.hip", "gx_kernels_point.hip",
 HEADERS = ["gx_device.h", "gx_robot.h", "gx_robot_ant.h", "gx_robot_ant_group.h", "gx_robot_legs.h", "gx_robot_legs_group.h", "gx_policy.h", "gx_kernels.h", "gx_robot_kernels.inl",
            "gx_split_rollout.inl", os.path.join("..", "..", "include", "guardx.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
-# LLVM's inter-procedural register allocation (on by default for amdgcn at -O3) let a noinline callee use, without
-# saving them, the VGPRs in whose lanes the CALLER parks spilled SGPRs (exec masks, v254/v255): after the call the
-# masks are garbage and masked-off lanes store through garbage addresses (found with rocgdb on
-# group_rollout_kernel<WalkerRobot,5,4,...> when it had TWO call sites of the step: HSA_STATUS_ERROR_MEMORY_APERTURE_
-# VIOLATION in the observation-row stores right after the second substep_call; gone with IPRA off).  Since reset_done's
-# fake step is tabulated with the layout pool (Pool::fake) the lane-group kernels have one call site: the Ant's is
-# inlined (no call at all), the Walker's stays a call (inlining it miscompiles, gx_robot_legs_group.h) and is built
-# WITH IPRA again -- every parity test and the soak pass, and the step is 18 % faster than with the callee saving
-# its callee-saved registers.  The Ant's translation unit keeps IPRA off for its thread-per-env kernels (two call
-# sites of the serial step); they are not on the latency path.
-PER_SOURCE_FLAGS = {
-    "gx_kernels_ant.hip": ["-mllvm", "-enable-ipra=0"],
-}
+# No per-source flags any more.  History: LLVM's inter-procedural register allocation (on by default for amdgcn at
+# -O3) let a noinline callee use, without saving them, the VGPRs in whose lanes the CALLER parks spilled SGPRs (exec
+# masks, v254/v255): after the call the masks are garbage and masked-off lanes store through garbage addresses (found
+# with rocgdb on group_rollout_kernel<WalkerRobot,5,4,...> when it had TWO call sites of the step:
+# HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION in the observation-row stores right after the second substep_call), and
+# the Ant / Walker translation units were built with -mllvm -enable-ipra=0.  Since reset_done's fake step is tabulated
+# with the layout pool (Pool::fake) every kernel has ONE call site of the step: the Ant's steps are inlined (no call
+# at all); the Walker's lane-group step stays a call (inlining it miscompiles, gx_robot_legs_group.h) and is built
+# with IPRA again -- every parity test and the soak pass, and it is 18 % faster than with the callee saving its
+# callee-saved registers.
+PER_SOURCE_FLAGS = {}
 
 
 def _extra(src):

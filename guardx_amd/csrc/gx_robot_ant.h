@@ -317,11 +317,12 @@ struct AntRobot {
     }
     GX_D static float clip1(float u) { return u < -1.0f ? -1.0f : (u > 1.0f ? 1.0f : u); }
 
-    // A real function call, on purpose.  Inlined into the rollout kernels (two call sites, ~8k instructions
-    // each, 512 registers) hipcc 7.2 produced a kernel in which a value kept live across the second copy
-    // came back wrong (cost of the envs re-initialised in that step; caught by the parity tests).  Behind
-    // the call ABI the callee owns its registers, the build is 3x faster and the step costs ~15 % more.
-    __device__ __attribute__((noinline)) static void substep_impl(float* q, float* v, const float* ctrl, float (&pose)[4],
+    // Inlined.  In round 1 it had to be a real call: inlined at TWO call sites per rollout kernel (the step and
+    // reset_done's fake step, ~8k instructions each) hipcc 7.2 produced a kernel in which a value kept live across
+    // the second copy came back wrong (caught by the parity tests).  The fake step now comes from Pool::fake, every
+    // kernel has one call site, and the inlined step is 19 % faster than the call (thread-per-env rollout, N = 8192:
+    // 49.8 -> 41.5 us per step).
+    __device__ __attribute__((always_inline)) static void substep_impl(float* q, float* v, const float* ctrl, float (&pose)[4],
                                                             float* qacc)
     {
         const float kDx[4] = {kD7, -kD7, -kD7, kD7};

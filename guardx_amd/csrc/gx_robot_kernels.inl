@@ -543,13 +543,15 @@ void thread_rollout_kernel(Params p_in, RolloutArgs r,
                 float rpose[4] = {rx, ry, 1.0f, 0.0f};
                 if (R::kRestFixed) {
                     build_obs_row<R, PMAX>(p, row, rpose, ob, zc, q, v, 0.f, 0.f, 0.f, 0.f);
-                } else { // the fake step (:719-724) moves the robot: its qpos/qvel feed the obs only
-                    float fq[R::NQ], fv[R::NV], fa[R::NV];
+                } else { // the fake step (:719-724) moves the robot: qpos | qvel | pose tabulated with the pool
+                    float fq[R::NQ], fv[R::NV];
+                    const float* frow = r.fake + (size_t)idx * (R::NQ + R::NV + 4);
 #pragma unroll
-                    for (int k = 0; k < R::NQ; ++k) fq[k] = q[k];
+                    for (int k = 0; k < R::NQ; ++k) fq[k] = frow[k];
 #pragma unroll
-                    for (int k = 0; k < R::NV; ++k) fv[k] = 0.f;
-                    for (int k = 0; k < p.physics_steps; ++k) R::template substep<false>(fq, fv, zc, rpose, fa);
+                    for (int k = 0; k < R::NV; ++k) fv[k] = frow[R::NQ + k];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) rpose[k] = frow[R::NQ + R::NV + k];
                     build_obs_row<R, PMAX>(p, row, rpose, ob, zc, fq, fv, 0.f, 0.f, 0.f, 0.f);
                 }
                 touched_layout = true;
