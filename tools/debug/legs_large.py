@@ -6,7 +6,7 @@ import bench
 from guardx_amd import ResamplingError
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
 for xml, A in (("xmls/ant.xml", 8), ("xmls/walker.xml", 10)):
-    for N in (2000, 4096, 8192):
+    for N in [int(x) for x in (os.environ.get("GX_LEGS_N") or "2000,4096,8192").split(",")]:
         for mode, name in ((1, "thread"), (2, "group")):
             env = bench.make_engine(N, 0, 1, n_candidates=300000, robot_base=xml)
             env.set_path(mode); env.set_prefetch(-1)
