@@ -963,3 +963,31 @@ def test_bench_two_ranks_on_one_gpu_rehearsal(torch_cuda):
     assert so["handoff"] == "tape" and so["value"] > line["value"]
     assert so["handoff_bytes_received_per_rank_per_epoch"] < so["packed_rows_bytes_per_rank_per_epoch"] / 2
     assert "roofline" in line
+
+
+def test_tape_handoff_is_refused_where_it_does_not_apply(torch_cuda):
+    """gx_rollout_tape / gx_expand_tape: robots whose reset_done observation needs a physics step (Ant, Walker) and
+    configurations with the pose history in the observation are GX_ERR_UNSUPPORTED, a rollout before reset() is
+    GX_ERR_STATE, a shard of the wrong size is caught by the Python mirror."""
+    torch = torch_cuda
+    from guardx_amd import Engine
+    from guardx_amd._native import GxError, GX_ERR_UNSUPPORTED, GX_ERR_STATE
+    acts = torch.zeros(4, 32, 8, device="cuda")
+    for cfg in (task_config(32, seed=1, **ANT), task_config(32, seed=1, observe_vel=True)):
+        e = Engine(cfg, n_candidates=20000)
+        e.reset()
+        with pytest.raises(GxError) as ei:
+            e.tape_floats(4)
+        assert ei.value.status == GX_ERR_UNSUPPORTED
+        e.close()
+    e = Engine(task_config(32, seed=1), n_candidates=20000)
+    with pytest.raises(GxError) as ei:
+        e.rollout_tape(acts[..., :2].contiguous())
+    assert ei.value.status == GX_ERR_STATE
+    e.reset()
+    sh, tok = e.rollout_tape(acts[..., :2].contiguous())
+    with pytest.raises(AssertionError):
+        e.expand_tape(sh[:-4], tok, 4)
+    out = e.expand_tape(sh, tok, 4)
+    assert out.shape == (4, 32, 48) and torch.isfinite(out).all()
+    e.close()

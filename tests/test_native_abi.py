@@ -63,6 +63,9 @@ def test_null_arguments_are_errors_not_crashes(native):
     assert lib.gx_step(None, None, None, None, None, None, None, None) == native.GX_ERR_ARG
     assert lib.gx_reset_done(None, None, None, None) == native.GX_ERR_ARG
     assert lib.gx_obs_dim(None) == -1
+    assert lib.gx_tape_floats(None, 1, None, None, None) == native.GX_ERR_ARG
+    assert lib.gx_rollout_tape(None, 1, None, None, None, None) == native.GX_ERR_ARG
+    assert lib.gx_expand_tape(None, 1, None, 0, None, None) == native.GX_ERR_ARG
     assert lib.gx_destroy(None) == native.GX_OK
 
 
