@@ -496,7 +496,15 @@ def main():
     mode = os.environ.get("GX_HANDOFF", "tape")
     handoff = None
     if gather:
-        handoff = gxd.TapeHandoff(env, EP_LEN) if mode == "tape" else RolloutHandoff(world)
+        if mode == "tape":
+            try:
+                handoff = gxd.TapeHandoff(env, EP_LEN)
+            except Exception as exc:  # noqa: BLE001 - same code on every rank, so every rank falls back together
+                print(f"bench.py: tape hand-off unavailable ({type(exc).__name__}: {exc}); using the packed rows",
+                      file=sys.stderr)
+                mode = "packed"
+        if mode != "tape":
+            handoff = RolloutHandoff(world)
 
     run_epochs(env, tapes, args.warmup, handoff)
     gxd.barrier()
