@@ -463,7 +463,9 @@ extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
         GX_HIP(claim_pool(e, e->cur, s));
         e->sp.k0 = e->key[0];
         e->sp.k1 = e->key[1];
-        e->sp.dbg = e->stamps ? e->stamps + 65536 : nullptr; // tools/debug/sampler_waves.py
+        // per-wave stamps of sample_phase2 (tools/debug/sampler_waves.py): only on request, the buffer must hold
+        // 65536 + 4 * 16384 words -- the other stamp tools pass much smaller ones
+        e->sp.dbg = (e->stamps && getenv("GX_SAMPLER_STAMPS")) ? e->stamps + 65536 : nullptr;
         launch_sample(e->sp, e->pools[e->cur], s);
         launch_fake_table(e->p, e->pools[e->cur], e->nobj_total, e->sp.M, s);
     }

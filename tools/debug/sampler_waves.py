@@ -1,5 +1,6 @@
 """Per-wave entry / exit stamps of sample_phase2_kernel (inline reset): lifetimes, start spread, waves per SIMD."""
 import os, sys, collections
+os.environ["GX_SAMPLER_STAMPS"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
