@@ -409,6 +409,39 @@ def other_robots(device, epochs=50):
     return out
 
 
+def reset_done_heavy(device, epochs=50):
+    """The headline epoch with the reset_done branch actually taken: with the force-limited Point a random policy
+    almost never reaches a 0.5 m goal 3 m away, so the headline's timed region holds next to no reset_done events.
+    Here episodes are shorter than the epoch (num_steps = 60: the timeout of engine.py:492 ends every episode on its
+    62nd step) and the goal is wide (2.9), so every env is re-initialised ~3 times per epoch inside the rollout
+    (layout draw, re-placement, re-initialised observation row).  Parity at exactly this size:
+    tests/test_gpu_parity.py::test_bench_workload_reset_done_heavy."""
+    from guardx_amd import Engine
+    cfg = dict(TASK, goal_size=2.9)
+    cfg.update(env_num=ENV_NUM, _seed=0, num_steps=60, device_id=torch.cuda.current_device())
+    env = Engine(cfg)
+    env.set_prefetch(EP_LEN)
+    tape = action_tape(EP_LEN, ENV_NUM, 0, device)
+
+    def epoch():
+        env.reset(check=False)
+        return env.rollout(tape)
+    epoch()
+    done = epoch()[3]
+    n_done = float(done.sum().item())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(epochs):
+        epoch()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    env.check_layouts()
+    env.close()
+    return {"env_steps_per_s": round(ENV_NUM * EP_LEN * epochs / dt, 1), "ms_per_epoch": round(dt / epochs * 1e3, 4),
+            "reset_done_events_per_epoch": n_done, "per_env": round(n_done / ENV_NUM, 2),
+            "config": "Goal_Point_8Hazards env_num=2000, goal_size=2.9, num_steps=60 (timeouts), 200-step epochs"}
+
+
 def api_loop_rate(env, tape, steps):
     """Python-driven Engine.step()/reset_done() loop (what an unmodified learner drives)."""
     torch.cuda.synchronize()
@@ -586,6 +619,7 @@ def main():
             extra("api_step_loop_env_steps_per_s", lambda: round(api_loop_rate(env, tapes[0], 2000), 1))
             extra("epoch_breakdown", lambda: epoch_breakdown(device))
             extra("closed_loop_policy_env_steps_per_s", lambda: round(closed_loop_rate(device), 1))
+            extra("reset_done_heavy", lambda: reset_done_heavy(device))
             extra("other_robots", lambda: other_robots(device))
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -466,7 +466,7 @@ extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
         // per-wave stamps of sample_phase2 (tools/debug/sampler_waves.py): only on request, the buffer must hold
         // 65536 + 4 * 16384 words -- the other stamp tools pass much smaller ones
         e->sp.dbg = (e->stamps && getenv("GX_SAMPLER_STAMPS")) ? e->stamps + 65536 : nullptr;
-        launch_sample(e->sp, e->pools[e->cur], s);
+        GX_HIP(launch_sample(e->sp, e->pools[e->cur], s));
         launch_fake_table(e->p, e->pools[e->cur], e->nobj_total, e->sp.M, s);
     }
     e->pf_valid = false;
@@ -502,7 +502,7 @@ extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
         SampleParams sp = e->sp;
         sp.k0 = k0; sp.k1 = k1;
         if (!e->pf_phase1) GX_HIP(hipEventCreateWithFlags(&e->pf_phase1, hipEventDisableTiming));
-        launch_sample(sp, e->pools[tgt], side, e->pf_phase1);
+        GX_HIP(launch_sample(sp, e->pools[tgt], side, e->pf_phase1));
         launch_fake_table(e->p, e->pools[tgt], e->nobj_total, sp.M, side);
         e->pf_phase1_pending = true;
         GX_HIP(hipEventRecord(e->pool_ready[tgt], side));
@@ -731,7 +731,7 @@ static gx_status rollout_impl(gx_engine* e, int32_t T, const float* d_actions, f
         if (st != GX_OK) return st;
         hipEvent_t hold = nullptr;
         if (e->pf_phase1_pending && getenv("GX_NO_OBS_HOLD") == nullptr) { hold = e->pf_phase1; e->pf_phase1_pending = false; }
-        launch_split_rollout(e->p, r, e->tape, e->obj0, e->b, s, hold);
+        GX_HIP(launch_split_rollout(e->p, r, e->tape, e->obj0, e->b, s, hold));
     } else if (use_group_path(e)) {   // latency regime: 16 lanes per env
         r.commit = take_commit(e);
         launch_group_rollout(e->p, r, e->b, s);
@@ -806,8 +806,8 @@ extern "C" gx_status gx_rollout_tape(gx_engine* e, int32_t T, const float* d_act
     st = flush_pending(e, s);
     if (st != GX_OK) return st;
     const size_t nt = (size_t)T * e->p.N * split_tape_width(e->p), no = (size_t)e->p.P * e->p.Npad * 4;
-    launch_split_rollout(e->p, r, d_shard, reinterpret_cast<float4*>(d_shard + nt), e->b, s, nullptr, 1,
-                         split_tape_has_action(e->p) ? nullptr : d_shard + nt + no);
+    GX_HIP(launch_split_rollout(e->p, r, d_shard, reinterpret_cast<float4*>(d_shard + nt), e->b, s, nullptr, 1,
+                                split_tape_has_action(e->p) ? nullptr : d_shard + nt + no));
     GX_HIP(hipEventRecord(e->keys_ev[slot], s));
     GX_HIP(hipGetLastError());
     e->key[0] = k0; e->key[1] = k1;
@@ -842,8 +842,8 @@ extern "C" gx_status gx_expand_tape(gx_engine* e, int32_t T, const float* d_shar
     r.obs_stride = W; r.sc_stride = W;
     // the pool must be complete on this stream (it is when the tape's rank has stepped, but this may be another stream)
     GX_HIP(hipStreamWaitEvent(s, e->pool_ready[pi], 0));
-    launch_split_rollout(e->p, r, const_cast<float*>(d_shard),
-                         reinterpret_cast<float4*>(const_cast<float*>(d_shard) + nt), e->b, s, nullptr, 2, nullptr);
+    GX_HIP(launch_split_rollout(e->p, r, const_cast<float*>(d_shard),
+                                reinterpret_cast<float4*>(const_cast<float*>(d_shard) + nt), e->b, s, nullptr, 2, nullptr));
     GX_HIP(hipEventRecord(e->expand_ev[pi], s));
     e->expand_pending[pi] = true;
     GX_HIP(hipGetLastError());

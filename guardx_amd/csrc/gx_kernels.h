@@ -52,7 +52,8 @@ struct DevBuffers {
 void launch_step(const Params& p, const DevBuffers& b, const float* act, float* obs, float* rew,
                  float* cost, float* done, float* qacc, hipStream_t s);
 // `after_phase1`: null, or an event recorded on `s` once the fully VALU-bound phases 0 and 1 are done
-void launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s, hipEvent_t after_phase1 = nullptr);
+// returns the status of the counter reset / event record it enqueues (ordering-critical: never dropped)
+hipError_t launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s, hipEvent_t after_phase1 = nullptr);
 void launch_reset_apply(const Params& p, const DevBuffers& b, int nobj_total, uint32_t k10,
                         uint32_t k11, uint32_t k20, uint32_t k21, float* obs, int* host_layout_size,
                         hipStream_t s);
@@ -99,8 +100,9 @@ bool split_tape_has_action(const Params& p); // the tape row carries the action 
 // `hold`: null, or an event the observation pass (not the dynamics pass) waits for
 // `which`: 3 both passes (gx_rollout), 1 the dynamics pass only (gx_rollout_tape; `act_copy` receives the actions),
 // 2 the observation pass only (gx_expand_tape)
-void launch_split_rollout(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b,
-                          hipStream_t s, hipEvent_t hold = nullptr, int which = 3, float* act_copy = nullptr);
+// returns the status of the stream-ordering calls it makes (the kernels' own launch errors surface in hipGetLastError)
+hipError_t launch_split_rollout(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b,
+                                hipStream_t s, hipEvent_t hold = nullptr, int which = 3, float* act_copy = nullptr);
 // install the reset_done recorded in b.rd_j (pending commit) for consumers other than the lane-group kernels
 void launch_commit_pending(const Params& p, const DevBuffers& b, int nobj_total, int n_rows, hipStream_t s);
 // fill Pool::fake for the valid layouts of a freshly sampled pool (no-op for robots whose rest state is a fixed point)
@@ -121,8 +123,8 @@ struct RobotLaunch {
                        hipStream_t s);
     static void commit_pending(const Params& p, const DevBuffers& b, int nobj_total, int n_rows, hipStream_t s);
     static void fake_table(const Params& p, const Pool& pl, int nobj_total, int M, hipStream_t s);
-    static void split(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b, hipStream_t s,
-                      hipEvent_t hold, int which, float* act_copy);
+    static hipError_t split(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b,
+                            hipStream_t s, hipEvent_t hold, int which, float* act_copy);
     static int split_width();
     static bool split_act_in_row();
 };

@@ -424,11 +424,12 @@ int pick_block(const Params& p)
     return 64;
 }
 
-void launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s, hipEvent_t after_phase1)
+hipError_t launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s, hipEvent_t after_phase1)
 {
     const int M = sp.M, W = (M + 63) / 64;
     const int grid = (M + kSampleBlock - 1) / kSampleBlock;
-    (void)hipMemsetAsync(pl.n_surv, 0, 2 * sizeof(int), s); // n_surv, n_surv0
+    hipError_t st = hipMemsetAsync(pl.n_surv, 0, 2 * sizeof(int), s); // n_surv, n_surv0
+    if (st != hipSuccess) return st;
     hipLaunchKernelGGL(sample_phase0_kernel, dim3(grid), dim3(kSampleBlock), 0, s, sp, pl.cand_ok, pl.n_surv + 1,
                        pl.surv0);
     // GX_SAMPLE_GRID_CAP (tests): a small cap makes phases 1 and 2 take many grid-stride iterations at small M
@@ -437,7 +438,8 @@ void launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s, hipEve
     const int grid1 = grid < (cap < 3072 ? cap : 3072) ? grid : (cap < 3072 ? cap : 3072);
     hipLaunchKernelGGL(sample_phase1_kernel<kSampleBlock>, dim3(grid1), dim3(kSampleBlock), 0, s, sp, pl.n_surv + 1,
                        pl.surv0, pl.n_surv, pl.surv);
-    if (after_phase1) (void)hipEventRecord(after_phase1, s);
+    if (after_phase1) st = hipEventRecord(after_phase1, s);
+    if (st != hipSuccess) return st;
     const size_t lds_wave = sizeof(P2Lds) + (size_t)(sp.nobj_total - 1) * kP2Block * sizeof(float2);
     const int wpb = kP2Waves * lds_wave <= 65536 ? kP2Waves : 1;
     const int wgs = (M + kP2Block * wpb - 1) / (kP2Block * wpb);
@@ -451,6 +453,7 @@ void launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s, hipEve
                        pl.layout_size);
     hipLaunchKernelGGL(compact_kernel, dim3(grid), dim3(kSampleBlock), 0, s, M, pl.cand_ok, pl.wave_off,
                        pl.cand_of);
+    return hipSuccess;
 }
 
 
@@ -512,10 +515,13 @@ bool split_tape_has_action(const Params& p)
     if (p.robot == PointRobot::kId) return RobotLaunch<PointRobot>::split_act_in_row();
     return false;
 }
-void launch_split_rollout(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b,
-                          hipStream_t s, hipEvent_t hold, int which, float* act_copy)
+hipError_t launch_split_rollout(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b,
+                                hipStream_t s, hipEvent_t hold, int which, float* act_copy)
 {
-    GX_ROBOT_DISPATCH(split(p, r, tape, obj0, b, s, hold, which, act_copy));
+    if (p.robot == SwimmerRobot::kId) return RobotLaunch<SwimmerRobot>::split(p, r, tape, obj0, b, s, hold, which, act_copy);
+    if (p.robot == PointBareRobot::kId) return RobotLaunch<PointBareRobot>::split(p, r, tape, obj0, b, s, hold, which, act_copy);
+    if (p.robot == PointRobot::kId) return RobotLaunch<PointRobot>::split(p, r, tape, obj0, b, s, hold, which, act_copy);
+    return hipErrorNotSupported;
 }
 
 void launch_commit_pending(const Params& p, const DevBuffers& b, int nobj_total, int n_rows, hipStream_t s)

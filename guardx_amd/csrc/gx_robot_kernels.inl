@@ -1328,16 +1328,17 @@ void RobotLaunch<R>::fake_table(const Params& p, const Pool& pl, int nobj_total,
 }
 
 template <class R>
-void RobotLaunch<R>::split(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b,
-                           hipStream_t s, hipEvent_t hold, int which, float* act_copy)
+hipError_t RobotLaunch<R>::split(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b,
+                                 hipStream_t s, hipEvent_t hold, int which, float* act_copy)
 {
     if constexpr (R::kRestFixed) {
         SplitArgs sa;
         sa.tape = tape; sa.obj0 = obj0; sa.act_copy = act_copy;
-        if (p.P <= 5) launch_split_p<R, 5>(p, r, sa, b, s, hold, which);
-        else if (p.P <= 9) launch_split_p<R, 9>(p, r, sa, b, s, hold, which);
-        else launch_split_p<R, 33>(p, r, sa, b, s, hold, which);
+        if (p.P <= 5) return launch_split_p<R, 5>(p, r, sa, b, s, hold, which);
+        if (p.P <= 9) return launch_split_p<R, 9>(p, r, sa, b, s, hold, which);
+        return launch_split_p<R, 33>(p, r, sa, b, s, hold, which);
     }
+    return hipErrorNotSupported;
 }
 template <class R>
 int RobotLaunch<R>::split_width()

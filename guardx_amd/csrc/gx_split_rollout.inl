@@ -287,21 +287,25 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
 // which: bit 0 = the dynamics pass, bit 1 = the observation pass (gx_rollout: both; the tape hand-off runs them on
 // different ranks: gx_rollout_tape / gx_expand_tape)
 template <class R, int PMAX>
-static void launch_split_p(const Params& p, const RolloutArgs& r, const SplitArgs& sa, const DevBuffers& b, hipStream_t s,
-                           hipEvent_t hold, int which)
+static hipError_t launch_split_p(const Params& p, const RolloutArgs& r, const SplitArgs& sa, const DevBuffers& b, hipStream_t s,
+                                hipEvent_t hold, int which)
 {
+    hipError_t st = hipSuccess; // of the wait that orders the observation pass behind the sampler: must not be dropped
     constexpr int B1 = 64, B2 = 64;
     const dim3 g1((p.N + B1 - 1) / B1), g2((unsigned)(((size_t)r.T * p.N + B2 - 1) / B2));
     const size_t lds1 = sizeof(float) * (size_t)B1 * p.D, lds2 = sizeof(float) * (size_t)B2 * (r.obs_stride | 1);
     if (PMAX == 5 && is_default_layout<R>(p)) {
         if (which & 1) hipLaunchKernelGGL((dyn_tape_kernel<R, B1, 5, true>), g1, dim3(B1), lds1, s, p, r, sa, b.dyn, b.obj);
-        if (hold) (void)hipStreamWaitEvent(s, hold, 0);
+        if (hold) st = hipStreamWaitEvent(s, hold, 0);
+        if (st != hipSuccess) return st;
         if (which & 2) hipLaunchKernelGGL((obs_tape_kernel<R, B2, 5, true>), g2, dim3(B2), lds2, s, p, r, sa);
     } else {
         if (which & 1) hipLaunchKernelGGL((dyn_tape_kernel<R, B1, PMAX, false>), g1, dim3(B1), lds1, s, p, r, sa, b.dyn, b.obj);
-        if (hold) (void)hipStreamWaitEvent(s, hold, 0);
+        if (hold) st = hipStreamWaitEvent(s, hold, 0);
+        if (st != hipSuccess) return st;
         if (which & 2) hipLaunchKernelGGL((obs_tape_kernel<R, B2, PMAX, false>), g2, dim3(B2), lds2, s, p, r, sa);
     }
+    return st;
 }
 
 } // namespace gx

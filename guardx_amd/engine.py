@@ -105,10 +105,12 @@ class Engine:
                     of a global batch of `env_num * world` envs and reproduces exactly
                     the rows an unsharded Engine(env_num*world) would produce
       emit_qacc     fill info['obs']['qacc'] (engine.py:763-764); costs one more output array
-      out_ring      step() returns tensors from a ring of `out_ring` preallocated output sets (default 8: a tensor
-                    is reused 8 step() calls after it was returned; the learners copy what they keep,
-                    trpo.py:58-64).  0 = a fresh allocation per call, the reference's "never mutated later"
-                    behaviour (engine.py:495), ~15 us more host time per step
+      out_ring      0 (default): the tensors step() returns are never written again, as in the reference
+                    (engine.py:495 hands out fresh buffers; trpo.py:529 mutates the obs it keeps in place) -- they
+                    are views of a slab allocated once per 32 calls and released when the last view dies.
+                    k > 0: opt-in ring of k preallocated output sets, a tensor is overwritten k step() calls
+                    after it was returned (for callers that copy what they keep, trpo.py:58-64; saves the slab
+                    allocations)
       point_actuators  'mjcf' (default): point.xml's <general> actuators inherit the class defaults the way
                     MuJoCo compiles them (ctrl clamp +-1, velocity-servo bias, force clamp +-.05, action
                     space Box(-1, 1)); 'bare': the round-1 reading without the defaults (force = 0.3*ctrl,
@@ -162,8 +164,10 @@ class Engine:
         'pillars_size': 0.2, 'observe_pillars': False,
     }
 
+    _SLAB_STEPS = 32     # step() outputs are carved out of one allocation per 32 calls
+
     def __init__(self, config={}, *, n_candidates=1_000_000, shard=None, emit_qacc=True, point_actuators='mjcf',
-                 out_ring=8):
+                 out_ring=0):
         self._ctor_config = deepcopy(config)
         self._ctor_kwargs = dict(n_candidates=n_candidates, shard=shard, emit_qacc=emit_qacc,
                                  point_actuators=point_actuators, out_ring=out_ring)
@@ -219,8 +223,8 @@ class Engine:
         assert self.obs_flat_size == self._lib.gx_obs_dim(self._h)
 
         self._act_shape = torch.Size((int(self.env_num), act_dim))
-        self._ring = [None] * max(0, int(out_ring))
-        self._ring_i = 0
+        self._out_ring = max(0, int(out_ring))
+        self._slab, self._slab_i = [], 0
         self._speculate = os.environ.get("GX_NO_SPECULATE", "0") != "1"
         self._spec = C.c_int32(0)
         self._spec_ref = C.byref(self._spec)
@@ -236,49 +240,36 @@ class Engine:
     # configuration
     # ------------------------------------------------------------------
     def parse(self, config):
-        """engine.py:322-328"""
-        self.config = deepcopy(self.DEFAULT)
-        self.config.update(deepcopy(self.EXTENSIONS))
-        self.config.update(deepcopy(config))
-        for key, value in self.config.items():
-            assert key in self.DEFAULT or key in self.EXTENSIONS, f'Bad key {key}'
-            setattr(self, key, value)
+        """Constructor contract of engine.py:322-328: unknown keys fail with AssertionError('Bad key <key>'), every
+        accepted key becomes an attribute and self.config the merged dict."""
+        known = {**self.DEFAULT, **self.EXTENSIONS}
+        for key in config:
+            assert key in known, f'Bad key {key}'
+        self.config = deepcopy({**known, **config})
+        vars(self).update(self.config)
 
-    def placements_dict_from_object(self, object_name):
-        """engine.py:507-531"""
-        placements_dict = {}
-        if hasattr(self, object_name + 's_num'):
-            plural = object_name + 's'
-            fmt = object_name + '{i}'
-            num = getattr(self, plural + '_num', None)
-            locations = getattr(self, plural + '_locations', [])
-            placements = getattr(self, plural + '_placements', None)
-            keepout = getattr(self, plural + '_keepout')
-        else:
-            fmt = object_name
-            num = 1
-            locations = getattr(self, object_name + '_locations', [])
-            placements = getattr(self, object_name + '_placements', None)
-            keepout = getattr(self, object_name + '_keepout')
-        for i in range(num):
-            if i < len(locations):
-                x, y = locations[i]
-                k = keepout + 1e-9
-                rects = [(x - k, y - k, x + k, y + k)]
-            else:
-                rects = placements
-            placements_dict[fmt.format(i=i)] = (rects, keepout)
-        return placements_dict
+    # what the layout sampler places, in placement order (engine.py:533-544): (object family, is it a numbered family)
+    _PLACED = (('goal', False), ('hazard', True), ('pillar', True), ('robot', False))
 
     def build_placements_dict(self):
-        """engine.py:533-544: order goal, hazard0.., robot"""
-        placements = OrderedDict()
-        placements.update(self.placements_dict_from_object('goal'))
-        placements.update(self.placements_dict_from_object('hazard'))
-        if self.pillars_num:                       # synthetic extension
-            placements.update(self.placements_dict_from_object('pillar'))
-        placements.update(self.placements_dict_from_object('robot'))
-        self.placements = placements
+        """name -> (rectangles or None, keepout) in placement order: goal, hazard0.., [pillar0..,] robot
+        (engine.py:507-544).  A fixed location i < len(<family>_locations) is a degenerate rectangle of half-width
+        keepout + 1e-9 around it (engine.py:524-526); otherwise the family's *_placements (None = the arena)."""
+        table = OrderedDict()
+        for family, numbered in self._PLACED:
+            stem = family + 's' if numbered else family
+            count = int(self.config[stem + '_num']) if numbered else 1
+            keepout = self.config[stem + '_keepout']
+            fixed = list(self.config[stem + '_locations'])[:count]
+            pad = keepout + 1e-9
+            for i in range(count):
+                name = f'{family}{i}' if numbered else family
+                if i < len(fixed):
+                    cx, cy = fixed[i]
+                    table[name] = ([(cx - pad, cy - pad, cx + pad, cy + pad)], keepout)
+                else:
+                    table[name] = (self.config[stem + '_placements'], keepout)
+        self.placements = table
 
     def _native_config(self, robot_id, n_candidates, rank, world):
         c = _native.GxConfig()
@@ -337,38 +328,33 @@ class Engine:
         c.device = int(self.device_id)
         return c
 
+    def _obs_table(self):
+        """One row per observation component, in the reference's insertion order (engine.py:386-407):
+        (key, enabled, width, low, high).  The flat observation concatenates the enabled rows in sorted-key order
+        (engine.py:773-777)."""
+        b, r, inf = int(self.lidar_num_bins), self.robot, np.inf
+        return (
+            ('goal_lidar', self.observe_goal_lidar, b, 0.0, 1.0),
+            ('goal_compass', self.observe_goal_comp, 2, -inf, inf),
+            ('hazards_lidar', self.observe_hazards, b, 0.0, 1.0),
+            ('pillars_lidar', self.observe_pillars and self.pillars_num, b, 0.0, 1.0),   # synthetic extension
+            ('qpos', self.observe_qpos, r.nq, -inf, inf),
+            ('qvel', self.observe_qvel, r.nv, -inf, inf),
+            ('ctrl', self.observe_ctrl, r.nu, -inf, inf),
+            ('vel', self.observe_vel, 2, -inf, inf),
+            ('acc', self.observe_acc, 2, -inf, inf),
+        )
+
     def build_observation_space(self):
-        """engine.py:386-418"""
-        d = OrderedDict()
-        inf = np.inf
-        if self.observe_goal_lidar:
-            d['goal_lidar'] = Box(0.0, 1.0, (self.lidar_num_bins,), dtype=np.float32)
-        if self.observe_goal_comp:
-            d['goal_compass'] = Box(-inf, inf, (2,), dtype=np.float32)
-        if self.observe_hazards:
-            d['hazards_lidar'] = Box(0.0, 1.0, (self.lidar_num_bins,), dtype=np.float32)
-        if self.observe_pillars and self.pillars_num:
-            d['pillars_lidar'] = Box(0.0, 1.0, (self.lidar_num_bins,), dtype=np.float32)
-        if self.observe_qpos:
-            d['qpos'] = Box(-inf, inf, (self.robot.nq,), dtype=np.float32)
-        if self.observe_qvel:
-            d['qvel'] = Box(-inf, inf, (self.robot.nv,), dtype=np.float32)
-        if self.observe_ctrl:
-            d['ctrl'] = Box(-inf, inf, (self.robot.nu,), dtype=np.float32)
-        if self.observe_vel:
-            d['vel'] = Box(-inf, inf, (2,), dtype=np.float32)
-        if self.observe_acc:
-            d['acc'] = Box(-inf, inf, (2,), dtype=np.float32)
-        self.obs_space_dict = d
-        self.obs_flat_size = int(sum(np.prod(v.shape) for v in d.values()))
-        self.observation_space = Box(-inf, inf, (self.obs_flat_size,), dtype=np.float32)
-        # column slices of the flat obs, sorted-key order (engine.py:773-777)
-        self._obs_slices = OrderedDict()
-        o = 0
-        for k in sorted(d.keys()):
-            n = int(np.prod(d[k].shape))
-            self._obs_slices[k] = slice(o, o + n)
-            o += n
+        rows = [row for row in self._obs_table() if row[1]]
+        self.obs_space_dict = OrderedDict((k, Box(lo, hi, (w,), dtype=np.float32)) for k, _, w, lo, hi in rows)
+        self.obs_flat_size = sum(w for _, _, w, _, _ in rows)
+        self.observation_space = Box(-np.inf, np.inf, (self.obs_flat_size,), dtype=np.float32)
+        self._obs_slices = OrderedDict()            # column ranges of the flat observation
+        col = 0
+        for k, _, w, _, _ in sorted(rows, key=lambda row: row[0]):
+            self._obs_slices[k] = slice(col, col + w)
+            col += w
 
     # ------------------------------------------------------------------
     # gym-style interface
@@ -411,23 +397,29 @@ class Engine:
         self.layout_size = int(n.value)
         return self.layout_size
 
-    def _out_slot(self):
-        """One set of step() outputs carved out of a single allocation: (obs, obs_rd, reward, cost, done, qacc)
-        and their device addresses."""
+    def _out_slab(self, k):
+        """`k` sets of step() outputs carved out of ONE allocation: per set (obs, obs_rd, reward, cost, done, qacc,
+        device addresses).  The views of a slab are made with six unbind() calls, not 6 k slicing operations."""
         N, D, nv = self.env_num, self.obs_flat_size, self.robot.nv
         Dp = (D + 3) // 4 * 4                      # keep every piece 16-byte aligned
-        flat = torch.empty(N * (2 * Dp + 3 + nv) + 16, dtype=torch.float32, device=self.device)
+        Np = (N + 3) // 4 * 4
+        per = 2 * N * Dp + 3 * Np + Np * nv
+        flat = torch.empty(k, per, dtype=torch.float32, device=self.device)
         o = 0
-        obs = flat[o:o + N * D].view(N, D); o += N * Dp
-        obs_rd = flat[o:o + N * D].view(N, D); o += N * Dp
-        rew = flat[o:o + N]; o += N
-        cost = flat[o:o + N]; o += N
-        done = flat[o:o + N]; o += N
-        o = (o + 3) // 4 * 4
-        qacc = flat[o:o + N * nv].view(N, nv) if self.emit_qacc else None
-        ptrs = (obs.data_ptr(), rew.data_ptr(), cost.data_ptr(), done.data_ptr(),
-                qacc.data_ptr() if qacc is not None else None, obs_rd.data_ptr())
-        return (obs, obs_rd, rew, cost, done, qacc, ptrs)
+        obs = flat[:, o:o + N * D].view(k, N, D).unbind(0); o += N * Dp
+        obs_rd = flat[:, o:o + N * D].view(k, N, D).unbind(0); o += N * Dp
+        rew = flat[:, o:o + N].unbind(0); o += Np
+        cost = flat[:, o:o + N].unbind(0); o += Np
+        done = flat[:, o:o + N].unbind(0); o += Np
+        qacc = flat[:, o:o + N * nv].view(k, N, nv).unbind(0) if self.emit_qacc else (None,) * k
+        base, off_rd, off_r, off_q = flat.data_ptr(), 4 * N * Dp, 8 * N * Dp, 4 * (2 * N * Dp + 3 * Np)
+        slots = []
+        for i in range(k):
+            b = base + 4 * per * i
+            ptrs = (b, b + off_r, b + off_r + 4 * Np, b + off_r + 8 * Np, (b + off_q) if self.emit_qacc else None,
+                    b + off_rd)
+            slots.append((obs[i], obs_rd[i], rew[i], cost[i], done[i], qacc[i], ptrs))
+        return slots
 
     def step(self, action):
         """One control step for every env (engine.py:469-495).  No auto-reset.  The same launch also
@@ -437,15 +429,15 @@ class Engine:
         if not (type(a) is torch.Tensor and a.dtype is torch.float32 and a.shape == self._act_shape
                 and a.device == self.device and a.is_contiguous() and not a.requires_grad):
             a = self._as_action(action)
-        if self._ring:
-            i = self._ring_i
-            slot = self._ring[i]
-            if slot is None:
-                slot = self._ring[i] = self._out_slot()
-            self._ring_i = i + 1 if i + 1 < len(self._ring) else 0
-        else:
-            slot = self._out_slot()
-        obs, obs_rd, reward, cost, done, qacc, p = slot
+        i = self._slab_i
+        if i >= len(self._slab):
+            # out_ring == 0 (default): a NEW slab -- tensors already handed out are never written again
+            # (engine.py:495 returns fresh buffers); out_ring > 0: wrap around and reuse the ring
+            if not self._out_ring or not self._slab:
+                self._slab = self._out_slab(self._out_ring or self._SLAB_STEPS)
+            i = 0
+        self._slab_i = i + 1
+        obs, obs_rd, reward, cost, done, qacc, p = self._slab[i]
         if self._speculate:
             st = self._lib.gx_step_rd(self._h, a.data_ptr(), p[0], p[1], p[2], p[3], p[4], p[5], self._spec_ref,
                                       self._stream())

@@ -74,3 +74,50 @@ def test_box_stand_in():
     assert b.shape == (43,) and b.dtype == np.float32
     a = Box(np.full(2, -np.inf, np.float32), np.full(2, np.inf, np.float32), dtype=np.float32)
     assert a.shape == (2,) and np.isinf(a.low).all()
+
+
+def _host_only(config, nq=3, nv=3, nu=3):
+    """the host-side configuration logic without a device: parse + placements + observation table"""
+    e = object.__new__(Engine)
+    e.parse(config)
+    e.robot = type('Robot', (), dict(nq=nq, nv=nv, nu=nu))()
+    e.build_placements_dict()
+    e.build_observation_space()
+    return e
+
+
+def test_placements_table_follows_the_reference_rules():
+    """engine.py:507-544: order goal, hazard0.., robot; `*_locations[i]` pins object i to the degenerate rectangle
+    of half-width keepout + 1e-9 around it, the others get the family's `*_placements` (None = the arena)."""
+    e = _host_only({'hazards_num': 3, 'hazards_locations': [(1.0, -0.5)], 'hazards_keepout': 0.25,
+                    'goal_placements': [(-1, -1, 0, 0)], 'robot_locations': [(0.5, 0.5), (9, 9)]})
+    assert list(e.placements) == ['goal', 'hazard0', 'hazard1', 'hazard2', 'robot']
+    assert e.placements['goal'] == ([(-1, -1, 0, 0)], 0.5)
+    k = 0.25 + 1e-9
+    assert e.placements['hazard0'] == ([(1.0 - k, -0.5 - k, 1.0 + k, -0.5 + k)], 0.25)
+    assert e.placements['hazard1'] == (None, 0.25) and e.placements['hazard2'] == (None, 0.25)
+    k = 0.4 + 1e-9
+    assert e.placements['robot'] == ([(0.5 - k, 0.5 - k, 0.5 + k, 0.5 + k)], 0.4)    # only the first location is used
+    p = _host_only(dict(configuration("Ant_8Hazards_8Pillars_synthetic")), 11, 11, 8).placements
+    assert list(p) == ['goal'] + [f'hazard{i}' for i in range(8)] + [f'pillar{i}' for i in range(8)] + ['robot']
+    assert p['pillar3'] == (None, 0.3)
+
+
+def test_observation_table_orders():
+    """engine.py:386-409: dict in insertion order; flat observation in sorted-key order (engine.py:773-777)"""
+    e = _host_only(dict(configuration("Goal_Point_8Hazards")))
+    assert list(e.obs_space_dict) == ['goal_lidar', 'goal_compass', 'hazards_lidar', 'qpos', 'qvel', 'ctrl']
+    assert e.obs_flat_size == 43 and e.observation_space.shape == (43,)
+    assert {k: (s.start, s.stop) for k, s in e._obs_slices.items()} == {
+        'ctrl': (0, 3), 'goal_compass': (3, 5), 'goal_lidar': (5, 21), 'hazards_lidar': (21, 37), 'qpos': (37, 40),
+        'qvel': (40, 43)}
+    assert float(e.obs_space_dict['goal_lidar'].low[0]) == 0.0 and float(e.obs_space_dict['goal_lidar'].high[0]) == 1.0
+    assert np.isinf(e.obs_space_dict['qpos'].low).all()
+    e = _host_only({'observe_vel': True, 'observe_acc': True, 'observe_hazards': False, 'lidar_num_bins': 10,
+                    'observe_ctrl': False}, 5, 5, 2)
+    assert list(e.obs_space_dict) == ['goal_lidar', 'goal_compass', 'qpos', 'qvel', 'vel', 'acc']
+    assert list(e._obs_slices) == ['acc', 'goal_compass', 'goal_lidar', 'qpos', 'qvel', 'vel']
+    assert e.obs_flat_size == 2 + 2 + 10 + 5 + 5 + 2
+    e = _host_only(dict(configuration("Ant_8Hazards_8Pillars_synthetic")), 11, 11, 8)
+    assert list(e._obs_slices) == ['ctrl', 'goal_compass', 'goal_lidar', 'hazards_lidar', 'pillars_lidar', 'qpos', 'qvel']
+    assert e.obs_flat_size == 80

@@ -344,6 +344,43 @@ def test_step_speculates_reset_done_without_installing_it(torch_cuda, oracle, ro
         assert_state_equal(E.get_state(), O.get_state())
 
 
+def test_step_outputs_are_never_overwritten_by_default(torch_cuda):
+    """Ownership (engine.py:495 returns fresh buffers): with the default out_ring=0 every tensor
+    step() / reset_done() handed out keeps its values however many calls follow (across slab boundaries: 32 calls
+    per slab); the opt-in ring of k sets overwrites a tensor exactly k calls later."""
+    torch = torch_cuda
+    from guardx_amd import Engine
+    N = 130
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    acts = torch.rand(80, N, 2, device='cuda', generator=gen) * 2 - 1
+    env = Engine(task_config(N, seed=2, num_steps=9, goal_size=2.8), n_candidates=30000)
+    env.reset()
+    kept, copies = [], []
+    for t in range(80):
+        o, r, d, info = env.step(acts[t])
+        rd = env.reset_done()
+        outs = (o, r, d, info['cost'], info['obs']['qacc'], rd)
+        kept.append(outs)
+        copies.append(tuple(x.clone() for x in outs))
+    torch.cuda.synchronize()
+    ptrs = {x.data_ptr() for outs in kept for x in outs}
+    assert len(ptrs) == 80 * 6                                   # no two live outputs share memory
+    for outs, cps in zip(kept, copies):
+        for a, b in zip(outs, cps):
+            assert torch.equal(a, b)
+    env.close()
+    ring = Engine(task_config(N, seed=2, num_steps=9, goal_size=2.8), n_candidates=30000, out_ring=8)
+    ring.reset()
+    first = ring.step(acts[0])[0]
+    snap = first.clone()
+    for t in range(1, 8):
+        assert ring.step(acts[t])[0].data_ptr() != first.data_ptr()
+    assert torch.equal(first, snap)                              # untouched for k - 1 further calls ...
+    again = ring.step(acts[8])[0]
+    assert again.data_ptr() == first.data_ptr() and not torch.equal(first, snap)   # ... and reused by call k
+    ring.close()
+
+
 def test_step_reset_done_above_the_group_limit(torch_cuda, oracle):
     """env_num > 16384 runs the thread-per-env kernels: step() does not speculate, reset_done() launches"""
     torch = torch_cuda
@@ -449,34 +486,72 @@ def test_pillars_config5_parity(torch_cuda, oracle, path, robot):
     np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
 
 
-def test_bench_workload_three_epochs(torch_cuda, oracle):
-    """EXACTLY bench.py's workload (BASELINE config 2): env_num=2000, n_candidates=1e6 (engine.py:263), 200-step
-    epochs of reset(check=False) + rollout with the default layout-pool prefetch, three epochs back to back,
-    against the checker: pool, layout_size, every observation / reward / cost / done, final state."""
-    torch = torch_cuda
-    N, T, M = 2000, 200, 1_000_000
-    E, O = _engines(task_config(N, seed=0, num_steps=T), oracle, n_candidates=M)
+def _bench_epochs(torch, oracle, cfg, A, epochs, N=2000, T=200, M=1_000_000, num_steps=None, prefetch=None):
+    """bench.py's epoch at its own sizes: env_num=2000, n_candidates=1e6 (engine.py:263), 200-step epochs of
+    reset(check=False) + rollout with the default layout-pool prefetch, back to back, against the checker:
+    pool head, layout_size, every observation / reward / cost / done row, final state, prefetch hits.
+    Returns the number of done events seen."""
+    cfg = dict(cfg)
+    cfg.update(env_num=N, _seed=0, num_steps=T if num_steps is None else num_steps)
+    E, O = _engines(cfg, oracle, n_candidates=M)
+    if prefetch is not None:
+        E.set_prefetch(prefetch)                      # bench.py: env.set_prefetch(EP_LEN)
     rng = np.random.default_rng(0)
-    for ep in range(3):
+    ndone = 0
+    for ep in range(epochs):
         og, oo = E.reset(check=False), O.reset()
         np.testing.assert_array_equal(og.cpu().numpy(), oo)
         if ep != 1:
             np.testing.assert_array_equal(E.get_pool(4096), O.get_pool(4096))
-        acts = rng.uniform(-1, 1, (T, N, 2)).astype(np.float32)
+        acts = rng.uniform(-1, 1, (T, N, A)).astype(np.float32)
         obs, rew, cost, done = E.rollout(torch.from_numpy(acts).cuda())
         obs, rew, cost, done = obs.cpu().numpy(), rew.cpu().numpy(), cost.cpu().numpy(), done.cpu().numpy()
         for t in range(T):
             o, r, d, info = O.step(acts[t])
             if d.any():
                 o = O.reset_done()
-            np.testing.assert_array_equal(obs[t], o)
-            np.testing.assert_array_equal(rew[t], r)
-            np.testing.assert_array_equal(done[t], d)
-            np.testing.assert_array_equal(cost[t], info['cost'])
+            np.testing.assert_array_equal(obs[t], o, err_msg=f"obs epoch {ep} step {t}")
+            np.testing.assert_array_equal(rew[t], r, err_msg=f"reward epoch {ep} step {t}")
+            np.testing.assert_array_equal(done[t], d, err_msg=f"done epoch {ep} step {t}")
+            np.testing.assert_array_equal(cost[t], info['cost'], err_msg=f"cost epoch {ep} step {t}")
+            ndone += int(d.sum())
         assert E.check_layouts() == O.layout_size > N
     assert_state_equal(E.get_state(), O.get_state())
     hits, misses, horizon = E.prefetch_stats()
-    assert (hits, misses, horizon) == (2, 0, T)       # epochs 2 and 3 took the prefetched pool
+    assert (hits, misses, horizon) == (epochs - 1, 0, T)       # every epoch after the first took the prefetched pool
+    E.close()
+    return ndone
+
+
+def test_bench_workload_three_epochs(torch_cuda, oracle):
+    """EXACTLY bench.py's headline workload (BASELINE config 2), three epochs back to back."""
+    _bench_epochs(torch_cuda, oracle, task_config(2000), 2, epochs=3)
+
+
+@pytest.mark.parametrize("name", ["Goal_Swimmer_8Hazards", "Goal_Ant_8Hazards", "Goal_Walker_8Hazards",
+                                  "Ant_8Hazards_8Pillars_synthetic"])
+def test_bench_workload_epochs_other_robots(torch_cuda, oracle, name):
+    """bench.py's `other_robots` epochs at the sizes it times them (env_num=2000, 1e6 layout candidates, 200 steps,
+    prefetch hits): BASELINE config 3 (Swimmer), Ant, Walker, and config 5's synthetic stand-in (Ant + 8 hazards + 8
+    pillars: the 18-object sampler and the two-objects-per-lane kernel instance)."""
+    from guardx_amd import configuration
+    cfg = configuration(name)
+    A = {'xmls/swimmer.xml': 2, 'xmls/ant.xml': 8, 'xmls/walker.xml': 10}[cfg['robot_base']]
+    _bench_epochs(torch_cuda, oracle, cfg, A, epochs=2)
+
+
+@pytest.mark.parametrize("name", ["Goal_Point_8Hazards", "Goal_Swimmer_8Hazards", "Ant_8Hazards_8Pillars_synthetic"])
+def test_bench_workload_reset_done_heavy(torch_cuda, oracle, name):
+    """bench.py's `reset_done_heavy` extra at the bench's sizes: the same epoch with episodes shorter than the
+    epoch (num_steps = 60: the timeout of engine.py:492 ends every episode on its 62nd step) and a goal wide enough
+    that envs also finish at scattered times -- every env runs the reset_done branch (layout draw, re-placement,
+    re-initialised observation row) about three times per epoch inside the rollout."""
+    from guardx_amd import configuration
+    cfg = dict(configuration(name))
+    cfg['goal_size'] = 2.9
+    A = {'xmls/point.xml': 2, 'xmls/swimmer.xml': 2, 'xmls/ant.xml': 8}[cfg['robot_base']]
+    ndone = _bench_epochs(torch_cuda, oracle, cfg, A, epochs=2, num_steps=60, prefetch=200)
+    assert ndone >= 2 * 3 * 2000
 
 
 def test_config4_shape_eight_shards_of_2000(torch_cuda, oracle):
