@@ -51,3 +51,132 @@ def test_point_steps_match_the_checker(oracle):
         obs, *_ = E.step(a[None])
         np.testing.assert_allclose(obs[0, 37:40], d.qpos[:3], rtol=2e-4, atol=2e-5)
         np.testing.assert_allclose(obs[0, 40:43], d.qvel[:3], rtol=2e-4, atol=2e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Beyond the Point: the articulated robots against MuJoCo itself -- joint-limit rows (Swimmer),
+# limit + foot-floor contact rows and the constraint solve (Ant, Walker), the one-step lag of xpos / xmat behind
+# qpos (engine.py:676-677, 754-762) and the "fake step" of mjx_reset_done (engine.py:719-731).  MuJoCo's C engine is
+# float64 with its own Newton solver; the restatement is fp32 with an active-set solve of the same convex problem:
+# the comparison is to 3e-3 of the step's change, which separates "same physics" from any of the [derived]
+# assumptions being wrong (a missing contact row or a wrong R changes qacc by tens of percent).
+# ---------------------------------------------------------------------------------------------------------------
+from helpers import task_config, random_state, SWIMMER, ANT, WALKER   # noqa: E402
+
+ROBOTS = {"swimmer": ("swimmer.xml", SWIMMER, 2), "ant": ("ant.xml", ANT, 8), "walker": ("walker.xml", WALKER, 10)}
+
+
+def _mj(robot):
+    m = mujoco.MjModel.from_xml_path(os.path.join(XML_DIR, ROBOTS[robot][0]))
+    return m, mujoco.MjData(m)
+
+
+def _robot_body(m):
+    return m.body('robot').id
+
+
+@pytest.mark.parametrize("robot", sorted(ROBOTS))
+def test_one_step_from_random_states_matches_mujoco(oracle, robot):
+    """qacc and one Euler step from random states that sit beyond joint limits / press feet into the floor"""
+    m, d = _mj(robot)
+    xml, extra, A = ROBOTS[robot]
+    N = 200
+    E = oracle.OracleEngine(task_config(N, **extra), n_candidates=4000)
+    E.reset(check=False)
+    rng = np.random.default_rng(7)
+    s = random_state(N, 8, rng, robot=robot, done_frac=0.0, near_frac=0.0)
+    s['objs'][:] = 50.0
+    s['hist'] = 2
+    E.set_state(s)
+    act = rng.uniform(-1.4, 1.4, (N, A)).astype(np.float32)        # beyond ctrlrange: clamped for the force only
+    obs, rew, done, info = E.step(act)
+    st = E.get_state()
+    nq, nv = E.nq, E.nv
+    active = 0
+    for i in range(N):
+        mujoco.mj_resetData(m, d)
+        d.qpos[:nq] = s['qpos'][i]; d.qvel[:nv] = s['qvel'][i]; d.ctrl[:] = act[i]
+        mujoco.mj_step(m, d)
+        active += int(d.nefc > 0)
+        if not np.isfinite(st['qpos'][i]).all():                    # the x / body-y slide singularity (Ant, Walker)
+            continue
+        dq = np.abs(d.qvel[:nv] - s['qvel'][i]).max() + 1e-3
+        np.testing.assert_allclose(st['qvel'][i], d.qvel[:nv], rtol=0, atol=3e-3 * dq, err_msg=f"{robot} env {i} qvel")
+        np.testing.assert_allclose(st['qpos'][i], d.qpos[:nq], rtol=0, atol=3e-3 * dq * m.opt.timestep + 1e-6,
+                                   err_msg=f"{robot} env {i} qpos")
+        # the pose the returned data carries is the kinematics of the PRE-step qpos (mj_step = forward; integrate)
+        rb = _robot_body(m)
+        R = d.xmat[rb].reshape(3, 3)
+        np.testing.assert_allclose(st['pose0'][i], [d.xpos[rb][0], d.xpos[rb][1], R[0, 0], R[1, 0]], rtol=0, atol=2e-5)
+    assert active > N // 4, "the sampled states never activated a constraint row"
+
+
+@pytest.mark.parametrize("robot", ["swimmer"])
+def test_limit_rows_activate_like_mujoco(robot):
+    """a joint beyond its range (and only then) yields one constraint row, with MuJoCo's aref and R"""
+    m, d = _mj(robot)
+    lim = np.deg2rad(100.0)
+    for q3, expect in ((lim - 1e-3, 0), (lim + 1e-3, 1), (-lim - 0.05, 1)):
+        mujoco.mj_resetData(m, d)
+        d.qpos[3] = q3
+        mujoco.mj_forward(m, d)
+        assert d.nefc == expect
+    np.testing.assert_allclose(m.opt.timestep, 0.03)
+    np.testing.assert_allclose(m.dof_armature, 0.1)
+    np.testing.assert_allclose(m.actuator_gear[:, 0], 20.0)
+
+
+@pytest.mark.parametrize("robot", ["ant", "walker"])
+def test_contact_rows_activate_like_mujoco(robot):
+    """only the foot spheres collide with the floor; pyramidal cones, condim 3: four rows per touching foot"""
+    m, d = _mj(robot)
+    assert m.opt.cone == int(mujoco.mjtCone.mjCONE_PYRAMIDAL)
+    mujoco.mj_resetData(m, d)
+    mujoco.mj_forward(m, d)
+    n0 = d.ncon
+    feet = 4 if robot == "ant" else 2
+    assert n0 <= feet
+    for c in d.contact[:d.ncon]:
+        assert c.dim == 3
+        g = {m.geom(c.geom1).name, m.geom(c.geom2).name}
+        assert any('floor' in n for n in g)
+
+
+@pytest.mark.parametrize("robot", ["ant", "walker"])
+def test_reset_done_fake_step_matches_mujoco(oracle, robot):
+    """mjx_reset_done (engine.py:702-731) builds the re-initialised observation from ONE physics step of the rest
+    state at the new layout (zero ctrl): for robots that move at rest (ankles outside their range, gravity on the
+    feet) qpos / qvel in that observation are the stepped ones.  A goal wider than the arena finishes every env on
+    the first step, so every row of reset_done() is such an observation."""
+    m, d = _mj(robot)
+    xml, extra, A = ROBOTS[robot]
+    N = 16
+    cfg = task_config(N, goal_size=50.0, **extra)
+    E = oracle.OracleEngine(cfg, n_candidates=20000)
+    E.reset(check=False)
+    E.step(np.zeros((N, A), np.float32))
+    rd = E.reset_done()
+    st = E.get_state()                                  # the re-initialised state (NOT stepped): rest at the layout
+    nq, nv = E.nq, E.nv
+    D = rd.shape[1]
+    qcol = slice(D - nq - nv, D - nv)                   # flat obs: ... qpos | qvel
+    vcol = slice(D - nv, D)
+    for i in range(N):
+        mujoco.mj_resetData(m, d)
+        d.qpos[:nq] = st['qpos'][i]
+        d.qvel[:] = 0; d.ctrl[:] = 0
+        mujoco.mj_step(m, d)
+        dv = np.abs(d.qvel[:nv]).max() + 1e-3
+        np.testing.assert_allclose(rd[i, vcol], d.qvel[:nv], rtol=0, atol=3e-3 * dv)
+        np.testing.assert_allclose(rd[i, qcol], d.qpos[:nq], rtol=0, atol=3e-3 * dv * m.opt.timestep + 1e-6)
+    assert np.abs(rd[:, vcol]).max() > 1e-3             # these robots do move at rest
+
+
+def test_point_rests_without_contact_forces():
+    """SURVEY Appendix B's most fragile assumption: the Point's sphere touches the floor at dist == 0 with margin 0,
+    which creates no active contact (no friction on the slides); a free glide decays by joint damping alone."""
+    m = mujoco.MjModel.from_xml_path(os.path.join(XML_DIR, "point.xml"))
+    d = mujoco.MjData(m)
+    d.qvel[0] = 1.0
+    mujoco.mj_forward(m, d)
+    assert d.nefc == 0
