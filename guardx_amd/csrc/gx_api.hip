@@ -332,10 +332,7 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
         Pool& pl = e->pools[i];
         alloc((void**)&pl.cand_ok, M);
         alloc((void**)&pl.cand_xy, sizeof(float2) * M * e->nobj_total);
-        // padded to whole scan tiles (the fast scan reads and writes 16 ints per thread); alloc() zero-fills
-        const size_t Wpad = ((size_t)W + kScanTile - 1) / kScanTile * kScanTile;
-        alloc((void**)&pl.wave_cnt, sizeof(int) * Wpad);
-        alloc((void**)&pl.wave_off, sizeof(int) * Wpad);
+        alloc((void**)&pl.wave_cnt, sizeof(int) * ((W + 63) / 64 * 64)); // whole 64-group blocks of scan_compact_kernel
         alloc((void**)&pl.cand_of, sizeof(int) * M);
         alloc((void**)&pl.layout_size, sizeof(int));
         alloc((void**)&pl.n_surv, 2 * sizeof(int));
@@ -394,7 +391,7 @@ extern "C" gx_status gx_destroy(gx_engine* e)
         if (q) (void)hipFree(q);
     for (int i = 0; i < gx_engine::kPools; ++i) {
         Pool& pl = e->pools[i];
-        void* pb[] = {pl.cand_ok, pl.cand_xy, pl.wave_cnt, pl.wave_off, pl.cand_of, pl.layout_size, pl.n_surv, pl.surv, pl.surv0, pl.fake};
+        void* pb[] = {pl.cand_ok, pl.cand_xy, pl.wave_cnt, pl.cand_of, pl.layout_size, pl.n_surv, pl.surv, pl.surv0, pl.fake};
         for (void* q : pb)
             if (q) (void)hipFree(q);
         if (e->pool_ready[i]) (void)hipEventDestroy(e->pool_ready[i]);

@@ -23,15 +23,13 @@ struct SampleParams {
     unsigned long long* dbg; // null, or per phase-2 wave: s_memtime at entry / exit, HW_ID, XCC_ID (gx_debug_stamps)
 };
 
-constexpr int kScanTile = 16 * 1024; // counts per tile of scan_kernel: wave_cnt / wave_off are padded to whole tiles
 
 // valid-layout pool of one reset_layout() (engine.py:433-444); two of them are kept so the
 // next epoch's pool can be sampled on a side stream while the current one is in use
 struct Pool {
     uint8_t* cand_ok;  // [M]
     float2* cand_xy;   // [M][nobj_total]  (rows written only for valid candidates)
-    int* wave_cnt;     // [ceil(M/64)]
-    int* wave_off;     // [ceil(M/64)]
+    int* wave_cnt;     // [ceil(M/64) padded to 64]: valid candidates per group of 64 (zeroed by phase 0, counted by phase 2)
     int* cand_of;      // [M] compacted candidate indices (ascending)
     int* layout_size;  // [1]
     int* n_surv;       // [2] phase-1 survivors, phase-0 survivors

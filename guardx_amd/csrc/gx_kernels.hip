@@ -78,7 +78,8 @@ GX_D int alloc_slot(bool want, int* __restrict__ counter)
 __global__ __launch_bounds__(kSampleBlock) void sample_phase0_kernel(SampleParams sp,
                                                                      uint8_t* __restrict__ ok,
                                                                      int* __restrict__ n_surv0,
-                                                                     uint32_t* __restrict__ surv0)
+                                                                     uint32_t* __restrict__ surv0,
+                                                                     int* __restrict__ wave_cnt)
 {
     const int tid = threadIdx.x;
     const int j = blockIdx.x * kSampleBlock + tid;
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(kSampleBlock) void sample_phase0_kernel(SampleParam
     const float fy = fmaxf(fabsf(sp.lo_y[2] - gy), fabsf(sp.hi_y[2] - gy));
     const bool feasible = !((fx * fx + fy * fy) * 1.0001f < sp.min_rg_sq);
     if (live) ok[j] = 0;
+    if (live && (j & 63) == 0) wave_cnt[j >> 6] = 0; // per-group success counts: incremented by phase 2
     const int slot = alloc_slot(live && feasible, n_surv0);
     if (slot >= 0) {
         uint4* rec = reinterpret_cast<uint4*>(surv0) + (size_t)slot * 2;
@@ -178,7 +180,8 @@ __global__ __launch_bounds__(kP2Block * kP2Waves) void sample_phase2_kernel(Samp
                                                                  const int* __restrict__ n_surv,
                                                                  const uint32_t* __restrict__ surv,
                                                                  uint8_t* __restrict__ ok,
-                                                                 float2* __restrict__ cand_xy)
+                                                                 float2* __restrict__ cand_xy,
+                                                                 int* __restrict__ wave_cnt)
 {
     extern __shared__ float4 smem4[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -207,6 +210,24 @@ __global__ __launch_bounds__(kP2Block * kP2Waves) void sample_phase2_kernel(Samp
         wave_sync(); // the previous batch's reads of `placed` are done
         placed[lane] = make_float2(gx, gy);
         bool alive = live; // placed everything so far
+        // The robot's ten tries were drawn in phase 1.  The layout succeeds iff its HIGHEST valid try (valid: clear of
+        // the goal and of every hazard / pillar, draw_placement :579-621) is >= 3.0 from the goal (:570-571).  Placed
+        // objects only ever invalidate tries, so as soon as no far try is valid any more the candidate cannot succeed
+        // and the lane stops owning draws (it keeps helping): exact, and ~10 % of the remaining candidates leave per
+        // hazard -- the late hazards, whose draws cost the most rounds, see a fifth of them.
+        float cx[10], cy[10];
+        unsigned rvalid = 0u, rfar = 0u; // bit t: try t conflicts with nothing placed so far / is far from the goal
+        {
+            const float tgr = sp.thr_sq[0][2];
+#pragma unroll
+            for (int t = 0; t < 10; ++t) {
+                cx[t] = u2f(rec[5 + 2 * t]); cy[t] = u2f(rec[6 + 2 * t]);
+                const float d2 = dsq(cx[t], cy[t], gx, gy);
+                if (!(d2 < tgr)) rvalid |= 1u << t;
+                if (!(d2 < sp.min_rg_sq)) rfar |= 1u << t;
+            }
+        }
+        if (!(rvalid & rfar)) alive = false;
         for (int o = 1; o < nobj - 1; ++o) { // hazards, then pillars
             const int tn = o <= sp.H ? 1 : 3;
             const float4 hb = sp.haz_bounds ? sp.haz_bounds[o - 1]
@@ -280,31 +301,27 @@ __global__ __launch_bounds__(kP2Block * kP2Waves) void sample_phase2_kernel(Samp
                 wave_sync(); // owner / best are rewritten by the next round
             }
             placed[o * kP2Block + lane] = make_float2(px, py);
+            if (alive) { // the robot tries this object rules out
+                const float thr = o <= sp.H ? sp.thr_sq[1][2] : sp.thr_sq[3][2];
+#pragma unroll
+                for (int t = 0; t < 10; ++t)
+                    if (dsq(cx[t], cy[t], px, py) < thr) rvalid &= ~(1u << t);
+                if (!(rvalid & rfar)) alive = false;
+            }
             wave_sync();
         }
         bool success = alive;
         float px = -__builtin_inff(), py = -__builtin_inff();
-        if (alive) { // robot: tries were drawn in phase 1
-            const float tg = sp.thr_sq[0][2], th = sp.thr_sq[1][2], tp = sp.thr_sq[3][2];
-            float cx[10], cy[10];
-#pragma unroll
-            for (int t = 0; t < 10; ++t) { cx[t] = u2f(rec[5 + 2 * t]); cy[t] = u2f(rec[6 + 2 * t]); }
-            unsigned valid = 0x3ffu; // bit t: try t conflicts with nothing placed
-            for (int q = 0; q < nobj - 1; ++q) {
-                const float2 pq = placed[q * kP2Block + lane];
-                const float thr = q == 0 ? tg : (q <= sp.H ? th : tp);
-#pragma unroll
-                for (int t = 0; t < 10; ++t)
-                    if (dsq(cx[t], cy[t], pq.x, pq.y) < thr) valid &= ~(1u << t);
-            }
+        if (alive) { // robot: the last valid try wins
 #pragma unroll
             for (int t = 0; t < 10; ++t)
-                if (valid & (1u << t)) { px = cx[t]; py = cy[t]; } // the last valid try wins
-            if (!valid) success = false;
+                if (rvalid & (1u << t)) { px = cx[t]; py = cy[t]; }
+            if (!rvalid) success = false;
             if (dsq(px, py, gx, gy) < sp.min_rg_sq) success = false; // :570-571
         }
         if (success) {
             ok[j] = 1;
+            atomicAdd(&wave_cnt[j >> 6], 1);
             for (int o = 0; o < nobj - 1; ++o) cand_xy[(size_t)j * nobj + o] = placed[o * kP2Block + lane];
             cand_xy[(size_t)j * nobj + nobj - 1] = make_float2(px, py);
         }
@@ -312,76 +329,54 @@ __global__ __launch_bounds__(kP2Block * kP2Waves) void sample_phase2_kernel(Samp
     if (sp.dbg && lane == 0 && wave0 * kP2Block < NS) sp.dbg[(size_t)wave0 * 4 + 1] = __builtin_amdgcn_s_memtime();
 }
 
-// per-wave count of valid candidates (in candidate order)
-__global__ __launch_bounds__(kSampleBlock) void count_kernel(int M, const uint8_t* __restrict__ ok,
-                                                             int* __restrict__ wave_cnt)
+// idx = where(success > 0)[0]  (engine.py:436): ordered compaction of the valid candidates, ONE launch.
+// wave_cnt[g] = number of valid candidates among the 64 of group g: zeroed by phase 0 (which visits every candidate),
+// incremented by phase 2 once per success.  Block b owns kGroupsPerBlock consecutive groups: it sums the counts of
+// every group in front of its range itself (at most M/64 ints, L2 resident -- 245 blocks x <= 61 KB for 1e6
+// candidates), so no block waits for another, scans its own counts in one wave, and writes cand_of; the last block
+// also writes layout_size.  Replaces count + one-block scan + compact (three launches, ~15 us).
+constexpr int kGroupsPerBlock = 64;
+__global__ __launch_bounds__(kSampleBlock) void scan_compact_kernel(int M, const uint8_t* __restrict__ ok,
+                                                                    const int* __restrict__ wave_cnt,
+                                                                    int* __restrict__ cand_of,
+                                                                    int* __restrict__ layout_size)
 {
-    const int j = blockIdx.x * kSampleBlock + threadIdx.x;
-    const bool live = j < M;
-    const unsigned long long m = __ballot(live && ok[live ? j : 0]);
-    if ((threadIdx.x & 63) == 0 && live) wave_cnt[j >> 6] = __popcll(m);
-}
-
-// exclusive scan of the per-wave valid counts (one block).  Tiles of 1024 threads x 16 counts: every thread
-// moves its 16 counts with four 16-byte loads / stores (the arrays are padded to whole tiles and the padding
-// is zero), scans them in registers, and the 1024 thread totals are scanned with wave shuffles plus one LDS
-// hop -- the whole kernel is a few microseconds instead of 16 dependent dword round trips per thread.
-constexpr int kScanBlock = 1024;
-static_assert(kScanTile == kScanBlock * 16, "16 counts per thread");
-__global__ __launch_bounds__(kScanBlock) void scan_kernel(const int* __restrict__ cnt,
-                                                          int* __restrict__ off, int W,
-                                                          int* __restrict__ total)
-{
-    __shared__ int wsum[kScanBlock / 64];
-    __shared__ int carry_s;
+    __shared__ int part[kSampleBlock / 64];
+    __shared__ int goff[kGroupsPerBlock];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) carry_s = 0;
+    const int W = (M + 63) >> 6;
+    const int g0 = blockIdx.x * kGroupsPerBlock;
+    // sum of the counts in front of this block's groups (g0 is a multiple of 64, wave_cnt is 16-byte aligned)
+    int acc = 0;
+    const int4* c4 = reinterpret_cast<const int4*>(wave_cnt);
+    for (int k = tid; k < g0 / 4; k += kSampleBlock) { const int4 v = c4[k]; acc += (v.x + v.y) + (v.z + v.w); }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if (lane == 0) part[wv] = acc;
     __syncthreads();
-    for (int base = 0; base < W; base += kScanTile) {
-        const int4* src = reinterpret_cast<const int4*>(cnt + base) + tid * 4;
-        int v[16];
+    int base = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int4 t = src[k];
-            v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
-        }
-        int sum = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { const int c = v[k]; v[k] = sum; sum += c; } // exclusive within the thread
-        // inclusive scan of the thread totals across the wave
-        int inc = sum;
+    for (int k = 0; k < kSampleBlock / 64; ++k) base += part[k];
+    // exclusive scan of this block's group counts (wave 0)
+    if (wv == 0) {
+        const int g = g0 + lane;
+        const int c = g < W ? wave_cnt[g] : 0;
+        int inc = c;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int up = __shfl_up(inc, d, 64);
             if (lane >= d) inc += up;
         }
-        if (lane == 63) wsum[wv] = inc;
-        __syncthreads();
-        int wbase = carry_s;
-        for (int k = 0; k < wv; ++k) wbase += wsum[k];
-        const int tbase = wbase + (inc - sum);
-        int4* dst = reinterpret_cast<int4*>(off + base) + tid * 4;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            dst[k] = make_int4(tbase + v[4 * k], tbase + v[4 * k + 1], tbase + v[4 * k + 2], tbase + v[4 * k + 3]);
-        __syncthreads();
-        if (tid == kScanBlock - 1) carry_s = tbase + sum;
-        __syncthreads();
+        goff[lane] = base + inc - c;
+        if (lane == 63 && blockIdx.x == gridDim.x - 1) *layout_size = base + inc;
     }
-    if (tid == 0) *total = carry_s;
-}
-
-// idx = where(success > 0)[0]  (engine.py:436): ordered compaction
-__global__ __launch_bounds__(kSampleBlock) void compact_kernel(int M, const uint8_t* __restrict__ ok,
-                                                               const int* __restrict__ off,
-                                                               int* __restrict__ cand_of)
-{
-    const int j = blockIdx.x * kSampleBlock + threadIdx.x;
-    const bool v = (j < M) && ok[j];
-    const unsigned long long m = __ballot(v);
-    const int lane = threadIdx.x & 63;
-    const int rank = __popcll(m & ((1ull << lane) - 1ull));
-    if (v) cand_of[off[j >> 6] + rank] = j;
+    __syncthreads();
+    for (int gg = wv; gg < kGroupsPerBlock; gg += kSampleBlock / 64) {
+        const int j = (g0 + gg) * 64 + lane;
+        const bool v = (j < M) && ok[j];
+        const unsigned long long m = __ballot(v);
+        if (v) cand_of[goff[gg] + __popcll(m & ((1ull << lane) - 1ull))] = j;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -431,7 +426,7 @@ hipError_t launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s, 
     hipError_t st = hipMemsetAsync(pl.n_surv, 0, 2 * sizeof(int), s); // n_surv, n_surv0
     if (st != hipSuccess) return st;
     hipLaunchKernelGGL(sample_phase0_kernel, dim3(grid), dim3(kSampleBlock), 0, s, sp, pl.cand_ok, pl.n_surv + 1,
-                       pl.surv0);
+                       pl.surv0, pl.wave_cnt);
     // GX_SAMPLE_GRID_CAP (tests): a small cap makes phases 1 and 2 take many grid-stride iterations at small M
     int cap = 1 << 30;
     if (const char* ev = getenv("GX_SAMPLE_GRID_CAP")) cap = atoi(ev) > 0 ? atoi(ev) : cap;
@@ -447,12 +442,9 @@ hipError_t launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s, 
     const int grid2 = wgs < cap2 ? wgs : cap2;
     const size_t lds2 = wpb * lds_wave;
     hipLaunchKernelGGL(sample_phase2_kernel, dim3(grid2), dim3(kP2Block * wpb), lds2, s, sp, pl.n_surv, pl.surv,
-                       pl.cand_ok, pl.cand_xy);
-    hipLaunchKernelGGL(count_kernel, dim3(grid), dim3(kSampleBlock), 0, s, M, pl.cand_ok, pl.wave_cnt);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kScanBlock), 0, s, pl.wave_cnt, pl.wave_off, W,
-                       pl.layout_size);
-    hipLaunchKernelGGL(compact_kernel, dim3(grid), dim3(kSampleBlock), 0, s, M, pl.cand_ok, pl.wave_off,
-                       pl.cand_of);
+                       pl.cand_ok, pl.cand_xy, pl.wave_cnt);
+    hipLaunchKernelGGL(scan_compact_kernel, dim3((W + kGroupsPerBlock - 1) / kGroupsPerBlock), dim3(kSampleBlock), 0, s,
+                       M, pl.cand_ok, pl.wave_cnt, pl.cand_of, pl.layout_size);
     return hipSuccess;
 }
 
