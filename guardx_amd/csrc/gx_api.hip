@@ -312,7 +312,7 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     for (int i = 0; i < gx_engine::kKeyRing; ++i) { e->h_keys[i] = nullptr; e->keys_cap[i] = 0; e->keys_ev[i] = nullptr; }
     memset(&e->b, 0, sizeof(e->b));
 
-    const size_t M = (size_t)sp.M, W = (M + 63) / 64;
+    const size_t M = (size_t)sp.M;
     hipError_t err = hipSuccess;
     auto alloc = [&](void** ptr, size_t bytes) {
         if (err == hipSuccess) err = hipMalloc(ptr, bytes);
@@ -330,9 +330,10 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     }
     for (int i = 0; i < gx_engine::kPools; ++i) {
         Pool& pl = e->pools[i];
-        alloc((void**)&pl.cand_ok, M);
+        const size_t tile = (size_t)sample_compact_tile();
+        alloc((void**)&pl.cand_ok, (M + tile - 1) / tile * tile);
         alloc((void**)&pl.cand_xy, sizeof(float2) * M * e->nobj_total);
-        alloc((void**)&pl.wave_cnt, sizeof(int) * ((W + 63) / 64 * 64)); // whole 64-group blocks of scan_compact_kernel
+        alloc((void**)&pl.blk_cnt, sizeof(int) * ((M + tile - 1) / tile));
         alloc((void**)&pl.cand_of, sizeof(int) * M);
         alloc((void**)&pl.layout_size, sizeof(int));
         alloc((void**)&pl.n_surv, 2 * sizeof(int));
@@ -391,7 +392,7 @@ extern "C" gx_status gx_destroy(gx_engine* e)
         if (q) (void)hipFree(q);
     for (int i = 0; i < gx_engine::kPools; ++i) {
         Pool& pl = e->pools[i];
-        void* pb[] = {pl.cand_ok, pl.cand_xy, pl.wave_cnt, pl.cand_of, pl.layout_size, pl.n_surv, pl.surv, pl.surv0, pl.fake};
+        void* pb[] = {pl.cand_ok, pl.cand_xy, pl.blk_cnt, pl.cand_of, pl.layout_size, pl.n_surv, pl.surv, pl.surv0, pl.fake};
         for (void* q : pb)
             if (q) (void)hipFree(q);
         if (e->pool_ready[i]) (void)hipEventDestroy(e->pool_ready[i]);

@@ -27,9 +27,9 @@ struct SampleParams {
 // valid-layout pool of one reset_layout() (engine.py:433-444); two of them are kept so the
 // next epoch's pool can be sampled on a side stream while the current one is in use
 struct Pool {
-    uint8_t* cand_ok;  // [M]
+    uint8_t* cand_ok;  // [M padded to whole compaction tiles] 0 / 1 (the padding stays 0)
     float2* cand_xy;   // [M][nobj_total]  (rows written only for valid candidates)
-    int* wave_cnt;     // [ceil(M/64) padded to 64]: valid candidates per group of 64 (zeroed by phase 0, counted by phase 2)
+    int* blk_cnt;      // [ceil(M / sample_compact_tile())] valid candidates per compaction tile (zeroed by phase 0, counted by phase 2)
     int* cand_of;      // [M] compacted candidate indices (ascending)
     int* layout_size;  // [1]
     int* n_surv;       // [2] phase-1 survivors, phase-0 survivors
@@ -50,7 +50,8 @@ struct DevBuffers {
 void launch_step(const Params& p, const DevBuffers& b, const float* act, float* obs, float* rew,
                  float* cost, float* done, float* qacc, hipStream_t s);
 // `after_phase1`: null, or an event recorded on `s` once the fully VALU-bound phases 0 and 1 are done
-// returns the status of the counter reset / event record it enqueues (ordering-critical: never dropped)
+int sample_compact_tile(); // candidates per block of the ordered compaction: cand_ok is padded to a multiple of it
+// returns the status of the event record it enqueues (ordering-critical: never dropped)
 hipError_t launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s, hipEvent_t after_phase1 = nullptr);
 void launch_reset_apply(const Params& p, const DevBuffers& b, int nobj_total, uint32_t k10,
                         uint32_t k11, uint32_t k20, uint32_t k21, float* obs, int* host_layout_size,

@@ -26,6 +26,8 @@ namespace gx {
 //    key after the goal), validate the saved robot tries, decide success.
 // ---------------------------------------------------------------------------
 constexpr int kSampleBlock = 256;
+constexpr int kCompactPerThread = 16;
+constexpr int kCompactTile = kSampleBlock * kCompactPerThread; // candidates per block of scan_compact_kernel (4096)
 constexpr int kSurvWords = 32; // j, rng(2), goal(2), robot tries(20), pad
 
 // squared distance with the operation order of sqrt(sum(square(a - b))) (engine.py:553);
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(kSampleBlock) void sample_phase0_kernel(SampleParam
                                                                      uint8_t* __restrict__ ok,
                                                                      int* __restrict__ n_surv0,
                                                                      uint32_t* __restrict__ surv0,
-                                                                     int* __restrict__ wave_cnt)
+                                                                     int* __restrict__ blk_cnt)
 {
     const int tid = threadIdx.x;
     const int j = blockIdx.x * kSampleBlock + tid;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(kSampleBlock) void sample_phase0_kernel(SampleParam
     const float fy = fmaxf(fabsf(sp.lo_y[2] - gy), fabsf(sp.hi_y[2] - gy));
     const bool feasible = !((fx * fx + fy * fy) * 1.0001f < sp.min_rg_sq);
     if (live) ok[j] = 0;
-    if (live && (j & 63) == 0) wave_cnt[j >> 6] = 0; // per-group success counts: incremented by phase 2
+    if (live && (j & (kCompactTile - 1)) == 0) blk_cnt[j / kCompactTile] = 0; // per-4096 success counts (phase 2)
     const int slot = alloc_slot(live && feasible, n_surv0);
     if (slot >= 0) {
         uint4* rec = reinterpret_cast<uint4*>(surv0) + (size_t)slot * 2;
@@ -169,11 +171,14 @@ struct P2Lds {
 // SIMDs of its CU: VALU issue is arbitrated oldest-first, a SIMD with n waves finishes after T_alone + (n-1) T_issue
 // (stamps: 160k + (n-1) 85k ticks), and with one-wave workgroups the hardware put 5 waves on 5 % of the SIMDs and 3 on
 // 25 % -- the kernel took the 5-wave time.
+// Order this wave's LDS traffic (lanes exchange data through LDS; a wave's LDS operations execute in program order, so
+// no instruction is needed -- only the compiler must not move them).  LDS-only fences: a fence over all address spaces
+// also makes the compiler wait for the wave's outstanding global loads and stores (s_waitcnt vmcnt(0)).
 GX_D void wave_sync()
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
 __global__ __launch_bounds__(kP2Block * kP2Waves) void sample_phase2_kernel(SampleParams sp,
@@ -181,7 +186,7 @@ __global__ __launch_bounds__(kP2Block * kP2Waves) void sample_phase2_kernel(Samp
                                                                  const uint32_t* __restrict__ surv,
                                                                  uint8_t* __restrict__ ok,
                                                                  float2* __restrict__ cand_xy,
-                                                                 int* __restrict__ wave_cnt)
+                                                                 int* __restrict__ blk_cnt)
 {
     extern __shared__ float4 smem4[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(kP2Block * kP2Waves) void sample_phase2_kernel(Samp
         }
         if (success) {
             ok[j] = 1;
-            atomicAdd(&wave_cnt[j >> 6], 1);
+            atomicAdd(&blk_cnt[j / kCompactTile], 1);
             for (int o = 0; o < nobj - 1; ++o) cand_xy[(size_t)j * nobj + o] = placed[o * kP2Block + lane];
             cand_xy[(size_t)j * nobj + nobj - 1] = make_float2(px, py);
         }
@@ -330,52 +335,56 @@ __global__ __launch_bounds__(kP2Block * kP2Waves) void sample_phase2_kernel(Samp
 }
 
 // idx = where(success > 0)[0]  (engine.py:436): ordered compaction of the valid candidates, ONE launch.
-// wave_cnt[g] = number of valid candidates among the 64 of group g: zeroed by phase 0 (which visits every candidate),
-// incremented by phase 2 once per success.  Block b owns kGroupsPerBlock consecutive groups: it sums the counts of
-// every group in front of its range itself (at most M/64 ints, L2 resident -- 245 blocks x <= 61 KB for 1e6
-// candidates), so no block waits for another, scans its own counts in one wave, and writes cand_of; the last block
-// also writes layout_size.  Replaces count + one-block scan + compact (three launches, ~15 us).
-constexpr int kGroupsPerBlock = 64;
+// blk_cnt[b] = number of valid candidates among the 4096 of block b: zeroed by phase 0 (which visits every candidate),
+// incremented by phase 2 once per success.  Block b sums the counts of the blocks in front of it itself (245 ints for
+// 1e6 candidates), so no block waits for another; each of its 256 threads takes the flags of 16 consecutive candidates
+// with ONE 16-byte load (the flags are 0 / 1 bytes), the block scans the 256 per-thread counts, and the threads write
+// their cand_of entries; the last block also writes layout_size and re-arms the survivor counters for the next
+// launch_sample on this pool.  Replaces memset + count + one-block scan + compact (four launches, ~20 us).
 __global__ __launch_bounds__(kSampleBlock) void scan_compact_kernel(int M, const uint8_t* __restrict__ ok,
-                                                                    const int* __restrict__ wave_cnt,
+                                                                    const int* __restrict__ blk_cnt,
                                                                     int* __restrict__ cand_of,
-                                                                    int* __restrict__ layout_size)
+                                                                    int* __restrict__ layout_size,
+                                                                    int* __restrict__ n_surv)
 {
     __shared__ int part[kSampleBlock / 64];
-    __shared__ int goff[kGroupsPerBlock];
+    __shared__ int wsum[kSampleBlock / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int W = (M + 63) >> 6;
-    const int g0 = blockIdx.x * kGroupsPerBlock;
-    // sum of the counts in front of this block's groups (g0 is a multiple of 64, wave_cnt is 16-byte aligned)
+    // this thread's 16 flags (cand_ok is padded to whole tiles and zero beyond M)
+    const int j0 = blockIdx.x * kCompactTile + tid * kCompactPerThread;
+    const uint4 f = *reinterpret_cast<const uint4*>(ok + j0);
+    const int mine = __popc(f.x) + __popc(f.y) + __popc(f.z) + __popc(f.w);
+    // valid candidates in front of this block: the per-block counts of the blocks before it
     int acc = 0;
-    const int4* c4 = reinterpret_cast<const int4*>(wave_cnt);
-    for (int k = tid; k < g0 / 4; k += kSampleBlock) { const int4 v = c4[k]; acc += (v.x + v.y) + (v.z + v.w); }
+    for (int k = tid; k < (int)blockIdx.x; k += kSampleBlock) acc += blk_cnt[k];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
-    if (lane == 0) part[wv] = acc;
-    __syncthreads();
-    int base = 0;
+    // inclusive scan of the per-thread counts across the wave
+    int inc = mine;
 #pragma unroll
-    for (int k = 0; k < kSampleBlock / 64; ++k) base += part[k];
-    // exclusive scan of this block's group counts (wave 0)
-    if (wv == 0) {
-        const int g = g0 + lane;
-        const int c = g < W ? wave_cnt[g] : 0;
-        int inc = c;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int up = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += up;
-        }
-        goff[lane] = base + inc - c;
-        if (lane == 63 && blockIdx.x == gridDim.x - 1) *layout_size = base + inc;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += up;
     }
+    if (lane == 0) part[wv] = acc;
+    if (lane == 63) wsum[wv] = inc;
     __syncthreads();
-    for (int gg = wv; gg < kGroupsPerBlock; gg += kSampleBlock / 64) {
-        const int j = (g0 + gg) * 64 + lane;
-        const bool v = (j < M) && ok[j];
-        const unsigned long long m = __ballot(v);
-        if (v) cand_of[goff[gg] + __popcll(m & ((1ull << lane) - 1ull))] = j;
+    int off = 0;
+#pragma unroll
+    for (int k = 0; k < kSampleBlock / 64; ++k) {
+        off += part[k];
+        if (k < wv) off += wsum[k];
+    }
+    off += inc - mine;
+    const uint32_t w[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if ((w[q] >> (8 * c)) & 0xffu) cand_of[off++] = j0 + 4 * q + c;
+    if (blockIdx.x == gridDim.x - 1 && tid == kSampleBlock - 1) {
+        *layout_size = off;
+        n_surv[0] = 0; n_surv[1] = 0; // consumed by phases 1 and 2 of THIS launch_sample, re-armed for the next one
     }
 }
 
@@ -421,20 +430,22 @@ int pick_block(const Params& p)
 
 hipError_t launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s, hipEvent_t after_phase1)
 {
-    const int M = sp.M, W = (M + 63) / 64;
+    const int M = sp.M;
     const int grid = (M + kSampleBlock - 1) / kSampleBlock;
-    hipError_t st = hipMemsetAsync(pl.n_surv, 0, 2 * sizeof(int), s); // n_surv, n_surv0
-    if (st != hipSuccess) return st;
+    // the survivor counters n_surv[0] (phase 1), n_surv[1] (phase 0) are zero here: zero-filled at allocation and
+    // re-armed by the previous launch's scan_compact_kernel (launches on one pool are ordered by the engine's events)
     hipLaunchKernelGGL(sample_phase0_kernel, dim3(grid), dim3(kSampleBlock), 0, s, sp, pl.cand_ok, pl.n_surv + 1,
-                       pl.surv0, pl.wave_cnt);
+                       pl.surv0, pl.blk_cnt);
     // GX_SAMPLE_GRID_CAP (tests): a small cap makes phases 1 and 2 take many grid-stride iterations at small M
     int cap = 1 << 30;
     if (const char* ev = getenv("GX_SAMPLE_GRID_CAP")) cap = atoi(ev) > 0 ? atoi(ev) : cap;
     const int grid1 = grid < (cap < 3072 ? cap : 3072) ? grid : (cap < 3072 ? cap : 3072);
     hipLaunchKernelGGL(sample_phase1_kernel<kSampleBlock>, dim3(grid1), dim3(kSampleBlock), 0, s, sp, pl.n_surv + 1,
                        pl.surv0, pl.n_surv, pl.surv);
-    if (after_phase1) st = hipEventRecord(after_phase1, s);
-    if (st != hipSuccess) return st;
+    if (after_phase1) {
+        const hipError_t st = hipEventRecord(after_phase1, s);
+        if (st != hipSuccess) return st;
+    }
     const size_t lds_wave = sizeof(P2Lds) + (size_t)(sp.nobj_total - 1) * kP2Block * sizeof(float2);
     const int wpb = kP2Waves * lds_wave <= 65536 ? kP2Waves : 1;
     const int wgs = (M + kP2Block * wpb - 1) / (kP2Block * wpb);
@@ -442,11 +453,13 @@ hipError_t launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s, 
     const int grid2 = wgs < cap2 ? wgs : cap2;
     const size_t lds2 = wpb * lds_wave;
     hipLaunchKernelGGL(sample_phase2_kernel, dim3(grid2), dim3(kP2Block * wpb), lds2, s, sp, pl.n_surv, pl.surv,
-                       pl.cand_ok, pl.cand_xy, pl.wave_cnt);
-    hipLaunchKernelGGL(scan_compact_kernel, dim3((W + kGroupsPerBlock - 1) / kGroupsPerBlock), dim3(kSampleBlock), 0, s,
-                       M, pl.cand_ok, pl.wave_cnt, pl.cand_of, pl.layout_size);
+                       pl.cand_ok, pl.cand_xy, pl.blk_cnt);
+    hipLaunchKernelGGL(scan_compact_kernel, dim3((M + kCompactTile - 1) / kCompactTile), dim3(kSampleBlock), 0, s, M,
+                       pl.cand_ok, pl.blk_cnt, pl.cand_of, pl.layout_size, pl.n_surv);
     return hipSuccess;
 }
+
+int sample_compact_tile() { return kCompactTile; }
 
 
 #define GX_ROBOT_DISPATCH(CALL)                                              \
