@@ -524,7 +524,7 @@ def main():
     env.set_prefetch(EP_LEN)
     tapes = [action_tape(EP_LEN, ENV_NUM, 1000 * rank + k, device) for k in range(4)]
     gather = world > 1
-    # the hand-off: "tape" (default) all-gathers the 80-B dynamics tape and expands it on every rank,
+    # the hand-off: "tape" (default) all-gathers the 48-B-per-env-step dynamics tape and expands it on every rank,
     # "packed" all-gathers the 192-B packed rows (what round 1 did; GX_HANDOFF=packed to compare)
     mode = os.environ.get("GX_HANDOFF", "tape")
     handoff = None
@@ -596,6 +596,19 @@ def main():
                    "layout_candidates_per_reset": 1_000_000,
                    "point_actuators": "mjcf defaults inherited (DESIGN.md 0.1)"},
     }
+    try:   # the 8-GPU hand-off as arithmetic (it cannot be measured on a one-GPU box): bytes on the wire vs the epoch
+        shard_bytes = int(sum(env.tape_floats(EP_LEN))) * 4
+        line["handoff_model"] = {
+            "shard_bytes_per_rank_per_epoch": shard_bytes,
+            "packed_rows_bytes_per_rank_per_epoch": int(EP_LEN * ENV_NUM * (env.obs_flat_size + 2 + 3) * 4),
+            "received_per_rank_at_8_gpus_bytes": 7 * shard_bytes,
+            "allgather_ms_at_8_gpus_310GBps": round(7 * shard_bytes / 310e9 * 1e3, 4),
+            "ms_per_step_this_run": round(dt / args.steps * 1e3, 4),
+            "note": "one async all-gather of the dynamics tape per epoch (48 B per env-step: qpos, qvel, action, done, "
+                    "two layout-row indices), overlapped with the following epoch; 310 GB/s = a realistic all-gather bus "
+                    "bandwidth over 7 xGMI links (537 GB/s peak per direction); arithmetic, not a measurement"}
+    except Exception as exc:  # noqa: BLE001
+        line["handoff_model"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
     if dt < 0.010:
         line["warning"] = f"timed region {dt*1e3:.2f} ms < 10 ms: use more --steps for a meaningful rate"
     if stepping_only is not None:

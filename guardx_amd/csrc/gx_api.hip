@@ -716,7 +716,8 @@ static gx_status rollout_impl(gx_engine* e, int32_t T, const float* d_actions, f
     r.act_out = d_act_out; r.obs_stride = obs_stride; r.sc_stride = sc_stride;
     e->last_policy = false;
     if (use_split_rollout(e, T)) { // light robots, small env_num: dynamics tape + one thread per (step, env) row
-        const size_t need = (size_t)T * e->p.N * split_tape_width(e->p);
+        const size_t nt = (size_t)T * e->p.N * split_tape_width(e->p);
+        const size_t need = nt + (size_t)e->p.N * split_entry_width(e->p); // [tape | entry records]
         if (need > e->tape_cap) {
             GX_HIP(hipStreamSynchronize(s));            // an earlier launch may still read the old tape
             if (e->tape) (void)hipFree(e->tape);
@@ -729,7 +730,7 @@ static gx_status rollout_impl(gx_engine* e, int32_t T, const float* d_actions, f
         if (st != GX_OK) return st;
         hipEvent_t hold = nullptr;
         if (e->pf_phase1_pending && getenv("GX_NO_OBS_HOLD") == nullptr) { hold = e->pf_phase1; e->pf_phase1_pending = false; }
-        GX_HIP(launch_split_rollout(e->p, r, e->tape, e->obj0, e->b, s, hold));
+        GX_HIP(launch_split_rollout(e->p, r, e->tape, e->obj0, e->tape + nt, e->b, s, hold));
     } else if (use_group_path(e)) {   // latency regime: 16 lanes per env
         r.commit = take_commit(e);
         launch_group_rollout(e->p, r, e->b, s);
@@ -766,20 +767,21 @@ extern "C" gx_status gx_rollout_packed(gx_engine* e, int32_t T, const float* d_a
 extern "C" int32_t gx_packed_width(const gx_engine* e) { return e ? e->p.D + e->na + 3 : -1; }
 
 // ---------------------------------------------------------------------------------------------------------------
-// tape hand-off: the rank that steps the envs runs only the serial dynamics pass and hands out its tape (80 B per
-// env-step for the Point instead of the 192 B packed row); whoever needs the rollout -- every rank, after ONE
-// all-gather of the tapes -- runs the observation pass on it.  Every rank samples the same layout pools (the key is
-// shared, engine.py:263), so the pool rows a tape's reset_done events refer to are local everywhere.
-// Buffer of one shard: [ tape T*N*W | layouts at entry P*Npad*4 | actions T*N*NA ] floats.
+// tape hand-off: the rank that steps the envs runs only the serial dynamics pass and hands out its tape (48 B per
+// env-step for the Point -- qpos, qvel, action, done, two layout-row indices -- instead of the 192 B packed row);
+// whoever needs the rollout -- every rank, after ONE all-gather of the tapes -- runs the observation pass on it, which
+// re-derives pose, ctrl and reward.  Every rank samples the same layout pools (the key is shared, engine.py:263), so
+// the pool rows a tape's reset_done events refer to are local everywhere.
+// Buffer of one shard: [ tape T*N*W | layouts at entry P*Npad*4 | entry records N*12 ] floats.
 // ---------------------------------------------------------------------------------------------------------------
-extern "C" gx_status gx_tape_floats(const gx_engine* e, int32_t T, int64_t* tape, int64_t* obj0, int64_t* act)
+extern "C" gx_status gx_tape_floats(const gx_engine* e, int32_t T, int64_t* tape, int64_t* obj0, int64_t* entry)
 {
-    if (!e || T < 1 || !tape || !obj0 || !act) return fail(GX_ERR_ARG, "bad argument");
+    if (!e || T < 1 || !tape || !obj0 || !entry) return fail(GX_ERR_ARG, "bad argument");
     if (!split_rollout_supported(e->p))
-        return fail(GX_ERR_UNSUPPORTED, "tape hand-off: Point / Swimmer without observe_vel / observe_acc only");
+        return fail(GX_ERR_UNSUPPORTED, "tape hand-off: Point / Swimmer without observe_vel / observe_acc, one physics step per control step");
     *tape = (int64_t)T * e->p.N * split_tape_width(e->p);
     *obj0 = (int64_t)e->p.P * e->p.Npad * 4;
-    *act = split_tape_has_action(e->p) ? 0 : (int64_t)T * e->p.N * e->na; // the Point's tape row carries its action
+    *entry = (int64_t)e->p.N * split_entry_width(e->p);
     return GX_OK;
 }
 
@@ -789,7 +791,7 @@ extern "C" gx_status gx_rollout_tape(gx_engine* e, int32_t T, const float* d_act
     if (!e || !d_actions || !d_shard || !token || T < 1) return fail(GX_ERR_ARG, "bad argument");
     if (!e->have_reset) return fail(GX_ERR_STATE, "gx_rollout_tape before gx_reset");
     if (!split_rollout_supported(e->p))
-        return fail(GX_ERR_UNSUPPORTED, "tape hand-off: Point / Swimmer without observe_vel / observe_acc only");
+        return fail(GX_ERR_UNSUPPORTED, "tape hand-off: Point / Swimmer without observe_vel / observe_acc, one physics step per control step");
     if ((reinterpret_cast<uintptr_t>(d_actions) & 7u) || (reinterpret_cast<uintptr_t>(d_shard) & 15u))
         return fail(GX_ERR_ARG, "d_actions must be 8-byte, d_shard 16-byte aligned");
     DeviceGuard guard(e->device);
@@ -804,8 +806,8 @@ extern "C" gx_status gx_rollout_tape(gx_engine* e, int32_t T, const float* d_act
     st = flush_pending(e, s);
     if (st != GX_OK) return st;
     const size_t nt = (size_t)T * e->p.N * split_tape_width(e->p), no = (size_t)e->p.P * e->p.Npad * 4;
-    GX_HIP(launch_split_rollout(e->p, r, d_shard, reinterpret_cast<float4*>(d_shard + nt), e->b, s, nullptr, 1,
-                                split_tape_has_action(e->p) ? nullptr : d_shard + nt + no));
+    GX_HIP(launch_split_rollout(e->p, r, d_shard, reinterpret_cast<float4*>(d_shard + nt), d_shard + nt + no, e->b, s,
+                                nullptr, 1));
     GX_HIP(hipEventRecord(e->keys_ev[slot], s));
     GX_HIP(hipGetLastError());
     e->key[0] = k0; e->key[1] = k1;
@@ -820,7 +822,7 @@ extern "C" gx_status gx_expand_tape(gx_engine* e, int32_t T, const float* d_shar
 {
     if (!e || !d_shard || !d_packed || T < 1) return fail(GX_ERR_ARG, "bad argument");
     if (!split_rollout_supported(e->p))
-        return fail(GX_ERR_UNSUPPORTED, "tape hand-off: Point / Swimmer without observe_vel / observe_acc only");
+        return fail(GX_ERR_UNSUPPORTED, "tape hand-off: Point / Swimmer without observe_vel / observe_acc, one physics step per control step");
     if (reinterpret_cast<uintptr_t>(d_shard) & 15u) return fail(GX_ERR_ARG, "d_shard must be 16-byte aligned");
     const int pi = (int)(token & 0xff);
     if (pi < 0 || pi >= gx_engine::kPools || (uint32_t)(token >> 8) != e->pool_gen[pi])
@@ -834,14 +836,15 @@ extern "C" gx_status gx_expand_tape(gx_engine* e, int32_t T, const float* d_shar
     r.T = T; r.do_reset = 1; r.nobj_total = e->nobj_total;
     r.cand_xy = e->pools[pi].cand_xy; r.n_rows = e->sp.M;
     const size_t nt = (size_t)T * e->p.N * split_tape_width(e->p), no = (size_t)e->p.P * e->p.Npad * 4;
-    r.act = split_tape_has_action(e->p) ? nullptr : d_shard + nt + no;
+    r.act = nullptr; // the tape rows carry the actions
     r.obs = d_packed; r.act_out = d_packed + e->p.D;
     r.rew = d_packed + e->p.D + e->na; r.cost = r.rew + 1; r.done = r.rew + 2;
     r.obs_stride = W; r.sc_stride = W;
     // the pool must be complete on this stream (it is when the tape's rank has stepped, but this may be another stream)
     GX_HIP(hipStreamWaitEvent(s, e->pool_ready[pi], 0));
     GX_HIP(launch_split_rollout(e->p, r, const_cast<float*>(d_shard),
-                                reinterpret_cast<float4*>(const_cast<float*>(d_shard) + nt), e->b, s, nullptr, 2, nullptr));
+                                reinterpret_cast<float4*>(const_cast<float*>(d_shard) + nt),
+                                const_cast<float*>(d_shard) + nt + no, e->b, s, nullptr, 2));
     GX_HIP(hipEventRecord(e->expand_ev[pi], s));
     e->expand_pending[pi] = true;
     GX_HIP(hipGetLastError());

@@ -94,14 +94,14 @@ void launch_policy_rollout(const Params& p, const RolloutArgs& r, const PolicyAr
 // two-kernel rollout of the light robots (gx_split_rollout.inl): dynamics tape, then one thread per (step, env) row
 struct SplitArgs;
 bool split_rollout_supported(const Params& p);
-int split_tape_width(const Params& p);
-bool split_tape_has_action(const Params& p); // the tape row carries the action (in its padding)
+int split_tape_width(const Params& p);   // floats per (step, env) tape row: qpos | qvel | action | done | layout rows
+int split_entry_width(const Params& p);  // floats per env of the entry record (state before the first step)
 // `hold`: null, or an event the observation pass (not the dynamics pass) waits for
-// `which`: 3 both passes (gx_rollout), 1 the dynamics pass only (gx_rollout_tape; `act_copy` receives the actions),
-// 2 the observation pass only (gx_expand_tape)
+// `which`: 3 both passes (gx_rollout), 1 the dynamics pass only (gx_rollout_tape), 2 the observation pass only
+// (gx_expand_tape); `entry`: [N][split_entry_width] written by the dynamics pass, read by the observation pass
 // returns the status of the stream-ordering calls it makes (the kernels' own launch errors surface in hipGetLastError)
-hipError_t launch_split_rollout(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b,
-                                hipStream_t s, hipEvent_t hold = nullptr, int which = 3, float* act_copy = nullptr);
+hipError_t launch_split_rollout(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, float* entry,
+                                const DevBuffers& b, hipStream_t s, hipEvent_t hold = nullptr, int which = 3);
 // install the reset_done recorded in b.rd_j (pending commit) for consumers other than the lane-group kernels
 void launch_commit_pending(const Params& p, const DevBuffers& b, int nobj_total, int n_rows, hipStream_t s);
 // fill Pool::fake for the valid layouts of a freshly sampled pool (no-op for robots whose rest state is a fixed point)
@@ -122,10 +122,10 @@ struct RobotLaunch {
                        hipStream_t s);
     static void commit_pending(const Params& p, const DevBuffers& b, int nobj_total, int n_rows, hipStream_t s);
     static void fake_table(const Params& p, const Pool& pl, int nobj_total, int M, hipStream_t s);
-    static hipError_t split(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b,
-                            hipStream_t s, hipEvent_t hold, int which, float* act_copy);
+    static hipError_t split(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, float* entry,
+                            const DevBuffers& b, hipStream_t s, hipEvent_t hold, int which);
     static int split_width();
-    static bool split_act_in_row();
+    static int split_entry_width();
 };
 bool policy_rollout_supported(const Params& p);
 size_t policy_lds_bytes(const Params& p, int impl);

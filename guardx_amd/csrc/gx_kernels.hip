@@ -502,8 +502,11 @@ void launch_thread_rollout(const Params& p, const RolloutArgs& r, const DevBuffe
 
 bool split_rollout_supported(const Params& p)
 {
-    // robots whose reset_done observation needs no physics step, no pose history in the observation
-    return (p.robot == PointRobot::kId || p.robot == PointBareRobot::kId || p.robot == SwimmerRobot::kId) && !p.hist_on;
+    // robots whose reset_done observation needs no physics step; no pose history in the observation; one physics step
+    // per control step (the tape carries qpos, and the pose a step returns is the kinematics of the qpos before its
+    // LAST substep)
+    return (p.robot == PointRobot::kId || p.robot == PointBareRobot::kId || p.robot == SwimmerRobot::kId) && !p.hist_on &&
+           p.physics_steps == 1;
 }
 int split_tape_width(const Params& p)
 {
@@ -513,19 +516,19 @@ int split_tape_width(const Params& p)
     else if (p.robot == PointRobot::kId) w = RobotLaunch<PointRobot>::split_width();
     return w;
 }
-bool split_tape_has_action(const Params& p)
+int split_entry_width(const Params& p)
 {
-    if (p.robot == SwimmerRobot::kId) return RobotLaunch<SwimmerRobot>::split_act_in_row();
-    if (p.robot == PointBareRobot::kId) return RobotLaunch<PointBareRobot>::split_act_in_row();
-    if (p.robot == PointRobot::kId) return RobotLaunch<PointRobot>::split_act_in_row();
-    return false;
+    if (p.robot == SwimmerRobot::kId) return RobotLaunch<SwimmerRobot>::split_entry_width();
+    if (p.robot == PointBareRobot::kId) return RobotLaunch<PointBareRobot>::split_entry_width();
+    if (p.robot == PointRobot::kId) return RobotLaunch<PointRobot>::split_entry_width();
+    return 0;
 }
-hipError_t launch_split_rollout(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b,
-                                hipStream_t s, hipEvent_t hold, int which, float* act_copy)
+hipError_t launch_split_rollout(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, float* entry,
+                                const DevBuffers& b, hipStream_t s, hipEvent_t hold, int which)
 {
-    if (p.robot == SwimmerRobot::kId) return RobotLaunch<SwimmerRobot>::split(p, r, tape, obj0, b, s, hold, which, act_copy);
-    if (p.robot == PointBareRobot::kId) return RobotLaunch<PointBareRobot>::split(p, r, tape, obj0, b, s, hold, which, act_copy);
-    if (p.robot == PointRobot::kId) return RobotLaunch<PointRobot>::split(p, r, tape, obj0, b, s, hold, which, act_copy);
+    if (p.robot == SwimmerRobot::kId) return RobotLaunch<SwimmerRobot>::split(p, r, tape, obj0, entry, b, s, hold, which);
+    if (p.robot == PointBareRobot::kId) return RobotLaunch<PointBareRobot>::split(p, r, tape, obj0, entry, b, s, hold, which);
+    if (p.robot == PointRobot::kId) return RobotLaunch<PointRobot>::split(p, r, tape, obj0, entry, b, s, hold, which);
     return hipErrorNotSupported;
 }
 

@@ -53,6 +53,15 @@ struct PointRobotT {
     static constexpr bool kRestFixed = true;
     GX_D static void place(float (&q)[NQ], float rx, float ry) { q[0] = rx; q[1] = ry; }
 
+    // xpos / xmat of the robot body for qpos `q` (mjx kinematics: hinge quaternion through the half angle): what a step
+    // that STARTS from q returns as its (one step stale) pose -- substep computes exactly this
+    GX_D static void pose_of(const float (&q)[NQ], float (&pose)[4])
+    {
+        float sh, ch;
+        sincos_f(0.5f * q[2], sh, ch);
+        pose[0] = q[0]; pose[1] = q[1]; pose[2] = ch * ch - sh * sh; pose[3] = 2.0f * (ch * sh);
+    }
+
     // jp.clip: NaN stays.  v_med3_f32 is the exact median for ordered operands (and keeps -0); one compare puts the
     // NaN back -- 3 instructions instead of two compare / select pairs on the serial chain of the dynamics pass
     GX_D static float clip(float x, float lim)
@@ -79,11 +88,8 @@ struct PointRobotT {
         constexpr float kInvM = (float)(1.0 / 0.005188790204786391);
         constexpr float kInvA = (float)(1.0 / (0.005188790204786391 + 0.02 * 0.01));
         constexpr float kEi = (float)(2.842182748581224e-05 + 0.02 * 0.005);
-        float sh, ch;
-        sincos_f(0.5f * q[2], sh, ch);
-        const float c = ch * ch - sh * sh;
-        const float sn = 2.0f * (ch * sh);
-        pose[0] = q[0]; pose[1] = q[1]; pose[2] = c; pose[3] = sn;
+        pose_of(q, pose);
+        const float c = pose[2], sn = pose[3];
         const float b = -(kMxc * sn), d = kMxc * c;
         const float w2 = v[2] * v[2];
         const float fx = (-(kDxy * v[0]) - (-(d * w2))) + actuate(ctrl[0], v[0]);
@@ -155,6 +161,14 @@ struct SwimmerRobot {
     }
     static constexpr bool kRestFixed = true;
     GX_D static void place(float (&q)[NQ], float rx, float ry) { q[0] = rx; q[1] = ry; }
+
+    // pose of the head link for qpos `q` (what substep computes for it, see PointRobotT::pose_of)
+    GX_D static void pose_of(const float (&q)[NQ], float (&pose)[4])
+    {
+        float sh1, ch1;
+        sincos_f(0.5f * q[2], sh1, ch1);
+        pose[0] = q[0]; pose[1] = q[1]; pose[2] = ch1 * ch1 - sh1 * sh1; pose[3] = 2.0f * (ch1 * sh1);
+    }
 
     struct Ldl3 { float rd0, rd1, rd2, l10, l20, l21; };
     GX_D static void ldl_solve(const Ldl3& f, float b0, float b1, float b2, float (&x)[3])

@@ -1328,12 +1328,12 @@ void RobotLaunch<R>::fake_table(const Params& p, const Pool& pl, int nobj_total,
 }
 
 template <class R>
-hipError_t RobotLaunch<R>::split(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, const DevBuffers& b,
-                                 hipStream_t s, hipEvent_t hold, int which, float* act_copy)
+hipError_t RobotLaunch<R>::split(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, float* entry,
+                                 const DevBuffers& b, hipStream_t s, hipEvent_t hold, int which)
 {
     if constexpr (R::kRestFixed) {
         SplitArgs sa;
-        sa.tape = tape; sa.obj0 = obj0; sa.act_copy = act_copy;
+        sa.tape = tape; sa.obj0 = obj0; sa.entry = entry;
         if (p.P <= 5) return launch_split_p<R, 5>(p, r, sa, b, s, hold, which);
         if (p.P <= 9) return launch_split_p<R, 9>(p, r, sa, b, s, hold, which);
         return launch_split_p<R, 33>(p, r, sa, b, s, hold, which);
@@ -1347,10 +1347,10 @@ int RobotLaunch<R>::split_width()
     return 0;
 }
 template <class R>
-bool RobotLaunch<R>::split_act_in_row()
+int RobotLaunch<R>::split_entry_width()
 {
-    if constexpr (R::kRestFixed) return SplitTape<R>::kAct >= 0;
-    return false;
+    if constexpr (R::kRestFixed) return SplitTape<R>::kE;
+    return 0;
 }
 
 template <class R>

@@ -1,13 +1,18 @@
 // gx_split_rollout.inl -- the fused T-step rollout of the light robots (Point, Swimmer) at small env_num as TWO
 // kernels instead of one persistent lane-group kernel (included by gx_robot_kernels.inl):
 //
-//   pass 1  dyn_tape_kernel   one thread per env, T steps: convert_action, mjx.step, reward / done / NaN guard /
-//           timeout, reset_done (layout index draw + re-placement) -- everything the NEXT step depends on -- and one
-//           80-byte tape row per (step, env): stepped pose, qpos, qvel, ctrl, reward, done, the layout row in effect
-//           and the layout row a reset_done installed.  ~200 instructions per step on the serial chain.
-//   pass 2  obs_tape_kernel   one thread per (step, env) tape row: lidars, compass, cost, the observation row (of the
-//           re-initialised env where reset_done fired) and the reward / cost / done outputs -- 400 000 independent
-//           rows at env_num = 2000, T = 200, i.e. the bandwidth regime of the thread-per-env kernels.
+//   pass 1  dyn_tape_kernel   one thread per env, T steps: convert_action, mjx.step, done / NaN guard / timeout,
+//           reset_done (layout index draw + re-placement) -- everything the NEXT step depends on -- and one SLIM tape
+//           row per (step, env): qpos, qvel after the step, the action, done, the layout row in effect and the layout row
+//           a reset_done installed: 12 floats for the Point (48 B), 16 for the Swimmer.  ~190 instructions per step on
+//           the serial chain.  (Rounds 1-2 also wrote the stepped pose, ctrl and the reward: 20 floats.)
+//   pass 2  obs_tape_kernel   one thread per (step, env) tape row: re-derives what pass 1 no longer writes -- the pose
+//           the step returned (kinematics of the qpos the step STARTED from: the previous row's qpos, or the robot
+//           position of the layout the previous row's reset_done installed), the pose before that (for
+//           convert_action -> ctrl and for reward_done's `last`), the reward -- then lidars, compass, cost, the
+//           observation row (of the re-initialised env where reset_done fired) and the reward / cost / done outputs:
+//           400 000 independent rows at env_num = 2000, T = 200, the bandwidth regime of the thread-per-env kernels.
+//           Rows 0 and 1 of an env take the state at entry from a 48-byte entry record pass 1 leaves per env.
 //
 // Same functions, same operation order as step_kernel / reset_done_kernel, hence the same bits
 // (tests/test_gpu_parity.py runs every rollout test on this path too).  Not used when observe_vel / observe_acc
@@ -24,19 +29,37 @@ namespace gx {
 
 template <class R>
 struct SplitTape {
-    static constexpr int kPose = 0, kQ = 4, kV = kQ + R::NQ, kCtrl = kV + R::NV, kRew = kCtrl + R::NU, kDone = kRew + 1,
-                         kJcur = kDone + 1, kJaft = kJcur + 1, kUsed = kJaft + 1, kW = (kUsed + 3) / 4 * 4,
-                         // the action rides in the row's padding where it fits (Point: 17 + 2 of 20 floats)
-                         kAct = (kUsed + R::NA <= kW) ? kUsed : -1;
+    static constexpr int kQ = 0, kV = kQ + R::NQ, kAct = kV + R::NV, kDone = kAct + R::NA, kJcur = kDone + 1,
+                         kJaft = kJcur + 1, kUsed = kJaft + 1, kW = (kUsed + 3) / 4 * 4;
+    // entry record of an env: qpos at entry | the stale pose (x, y, cos, sin) | done0 | number of step() calls so far
+    static constexpr int kEQ = 0, kEPose = R::NQ, kEDone = kEPose + 4, kEHist = kEDone + 1, kE = 12;
+    static_assert(kEHist < kE, "entry record too small for this robot");
 };
 
 struct SplitArgs {
     float* tape;        // [T][N][kW]
     float4* obj0;       // [P][Npad] snapshot of the layouts at entry (pass 2 reads it for rows with jcur < 0)
-    float* act_copy;    // null, or [T][N][NA]: pass 1 copies the actions it consumed (tape hand-off, gx_rollout_tape)
+    float* entry;       // [N][kE] state at entry (pass 2 needs it for the rows of steps 0 and 1)
 };
 
 GX_D bool moderate(float x) { return fabsf(x) < 1e18f; } // false for NaN / Inf too
+
+template <int W>
+GX_D void load_row(const float* __restrict__ p, float (&v)[W])
+{
+#pragma unroll
+    for (int k = 0; k < W / 4; ++k) {
+        const float4 t4 = reinterpret_cast<const float4*>(p)[k];
+        v[4 * k] = t4.x; v[4 * k + 1] = t4.y; v[4 * k + 2] = t4.z; v[4 * k + 3] = t4.w;
+    }
+}
+template <int W>
+GX_D void store_row(float* __restrict__ p, const float (&v)[W])
+{
+#pragma unroll
+    for (int k = 0; k < W / 4; ++k)
+        reinterpret_cast<float4*>(p)[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+}
 
 template <class R, int BLOCK, int PMAX, bool kDef>
 __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArgs r, SplitArgs sa,
@@ -51,7 +74,18 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
     if (i >= p.N) return;
     float q[R::NQ], v[R::NV], pose0[4], done0, steps;
     R::load(dyn, p.Npad, i, q, v, pose0, done0, steps);
-    // layout at entry: snapshot for pass 2, goal for reward / done, magnitude check for the NaN-guard shortcut
+    {   // the state at entry, for the rows of steps 0 and 1 in pass 2
+        float ev[TP::kE];
+#pragma unroll
+        for (int k = 0; k < TP::kE; ++k) ev[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < R::NQ; ++k) ev[TP::kEQ + k] = q[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ev[TP::kEPose + k] = pose0[k];
+        ev[TP::kEDone] = done0; ev[TP::kEHist] = (float)r.hist0;
+        store_row<TP::kE>(sa.entry + (size_t)i * TP::kE, ev);
+    }
+    // layout at entry: snapshot for pass 2, goal for done, magnitude check for the NaN-guard shortcut
     float gx = 0.f, gy = 0.f;
     // the shortcut also needs a closeness that cannot overflow: exp(-gain*dist) with gain >= 0, or a positive max_dist
     const bool cfg_ok = p.lidar_max_dist_set ? (p.lidar_max_dist > 0.0f) : (p.neg_gain <= 0.0f);
@@ -69,7 +103,7 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
     const int L = r.do_reset ? *r.layout_size : 0;
     int jcur = -1;
     float* row = tile + tid * p.D;
-    // the action of step t+2 is requested at step t: one step (~1400 cycles) does not cover an HBM miss plus the
+    // the action of step t+2 is requested at step t: one step (~1300 cycles) does not cover an HBM miss plus the
     // queue of tape stores in front of it (SQ_WAIT_ANY was 409 of 1434 cycles per step with a one-step prefetch)
     float an[R::NA], an2[R::NA];
     load_action<R>(r.act, (size_t)i, an);
@@ -85,10 +119,6 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
 #pragma unroll
         for (int d = 0; d < R::NA; ++d) { a[d] = an[d]; an[d] = an2[d]; }
         if (t + 2 < r.T) load_action<R>(r.act, (size_t)(t + 2) * p.N + i, an2);
-        if (TP::kAct < 0 && sa.act_copy) {
-#pragma unroll
-            for (int d = 0; d < R::NA; ++d) sa.act_copy[((size_t)t * p.N + i) * R::NA + d] = a[d];
-        }
         const bool have_last = (r.hist0 + t) >= 1;
         const float last_done = done0;
 
@@ -119,16 +149,15 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
             bad = build_obs_row<R, PMAX>(p, row, pose, ob, ctrl, q, v, 0.f, 0.f, 0.f, 0.f);
         }
 
-        // reward_done :787-802
+        // the done half of reward_done :787-802 (the reward itself is pass 2's)
         const float dg = dist2(gx, gy, pose[0], pose[1]);
         float last = dg;
         if (have_last && !(last_done > 0.0f)) last = dprev;
         dprev = dg;
         const float dd = last - dg;
-        float rw = dd * p.reward_distance;
         float dn = dg < p.goal_size ? 1.0f : 0.0f;
-        if (fabsf(dd) > 1.0f) { dn = 1.0f; rw = 0.0f; }
-        if (bad) { rw = 0.0f; dn = 1.0f; }        // :696-699
+        if (fabsf(dd) > 1.0f) dn = 1.0f;
+        if (bad) dn = 1.0f;                        // :696-699
         if (steps > p.num_steps_f) dn = 1.0f;      // :492
         steps = dn > 0.0f ? 0.0f : steps + 1.0f;   // :493
 
@@ -147,27 +176,18 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
         }
 
         // tape row
-        float* tp = sa.tape + ((size_t)t * p.N + i) * TP::kW;
         float rowv[TP::kW];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) rowv[TP::kPose + k] = pose[k];
 #pragma unroll
         for (int k = 0; k < R::NQ; ++k) rowv[TP::kQ + k] = q[k];
 #pragma unroll
         for (int k = 0; k < R::NV; ++k) rowv[TP::kV + k] = v[k];
 #pragma unroll
-        for (int k = 0; k < R::NU; ++k) rowv[TP::kCtrl + k] = ctrl[k];
-        rowv[TP::kRew] = rw; rowv[TP::kDone] = dn;
+        for (int k = 0; k < R::NA; ++k) rowv[TP::kAct + k] = a[k];
+        rowv[TP::kDone] = dn;
         rowv[TP::kJcur] = __int_as_float(jcur); rowv[TP::kJaft] = __int_as_float(jaft);
 #pragma unroll
         for (int k = TP::kUsed; k < TP::kW; ++k) rowv[k] = 0.f;
-        if (TP::kAct >= 0) {
-#pragma unroll
-            for (int d = 0; d < R::NA; ++d) rowv[(TP::kAct >= 0 ? TP::kAct : 0) + d] = a[d];
-        }
-#pragma unroll
-        for (int k = 0; k < TP::kW / 4; ++k)
-            reinterpret_cast<float4*>(tp)[k] = make_float4(rowv[4 * k], rowv[4 * k + 1], rowv[4 * k + 2], rowv[4 * k + 3]);
+        store_row<TP::kW>(sa.tape + ((size_t)t * p.N + i) * TP::kW, rowv);
 
         // commit the history, then the re-initialisation (the stale pose stays, :731)
 #pragma unroll
@@ -194,6 +214,24 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
     }
 }
 
+// qpos an env starts step t+1 from, given its tape row of step t: the stepped qpos, or -- where reset_done fired --
+// the rest pose at the robot position of the layout it installed (layout2qpos :623-639)
+template <class R>
+GX_D void next_start(const float (&rowv)[SplitTape<R>::kW], const RolloutArgs& r, float (&s)[R::NQ])
+{
+    using TP = SplitTape<R>;
+    const int jaft = __float_as_int(rowv[TP::kJaft]);
+    if (jaft >= 0 && jaft < r.n_rows) {
+        const float2 rb = r.cand_xy[(size_t)jaft * r.nobj_total + r.nobj_total - 1];
+#pragma unroll
+        for (int k = 0; k < R::NQ; ++k) s[k] = 0.f;
+        R::place(s, rb.x, rb.y);
+    } else {
+#pragma unroll
+        for (int k = 0; k < R::NQ; ++k) s[k] = rowv[TP::kQ + k];
+    }
+}
+
 template <class R, int BLOCK, int PMAX, bool kDef>
 __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArgs r, SplitArgs sa)
 {
@@ -207,6 +245,7 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
     const bool live = g < G;
     const size_t gg = live ? g : 0;
     const int i = (int)(gg % (size_t)p.N);
+    const int t = (int)(gg / (size_t)p.N);
     const int RS = r.obs_stride;
     const bool packed = r.act_out != nullptr;
     // LDS row stride: RS + 1 when RS is a multiple of 4 floats (48 for the Point's packed rows: 64 rows on 4 banks,
@@ -214,24 +253,48 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
     const int LS = (RS & 3) ? RS : RS + 1;
     float* row = tile + tid * LS;
 
-    const float* tp = sa.tape + gg * TP::kW;
-    float rowv[TP::kW];
-#pragma unroll
-    for (int k = 0; k < TP::kW / 4; ++k) {
-        const float4 t4 = reinterpret_cast<const float4*>(tp)[k];
-        rowv[4 * k] = t4.x; rowv[4 * k + 1] = t4.y; rowv[4 * k + 2] = t4.z; rowv[4 * k + 3] = t4.w;
-    }
-    float pose[4], q[R::NQ], v[R::NV], ctrl[R::NU];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) pose[k] = rowv[TP::kPose + k];
+    float rowv[TP::kW], ev[TP::kE];
+    load_row<TP::kW>(sa.tape + gg * TP::kW, rowv);
+    float q[R::NQ], v[R::NV], a[R::NA];
 #pragma unroll
     for (int k = 0; k < R::NQ; ++k) q[k] = rowv[TP::kQ + k];
 #pragma unroll
     for (int k = 0; k < R::NV; ++k) v[k] = rowv[TP::kV + k];
 #pragma unroll
-    for (int k = 0; k < R::NU; ++k) ctrl[k] = rowv[TP::kCtrl + k];
-    const float rw = rowv[TP::kRew], dn = rowv[TP::kDone];
+    for (int k = 0; k < R::NA; ++k) a[k] = rowv[TP::kAct + k];
+    const float dn = rowv[TP::kDone];
     const int jcur = __float_as_int(rowv[TP::kJcur]), jaft = __float_as_int(rowv[TP::kJaft]);
+
+    // what the step started from (s), the stale pose it found (pose0) and the done flag before it
+    float s[R::NQ], pose0[4], last_done, hist0;
+    if (t < 2) load_row<TP::kE>(sa.entry + (size_t)i * TP::kE, ev);
+    if (t == 0) {
+#pragma unroll
+        for (int k = 0; k < R::NQ; ++k) s[k] = ev[TP::kEQ + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pose0[k] = ev[TP::kEPose + k];
+        last_done = ev[TP::kEDone];
+    } else {
+        float prev[TP::kW];
+        load_row<TP::kW>(sa.tape + (gg - (size_t)p.N) * TP::kW, prev);
+        next_start<R>(prev, r, s);
+        last_done = prev[TP::kDone];
+        float sp[R::NQ]; // what the PREVIOUS step started from: its pose is this step's stale pose (reset_done keeps it, :731)
+        if (t == 1) {
+#pragma unroll
+            for (int k = 0; k < R::NQ; ++k) sp[k] = ev[TP::kEQ + k];
+        } else {
+            float pp[TP::kW];
+            load_row<TP::kW>(sa.tape + (gg - 2 * (size_t)p.N) * TP::kW, pp);
+            next_start<R>(pp, r, sp);
+        }
+        R::pose_of(sp, pose0);
+    }
+    hist0 = t < 2 ? ev[TP::kEHist] : 2.0f; // number of step() calls before the rollout (only its first rows care)
+    const bool have_last = ((int)hist0 + t) >= 1;
+    float pose[4], ctrl[R::NU];
+    R::pose_of(s, pose);                  // mjx.step = forward(qpos_t); integrate: the returned xpos / xmat are one step stale
+    R::convert_action(pose0, a, ctrl);    // :672-685, PRE-step xmat
 
     float4 ob[PMAX];
     if (jcur >= 0 && jcur < r.n_rows) { float rx_, ry_; load_layout<PMAX>(p, r.cand_xy, r.nobj_total, jcur, ob, rx_, ry_); }
@@ -247,6 +310,15 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
         if (k > 0 && 2 * k < p.nobj) cs = cs + cost_term(p, 2 * k, ob[k].x, ob[k].y, pose);
         if (2 * k + 1 < p.nobj) cs = cs + cost_term(p, 2 * k + 1, ob[k].z, ob[k].w, pose);
     }
+    // reward_done :787-802 (done itself, with the NaN guard and the timeout folded in, comes from the tape)
+    const float dg = dist2(ob[0].x, ob[0].y, pose[0], pose[1]);
+    float last = dg;
+    if (have_last && !(last_done > 0.0f)) last = dist2(ob[0].x, ob[0].y, pose0[0], pose0[1]);
+    const float dd = last - dg;
+    float rw = dd * p.reward_distance;
+    if (fabsf(dd) > 1.0f) rw = 0.0f;
+    bool bad = build_obs_row<R, PMAX>(p, row, pose, ob, ctrl, q, v, 0.f, 0.f, 0.f, 0.f);
+    if (bad) rw = 0.0f;                   // :696-699
     if (jaft >= 0 && jaft < r.n_rows) { // reset_done fired: the row the learner sees is the re-initialised env's
         float rx, ry;
         load_layout<PMAX>(p, r.cand_xy, r.nobj_total, jaft, ob, rx, ry);
@@ -258,16 +330,9 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
         for (int k = 0; k < R::NU; ++k) ctrl[k] = 0.f;
         R::place(q, rx, ry);
         pose[0] = rx; pose[1] = ry; pose[2] = 1.0f; pose[3] = 0.0f;
+        build_obs_row<R, PMAX>(p, row, pose, ob, ctrl, q, v, 0.f, 0.f, 0.f, 0.f);
     }
-    build_obs_row<R, PMAX>(p, row, pose, ob, ctrl, q, v, 0.f, 0.f, 0.f, 0.f);
     if (packed) {
-        float a[R::NA];
-        if (TP::kAct >= 0) {
-#pragma unroll
-            for (int k = 0; k < R::NA; ++k) a[k] = rowv[(TP::kAct >= 0 ? TP::kAct : 0) + k];
-        } else {
-            load_action<R>(r.act, gg, a);
-        }
 #pragma unroll
         for (int k = 0; k < R::NA; ++k) row[p.D + k] = a[k];
         row[p.D + R::NA] = rw; row[p.D + R::NA + 1] = cs; row[p.D + R::NA + 2] = dn;
@@ -280,7 +345,7 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
     if (LS == RS) flush_tile<BLOCK>(tile, r.obs + g0 * RS, nrow * RS);
     else if ((reinterpret_cast<uintptr_t>(r.obs) & 15u) == 0) flush_tile_padded<BLOCK>(tile, LS, r.obs + g0 * RS, nrow, RS);
     else {
-        for (int k = tid; k < nrow * RS; k += BLOCK) { const int rw = k / RS; r.obs[g0 * RS + k] = tile[rw * LS + (k - rw * RS)]; }
+        for (int k = tid; k < nrow * RS; k += BLOCK) { const int rw_ = k / RS; r.obs[g0 * RS + k] = tile[rw_ * LS + (k - rw_ * RS)]; }
     }
 }
 

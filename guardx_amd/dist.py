@@ -66,7 +66,8 @@ class TapeHandoff:
                                                    #   PREVIOUS epoch's gathered tapes on a side stream
         h.drain(); h.rollout                       # (world, T, N, obs+act+3): the last expanded epoch
 
-    The rank that steps writes 80 B per env-step (Point) instead of the 192-B packed row; ONE
+    The rank that steps writes 48 B per env-step (Point: qpos, qvel, action, done, two layout-row indices) instead of
+    the 192-B packed row; ONE
     all_gather_into_tensor per epoch moves the shards as they are; every rank runs the observation pass
     (Engine.expand_tape) over all `world` tapes and so holds the same rows rollout(packed=True) + an all-gather of
     the packed shards would have given it, bit for bit.  The all-gather of epoch k overlaps epoch k+1 entirely:

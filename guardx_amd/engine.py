@@ -504,15 +504,15 @@ class Engine:
     # tape hand-off (multi-GPU): step here, build the observations wherever the rollout is needed
     # ------------------------------------------------------------------
     def tape_floats(self, T):
-        """(tape, layouts, actions) float counts of one shard buffer of rollout_tape(T)."""
+        """(tape, layouts, entry records) float counts of one shard buffer of rollout_tape(T)."""
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
         _native.check(self._lib.gx_tape_floats(self._h, int(T), C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
     def rollout_tape(self, actions, out=None):
         """The serial half of rollout(): T x (step -> reset_done) without building observations.  Returns
-        (shard, token): `shard` a flat float32 tensor [tape | layouts at entry | actions] (80 B per env-step for
-        the Point against 192 B of packed rows) to all-gather as is, `token` naming the layout pool in effect.
+        (shard, token): `shard` a flat float32 tensor [tape | layouts at entry | entry records] (48 B per env-step
+        for the Point against 192 B of packed rows) to all-gather as is, `token` naming the layout pool in effect.
         expand_tape(shard, token) -- here or on any rank's engine of the same configuration -- gives the packed
         (T, N, D + A + 3) rows of rollout(packed=True), bit for bit; call it before the second reset() after
         this rollout.  step() / reset_done() may follow, but the last observation is only known after expand_tape."""

@@ -159,13 +159,15 @@ int32_t gx_packed_width(const gx_engine* e);
  * rollout (safe_rl_libX/trpo/trpo.py:34-42: obs, act, rew, cost, done) runs the observation pass on the gathered
  * tapes and gets the packed rows of gx_rollout_packed, bit for bit.  All ranks sample identical layout pools (shared
  * key, engine.py:263), so the pool rows a tape's reset_done events refer to are local on every rank.
- *   d_shard: gx_tape_floats() floats = [ tape | layouts at entry | actions ], 16-byte aligned; all-gather it as is
- *            (the Point's 20-float tape row has room for the action: its `actions` part is empty).
+ *   d_shard: gx_tape_floats() floats = [ tape | layouts at entry | entry records ], 16-byte aligned; all-gather it as
+ *            is.  A tape row is qpos | qvel | action | done | layout row in effect | layout row reset_done installed:
+ *            12 floats (48 B) per env-step for the Point, 16 for the Swimmer; the observation pass re-derives the
+ *            pose, ctrl and the reward from consecutive rows.  One physics step per control step only.
  *   token:   names the layout pool in effect; gx_expand_tape (on any engine of the same configuration and key
  *            history, e.g. the other ranks') must be CALLED before the second gx_reset after the rollout --
  *            the engines keep three pools for that; GX_ERR_STATE afterwards.  The next sampler that reuses the
  *            pool is ordered behind the expansion by an event, whatever stream it ran on. */
-gx_status gx_tape_floats(const gx_engine* e, int32_t T, int64_t* tape, int64_t* layouts, int64_t* actions);
+gx_status gx_tape_floats(const gx_engine* e, int32_t T, int64_t* tape, int64_t* layouts, int64_t* entry);
 gx_status gx_rollout_tape(gx_engine* e, int32_t T, const float* d_actions, float* d_shard, int64_t* token,
                           void* stream);
 gx_status gx_expand_tape(gx_engine* e, int32_t T, const float* d_shard, int64_t token, float* d_packed,
