@@ -239,6 +239,7 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     p.neg_gain = -cfg->lidar_exp_gain;
     p.bin_size = (float)((3.14159265358979323846 * 2) / p.bins); // engine.py:880
     p.goal_size = cfg->goal_size;
+    p.goal_cut = sqrt_cutoff(cfg->goal_size);
     p.hazards_size = cfg->hazards_size;
     p.pillars_size = cfg->pillars_size;
     p.reward_distance = cfg->reward_distance;

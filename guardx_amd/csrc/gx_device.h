@@ -31,6 +31,7 @@ struct Params {
     int lidar_alias, lidar_max_dist_set;
     float lidar_max_dist, neg_gain, bin_size;
     float goal_size, hazards_size, pillars_size, reward_distance, num_steps_f, dt;
+    float goal_cut; // min{x : fl(sqrt(x)) >= goal_size}: sqrtf(d2) < goal_size  <=>  d2 < goal_cut, exactly
     int physics_steps;
     int env_total, env_offset;
     int have_last, have_last_last; // None-ness of _last_done / _last_last_done

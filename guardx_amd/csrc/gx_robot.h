@@ -26,6 +26,7 @@ template <bool kBare>
 struct PointRobotT {
     static constexpr int kId = kBare ? 4 : 0, NQ = 3, NV = 3, NU = 3, NA = 2, NDYN = 3;
     static constexpr float kH = 0.02f;
+    static constexpr float kIo = 2.842182748581224e-05f; // inertia about the hinge axis (enters substep through kInvD3*)
     // default Goal_Point_8Hazards observation: ctrl[0:3] compass[3:5] glidar[5:21] hlidar[21:37] qpos[37:40] qvel[40:43]
     static constexpr int kD = 43, kOffCtrl = 0, kOffComp = 3, kOffGl = 5, kOffHl = 21, kOffQpos = 37, kOffQvel = 40;
 
@@ -69,45 +70,54 @@ struct PointRobotT {
         const float m = __builtin_amdgcn_fmed3f(x, -lim, lim);
         return x == x ? m : x;
     }
-    // qfrc_actuator of one DOF [derived: mjx fwd_actuation]
+    // qfrc_actuator of one DOF [derived: mjx fwd_actuation].  kNoNaN: the caller guarantees ctrl and vel are not NaN
+    // (the dynamics pass checks that after the fact and redoes the step otherwise), so the median alone is the clip
+    template <bool kNoNaN = false>
     GX_D static float actuate(float ctrl, float vel)
     {
         constexpr float kGear = 0.3f, kCtrlLim = 1.0f, kForceLim = 0.05f, kKv = 1.0f;
         if (kBare) return kGear * ctrl;
+        if (kNoNaN) {
+            const float u = __builtin_amdgcn_fmed3f(ctrl, -kCtrlLim, kCtrlLim);
+            const float force = __builtin_amdgcn_fmed3f(u - kKv * (kGear * vel), -kForceLim, kForceLim);
+            return kGear * force;
+        }
         const float u = clip(ctrl, kCtrlLim);
         const float force = clip(u - kKv * (kGear * vel), kForceLim);
         return kGear * force;
     }
 
-    template <bool kQacc>
+    template <bool kQacc, bool kNoNaN = false>
     GX_D static void substep(float (&q)[NQ], float (&v)[NV], const float (&ctrl)[NU], float (&pose)[4],
                              float (&qacc)[NV])
     {
         constexpr float kMxc = 0.0001f, kDxy = 0.01f, kDt = 0.005f;
-        constexpr float kIo = 2.842182748581224e-05f;
         constexpr float kInvM = (float)(1.0 / 0.005188790204786391);
         constexpr float kInvA = (float)(1.0 / (0.005188790204786391 + 0.02 * 0.01));
-        constexpr float kEi = (float)(2.842182748581224e-05 + 0.02 * 0.005);
         pose_of(q, pose);
         const float c = pose[2], sn = pose[3];
         const float b = -(kMxc * sn), d = kMxc * c;
         const float w2 = v[2] * v[2];
-        const float fx = (-(kDxy * v[0]) - (-(d * w2))) + actuate(ctrl[0], v[0]);
-        const float fy = (-(kDxy * v[1]) - (b * w2)) + actuate(ctrl[1], v[1]);
-        const float ft = (-(kDt * v[2]) - 0.0f) + actuate(ctrl[2], v[2]);
+        const float fx = (-(kDxy * v[0]) - (-(d * w2))) + actuate<kNoNaN>(ctrl[0], v[0]);
+        const float fy = (-(kDxy * v[1]) - (b * w2)) + actuate<kNoNaN>(ctrl[1], v[1]);
+        const float ft = (-(kDt * v[2]) - 0.0f) + actuate<kNoNaN>(ctrl[2], v[2]);
         const float t = b * fx + d * fy;
-        const float s2 = b * b + d * d;
+        // Schur complement of the hinge row after eliminating the two slides: Io - (b^2 + d^2) / m with
+        // b^2 + d^2 = (m xc)^2 (sin^2 + cos^2) = (m xc)^2 -- a constant of the model, so the "division" of the 3x3
+        // solve is a multiplication by its reciprocal (round 3; rounds 1-2 divided by the fp32 value of
+        // kIo - (b*b + d*d) * kInvM, equal to 1e-9 relative)
+        constexpr float kInvD3M = (float)(1.0 / (2.842182748581224e-05 - (1.0e-4 * 1.0e-4) / 0.005188790204786391));
+        constexpr float kInvD3A = (float)(1.0 / ((2.842182748581224e-05 + 0.02 * 0.005) -
+                                                 (1.0e-4 * 1.0e-4) / (0.005188790204786391 + 0.02 * 0.01)));
         if (kQacc) {
             const float y3 = ft - t * kInvM;
-            const float d3 = kIo - s2 * kInvM;
-            const float q3 = y3 / d3;
+            const float q3 = y3 * kInvD3M;
             qacc[0] = (fx - b * q3) * kInvM;
             qacc[1] = (fy - d * q3) * kInvM;
             qacc[2] = q3;
         }
         const float y3 = ft - t * kInvA;
-        const float d3 = kEi - s2 * kInvA;
-        const float q3 = y3 / d3;
+        const float q3 = y3 * kInvD3A;
         const float q1 = (fx - b * q3) * kInvA;
         const float q2 = (fy - d * q3) * kInvA;
         v[0] = v[0] + kH * q1;
@@ -205,7 +215,7 @@ struct SwimmerRobot {
         return true;
     }
 
-    template <bool kQacc>
+    template <bool kQacc, bool kNoNaN = false> // kNoNaN: nothing to gain here (the clamp below passes NaN through by itself)
     GX_D static void substep(float (&q)[NQ], float (&v)[NV], const float (&ctrl)[NU], float (&pose)[4],
                              float (&qacc)[NV])
     {

@@ -43,6 +43,7 @@ struct SplitArgs {
 };
 
 GX_D bool moderate(float x) { return fabsf(x) < 1e18f; } // false for NaN / Inf too
+constexpr int kActBlock = 16; // steps whose actions the dynamics pass fetches at once
 
 template <int W>
 GX_D void load_row(const float* __restrict__ p, float (&v)[W])
@@ -103,42 +104,95 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
     const int L = r.do_reset ? *r.layout_size : 0;
     int jcur = -1;
     float* row = tile + tid * p.D;
-    // the action of step t+2 is requested at step t: one step (~1300 cycles) does not cover an HBM miss plus the
-    // queue of tape stores in front of it (SQ_WAIT_ANY was 409 of 1434 cycles per step with a one-step prefetch)
-    float an[R::NA], an2[R::NA];
-    load_action<R>(r.act, (size_t)i, an);
+    // ACTIONS THROUGH LDS.  vmcnt counts loads and stores alike, in order: a per-step action load, however early it is
+    // issued, makes the step that consumes it wait (s_waitcnt vmcnt) for the tape stores issued after it too -- one L2
+    // store round trip per step, which is what bounded this kernel in rounds 1-2 (~580 ns per step whatever the
+    // instruction count).  The actions of kActBlock steps are therefore fetched at once into registers a whole block
+    // ahead, parked in LDS (lgkmcnt: its own counter) when the block ends, and read from there step by step: the loop
+    // waits for global memory once per kActBlock steps, and the tape stores drain behind the arithmetic.
+    float* actl = tile + BLOCK * p.D; // [2][kActBlock][BLOCK][NA]
+    float anx[kActBlock][R::NA];
 #pragma unroll
-    for (int d = 0; d < R::NA; ++d) an2[d] = 0.f;
-    if (r.T > 1) load_action<R>(r.act, (size_t)p.N + i, an2);
-    // distance to the goal after the previous step: reward_done's `last` (:787-802) is dist(goal, previous position),
-    // i.e. the same operands as the previous step's `dg` whenever it is used (a reset_done changes the goal, but then
-    // last_done > 0 and `last` is the new dg) -- one correctly rounded sqrt less on the serial chain
-    float dprev = dist2(gx, gy, pose0[0], pose0[1]);
-    for (int t = 0; t < r.T; ++t) {
+    for (int k = 0; k < kActBlock; ++k) {
+#pragma unroll
+        for (int d = 0; d < R::NA; ++d) anx[k][d] = 0.f;
+        if (k < r.T) load_action<R>(r.act, (size_t)k * p.N + i, anx[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < kActBlock; ++k)
+#pragma unroll
+        for (int d = 0; d < R::NA; ++d) actl[(k * BLOCK + tid) * R::NA + d] = anx[k][d];
+    int abuf = 0;
+    // FAST PATH / EXACT PATH.  Almost every step is "ordinary": nothing is NaN or huge and the robot moved a few
+    // centimetres.  For such a step (i) jp.clip is the bare median (no NaN to put back), (ii) no observation entry can be
+    // non-finite (exp <= 1, alias in [0,1], compass a sum of two products < 1e37), (iii) reward_done's teleport test
+    // |last - dist| > 1 is false by the triangle inequality (both distances are to the same goal, from positions less
+    // than 0.95 apart; their correctly rounded square roots differ from the true ones by < 1e-3 below 1e4), and
+    // (iv) dist < goal_size  <=>  dist^2 < goal_cut exactly -- so the step needs no NaN select, no observation and NO
+    // SQUARE ROOT (the reward is the observation pass's).  Whether the step was ordinary is checked AFTER it (one sum of
+    // magnitudes, two squared lengths); if not, the step is redone from the saved state with the exact forms: same
+    // results either way, the serial chain is ~45 instructions shorter.
+    //   s_ok: qpos, qvel at the start of the step are finite and < 1e18 (so is the pose the step returns, and its
+    //         velocity-servo term cannot be NaN);  p_ok: the stale pose's cos / sin are finite (ctrl = pose0 * action)
+    bool s_ok, p_ok;
+    {
+        float m0 = fabsf(pose0[2]) + fabsf(pose0[3]), m1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < R::NQ; ++k) m1 = m1 + fabsf(q[k]);
+#pragma unroll
+        for (int k = 0; k < R::NV; ++k) m1 = m1 + fabsf(v[k]);
+        s_ok = moderate(m1); p_ok = moderate(m0);
+    }
+#pragma unroll 1
+    for (int tb = 0; tb < r.T; tb += kActBlock) { // blocks of kActBlock steps (two loops: the block's addresses are
+                                                  // computed once per block, not carried through every step)
+    if (tb + kActBlock < r.T) { // request the next block's actions (consumed kActBlock steps from now)
+#pragma unroll
+        for (int k = 0; k < kActBlock; ++k)
+            if (tb + kActBlock + k < r.T) load_action<R>(r.act, (size_t)(tb + kActBlock + k) * p.N + i, anx[k]);
+    }
+    const int kend = r.T - tb < kActBlock ? r.T - tb : kActBlock;
+#pragma unroll 1
+    for (int kb = 0; kb < kend; ++kb) {
+        const int t = tb + kb;
         float a[R::NA];
 #pragma unroll
-        for (int d = 0; d < R::NA; ++d) { a[d] = an[d]; an[d] = an2[d]; }
-        if (t + 2 < r.T) load_action<R>(r.act, (size_t)(t + 2) * p.N + i, an2);
+        for (int d = 0; d < R::NA; ++d) a[d] = actl[((abuf * kActBlock + kb) * BLOCK + tid) * R::NA + d];
         const bool have_last = (r.hist0 + t) >= 1;
         const float last_done = done0;
 
         float ctrl[R::NU];
         R::convert_action(pose0, a, ctrl); // :672-685, PRE-step xmat
-        float pose[4], qacc[R::NV];
-        for (int k = 0; k < p.physics_steps; ++k) R::template substep<false>(q, v, ctrl, pose, qacc);
-
-        // NaN / Inf guard :696-699
-        // sum of magnitudes < 1e18  =>  every term finite and < 1e18 (NaN / Inf make the comparison false)
-        float mag = (fabsf(pose[0]) + fabsf(pose[1])) + (fabsf(pose[2]) + fabsf(pose[3]));
+        float pose[4], qacc[R::NV], qf[R::NQ], vf[R::NV];
 #pragma unroll
-        for (int k = 0; k < R::NQ; ++k) mag = mag + fabsf(q[k]);
+        for (int k = 0; k < R::NQ; ++k) qf[k] = q[k];
 #pragma unroll
-        for (int k = 0; k < R::NV; ++k) mag = mag + fabsf(v[k]);
+        for (int k = 0; k < R::NV; ++k) vf[k] = v[k];
+        R::template substep<false, true>(qf, vf, ctrl, pose, qacc);
+        float mag = 0.f;
 #pragma unroll
-        for (int k = 0; k < R::NU; ++k) mag = mag + fabsf(ctrl[k]);
-        const bool fin = objs_ok && moderate(mag);
-        bool bad = false;
-        if (!fin) { // rare: evaluate the observation exactly
+        for (int k = 0; k < R::NQ; ++k) mag = mag + fabsf(qf[k]);
+#pragma unroll
+        for (int k = 0; k < R::NV; ++k) mag = mag + fabsf(vf[k]);
+#pragma unroll
+        for (int k = 0; k < R::NA; ++k) mag = mag + fabsf(a[k]);
+        const float mx = pose[0] - pose0[0], my = pose[1] - pose0[1];
+        const float gdx = gx - pose[0], gdy = gy - pose[1];
+        const float d2 = gdx * gdx + gdy * gdy;                 // dist2()'s radicand
+        const bool ordinary = objs_ok && s_ok && p_ok && p.physics_steps == 1 && moderate(mag) &&
+                              (mx * mx + my * my) < 0.9f && d2 < 1e8f;
+        float dn;
+        if (ordinary) {
+#pragma unroll
+            for (int k = 0; k < R::NQ; ++k) q[k] = qf[k];
+#pragma unroll
+            for (int k = 0; k < R::NV; ++k) v[k] = vf[k];
+            dn = d2 < p.goal_cut ? 1.0f : 0.0f;
+            p_ok = true;   // this step's pose: the kinematics of a moderate qpos
+            s_ok = true;   // moderate(mag)
+        } else { // rare: the step again, exactly (from the untouched q, v)
+            for (int k = 0; k < p.physics_steps; ++k) R::template substep<false>(q, v, ctrl, pose, qacc);
+            // NaN / Inf guard :696-699
             float4 ob[PMAX];
             if (jcur >= 0) { float rx_, ry_; load_layout<PMAX>(p, r.cand_xy, r.nobj_total, jcur, ob, rx_, ry_); }
             else {
@@ -146,18 +200,23 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
                 for (int k = 0; k < PMAX; ++k)
                     ob[k] = (k < p.P) ? sa.obj0[(size_t)k * p.Npad + i] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            bad = build_obs_row<R, PMAX>(p, row, pose, ob, ctrl, q, v, 0.f, 0.f, 0.f, 0.f);
+            const bool bad = build_obs_row<R, PMAX>(p, row, pose, ob, ctrl, q, v, 0.f, 0.f, 0.f, 0.f);
+            // the done half of reward_done :787-802 (the reward itself is pass 2's)
+            const float dg = dist2(gx, gy, pose[0], pose[1]);
+            float last = dg;
+            if (have_last && !(last_done > 0.0f)) last = dist2(gx, gy, pose0[0], pose0[1]);
+            const float dd = last - dg;
+            dn = dg < p.goal_size ? 1.0f : 0.0f;
+            if (fabsf(dd) > 1.0f) dn = 1.0f;
+            if (bad) dn = 1.0f;                    // :696-699
+            float m1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < R::NQ; ++k) m1 = m1 + fabsf(q[k]);
+#pragma unroll
+            for (int k = 0; k < R::NV; ++k) m1 = m1 + fabsf(v[k]);
+            p_ok = moderate(fabsf(pose[2]) + fabsf(pose[3]));
+            s_ok = moderate(m1);
         }
-
-        // the done half of reward_done :787-802 (the reward itself is pass 2's)
-        const float dg = dist2(gx, gy, pose[0], pose[1]);
-        float last = dg;
-        if (have_last && !(last_done > 0.0f)) last = dprev;
-        dprev = dg;
-        const float dd = last - dg;
-        float dn = dg < p.goal_size ? 1.0f : 0.0f;
-        if (fabsf(dd) > 1.0f) dn = 1.0f;
-        if (bad) dn = 1.0f;                        // :696-699
         if (steps > p.num_steps_f) dn = 1.0f;      // :492
         steps = dn > 0.0f ? 0.0f : steps + 1.0f;   // :493
 
@@ -201,7 +260,14 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
             R::place(q, nq0, nq1);
             jcur = jaft;
             objs_ok = cfg_ok; // pool rows lie inside the placement extents
+            s_ok = true;      // ... and so does the robot, at rest
         }
+    }
+    abuf ^= 1; // park the next block's actions
+#pragma unroll
+    for (int k = 0; k < kActBlock; ++k)
+#pragma unroll
+        for (int d = 0; d < R::NA; ++d) actl[((abuf * kActBlock + k) * BLOCK + tid) * R::NA + d] = anx[k][d];
     }
     R::store(dyn, p.Npad, i, q, v, pose0, done0, steps);
     if (jcur >= 0) { // the layout a reset_done installed becomes the env's layout
@@ -358,7 +424,8 @@ static hipError_t launch_split_p(const Params& p, const RolloutArgs& r, const Sp
     hipError_t st = hipSuccess; // of the wait that orders the observation pass behind the sampler: must not be dropped
     constexpr int B1 = 64, B2 = 64;
     const dim3 g1((p.N + B1 - 1) / B1), g2((unsigned)(((size_t)r.T * p.N + B2 - 1) / B2));
-    const size_t lds1 = sizeof(float) * (size_t)B1 * p.D, lds2 = sizeof(float) * (size_t)B2 * (r.obs_stride | 1);
+    const size_t lds1 = sizeof(float) * ((size_t)B1 * p.D + 2 * (size_t)kActBlock * B1 * R::NA); // obs rows + two action blocks
+    const size_t lds2 = sizeof(float) * (size_t)B2 * (r.obs_stride | 1);
     if (PMAX == 5 && is_default_layout<R>(p)) {
         if (which & 1) hipLaunchKernelGGL((dyn_tape_kernel<R, B1, 5, true>), g1, dim3(B1), lds1, s, p, r, sa, b.dyn, b.obj);
         if (hold) st = hipStreamWaitEvent(s, hold, 0);

@@ -485,23 +485,24 @@ static void point_substep_s(ptstate* s, const float ctrl[3], float pose[4], floa
     float fy = (-(PT_DXY * s->vy) - (b * w2)) + point_act(ctrl[1], s->vy, bare);
     float ft = (-(PT_DT * s->om) - 0.0f) + point_act(ctrl[2], s->om, bare);
     float t = b * fx + d * fy;
-    float s2 = b * b + d * d;
+    /* Schur complement of the hinge row after eliminating the slides: Io - (b^2 + d^2)/m, and b^2 + d^2 =
+     * (m xc)^2 (sin^2 + cos^2) = (m xc)^2 is a model constant: the solve multiplies by its reciprocal (round 3) */
     /* data.qacc = M^-1 f (no damping in M) */
     {
         const float ia = (float)(1.0 / 0.005188790204786391);
+        const float id3 = (float)(1.0 / (2.842182748581224e-05 - (1.0e-4 * 1.0e-4) / 0.005188790204786391));
         float y3 = ft - t * ia;
-        float d3 = PT_IO - s2 * ia;
-        float q3 = y3 / d3;
+        float q3 = y3 * id3;
         qacc[0] = (fx - b * q3) * ia;
         qacc[1] = (fy - d * q3) * ia;
         qacc[2] = q3;
     }
     /* Euler, damping implicit: (M + h D) qa = f */
     const float ia = (float)(1.0 / (0.005188790204786391 + 0.02 * 0.01));
-    const float ei = (float)(2.842182748581224e-05 + 0.02 * 0.005);
+    const float id3 = (float)(1.0 / ((2.842182748581224e-05 + 0.02 * 0.005) -
+                                     (1.0e-4 * 1.0e-4) / (0.005188790204786391 + 0.02 * 0.01)));
     float y3 = ft - t * ia;
-    float d3 = ei - s2 * ia;
-    float q3 = y3 / d3;
+    float q3 = y3 * id3;
     float q1 = (fx - b * q3) * ia;
     float q2 = (fy - d * q3) * ia;
     s->vx = s->vx + PT_H * q1;
