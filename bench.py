@@ -159,6 +159,24 @@ def time_launches(launch, nlaunch):
     return float(np.median(per)), float(cadence)
 
 
+def _evidence(fn_name):
+    """Numbers from the committed rocprofv3 summaries (tools/profile_evidence.py), or (None, reason) when the
+    summaries are missing or were taken on another build of the library than the one loaded here."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import profile_evidence as pe
+        from guardx_amd import _native
+        have, _ = pe.build_id()
+        lib_id = _native.load().gx_build_id().decode()
+        if have is None:
+            return None, f"no profiles/{pe.TAG}_build_id.txt"
+        if have != lib_id:
+            return None, f"profiles/{pe.TAG}_* were taken on build {have}, this library is {lib_id}: re-run tools/collect_profiles.sh"
+        return getattr(pe, fn_name)(), None
+    except Exception as exc:  # noqa: BLE001 - evidence is optional, the measured numbers are not
+        return None, f"{type(exc).__name__}: {exc}"[:200]
+
+
 def roofline_rollout(env_num, T, nlaunch, device):
     """The step path of the headline workload: one gx_rollout call = T fused step+reset_done passes over env_num
     envs = the dynamics-tape kernel + the observation-pass kernel (gx_split_rollout.inl)."""
@@ -179,29 +197,36 @@ def roofline_rollout(env_num, T, nlaunch, device):
     env.close()
     t = min(per, cadence)
     ach = ALGO_BYTES_PER_ENV_STEP * env_num * T / t / 1e9
-    # rocprofv3 PMC, profiles/r02_rollout_N2000_T200_pmc_{FETCH,WRITE}_SIZE.csv (KB per launch; FETCH x2 on gfx950)
-    pmc_kb = 2 * (1742.6 + 16662.1) + (31500.0 + 71875.0)
-    return {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 6),
-            "traffic": round(pmc_kb * 1024 / 1e9 * (env_num * T) / (2000 * 200), 4),
-            "traffic_note": "NOT measured in this run: GB per gx_rollout call from the committed rocprofv3 PMC passes at "
-                            "env_num=2000, T=200: 2*FETCH_SIZE + WRITE_SIZE = 36.8 MB + 103.4 MB "
-                            "(profiles/r02_rollout_N2000_T200_pmc_*.csv) against 148.8 MB algorithmic: the 32 MB "
-                            "dynamics tape is written once and read once instead of the 36 B/env-step state round trip",
-            "kernel": "gx::dyn_tape_kernel<PointRobot,64,5,true> + gx::obs_tape_kernel<PointRobot,64,5,true> "
-                      "(the two launches of one gx_rollout call = 200 fused step+reset_done passes)",
-            "kernels_us_rocprof": {"dyn_tape_kernel": 118.3, "obs_tape_kernel": 33.8,
-                                   "source": "profiles/r02_rollout_N2000_T200_kernel_stats.csv (standalone)"},
-            "obs_pass_alone": {"GBps_pmc_traffic": round((2 * 16662.1 + 71875.0) * 1024 / 33.8e-6 / 1e9, 1),
-                               "frac_of_peak": round((2 * 16662.1 + 71875.0) * 1024 / 33.8e-6 / 1e9 / HBM_PEAK_GBS, 4),
-                               "note": "the 400k-row observation pass alone (profiled, not this run): 105.8 MB in 33.8 us"},
-            "env_num": env_num, "steps_per_launch": T,
-            "avg_launch_us": round(t * 1e6, 3), "event_pair_us": round(per * 1e6, 3),
-            "back_to_back_us": round(cadence * 1e6, 3),
-            "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
-            "note": "env_num=2000 is latency-bound by construction (0.74 MB of algorithmic traffic per step): the serial "
-                    "dynamics pass (32 waves, ~1400 cycles per step) takes 3/4 of the call; see roofline_large_batch for "
-                    "the bandwidth regime"}
+    out = {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+           "kernel": "gx::dyn_tape_kernel<PointRobot,64,5,true> + gx::obs_tape_kernel<PointRobot,64,5,true> "
+                     "(the two launches of one gx_rollout call = 200 fused step+reset_done passes)",
+           "env_num": env_num, "steps_per_launch": T,
+           "avg_launch_us": round(t * 1e6, 3), "event_pair_us": round(per * 1e6, 3),
+           "back_to_back_us": round(cadence * 1e6, 3),
+           "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
+           "note": "env_num=2000 is latency-bound by construction (0.74 MB of algorithmic traffic per step): the serial "
+                   "dynamics pass (32 waves, one per SIMD) takes 3/4 of the call; see roofline_large_batch for "
+                   "the bandwidth regime"}
+    ev, why = _evidence("rollout_numbers")
+    if ev is None:
+        out["traffic_note"] = "no PMC traffic figure: " + why
+        return out
+    scale = (env_num * T) / (2000 * 200)
+    out["traffic"] = round((ev["dyn_bytes"] + ev["obs_bytes"]) / 1e9 * scale, 4)
+    out["traffic_note"] = ("NOT measured in this run: GB per gx_rollout call from the committed rocprofv3 PMC passes at "
+                           "env_num=2000, T=200 (2*FETCH_SIZE + WRITE_SIZE per kernel: dynamics pass "
+                           f"{ev['dyn_bytes'] / 1e6:.1f} MB, observation pass {ev['obs_bytes'] / 1e6:.1f} MB) against "
+                           f"{ALGO_BYTES_PER_ENV_STEP * 2000 * 200 / 1e6:.1f} MB algorithmic; read from " + ", ".join(ev["files"][1:3]))
+    out["kernels_us_rocprof"] = {"dyn_tape_kernel": round(ev["dyn_us"], 1), "obs_tape_kernel": round(ev["obs_us"], 1),
+                                 "source": ev["files"][0] + " (standalone)"}
+    out["obs_pass_alone"] = {"GBps_pmc_traffic": round(ev["obs_bytes"] / (ev["obs_us"] * 1e-6) / 1e9, 1),
+                             "frac_of_peak": round(ev["obs_bytes"] / (ev["obs_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                             "note": "the 400k-row observation pass alone (profiled, not this run)"}
+    out["dyn_pass_alone"] = {"valu_per_wave_step": round(ev["dyn_valu"] / ev["dyn_waves"] / 200, 1),
+                             "salu_per_wave_step": round(ev["dyn_salu"] / ev["dyn_waves"] / 200, 1),
+                             "waves": int(ev["dyn_waves"]), "ns_per_step": round(ev["dyn_us"] * 1e3 / 200, 1)}
+    return out
 
 
 def roofline_step(env_num, nlaunch, device):
@@ -224,15 +249,20 @@ def roofline_step(env_num, nlaunch, device):
     env.close()
     t = min(per, cadence)
     ach = ALGO_BYTES_PER_ENV_STEP * env_num / t / 1e9
-    return {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 6),
-            "traffic": round(380 * env_num / 1e9, 4),
-            "traffic_note": "NOT measured in this run: GB per launch from the committed rocprofv3 PMC passes "
-                            "(2*FETCH_SIZE + WRITE_SIZE = 380 B/env, profiles/r01_step_N4194304_pmc_*.csv)",
-            "kernel": "gx::step_kernel<256,5,true>", "env_num": env_num,
-            "avg_launch_us": round(t * 1e6, 3), "event_pair_us": round(per * 1e6, 3),
-            "back_to_back_us": round(cadence * 1e6, 3),
-            "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP}
+    out = {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+           "kernel": "gx::step_kernel<PointRobot,64,5,true,true>", "env_num": env_num,
+           "avg_launch_us": round(t * 1e6, 3), "event_pair_us": round(per * 1e6, 3),
+           "back_to_back_us": round(cadence * 1e6, 3),
+           "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP}
+    ev, why = _evidence("step_large_numbers")
+    if ev is None:
+        out["traffic_note"] = "no PMC traffic figure: " + why
+    else:
+        out["traffic"] = round(ev["bytes_per_env"] * env_num / 1e9, 4)
+        out["traffic_note"] = ("NOT measured in this run: GB per launch from the committed rocprofv3 PMC passes at 2^22 envs "
+                               f"(2*FETCH_SIZE + WRITE_SIZE = {ev['bytes_per_env']:.1f} B/env; " + ", ".join(ev["files"][1:]) + ")")
+    return out
 
 
 def large_batch_fused(env_num, K, device, reps=4):
@@ -338,14 +368,20 @@ def epoch_breakdown(device):
             "note": "reset() = exact restatement of the reference's 1e6-candidate rejection sampler "
                     "(6e8 Threefry-2x32 blocks cut to under 3e8 by exact early rejection and lazy evaluation of the draws); it is integer-VALU "
                     "bound and bounds the epoch",
-            "valu_issue": {
-                "wave_instructions_per_epoch": 301e6,
-                "ns_per_wave_instruction_per_simd": 1.73, "simds": 1024,
-                "issue_floor_us": round(301e6 * 1.73e-9 / 1024 * 1e6, 1),
-                "note": "NOT measured in this run: SQ_INSTS_VALU of every kernel of one epoch (profiles/r02_sampler_pmc_SQ.csv, "
-                        "r02_rollout_N2000_T200_pmc_SQ.csv) x the measured issue cost of the sampler's own Threefry code "
-                        "(profiles/r02_probe_threefry_chain.log: 110 ns per 63.5-instruction block per SIMD) / 1024 SIMDs: the time "
-                        "the vector ALUs need just to issue one epoch's instructions; compare with the headline ms_per_step"}}
+            "valu_issue": valu_issue_floor()}
+
+
+def valu_issue_floor():
+    """the time the vector ALUs need just to issue one epoch's instructions, from the committed counters"""
+    n, why = _evidence("epoch_valu_instructions")
+    if n is None:
+        return {"note": "no counter evidence: " + why}
+    ns = 1.73   # profiles/r02_probe_threefry_chain.log: 110 ns per 63.5-instruction Threefry block per SIMD
+    return {"wave_instructions_per_epoch": round(n), "ns_per_wave_instruction_per_simd": ns, "simds": 1024,
+            "issue_floor_us": round(n * ns * 1e-9 / 1024 * 1e6, 1),
+            "note": "NOT measured in this run: SQ_INSTS_VALU of every kernel of one epoch (profiles/r03_sampler_pmc_SQ.csv, "
+                    "r03_rollout_N2000_T200_pmc_SQ.csv) x the measured issue cost of the sampler's own Threefry code / 1024 "
+                    "SIMDs; compare with the headline ms_per_step"}
 
 
 def closed_loop_rate(device, epochs=50):

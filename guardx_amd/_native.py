@@ -51,6 +51,7 @@ SYMBOLS = {
     "gx_last_error": (C.c_char_p, []),
     "gx_abi_version": (C.c_int32, []),
     "gx_build_id": (C.c_char_p, []),
+    "gx_build_compiler": (C.c_char_p, []),
     "gx_create": (C.c_int, [C.POINTER(GxConfig), C.POINTER(C.c_void_p)]),
     "gx_destroy": (C.c_int, [C.c_void_p]),
     "gx_obs_dim": (C.c_int32, [C.c_void_p]),

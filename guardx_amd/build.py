@@ -47,12 +47,32 @@ BUILD_ID_FILE = os.path.join(LIB_DIR, "BUILD_ID")
 LOCK_FILE = os.path.join(LIB_DIR, ".build.lock")
 
 
+_COMPILER = None
+
+
+def compiler_id():
+    """`hipcc --version` in one line (HIP version + clang version): part of the build identity, because at least one
+    kernel here depends on what a particular compiler does (the Walker's lane-group step must stay a call:
+    inlining it miscompiles, gx_robot_legs_group.h) -- a different compiler is a different build."""
+    global _COMPILER
+    if _COMPILER is None:
+        try:
+            out = subprocess.run([os.environ.get("HIPCC", "hipcc"), "--version"], capture_output=True, text=True,
+                                 timeout=60).stdout
+            keep = [ln.strip() for ln in out.splitlines() if ln.startswith(("HIP version", "AMD clang version"))]
+            _COMPILER = "; ".join(keep) or "unknown"
+        except Exception:  # noqa: BLE001 - no compiler on this machine: the prebuilt library's own record stands
+            _COMPILER = "unknown"
+    return _COMPILER
+
+
 def source_hash():
-    """sha256 over every source, header and flag that goes into the library: the identity of a build.  It is
-    compiled into the library (gx_build_id()) and checked at load time, so a stale or foreign .so is never
-    loaded silently, whatever the file times say (the tree is copied to the GPU box without them)."""
+    """sha256 over every source, header, flag and the compiler version that goes into the library: the identity of
+    a build.  It is compiled into the library (gx_build_id()) and checked at load time, so a stale or foreign .so
+    is never loaded silently, whatever the file times say (the tree is copied to the GPU box without them)."""
     import hashlib
     h = hashlib.sha256()
+    h.update(compiler_id().encode() + b"\0")
     names = sorted(set(SOURCES) | set(HEADERS) | {"gx_split_rollout.inl"})
     for n in names:
         path = os.path.join(CSRC, n)
@@ -86,7 +106,7 @@ def _dep_hash(src):
     for n in [src] + sorted(set(HEADERS) | {"gx_split_rollout.inl"}):
         with open(os.path.join(CSRC, n), "rb") as f:
             h.update(n.encode() + b"\0" + f.read())
-    h.update(repr((FLAGS, _extra(src))).encode())
+    h.update(repr((FLAGS, _extra(src), compiler_id())).encode())
     return h.hexdigest()[:24]
 
 
@@ -119,8 +139,9 @@ def _build_locked(force, verbose, jobs):
             have = None
         if not force and os.path.exists(obj) and have == want:
             return
-        cmd = [hipcc] + FLAGS + _extra(src) + (['-DGX_BUILD_ID="%s"' % bid] if src == "gx_api.hip" else []) + \
-              ["-c", path, "-o", obj]
+        cmd = [hipcc] + FLAGS + _extra(src) + \
+              (['-DGX_BUILD_ID="%s"' % bid, '-DGX_BUILD_COMPILER="%s"' % compiler_id().replace('"', "'")]
+               if src == "gx_api.hip" else []) + ["-c", path, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

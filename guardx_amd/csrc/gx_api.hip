@@ -159,6 +159,10 @@ extern "C" int32_t gx_abi_version(void) { return 2; }
 #define GX_BUILD_ID "unknown"
 #endif
 extern "C" const char* gx_build_id(void) { return GX_BUILD_ID; } // guardx_amd/build.py:source_hash() of the sources
+#ifndef GX_BUILD_COMPILER
+#define GX_BUILD_COMPILER "unknown"
+#endif
+extern "C" const char* gx_build_compiler(void) { return GX_BUILD_COMPILER; } // `hipcc --version` the library was built with
 extern "C" int32_t gx_obs_dim(const gx_engine* e) { return e ? e->p.D : -1; }
 extern "C" int32_t gx_act_dim(const gx_engine* e) { return e ? e->na : -1; }
 extern "C" gx_status gx_dims(const gx_engine* e, int32_t* nq, int32_t* nv, int32_t* nu, int32_t* na)

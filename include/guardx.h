@@ -96,6 +96,8 @@ const char* gx_last_error(void);
 int32_t gx_abi_version(void);
 /* identity of the sources and flags this library was built from (guardx_amd/build.py:source_hash) */
 const char* gx_build_id(void);
+/* `hipcc --version` (HIP + clang version lines) the library was built with; it is part of gx_build_id()'s hash */
+const char* gx_build_compiler(void);
 
 gx_status gx_create(const gx_config* cfg, gx_engine** out);
 gx_status gx_destroy(gx_engine* e);

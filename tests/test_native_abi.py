@@ -113,3 +113,44 @@ def test_no_kernel_reads_the_aql_packet():
     for k, v in ks.items():
         if "group_rollout_kernel" in k and ("PointRobot" in k or "SwimmerRobot" in k) and k.endswith("ELi0EEEvNS_6ParamsENS_11RolloutArgsENS_10PolicyArgsEP15HIP_vector_typeIfLj4EES8_S8_"):
             assert v["scratch"] == 0, (k, v)
+
+
+def test_walker_lane_group_step_is_still_one_call():
+    """The Walker's lane-group step must stay ONE real call: inlined into group_rollout_kernel it miscompiles with
+    hipcc 7.2 (dynamics blow up, gx_robot_legs_group.h), and with two call sites LLVM's inter-procedural register
+    allocation clobbered the caller's spilled exec masks.  A compiler that silently re-inlines
+    the step -- or duplicates the call site -- shows up here instead of as a parity failure on the GPU: every
+    open-loop Walker lane-group kernel contains exactly one s_swappc_b64, the Ant's (inlined on purpose) none.
+    The compiler's version is part of the library's identity (gx_build_compiler, hashed into gx_build_id)."""
+    import shutil
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import kernel_descriptors as kd
+    from guardx_amd import _native, build as gx_build
+    lib = _native.load()
+    assert lib.gx_build_compiler().decode() == gx_build.compiler_id()
+    objdump = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    walker, ant = {}, {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for i, (triple, data) in enumerate(kd.code_objects(_native.LIB_PATH)):
+            if "gfx950" not in triple or data[:4] != b"\x7fELF":
+                continue
+            names = [k for k in kd.descriptors(data)
+                     if "group_rollout_kernel" in k and ("WalkerRobot" in k or "AntRobot" in k) and "ELi0EEEvNS_6Params" in k]
+            if not names:
+                continue
+            path = os.path.join(tmp, f"co{i}.elf")
+            with open(path, "wb") as f:
+                f.write(data)
+            for n in names:
+                asm = subprocess.run([objdump, "-d", "--mcpu=gfx950", "--disassemble-symbols=" + n, path],
+                                     capture_output=True, text=True, check=True).stdout
+                (walker if "WalkerRobot" in n else ant)[n] = asm.count("s_swappc_b64")
+    assert len(walker) >= 4 and len(ant) >= 4, (len(walker), len(ant))
+    assert set(walker.values()) == {1}, walker
+    assert set(ant.values()) == {0}, ant

@@ -1,0 +1,47 @@
+"""bench.py quotes profile numbers (PMC traffic, kernel times, VALU counts): they are READ from the committed rocprofv3
+summaries under profiles/ (tools/profile_evidence.py), and those summaries must have been taken on THIS build of the
+library -- a kernel change without re-running tools/collect_profiles.sh fails here instead of leaving stale evidence."""
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import profile_evidence as pe  # noqa: E402
+
+
+def test_profiles_were_taken_on_this_build():
+    from guardx_amd import build as gx_build
+    have, compiler = pe.build_id()
+    assert have is not None, f"profiles/{pe.TAG}_build_id.txt is missing: run tools/collect_profiles.sh {pe.TAG} through gpurun"
+    assert have == gx_build.source_hash(), (
+        f"profiles/{pe.TAG}_* were taken on build {have}; the tree is {gx_build.source_hash()}: the kernels changed, "
+        f"re-run tools/collect_profiles.sh {pe.TAG} on the GPU box and copy gpurun_out/{pe.TAG}_* into profiles/")
+    assert compiler == gx_build.compiler_id()
+
+
+def test_quoted_numbers_come_out_of_the_files():
+    r = pe.rollout_numbers()
+    # one gx_rollout call = one dynamics launch over 32 one-wave workgroups + one observation launch over 400 000 rows
+    assert r["dyn_waves"] == 32 and 50 < r["dyn_us"] < 200 and 15 < r["obs_us"] < 80
+    algo = 372 * 2000 * 200
+    total = r["dyn_bytes"] + r["obs_bytes"]
+    assert 0.6 * algo < total < 1.2 * algo, (total, algo)            # no wasted re-reads: traffic ~ algorithmic bytes
+    # the slim tape: the dynamics pass writes 48 B per env-step (+ the entry records), not 80
+    assert 0.9 * 48 * 400_000 < r["dyn_write_kb"] * 1024 < 1.15 * 48 * 400_000, r["dyn_write_kb"]
+    s = pe.step_large_numbers()
+    assert 370 < s["bytes_per_env"] < 400, s["bytes_per_env"]          # 380 B per env-step, the kernel's own byte count
+    n = pe.epoch_valu_instructions()
+    assert 1.5e8 < n < 3.5e8
+    smp = pe.sampler_numbers()
+    assert smp["sample_phase1_kernel_us"] > smp["sample_phase2_kernel_us"] > smp["scan_compact_kernel_us"]
+
+
+def test_bench_has_no_typed_in_profile_numbers():
+    """the literals the round-2 verdict listed (PMC KB, kernel us, 301e6 instructions) are gone from bench.py"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for lit in ("1742.6", "16662.1", "31500.0", "71875.0", "118.3", "33.8", "301e6"):
+        assert lit not in src, lit
+    assert "profile_evidence" in src and re.search(r"_evidence\(\"rollout_numbers\"\)", src)

@@ -1,0 +1,44 @@
+#!/bin/bash
+# Collect every rocprofv3 summary bench.py / DESIGN.md quote, on the GPU box (through gpurun, from the repo root):
+#   tools/collect_profiles.sh r03      -> gpurun_out/r03_*.csv, r03_build_id.txt  (copy them into profiles/)
+# Counter passes are separate runs with --pmc only (no --kernel-trace/--stats mixed in).
+set -e
+tag=${1:-r03}
+out=$PWD/gpurun_out
+mkdir -p $out
+export TMPDIR=/tmp
+python3 -c "
+from guardx_amd import _native
+l = _native.load(); print(l.gx_build_id().decode()); print(l.gx_build_compiler().decode())" > $out/${tag}_build_id.txt
+kt() { # name, command...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_${tag}_$name -- "$@" > $out/${tag}_${name}_kt.log 2>&1
+  cp $(find /tmp/kt_${tag}_$name -name "*kernel_stats.csv" | head -1) $out/${tag}_${name}_kernel_stats.csv
+}
+pmc() { # name, counters-label, counters..., -- command...
+  local name=$1 label=$2; shift 2
+  local ctrs=()
+  while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done
+  shift
+  rocprofv3 --pmc "${ctrs[@]}" --output-format csv -d /tmp/pmc_${tag}_${name}_$label -- "$@" > $out/${tag}_${name}_pmc_$label.log 2>&1
+  python3 tools/pmc_means.py $(find /tmp/pmc_${tag}_${name}_$label -name "*counter_collection.csv" | head -1) > $out/${tag}_${name}_pmc_$label.csv
+}
+ROLL="python3 tools/profile_step.py --mode rollout --env-num 2000 --launches 200"
+STEP="python3 tools/profile_step.py --mode step --env-num 4194304 --launches 20"
+FUSE="python3 tools/profile_step.py --mode rollout --env-num 4194304 --launches 16"
+RST="python3 tools/profile_reset.py"
+SQ="SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES SQ_INSTS_SALU"
+kt rollout_N2000_T200 $ROLL
+pmc rollout_N2000_T200 FETCH_SIZE FETCH_SIZE -- $ROLL
+pmc rollout_N2000_T200 WRITE_SIZE WRITE_SIZE -- $ROLL
+pmc rollout_N2000_T200 SQ $SQ -- $ROLL
+kt step_N4194304 $STEP
+pmc step_N4194304 FETCH_SIZE FETCH_SIZE -- $STEP
+pmc step_N4194304 WRITE_SIZE WRITE_SIZE -- $STEP
+pmc thread_rollout_N4194304_K16 FETCH_SIZE FETCH_SIZE -- $FUSE
+pmc thread_rollout_N4194304_K16 WRITE_SIZE WRITE_SIZE -- $FUSE
+kt sampler $RST
+pmc sampler SQ SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_BUSY_CYCLES -- $RST
+kt bench_noextras python3 bench.py --no-cpu-baseline --no-extras
+rm -f $out/${tag}_*_kt.log $out/${tag}_*_pmc_*.log
+ls $out/${tag}_* | wc -l
