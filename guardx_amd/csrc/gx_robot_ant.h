@@ -258,9 +258,39 @@ struct AntRobot {
             }
         return m;
     }
+    // CANONICAL ROW ORDER (round 3): whatever is summed over the six constraint rows of one leg is summed as
+    //     ((t0 + t4) + t2) + ((t1 + t5) + t3),      t_k = -0 for a row that does not take part,
+    // and then added to what it extends -- the order in which the four lanes that share a leg in the lane-group kernel
+    // (gx_robot_ant_group.h: lane r owns rows r and r + 4) combine their partial sums with two butterfly exchanges.
+    // -0 is the identity of IEEE addition for EVERY x (x + (-0) = x, signed zeros included), so a row that does not
+    // take part can simply be skipped here: U = -0; U += t0, t4, t2 as they take part; V likewise; sum = U + V.
+    static constexpr int kTerms = 20;
+    // adds the twenty products row k of leg l contributes to the Newton system:
+    // [0..5] base block (0,0) (1,0) (1,1) (2,0) (2,1) (2,2); [6..8] / [9..11] coupling columns hip / beta;
+    // [12..14] base right-hand side; [15..17] Lhh, Lhb, Lbb; [18..19] leg right-hand side
+    GX_D static void add_row_terms(const Rows& rows, int l, int k, uint32_t act, float (&t)[kTerms])
+    {
+        static_assert(kRows == 6, "canonical row order is written for six rows per leg");
+        if (!((act >> (l * kRows + k)) & 1u)) return;
+        const Row R = row_of(rows, l, k);
+        const float da = R.D * R.aref;
+        int e = 0;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const float dj = R.D * R.J[b];
+#pragma unroll
+            for (int c = 0; c <= b; ++c) { t[e] = t[e] + dj * R.J[c]; ++e; }
+            t[6 + b] = t[6 + b] + dj * R.J[3];
+            t[9 + b] = t[9 + b] + dj * R.J[4];
+            t[12 + b] = t[12 + b] + da * R.J[b];
+        }
+        const float d3 = R.D * R.J[3], d4 = R.D * R.J[4];
+        t[15] = t[15] + d3 * R.J[3]; t[16] = t[16] + d3 * R.J[4]; t[17] = t[17] + d4 * R.J[4];
+        t[18] = t[18] + da * R.J[3]; t[19] = t[19] + da * R.J[4];
+    }
     // minimiser of the quadratic piece selected by `act`: (M + J_A' D J_A) a = f + J_A' D aref_A
-    // every leg first sums its own rows (leg-local partial sums), then the base block and the base right-hand
-    // side take the four partials in leg order -- the order the leg-parallel form (substep_group) reproduces
+    // every leg first sums its own rows (canonical row order), then the base block and the base right-hand
+    // side take the four leg sums in leg order -- the order the leg-parallel form (substep_group) reproduces
     GX_D static void newton_solve(const Arrow& M, const float* f, const Rows& rows, uint32_t act, float* a)
     {
         Arrow Hm = M;
@@ -269,40 +299,40 @@ struct AntRobot {
         for (int k = 0; k < 11; ++k) r[k] = f[k];
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
-            float PB[3][3], Pr[3] = {0.0f, 0.0f, 0.0f};
+            float U[kTerms], V[kTerms];
 #pragma unroll
-            for (int b = 0; b < 3; ++b)
+            for (int e = 0; e < kTerms; ++e) { U[e] = -0.0f; V[e] = -0.0f; }
+            add_row_terms(rows, l, 0, act, U); add_row_terms(rows, l, 4, act, U); add_row_terms(rows, l, 2, act, U);
+            add_row_terms(rows, l, 1, act, V); add_row_terms(rows, l, 5, act, V); add_row_terms(rows, l, 3, act, V);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) PB[b][c] = 0.0f;
-#pragma unroll
-            for (int k = 0; k < kRows; ++k) {
-                if (!((act >> (l * kRows + k)) & 1u)) continue;
-                const Row R = row_of(rows, l, k);
-                const float da = R.D * R.aref;
-#pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    const float dj = R.D * R.J[b];
-#pragma unroll
-                    for (int c = 0; c <= b; ++c) PB[b][c] = PB[b][c] + dj * R.J[c];
-                    Hm.C[l][b][0] = Hm.C[l][b][0] + dj * R.J[3];
-                    Hm.C[l][b][1] = Hm.C[l][b][1] + dj * R.J[4];
-                    Pr[b] = Pr[b] + da * R.J[b];
-                }
-                const float d3 = R.D * R.J[3], d4 = R.D * R.J[4];
-                Hm.Lhh[l] = Hm.Lhh[l] + d3 * R.J[3];
-                Hm.Lhb[l] = Hm.Lhb[l] + d3 * R.J[4];
-                Hm.Lbb[l] = Hm.Lbb[l] + d4 * R.J[4];
-                r[3 + 2 * l] = r[3 + 2 * l] + da * R.J[3];
-                r[4 + 2 * l] = r[4 + 2 * l] + da * R.J[4];
-            }
+            for (int e = 0; e < kTerms; ++e) U[e] = U[e] + V[e];
+            int e = 0;
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
 #pragma unroll
-                for (int c = 0; c <= b; ++c) Hm.B[b][c] = Hm.B[b][c] + PB[b][c];
-                r[b] = r[b] + Pr[b];
+                for (int c = 0; c <= b; ++c) Hm.B[b][c] = Hm.B[b][c] + U[e++];
+                Hm.C[l][b][0] = Hm.C[l][b][0] + U[6 + b];
+                Hm.C[l][b][1] = Hm.C[l][b][1] + U[9 + b];
+                r[b] = r[b] + U[12 + b];
             }
+            Hm.Lhh[l] = Hm.Lhh[l] + U[15];
+            Hm.Lhb[l] = Hm.Lhb[l] + U[16];
+            Hm.Lbb[l] = Hm.Lbb[l] + U[17];
+            r[3 + 2 * l] = r[3 + 2 * l] + U[18];
+            r[4 + 2 * l] = r[4 + 2 * l] + U[19];
         }
         arrow_solve(Hm, r, a);
+    }
+    // adds the five entries of J' force of row k of leg l when the row is present and violated at `a`
+    GX_D static void add_force_terms(const Rows& rows, int l, int k, const float* a, float (&t)[5])
+    {
+        const Row R = row_of(rows, l, k);
+        if (!R.present) return;
+        const float res = dot5(R.J, a, l) - R.aref;
+        if (!(res < 0.0f)) return;
+        const float frc = R.D * (-res);
+#pragma unroll
+        for (int e = 0; e < 5; ++e) t[e] = t[e] + frc * R.J[e];
     }
 
     // pose of the robot body (x, y, cos, sin) from qpos: the y slide acts along the rotated body axis
@@ -455,22 +485,13 @@ struct AntRobot {
             }
             keep_compact(rows);
 #pragma unroll
-            for (int l = 0; l < 4; ++l) {
-                float Pf[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-                for (int k = 0; k < kRows; ++k) {
-                    const Row R = row_of(rows, l, k);
-                    if (!R.present) continue;
-                    const float res = dot5(R.J, a, l) - R.aref;
-                    if (!(res < 0.0f)) continue;
-                    const float frc = R.D * (-res);
-                    Pf[0] = Pf[0] + frc * R.J[0];
-                    Pf[1] = Pf[1] + frc * R.J[1];
-                    Pf[2] = Pf[2] + frc * R.J[2];
-                    fc[3 + 2 * l] = fc[3 + 2 * l] + frc * R.J[3];
-                    fc[4 + 2 * l] = fc[4 + 2 * l] + frc * R.J[4];
-                }
-                fc[0] = fc[0] + Pf[0]; fc[1] = fc[1] + Pf[1]; fc[2] = fc[2] + Pf[2];
+            for (int l = 0; l < 4; ++l) { // rows in canonical order, legs in leg order
+                float U[5] = {-0.0f, -0.0f, -0.0f, -0.0f, -0.0f}, V[5] = {-0.0f, -0.0f, -0.0f, -0.0f, -0.0f};
+                add_force_terms(rows, l, 0, a, U); add_force_terms(rows, l, 4, a, U); add_force_terms(rows, l, 2, a, U);
+                add_force_terms(rows, l, 1, a, V); add_force_terms(rows, l, 5, a, V); add_force_terms(rows, l, 3, a, V);
+                fc[3 + 2 * l] = fc[3 + 2 * l] + (U[3] + V[3]);
+                fc[4 + 2 * l] = fc[4 + 2 * l] + (U[4] + V[4]);
+                fc[0] = fc[0] + (U[0] + V[0]); fc[1] = fc[1] + (U[1] + V[1]); fc[2] = fc[2] + (U[2] + V[2]);
             }
         }
         // Euler with implicit joint damping: (M + h diag(damping)) qacc_int = f + J' force

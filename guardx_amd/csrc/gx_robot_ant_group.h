@@ -6,6 +6,13 @@
 // terms in leg order through DPP quad broadcasts, which is exactly the order the serial form (and the CPU
 // checker) sums them in: the two forms agree bit for bit.  ~3x fewer instructions per lane, and the code is
 // not unrolled over the legs, so it fits the instruction cache.
+//
+// Round 3: the four quads of a group are no longer pure replicas.  Lane l = 4 r + L (r = its quad, L = its leg) owns
+// rows r and r + 4 of leg L's six constraint rows (r >= 2: row r only): it builds those rows, the products of the
+// Newton matrix / right-hand side / constraint force that belong to them, and its share of the active-set test; the
+// four partial sums of a leg meet in two butterfly exchanges across the quads (DPP row_ror:8, row_ror:4), which
+// evaluates ((t0 + t4) + t2) + ((t1 + t5) + t3) (t_k = -0 for a row that does not take part) on every lane -- the canonical row order of AntRobot::rowsum and of
+// the CPU checker, so the forms still agree bit for bit.  Per Newton iteration a lane handles 2 rows instead of 6.
 #pragma once
 #include "gx_robot_ant.h"
 
@@ -43,47 +50,68 @@ struct AntGroup {
 
     struct LegBlk { float C[3][2], Lhh, Lhb, Lbb; };
 
-    // full row k of this lane's leg (same operations as AntRobot::row_of)
-    GX_D static Row row_of(const Lim (&lim)[2], const Foot& ft, float c, float s, int k)
+    // value held by the lane N places up (cyclically) in this lane's 16-lane row = the same leg in quad (r + N / 4) % 4
+    template <int N>
+    GX_D static float ror(float x)
     {
-        Row R;
-        if (k < 2) {
-            const Lim& m = lim[k];
-            R.present = m.sg != 0.0f;
-            R.J[0] = 0.0f; R.J[1] = 0.0f; R.J[2] = 0.0f;
-            R.J[3] = (k == 0) ? m.sg : 0.0f;
-            R.J[4] = (k == 1) ? m.sg : 0.0f;
-            R.aref = m.aref; R.D = m.D;
-        } else {
-            const int kk = k - 2;
-            const float sgn = (kk & 1) ? -A::kMu : A::kMu;
-            R.present = ft.on;
-            if (kk < 2) {
-                R.J[0] = sgn * 0.0f; R.J[1] = sgn * ft.T1[0]; R.J[2] = sgn * c; R.J[3] = sgn * ft.T1[1];
-                R.J[4] = ft.jbz + sgn * ft.T1[2];
-            } else {
-                R.J[0] = sgn * 1.0f; R.J[1] = sgn * ft.T2[0]; R.J[2] = sgn * (-s); R.J[3] = sgn * ft.T2[1];
-                R.J[4] = ft.jbz + sgn * ft.T2[2];
-            }
-            R.aref = ft.aref[kk]; R.D = ft.D;
-        }
-        return R;
+        return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x120 + N, 0xf, 0xf, true));
     }
+    template <int N>
+    GX_D static int rori(int x) { return __builtin_amdgcn_mov_dpp(x, 0x120 + N, 0xf, 0xf, true); }
+    // (p0 + p2) + (p1 + p3) over the four quads' partial sums p_r of one leg, on every lane of the leg
+    // (quad 0 / 2 form p0 + p2 / p2 + p0, quads 1 / 3 p1 + p3 / p3 + p1: the same bits; likewise the second stage)
+    GX_D static float quads_sum(float p)
+    {
+        const float s1 = p + ror<8>(p);
+        return s1 + ror<4>(s1);
+    }
+    GX_D static uint32_t quads_or(uint32_t m)
+    {
+        const uint32_t m1 = m | (uint32_t)rori<8>((int)m);
+        return m1 | (uint32_t)rori<4>((int)m1);
+    }
+    // the rows this lane owns: A = row r (a joint-limit row for r < 2, pyramid row r - 2 otherwise), B = row r + 4
+    // (pyramid rows 2, 3; quads 0 and 1 only; absent -- never present, never active -- for quads 2 and 3).  Same
+    // operations as AntRobot::row_of, written with selects because r differs from lane to lane.
+    struct MyRows { Row A, B; };
+    // pj / paref: the lane's pyramid row (row r + 4 for r < 2, row r for r >= 2) and its aref, built once per step
+    GX_D static MyRows my_rows(const Lim (&lim)[2], int foot_on, float foot_D, const float (&pj)[5], float paref, int r)
+    {
+        MyRows M;
+        const bool islim = r < 2;
+        const float lsg = (r & 1) ? lim[1].sg : lim[0].sg;
+        const float laref = (r & 1) ? lim[1].aref : lim[0].aref;
+        const float lD = (r & 1) ? lim[1].D : lim[0].D;
+        M.A.present = islim ? (lsg != 0.0f) : (foot_on != 0);
+        M.A.J[0] = islim ? 0.0f : pj[0];
+        M.A.J[1] = islim ? 0.0f : pj[1];
+        M.A.J[2] = islim ? 0.0f : pj[2];
+        M.A.J[3] = islim ? ((r == 0) ? lsg : 0.0f) : pj[3];
+        M.A.J[4] = islim ? ((r == 1) ? lsg : 0.0f) : pj[4];
+        M.A.aref = islim ? laref : paref;
+        M.A.D = islim ? lD : foot_D;
+        M.B.present = islim && (foot_on != 0);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) M.B.J[k] = pj[k];
+        M.B.aref = paref;
+        M.B.D = foot_D;
+        return M;
+    }
+    // this lane's share of a row sum, then the butterfly.  A row that does not take part contributes -0, the identity
+    // of IEEE addition (x + (-0) = x for every x): tA + tB is tA for the lanes that own one row
+    GX_D static float rows_sum(float tA, float tB) { return quads_sum(tA + tB); }
+
     GX_D static float dot5(const float* J, const float (&ab)[3], float ah, float abt)
     {
         return (((J[0] * ab[0] + J[1] * ab[1]) + J[2] * ab[2]) + J[3] * ah) + J[4] * abt;
     }
-    // 6-bit active mask of this leg's rows
-    GX_D static uint32_t active_leg(const Lim (&lim)[2], const Foot& ft, float c, float s, const float (&ab)[3],
-                                    float ah, float abt)
+    // 6-bit active mask of this leg's rows: every lane tests the rows it owns, the quads OR their bits together
+    GX_D static uint32_t active_leg(const MyRows& M, int r, const float (&ab)[3], float ah, float abt)
     {
         uint32_t m = 0;
-#pragma unroll
-        for (int k = 0; k < A::kRows; ++k) {
-            const Row R = row_of(lim, ft, c, s, k);
-            if (R.present && (dot5(R.J, ab, ah, abt) - R.aref < 0.0f)) m |= 1u << k;
-        }
-        return m;
+        if (M.A.present && (dot5(M.A.J, ab, ah, abt) - M.A.aref < 0.0f)) m |= 1u << r;
+        if (M.B.present && (dot5(M.B.J, ab, ah, abt) - M.B.aref < 0.0f)) m |= 1u << (r + 4);
+        return quads_or(m);
     }
     GX_D static uint32_t gather_mask(uint32_t own)
     {
@@ -124,17 +152,19 @@ struct AntGroup {
 
     // the lane-group kernels' ONE call site of the step (reset_done's fake step comes from Pool::fake): inlined
     __device__ __attribute__((always_inline)) static void substep_call(float* q, float* v, const float* ctrl, float* pose,
-                                                                  float* qacc, int L)
+                                                                  float* qacc, int l16)
     {
         substep(*reinterpret_cast<float (*)[11]>(q), *reinterpret_cast<float (*)[11]>(v),
                 *reinterpret_cast<const float (*)[8]>(ctrl), *reinterpret_cast<float (*)[4]>(pose),
-                *reinterpret_cast<float (*)[11]>(qacc), L);
+                *reinterpret_cast<float (*)[11]>(qacc), l16);
     }
 
-    // q, v, ctrl, qacc: the full arrays (every lane holds a copy, as in the serial form); L = lane & 3
+    // q, v, ctrl, qacc: the full arrays (every lane holds a copy, as in the serial form); l16 = lane & 15:
+    // leg L = l16 & 3, quad r = l16 >> 2
     GX_D static void substep(float (&q)[11], float (&v)[11], const float (&ctrl)[8], float (&pose)[4], float (&qacc)[11],
-                             int L)
+                             int l16)
     {
+        const int L = l16 & 3, rq = l16 >> 2;
         A::pose_of(q, pose);
         const float c = pose[2], s = pose[3];
         const float y = q[2], om = v[1], vy = v[2];
@@ -203,10 +233,9 @@ struct AntGroup {
         const float dist = (A::kZ0 - A::kL * sb) - A::kRf;
         const float pos = dist - A::kMargin;
         ft.on = 0; ft.jbz = 0.0f; ft.D = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { ft.T1[k] = 0.0f; ft.T2[k] = 0.0f; }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) ft.aref[k] = 0.0f;
+        // the ONE pyramid row this lane owns (rows 4, 5 = T2 based for quads 0, 1; rows 2, 3 = T1 based for quads 2, 3;
+        // sign by the parity of the quad) and its aref -- the same operations as AntRobot::row_of / substep_impl
+        float pj[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, paref = 0.0f;
         if (pos < 0.0f) {
             const float zc = A::kRf + 0.5f * dist;
             const float lf = A::kA + A::kL * cb;
@@ -219,14 +248,16 @@ struct AntGroup {
             float rr = ((1.0f - imp) * A::kInvwPyr) / imp;
             if (rr < 1e-15f) rr = 1e-15f;
             ft.on = 1; ft.jbz = jbz; ft.D = 1.0f / rr;
-            ft.T1[0] = s * jtx + c * jty; ft.T1[1] = s * jhx + c * jhy; ft.T1[2] = s * jbx + c * jby;
-            ft.T2[0] = c * jtx - s * jty; ft.T2[1] = c * jhx - s * jhy; ft.T2[2] = c * jbx - s * jby;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const Row R = row_of(lim, ft, c, s, 2 + k);
-                const float jv = (((R.J[0] * v[0] + R.J[1] * om) + R.J[2] * vy) + R.J[3] * dphi) + R.J[4] * dbeta;
-                ft.aref[k] = -(A::kB * jv) - (A::kK * imp) * pos;
+            const float sgn = (rq & 1) ? -A::kMu : A::kMu;
+            if (rq >= 2) {
+                const float T1t = s * jtx + c * jty, T1h = s * jhx + c * jhy, T1b = s * jbx + c * jby;
+                pj[0] = sgn * 0.0f; pj[1] = sgn * T1t; pj[2] = sgn * c; pj[3] = sgn * T1h; pj[4] = jbz + sgn * T1b;
+            } else {
+                const float T2t = c * jtx - s * jty, T2h = c * jhx - s * jhy, T2b = c * jbx - s * jby;
+                pj[0] = sgn * 1.0f; pj[1] = sgn * T2t; pj[2] = sgn * (-s); pj[3] = sgn * T2h; pj[4] = jbz + sgn * T2b;
             }
+            const float jv = (((pj[0] * v[0] + pj[1] * om) + pj[2] * vy) + pj[3] * dphi) + pj[4] * dbeta;
+            paref = -(A::kB * jv) - (A::kK * imp) * pos;
         }
         const int own_any = (lim[0].sg != 0.0f) | (lim[1].sg != 0.0f) | ft.on;
         const int any_row = quadi<0>(own_any) | quadi<1>(own_any) | quadi<2>(own_any) | quadi<3>(own_any);
@@ -255,37 +286,36 @@ struct AntGroup {
         float fcb[3] = {fbase[0], fbase[1], fbase[2]};
         float fch = fh, fcbt = fb;
         if (any_row) {
-            uint32_t act = gather_mask(active_leg(lim, ft, c, s, ab, ah, abt));
+            const MyRows MR = my_rows(lim, ft.on, ft.D, pj, paref, rq);
+            const Row& RA = MR.A;
+            const Row& RB = MR.B;
+            uint32_t act = gather_mask(active_leg(MR, rq, ab, ah, abt));
             for (int it = 0; it < A::kIters; ++it) {
                 const uint32_t own = (act >> (6 * L)) & 63u;
+                const bool onA = (own >> rq) & 1u, onB = (own >> (rq + 4)) & 1u; // (bit r + 4 is never set for r >= 2)
+                // this lane's rows' products (+0 for a row outside the active set), in the order of AntRobot::newton_solve
+                const float DA = onA ? RA.D : 0.0f, DB = onB ? RB.D : 0.0f;
+                const float daA = DA * RA.aref, daB = DB * RB.aref;
                 LegBlk Hk = K;
-                float PB[3][3], Pr[3] = {0.0f, 0.0f, 0.0f};
-                float rh = fh, rbt = fb;
+                float PB[3][3], Pr[3];
+                float djA[3], djB[3];
 #pragma unroll
-                for (int b = 0; b < 3; ++b)
+                for (int b = 0; b < 3; ++b) { djA[b] = DA * RA.J[b]; djB[b] = DB * RB.J[b]; }
 #pragma unroll
-                    for (int cc = 0; cc < 3; ++cc) PB[b][cc] = 0.0f;
+                for (int b = 0; b < 3; ++b) {
 #pragma unroll
-                for (int k = 0; k < A::kRows; ++k) {
-                    if (!((own >> k) & 1u)) continue;
-                    const Row R = row_of(lim, ft, c, s, k);
-                    const float da = R.D * R.aref;
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) {
-                        const float dj = R.D * R.J[b];
-#pragma unroll
-                        for (int cc = 0; cc <= b; ++cc) PB[b][cc] = PB[b][cc] + dj * R.J[cc];
-                        Hk.C[b][0] = Hk.C[b][0] + dj * R.J[3];
-                        Hk.C[b][1] = Hk.C[b][1] + dj * R.J[4];
-                        Pr[b] = Pr[b] + da * R.J[b];
-                    }
-                    const float d3 = R.D * R.J[3], d4 = R.D * R.J[4];
-                    Hk.Lhh = Hk.Lhh + d3 * R.J[3];
-                    Hk.Lhb = Hk.Lhb + d3 * R.J[4];
-                    Hk.Lbb = Hk.Lbb + d4 * R.J[4];
-                    rh = rh + da * R.J[3];
-                    rbt = rbt + da * R.J[4];
+                    for (int cc = 0; cc < 3; ++cc)
+                        PB[b][cc] = (cc <= b) ? rows_sum(onA ? djA[b] * RA.J[cc] : -0.0f, onB ? djB[b] * RB.J[cc] : -0.0f) : 0.0f;
+                    Hk.C[b][0] = Hk.C[b][0] + rows_sum(onA ? djA[b] * RA.J[3] : -0.0f, onB ? djB[b] * RB.J[3] : -0.0f);
+                    Hk.C[b][1] = Hk.C[b][1] + rows_sum(onA ? djA[b] * RA.J[4] : -0.0f, onB ? djB[b] * RB.J[4] : -0.0f);
+                    Pr[b] = rows_sum(onA ? daA * RA.J[b] : -0.0f, onB ? daB * RB.J[b] : -0.0f);
                 }
+                const float d3A = DA * RA.J[3], d4A = DA * RA.J[4], d3B = DB * RB.J[3], d4B = DB * RB.J[4];
+                Hk.Lhh = Hk.Lhh + rows_sum(onA ? d3A * RA.J[3] : -0.0f, onB ? d3B * RB.J[3] : -0.0f);
+                Hk.Lhb = Hk.Lhb + rows_sum(onA ? d3A * RA.J[4] : -0.0f, onB ? d3B * RB.J[4] : -0.0f);
+                Hk.Lbb = Hk.Lbb + rows_sum(onA ? d4A * RA.J[4] : -0.0f, onB ? d4B * RB.J[4] : -0.0f);
+                const float rh = fh + rows_sum(onA ? daA * RA.J[3] : -0.0f, onB ? daB * RB.J[3] : -0.0f);
+                const float rbt = fb + rows_sum(onA ? daA * RA.J[4] : -0.0f, onB ? daB * RB.J[4] : -0.0f);
                 float HB[3][3], rb[3];
 #pragma unroll
                 for (int b = 0; b < 3; ++b) {
@@ -294,24 +324,20 @@ struct AntGroup {
                     rb[b] = add_legs(fbase[b], Pr[b]);
                 }
                 arrow_solve(HB, Hk, rb, rh, rbt, ab, ah, abt);
-                const uint32_t nact = gather_mask(active_leg(lim, ft, c, s, ab, ah, abt));
+                const uint32_t nact = gather_mask(active_leg(MR, rq, ab, ah, abt));
                 if (nact == act) break;
                 act = nact;
             }
-            float Pf[3] = {0.0f, 0.0f, 0.0f};
+            // constraint force of the rows violated at the solution
+            float fA = 0.0f, fB = 0.0f;
+            bool vA = false, vB = false;
+            if (RA.present) { const float res = dot5(RA.J, ab, ah, abt) - RA.aref; if (res < 0.0f) { vA = true; fA = RA.D * (-res); } }
+            if (RB.present) { const float res = dot5(RB.J, ab, ah, abt) - RB.aref; if (res < 0.0f) { vB = true; fB = RB.D * (-res); } }
+            float Pf[3];
 #pragma unroll
-            for (int k = 0; k < A::kRows; ++k) {
-                const Row R = row_of(lim, ft, c, s, k);
-                if (!R.present) continue;
-                const float res = dot5(R.J, ab, ah, abt) - R.aref;
-                if (!(res < 0.0f)) continue;
-                const float frc = R.D * (-res);
-                Pf[0] = Pf[0] + frc * R.J[0];
-                Pf[1] = Pf[1] + frc * R.J[1];
-                Pf[2] = Pf[2] + frc * R.J[2];
-                fch = fch + frc * R.J[3];
-                fcbt = fcbt + frc * R.J[4];
-            }
+            for (int b = 0; b < 3; ++b) Pf[b] = rows_sum(vA ? fA * RA.J[b] : -0.0f, vB ? fB * RB.J[b] : -0.0f);
+            fch = fch + rows_sum(vA ? fA * RA.J[3] : -0.0f, vB ? fB * RB.J[3] : -0.0f);
+            fcbt = fcbt + rows_sum(vA ? fA * RA.J[4] : -0.0f, vB ? fB * RB.J[4] : -0.0f);
 #pragma unroll
             for (int b = 0; b < 3; ++b) fcb[b] = add_legs(fcb[b], Pf[b]);
         }

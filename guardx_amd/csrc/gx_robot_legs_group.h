@@ -402,7 +402,7 @@ template <class R, bool kQacc>
 GX_D void group_substep(float (&q)[R::NQ], float (&v)[R::NV], const float (&ctrl)[R::NU], float (&pose)[4],
                         float (&qacc)[R::NV], int lane)
 {
-    if constexpr (R::kId == AntRobot::kId) AntGroup::substep_call(q, v, ctrl, pose, qacc, lane & 3);
+    if constexpr (R::kId == AntRobot::kId) AntGroup::substep_call(q, v, ctrl, pose, qacc, lane & 15);
     else if constexpr (R::kId == WalkerRobot::kId) WalkerGroup::substep_call(q, v, ctrl, pose, qacc, lane & 1);
     else R::template substep<kQacc>(q, v, ctrl, pose, qacc);
 }
