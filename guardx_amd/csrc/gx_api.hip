@@ -119,10 +119,10 @@ static bool use_group_path(const gx_engine* e)
     if (e->path_mode == 1) return false;
     if (e->path_mode == 2) return true;
     // latency regime (path_mode 3: rollouts split, steps here).  Measured crossovers of the two families (fused
-    // step incl. reset_done): Point / Swimmer 16384 envs; Ant ~15 k (lane-group 31.7 us at 12288 and 42.3 us at
-    // 16384 against a flat ~41 us of the inlined serial step); Walker ~11.5 k (41.8 us at 8192, 61.0 us at 12288
-    // against ~59 us) -- tools/debug/legs_large.py, re-measured after the fake-step table
-    const int limit = e->cfg.robot == AntRobot::kId ? 15000 : (e->cfg.robot == WalkerRobot::kId ? 11500 : 16384);
+    // step incl. reset_done, tools/debug/legs_large.py, round 3 -- after the legs' lanes stopped replicating work):
+    // Point / Swimmer 16384 envs; Ant ~27 k (lane-group 38.6 us at 24576 against ~44 us of the serial step);
+    // Walker ~16 k (61.6 us at 16384 against 60.7 us)
+    const int limit = e->cfg.robot == AntRobot::kId ? 27000 : (e->cfg.robot == WalkerRobot::kId ? 16000 : 16384);
     return e->p.N <= limit;
 }
 

@@ -172,11 +172,14 @@ struct WalkerGroup {
         return (uint32_t)quadi<0>((int)own) | ((uint32_t)quadi<1>((int)own) << 16);
     }
 
-    // A real call (the Ant's copy of this wrapper is inlined): hipcc 7.2 miscompiles the lane-group kernels with the
-    // Walker's 15k-instruction step inlined (dynamics blow up in test_variant_configs[group-walker], at -O3 and -O2,
-    // with or without IPRA).  It is the kernels' only call site -- reset_done's fake step comes from Pool::fake --
-    // and with one call site the build with LLVM's inter-procedural register allocation passes every parity test
-    // and the soak again (build.py), which is worth 18 % here: the callee no longer saves ~100 callee-saved VGPRs.
+    // Inlined, like the Ant's (round 3).  Rounds 1-2 had to keep this a real call: with the 15k-instruction step of
+    // that form inlined, hipcc 7.2 produced lane-group kernels whose dynamics blew up (test_variant_configs[group-walker],
+    // -O3 and -O2, with or without IPRA), and as a callee it was exposed to LLVM's inter-procedural register allocation
+    // using the VGPR lanes in which the caller parks spilled exec masks -- which came back in round 3 with ONE call
+    // site as soon as the callee grew (the right-hand-side sharing of `eliminate`): wrong rows after an in-kernel
+    // reset_done.  The round-3 step is a third shorter; inlined it passes every parity test and the soak
+    // (profiles/r03_soak_walker.log) and costs no call ABI.  tests/test_native_abi.py checks that no lane-group kernel
+    // contains a call, and the compiler version is part of the library's identity.
     __device__ __attribute__((always_inline)) static void substep_call(float* q, float* v, const float* ctrl, float* pose,
                                                                   float* qacc, int l16)
     {
