@@ -226,6 +226,12 @@ class Engine:
         self._out_ring = max(0, int(out_ring))
         self._slab, self._slab_i = [], 0
         self._speculate = os.environ.get("GX_NO_SPECULATE", "0") != "1"
+        # the per-step entry points, looked up once (step() + reset_done() is host-bound at env_num = 2000)
+        self._gx_step_rd, self._gx_step = self._lib.gx_step_rd, self._lib.gx_step
+        self._gx_commit = self._lib.gx_reset_done_commit
+        self._raw_stream = torch._C._cuda_getCurrentRawStream
+        self._dev_index = self.device.index
+        self._qacc_in_info = bool(self.observe_qacc)
         self._spec = C.c_int32(0)
         self._spec_ref = C.byref(self._spec)
         self._rd_obs = None          # what reset_done() returns for the step just made (speculated in-kernel)
@@ -414,10 +420,11 @@ class Engine:
         qacc = flat[:, o:o + N * nv].view(k, N, nv).unbind(0) if self.emit_qacc else (None,) * k
         base, off_rd, off_r, off_q = flat.data_ptr(), 4 * N * Dp, 8 * N * Dp, 4 * (2 * N * Dp + 3 * Np)
         slots = []
+        vp = C.c_void_p       # ready-made ctypes arguments: no int -> c_void_p conversion per step() call
         for i in range(k):
             b = base + 4 * per * i
-            ptrs = (b, b + off_r, b + off_r + 4 * Np, b + off_r + 8 * Np, (b + off_q) if self.emit_qacc else None,
-                    b + off_rd)
+            ptrs = (vp(b), vp(b + off_r), vp(b + off_r + 4 * Np), vp(b + off_r + 8 * Np),
+                    vp(b + off_q) if self.emit_qacc else None, vp(b + off_rd))
             slots.append((obs[i], obs_rd[i], rew[i], cost[i], done[i], qacc[i], ptrs))
         return slots
 
@@ -438,17 +445,17 @@ class Engine:
             i = 0
         self._slab_i = i + 1
         obs, obs_rd, reward, cost, done, qacc, p = self._slab[i]
+        stream = self._raw_stream(self._dev_index)
         if self._speculate:
-            st = self._lib.gx_step_rd(self._h, a.data_ptr(), p[0], p[1], p[2], p[3], p[4], p[5], self._spec_ref,
-                                      self._stream())
+            st = self._gx_step_rd(self._h, a.data_ptr(), p[0], p[1], p[2], p[3], p[4], p[5], self._spec_ref, stream)
         else:   # two-launch form (step, then reset_done on demand): debugging / A-B timing only
             self._spec.value = 0
-            st = self._lib.gx_step(self._h, a.data_ptr(), p[0], p[1], p[2], p[3], p[4], self._stream())
+            st = self._gx_step(self._h, a.data_ptr(), p[0], p[1], p[2], p[3], p[4], stream)
         if st:
             _native.check(st)
         self._rd_obs = obs_rd if self._spec.value else None
         info = {'cost': cost,
-                'obs': _LazyObsDict(obs, self._obs_slices, qacc if self.observe_qacc else None)}
+                'obs': _LazyObsDict(obs, self._obs_slices, qacc if self._qacc_in_info else None)}
         self._obs, self._reward, self._done, self._info = obs, reward, done, info
         return obs, reward, done, info
 
@@ -460,7 +467,9 @@ class Engine:
         if self._rd_obs is not None:
             # already evaluated by the step() launch: request the re-initialisation (installed by the next
             # launch on this engine) and hand out the observation -- no kernel of its own
-            _native.check(self._lib.gx_reset_done_commit(self._h))
+            st = self._gx_commit(self._h)
+            if st:
+                _native.check(st)
             return self._rd_obs
         out = self._new(self.env_num, self.obs_flat_size)
         _native.check(self._lib.gx_reset_done(self._h, self._obs.data_ptr(), out.data_ptr(),
