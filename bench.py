@@ -120,6 +120,29 @@ def run_epochs(env, tapes, epochs, handoff):
     env.check_layouts()                  # engine.py:444 for every reset above (one sync)
 
 
+PRECONDITION_MS = 40.0
+
+
+def precondition_clocks(device, ms=PRECONDITION_MS):
+    """Keep the GPU busy for `ms` with work that is NOT the workload (fp32 torch.mm), so that the firmware's clock /
+    power ramp is over when the W warm-up epochs start.  Measured on this pool (tools/debug/cold_start_probe.py,
+    DESIGN.md section 6): after >= 50 ms of idle the first ~25 epochs (13 ms) run 10 % -> 0 % slower than the steady
+    state whatever ran before the idle gap, and 30 ms of any sustained compute removes that.  The driver's region
+    (5 + 20 epochs = 13 ms) would otherwise sit entirely inside the ramp.  The line reports `cold_start` beside."""
+    a = torch.ones(2048, 2048, device=device)
+    b = torch.ones(2048, 2048, device=device)
+    c = a @ b                                            # library initialisation happens here, outside the busy loop
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 0
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(8):
+            torch.mm(a, b, out=c)
+        n += 8
+        torch.cuda.synchronize()
+    return {"ms": round((time.perf_counter() - t0) * 1e3, 1), "work": f"{n} x fp32 torch.mm 2048^3 (not the workload)"}
+
+
 def _fresh_engine(env_num):
     from guardx_amd import ResamplingError
     env = make_engine(env_num, 0, 1, n_candidates=200_000)
@@ -539,6 +562,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-precondition", action="store_true",
+                    help="skip the 40 ms of unrelated GPU work before the warm-up epochs (clock ramp, see precondition_clocks)")
     args = ap.parse_args()
     if args.steps < 1 or args.warmup < 0:
         ap.error("--steps >= 1, --warmup >= 0")
@@ -575,14 +600,18 @@ def main():
         if mode != "tape":
             handoff = RolloutHandoff(world)
 
-    run_epochs(env, tapes, args.warmup, handoff)
-    gxd.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_epochs(env, tapes, args.steps, handoff)
-    torch.cuda.synchronize()
-    gxd.barrier()
-    dt = gxd.max_over_ranks(time.perf_counter() - t0, device)
+    def timed_region():
+        run_epochs(env, tapes, args.warmup, handoff)
+        gxd.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_epochs(env, tapes, args.steps, handoff)
+        torch.cuda.synchronize()
+        gxd.barrier()
+        return gxd.max_over_ranks(time.perf_counter() - t0, device)
+
+    precond = None if args.no_precondition else precondition_clocks(device)
+    dt = timed_region()
 
     env_steps = ENV_NUM * world * EP_LEN * args.steps
     value = env_steps / dt
@@ -645,6 +674,16 @@ def main():
                     "bandwidth over 7 xGMI links (537 GB/s peak per direction); arithmetic, not a measurement"}
     except Exception as exc:  # noqa: BLE001
         line["handoff_model"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+    line["clock_preconditioning"] = (dict(precond, note="unrelated GPU work before the W warm-up epochs so that the "
+                                          "firmware clock ramp (13 ms on this pool) is not inside the timed region; "
+                                          "`cold_start` below is the same W + K epochs after 1 s of idle without it")
+                                     if precond else None)
+    if precond and world == 1:
+        time.sleep(1.0)
+        dtc = timed_region()
+        line["cold_start"] = {"value": round(env_steps / dtc, 1), "unit": "env-steps/s",
+                              "ms_per_step": round(dtc / args.steps * 1e3, 6),
+                              "note": "same W warm-up + K timed epochs started from an idle GPU (1 s sleep), no preconditioning"}
     if dt < 0.010:
         line["warning"] = f"timed region {dt*1e3:.2f} ms < 10 ms: use more --steps for a meaningful rate"
     if stepping_only is not None:
