@@ -105,12 +105,22 @@ static int take_commit(gx_engine* e)
     return c;
 }
 
-// fused rollouts of the light robots at small env_num: two kernels (a serial dynamics tape, then one thread per
+// env_num at which the lane-group form of a step beats the thread-per-env form.  Measured crossovers of the two
+// families (fused step incl. reset_done, tools/debug/legs_large.py, round 3 -- after the legs' lanes stopped
+// replicating work): Point / Swimmer 16384 envs; Ant ~27 k (lane-group 38.6 us at 24576 against ~44 us of the serial
+// step); Walker ~16 k (61.6 us at 16384 against 60.7 us)
+static bool in_group_regime(const gx_engine* e)
+{
+    const int limit = e->cfg.robot == AntRobot::kId ? 27000 : (e->cfg.robot == WalkerRobot::kId ? 16000 : 16384);
+    return e->p.N <= limit;
+}
+
+// fused rollouts at small env_num: two kernels (a serial dynamics tape, then one thread per
 // (step, env) row) instead of the persistent lane-group kernel, from 8 steps up
 static bool use_split_rollout(const gx_engine* e, int T)
 {
     if (e->path_mode == 1 || e->path_mode == 2) return false;
-    if (!split_rollout_supported(e->p) || e->p.N > 16384) return false; // (light robots: limit 16384 either way)
+    if (!split_rollout_supported(e->p) || !in_group_regime(e)) return false;
     return e->path_mode == 3 || T >= 8;
 }
 
@@ -118,12 +128,7 @@ static bool use_group_path(const gx_engine* e)
 {
     if (e->path_mode == 1) return false;
     if (e->path_mode == 2) return true;
-    // latency regime (path_mode 3: rollouts split, steps here).  Measured crossovers of the two families (fused
-    // step incl. reset_done, tools/debug/legs_large.py, round 3 -- after the legs' lanes stopped replicating work):
-    // Point / Swimmer 16384 envs; Ant ~27 k (lane-group 38.6 us at 24576 against ~44 us of the serial step);
-    // Walker ~16 k (61.6 us at 16384 against 60.7 us)
-    const int limit = e->cfg.robot == AntRobot::kId ? 27000 : (e->cfg.robot == WalkerRobot::kId ? 16000 : 16384);
-    return e->p.N <= limit;
+    return in_group_regime(e); // latency regime (path_mode 3: rollouts split, steps here)
 }
 
 struct DeviceGuard {
@@ -783,7 +788,7 @@ extern "C" gx_status gx_tape_floats(const gx_engine* e, int32_t T, int64_t* tape
 {
     if (!e || T < 1 || !tape || !obj0 || !entry) return fail(GX_ERR_ARG, "bad argument");
     if (!split_rollout_supported(e->p))
-        return fail(GX_ERR_UNSUPPORTED, "tape hand-off: Point / Swimmer without observe_vel / observe_acc, one physics step per control step");
+        return fail(GX_ERR_UNSUPPORTED, "tape hand-off: needs a task without observe_vel / observe_acc and one physics step per control step");
     *tape = (int64_t)T * e->p.N * split_tape_width(e->p);
     *obj0 = (int64_t)e->p.P * e->p.Npad * 4;
     *entry = (int64_t)e->p.N * split_entry_width(e->p);
@@ -796,7 +801,7 @@ extern "C" gx_status gx_rollout_tape(gx_engine* e, int32_t T, const float* d_act
     if (!e || !d_actions || !d_shard || !token || T < 1) return fail(GX_ERR_ARG, "bad argument");
     if (!e->have_reset) return fail(GX_ERR_STATE, "gx_rollout_tape before gx_reset");
     if (!split_rollout_supported(e->p))
-        return fail(GX_ERR_UNSUPPORTED, "tape hand-off: Point / Swimmer without observe_vel / observe_acc, one physics step per control step");
+        return fail(GX_ERR_UNSUPPORTED, "tape hand-off: needs a task without observe_vel / observe_acc and one physics step per control step");
     if ((reinterpret_cast<uintptr_t>(d_actions) & 7u) || (reinterpret_cast<uintptr_t>(d_shard) & 15u))
         return fail(GX_ERR_ARG, "d_actions must be 8-byte, d_shard 16-byte aligned");
     DeviceGuard guard(e->device);
@@ -827,7 +832,7 @@ extern "C" gx_status gx_expand_tape(gx_engine* e, int32_t T, const float* d_shar
 {
     if (!e || !d_shard || !d_packed || T < 1) return fail(GX_ERR_ARG, "bad argument");
     if (!split_rollout_supported(e->p))
-        return fail(GX_ERR_UNSUPPORTED, "tape hand-off: Point / Swimmer without observe_vel / observe_acc, one physics step per control step");
+        return fail(GX_ERR_UNSUPPORTED, "tape hand-off: needs a task without observe_vel / observe_acc and one physics step per control step");
     if (reinterpret_cast<uintptr_t>(d_shard) & 15u) return fail(GX_ERR_ARG, "d_shard must be 16-byte aligned");
     const int pi = (int)(token & 0xff);
     if (pi < 0 || pi >= gx_engine::kPools || (uint32_t)(token >> 8) != e->pool_gen[pi])
@@ -839,7 +844,7 @@ extern "C" gx_status gx_expand_tape(gx_engine* e, int32_t T, const float* d_shar
     memset(&r, 0, sizeof r);
     const int W = e->p.D + e->na + 3;
     r.T = T; r.do_reset = 1; r.nobj_total = e->nobj_total;
-    r.cand_xy = e->pools[pi].cand_xy; r.n_rows = e->sp.M;
+    r.cand_xy = e->pools[pi].cand_xy; r.n_rows = e->sp.M; r.fake = e->pools[pi].fake;
     const size_t nt = (size_t)T * e->p.N * split_tape_width(e->p), no = (size_t)e->p.P * e->p.Npad * 4;
     r.act = nullptr; // the tape rows carry the actions
     r.obs = d_packed; r.act_out = d_packed + e->p.D;

@@ -502,11 +502,10 @@ void launch_thread_rollout(const Params& p, const RolloutArgs& r, const DevBuffe
 
 bool split_rollout_supported(const Params& p)
 {
-    // robots whose reset_done observation needs no physics step; no pose history in the observation; one physics step
-    // per control step (the tape carries qpos, and the pose a step returns is the kinematics of the qpos before its
-    // LAST substep)
-    return (p.robot == PointRobot::kId || p.robot == PointBareRobot::kId || p.robot == SwimmerRobot::kId) && !p.hist_on &&
-           p.physics_steps == 1;
+    // no pose history in the observation; one physics step per control step (the tape carries qpos, and the pose a step
+    // returns is the kinematics of the qpos before its LAST substep).  Every robot: the reset_done observation of the
+    // Ant / Walker (which needs a physics step) comes from the pool's fake-step table
+    return !p.hist_on && p.physics_steps == 1;
 }
 int split_tape_width(const Params& p)
 {
@@ -514,6 +513,8 @@ int split_tape_width(const Params& p)
     if (p.robot == SwimmerRobot::kId) w = RobotLaunch<SwimmerRobot>::split_width();
     else if (p.robot == PointBareRobot::kId) w = RobotLaunch<PointBareRobot>::split_width();
     else if (p.robot == PointRobot::kId) w = RobotLaunch<PointRobot>::split_width();
+    else if (p.robot == AntRobot::kId) w = RobotLaunch<AntRobot>::split_width();
+    else if (p.robot == WalkerRobot::kId) w = RobotLaunch<WalkerRobot>::split_width();
     return w;
 }
 int split_entry_width(const Params& p)
@@ -521,6 +522,8 @@ int split_entry_width(const Params& p)
     if (p.robot == SwimmerRobot::kId) return RobotLaunch<SwimmerRobot>::split_entry_width();
     if (p.robot == PointBareRobot::kId) return RobotLaunch<PointBareRobot>::split_entry_width();
     if (p.robot == PointRobot::kId) return RobotLaunch<PointRobot>::split_entry_width();
+    if (p.robot == AntRobot::kId) return RobotLaunch<AntRobot>::split_entry_width();
+    if (p.robot == WalkerRobot::kId) return RobotLaunch<WalkerRobot>::split_entry_width();
     return 0;
 }
 hipError_t launch_split_rollout(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, float* entry,
@@ -529,6 +532,8 @@ hipError_t launch_split_rollout(const Params& p, const RolloutArgs& r, float* ta
     if (p.robot == SwimmerRobot::kId) return RobotLaunch<SwimmerRobot>::split(p, r, tape, obj0, entry, b, s, hold, which);
     if (p.robot == PointBareRobot::kId) return RobotLaunch<PointBareRobot>::split(p, r, tape, obj0, entry, b, s, hold, which);
     if (p.robot == PointRobot::kId) return RobotLaunch<PointRobot>::split(p, r, tape, obj0, entry, b, s, hold, which);
+    if (p.robot == AntRobot::kId) return RobotLaunch<AntRobot>::split(p, r, tape, obj0, entry, b, s, hold, which);
+    if (p.robot == WalkerRobot::kId) return RobotLaunch<WalkerRobot>::split(p, r, tape, obj0, entry, b, s, hold, which);
     return hipErrorNotSupported;
 }
 

@@ -1337,20 +1337,23 @@ hipError_t RobotLaunch<R>::split(const Params& p, const RolloutArgs& r, float* t
         if (p.P <= 5) return launch_split_p<R, 5>(p, r, sa, b, s, hold, which);
         if (p.P <= 9) return launch_split_p<R, 9>(p, r, sa, b, s, hold, which);
         return launch_split_p<R, 33>(p, r, sa, b, s, hold, which);
+    } else { // Ant, Walker: the dynamics pass is the lane-group form of the step
+        SplitArgs sa;
+        sa.tape = tape; sa.obj0 = obj0; sa.entry = entry;
+        if (p.P <= 5) return launch_split_group_p<R, 5>(p, r, sa, b, s, hold, which);
+        if (p.P <= 9) return launch_split_group_p<R, 9>(p, r, sa, b, s, hold, which);
+        return launch_split_group_p<R, 33>(p, r, sa, b, s, hold, which);
     }
-    return hipErrorNotSupported;
 }
 template <class R>
 int RobotLaunch<R>::split_width()
 {
-    if constexpr (R::kRestFixed) return SplitTape<R>::kW;
-    return 0;
+    return SplitTape<R>::kW;
 }
 template <class R>
 int RobotLaunch<R>::split_entry_width()
 {
-    if constexpr (R::kRestFixed) return SplitTape<R>::kE;
-    return 0;
+    return SplitTape<R>::kE;
 }
 
 template <class R>

@@ -29,11 +29,13 @@ namespace gx {
 
 template <class R>
 struct SplitTape {
+    // kFidx (Ant, Walker): row of Pool::fake (= index into the compacted layout list) of the layout a reset_done installed
     static constexpr int kQ = 0, kV = kQ + R::NQ, kAct = kV + R::NV, kDone = kAct + R::NA, kJcur = kDone + 1,
-                         kJaft = kJcur + 1, kUsed = kJaft + 1, kW = (kUsed + 3) / 4 * 4;
+                         kJaft = kJcur + 1, kFidx = kJaft + 1, kUsed = kFidx + (R::kRestFixed ? 0 : 1),
+                         kW = (kUsed + 3) / 4 * 4;
     // entry record of an env: qpos at entry | the stale pose (x, y, cos, sin) | done0 | number of step() calls so far
-    static constexpr int kEQ = 0, kEPose = R::NQ, kEDone = kEPose + 4, kEHist = kEDone + 1, kE = 12;
-    static_assert(kEHist < kE, "entry record too small for this robot");
+    static constexpr int kEQ = 0, kEPose = R::NQ, kEDone = kEPose + 4, kEHist = kEDone + 1, kE = (kEHist + 1 + 3) / 4 * 4;
+    static_assert(!R::kRestFixed || kE == 12, "entry record of the light robots: 12 floats (include/guardx.h)");
 };
 
 struct SplitArgs {
@@ -280,6 +282,214 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
     }
 }
 
+// ---------------------------------------------------------------------------
+// Pass 1 for the robots with contact dynamics (Ant, Walker): the lane-group form of the step (16 lanes per env, rows /
+// bodies / right-hand sides of a leg spread over the lanes: gx_robot_ant_group.h, gx_robot_legs_group.h) without the
+// observation.  Per step the persistent lane-group rollout kernel spends ~1.4 us on the lidar exchange and the rows and
+// waits once for its own stores (every __syncthreads of the exchange is also an s_waitcnt vmcnt(0)); here a step is
+// the dynamics, two square roots and one 144 / 160-byte tape row written by the group's first lane, with the actions of
+// kActBlock steps parked in LDS (see dyn_tape_kernel).  The NaN guard takes the same shortcut: finite, moderate qpos /
+// qvel / action and moderate objects cannot produce a non-finite observation entry (ctrl is the action, the pose the
+// kinematics of a moderate qpos); otherwise the wave evaluates the observation exactly with group_observe.
+// ---------------------------------------------------------------------------
+template <class R, int OPL, int BPL, bool kDef>
+__global__ __launch_bounds__(64) void group_dyn_tape_kernel(Params p_in, RolloutArgs r, SplitArgs sa,
+                                                            float4* __restrict__ dyn, float4* __restrict__ obj)
+{
+    using TP = SplitTape<R>;
+    constexpr int BT = 64, EPW = BT / kGL; // envs per wave
+    const Params p = fold_params<R, kDef>(p_in);
+    __shared__ GroupLds<OPL, BPL, BT> S;
+    __shared__ float actl[2][kActBlock][EPW][R::NA];
+    const int lane = threadIdx.x, l = lane & (kGL - 1), g = lane >> 4;
+    const int env = blockIdx.x * EPW + g;
+    const bool live = env < p.N;
+    const int e = live ? env : 0;
+    const bool writer = live && l == 0;
+
+    float q[R::NQ], v[R::NV], pose0[4], done0, steps;
+    R::load(dyn, p.Npad, e, q, v, pose0, done0, steps);
+    if (writer) { // the state at entry, for the rows of steps 0 and 1 in pass 2
+        float ev[TP::kE];
+#pragma unroll
+        for (int k = 0; k < TP::kE; ++k) ev[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < R::NQ; ++k) ev[TP::kEQ + k] = q[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ev[TP::kEPose + k] = pose0[k];
+        ev[TP::kEDone] = done0; ev[TP::kEHist] = (float)r.hist0;
+        store_row<TP::kE>(sa.entry + (size_t)env * TP::kE, ev);
+    }
+    // layout at entry: snapshot for pass 2 (lane k copies pair k), goal, magnitude check for the NaN-guard shortcut
+    const float2* obj2 = reinterpret_cast<const float2*>(obj);
+    float gx, gy;
+    { const float2 g2 = obj2[(size_t)e * 2]; gx = g2.x; gy = g2.y; }
+    const bool cfg_ok = p.lidar_max_dist_set ? (p.lidar_max_dist > 0.0f) : (p.neg_gain <= 0.0f);
+    bool mine_ok = true;
+    for (int k = l; k < p.P; k += kGL) {
+        const float4 o4 = obj[(size_t)k * p.Npad + e];
+        if (live) sa.obj0[(size_t)k * p.Npad + e] = o4;
+        mine_ok = mine_ok && moderate(o4.x) && moderate(o4.y);
+        if (2 * k + 1 < p.nobj) mine_ok = mine_ok && moderate(o4.z) && moderate(o4.w);
+    }
+    const int gsh = (lane & ~(kGL - 1)) & 63;
+    bool objs_ok = cfg_ok && (((__ballot(!mine_ok) >> gsh) & 0xFFFFull) == 0ull);
+    const int L = r.do_reset ? *r.layout_size : 0;
+    int jcur = -1;
+    bool s_ok;
+    {
+        float m1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < R::NQ; ++k) m1 = m1 + fabsf(q[k]);
+#pragma unroll
+        for (int k = 0; k < R::NV; ++k) m1 = m1 + fabsf(v[k]);
+        s_ok = moderate(m1);
+    }
+    // actions: lane d of the group fetches entry d of kActBlock steps at once, parks them in LDS a block ahead
+    float anx[kActBlock];
+#pragma unroll
+    for (int k = 0; k < kActBlock; ++k) {
+        anx[k] = 0.f;
+        if (k < r.T && l < R::NA) anx[k] = r.act[((size_t)k * p.N + e) * R::NA + l];
+    }
+    if (l < R::NA) {
+#pragma unroll
+        for (int k = 0; k < kActBlock; ++k) actl[0][k][g][l] = anx[k];
+    }
+    int abuf = 0;
+#pragma unroll 1
+    for (int tb = 0; tb < r.T; tb += kActBlock) {
+    if (tb + kActBlock < r.T && l < R::NA) {
+#pragma unroll
+        for (int k = 0; k < kActBlock; ++k)
+            if (tb + kActBlock + k < r.T) anx[k] = r.act[((size_t)(tb + kActBlock + k) * p.N + e) * R::NA + l];
+    }
+    const int kend = r.T - tb < kActBlock ? r.T - tb : kActBlock;
+#pragma unroll 1
+    for (int kb = 0; kb < kend; ++kb) {
+        const int t = tb + kb;
+        float a[R::NA];
+#pragma unroll
+        for (int d = 0; d < R::NA; ++d) a[d] = actl[abuf][kb][g][d];
+        const bool have_last = (r.hist0 + t) >= 1;
+        const float last_done = done0;
+        const float L1x = pose0[0], L1y = pose0[1];
+
+        float ctrl[R::NU];
+        R::convert_action(pose0, a, ctrl);
+        float pose[4], qacc[R::NV];
+#pragma unroll
+        for (int k = 0; k < R::NV; ++k) qacc[k] = 0.f;
+        group_substep<R, false>(q, v, ctrl, pose, qacc, l);
+
+        // NaN / Inf guard :696-699
+        float mag = 0.f;
+#pragma unroll
+        for (int k = 0; k < R::NQ; ++k) mag = mag + fabsf(q[k]);
+#pragma unroll
+        for (int k = 0; k < R::NV; ++k) mag = mag + fabsf(v[k]);
+        const bool sm_ok = moderate(mag); // the stepped state: the next step's start
+#pragma unroll
+        for (int k = 0; k < R::NA; ++k) mag = mag + fabsf(a[k]);
+        const bool ordinary = objs_ok && s_ok && moderate(mag);
+        bool bad = false;
+        if (__ballot(!ordinary) != 0ull) { // rare, wave-uniform: the observation exactly
+            float ox[OPL], oy[OPL];
+#pragma unroll
+            for (int j = 0; j < OPL; ++j) {
+                const int o = l + kGL * j;
+                float2 t2 = make_float2(0.f, 0.f);
+                if (o < p.nobj) {
+                    if (jcur >= 0) t2 = r.cand_xy[(size_t)jcur * r.nobj_total + o];
+                    else t2 = obj2[((size_t)(o >> 1) * p.Npad + e) * 2 + (o & 1)]; // `obj` is rewritten only at the end
+                }
+                ox[j] = t2.x; oy[j] = t2.y;
+            }
+            const GroupObs<OPL, BPL> ob = group_observe<OPL, BPL, BT, false>(p, S, lane, pose, gx, gy, ox, oy);
+            bad = ob.bad;
+            if (p.off_ctrl >= 0) {
+#pragma unroll
+                for (int k = 0; k < R::NU; ++k) bad = bad || notfinite(ctrl[k]);
+            }
+            if (p.off_qpos >= 0) {
+#pragma unroll
+                for (int k = 0; k < R::NQ; ++k) bad = bad || notfinite(q[k]);
+            }
+            if (p.off_qvel >= 0) {
+#pragma unroll
+                for (int k = 0; k < R::NV; ++k) bad = bad || notfinite(v[k]);
+            }
+        }
+        // the done half of reward_done :787-802 (the reward itself is pass 2's)
+        const float dg = dist2(gx, gy, pose[0], pose[1]);
+        float last = dg;
+        if (have_last && !(last_done > 0.0f)) last = dist2(gx, gy, L1x, L1y);
+        const float dd = last - dg;
+        float dn = dg < p.goal_size ? 1.0f : 0.0f;
+        if (fabsf(dd) > 1.0f) dn = 1.0f;
+        if (bad) dn = 1.0f;                        // :696-699
+        if (steps > p.num_steps_f) dn = 1.0f;      // :492
+        steps = dn > 0.0f ? 0.0f : steps + 1.0f;   // :493
+
+        // reset_done :497-505 for the env that just finished: the draw and the re-placement
+        int jaft = -1, fidx = 0;
+        float nq0 = 0.f, nq1 = 0.f;
+        if (r.do_reset && live && dn > 0.0f && L > 0) {
+            const uint4 kk = r.keys ? r.keys[t] : r.key0;
+            const uint32_t idx = randint_at(kk.x, kk.y, kk.z, kk.w, (uint32_t)p.env_total, (uint32_t)L,
+                                            (uint32_t)(p.env_offset + env));
+            jaft = r.cand_of[idx];
+            fidx = (int)idx;
+            const float2* rowp = r.cand_xy + (size_t)jaft * r.nobj_total;
+            const float2 g2 = rowp[0], rb = rowp[r.nobj_total - 1];
+            nq0 = rb.x; nq1 = rb.y;
+            gx = g2.x; gy = g2.y;
+        }
+        if (writer) { // tape row
+            float rowv[TP::kW];
+#pragma unroll
+            for (int k = 0; k < R::NQ; ++k) rowv[TP::kQ + k] = q[k];
+#pragma unroll
+            for (int k = 0; k < R::NV; ++k) rowv[TP::kV + k] = v[k];
+#pragma unroll
+            for (int k = 0; k < R::NA; ++k) rowv[TP::kAct + k] = a[k];
+            rowv[TP::kDone] = dn;
+            rowv[TP::kJcur] = __int_as_float(jcur); rowv[TP::kJaft] = __int_as_float(jaft);
+            rowv[TP::kFidx] = __int_as_float(fidx);
+#pragma unroll
+            for (int k = TP::kUsed; k < TP::kW; ++k) rowv[k] = 0.f;
+            store_row<TP::kW>(sa.tape + ((size_t)t * p.N + env) * TP::kW, rowv);
+        }
+        // commit the history, then the re-initialisation (the stale pose stays, :731)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pose0[k] = pose[k];
+        done0 = dn;
+        s_ok = sm_ok;
+        if (jaft >= 0) {
+#pragma unroll
+            for (int k = 0; k < R::NQ; ++k) q[k] = 0.f;
+#pragma unroll
+            for (int k = 0; k < R::NV; ++k) v[k] = 0.f;
+            R::place(q, nq0, nq1);
+            jcur = jaft;
+            objs_ok = cfg_ok; // pool rows lie inside the placement extents
+            s_ok = true;      // ... and so does the robot, at rest
+        }
+    }
+    abuf ^= 1; // park the next block's actions
+    if (l < R::NA) {
+#pragma unroll
+        for (int k = 0; k < kActBlock; ++k) actl[abuf][k][g][l] = anx[k];
+    }
+    }
+    if (writer) R::store(dyn, p.Npad, env, q, v, pose0, done0, steps);
+    if (live && jcur >= 0) { // the layout a reset_done installed becomes the env's layout
+        float2* objw = reinterpret_cast<float2*>(obj);
+        for (int o = l; o < p.nobj; o += kGL)
+            objw[((size_t)(o >> 1) * p.Npad + env) * 2 + (o & 1)] = r.cand_xy[(size_t)jcur * r.nobj_total + o];
+    }
+}
+
 // qpos an env starts step t+1 from, given its tape row of step t: the stepped qpos, or -- where reset_done fired --
 // the rest pose at the robot position of the layout it installed (layout2qpos :623-639)
 template <class R>
@@ -396,6 +606,15 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
         for (int k = 0; k < R::NU; ++k) ctrl[k] = 0.f;
         R::place(q, rx, ry);
         pose[0] = rx; pose[1] = ry; pose[2] = 1.0f; pose[3] = 0.0f;
+        if constexpr (!R::kRestFixed) { // the fake step (:719-724) moves the robot: its qpos / qvel / pose feed this row
+            const float* frow = r.fake + (size_t)__float_as_int(rowv[TP::kFidx]) * (R::NQ + R::NV + 4);
+#pragma unroll
+            for (int k = 0; k < R::NQ; ++k) q[k] = frow[k];
+#pragma unroll
+            for (int k = 0; k < R::NV; ++k) v[k] = frow[R::NQ + k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pose[k] = frow[R::NQ + R::NV + k];
+        }
         build_obs_row<R, PMAX>(p, row, pose, ob, ctrl, q, v, 0.f, 0.f, 0.f, 0.f);
     }
     if (packed) {
@@ -436,6 +655,33 @@ static hipError_t launch_split_p(const Params& p, const RolloutArgs& r, const Sp
         if (hold) st = hipStreamWaitEvent(s, hold, 0);
         if (st != hipSuccess) return st;
         if (which & 2) hipLaunchKernelGGL((obs_tape_kernel<R, B2, PMAX, false>), g2, dim3(B2), lds2, s, p, r, sa);
+    }
+    return st;
+}
+
+// the same for the robots whose dynamics pass is the lane-group kernel (Ant, Walker)
+template <class R, int PMAX>
+static hipError_t launch_split_group_p(const Params& p, const RolloutArgs& r, const SplitArgs& sa, const DevBuffers& b,
+                                       hipStream_t s, hipEvent_t hold, int which)
+{
+    hipError_t st = hipSuccess;
+    constexpr int B2 = 64;
+    const dim3 g1((p.N + 3) / 4), g2((unsigned)(((size_t)r.T * p.N + B2 - 1) / B2));
+    const size_t lds2 = sizeof(float) * (size_t)B2 * (r.obs_stride | 1);
+    if (which & 1) {
+#define GX_GDYN_LAUNCH(OPL, BPL, DEF) \
+    hipLaunchKernelGGL((group_dyn_tape_kernel<R, OPL, BPL, DEF>), g1, dim3(64), 0, s, p, r, sa, b.dyn, b.obj)
+        if (is_default_layout<R>(p)) GX_GDYN_LAUNCH(1, 1, true);
+        else if (p.nobj <= 16 && p.bins <= 16) GX_GDYN_LAUNCH(1, 1, false);
+        else if (p.nobj <= 32 && p.bins <= 16) GX_GDYN_LAUNCH(2, 1, false);
+        else GX_GDYN_LAUNCH(5, 4, false);
+#undef GX_GDYN_LAUNCH
+    }
+    if (hold) st = hipStreamWaitEvent(s, hold, 0);
+    if (st != hipSuccess) return st;
+    if (which & 2) {
+        if (PMAX == 5 && is_default_layout<R>(p)) hipLaunchKernelGGL((obs_tape_kernel<R, B2, 5, true>), g2, dim3(B2), lds2, s, p, r, sa);
+        else hipLaunchKernelGGL((obs_tape_kernel<R, B2, PMAX, false>), g2, dim3(B2), lds2, s, p, r, sa);
     }
     return st;
 }

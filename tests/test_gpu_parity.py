@@ -887,7 +887,7 @@ def test_deferred_layout_check(torch_cuda):
         bad.reset()
 
 
-@pytest.mark.parametrize("robot", ["point", "swimmer"])
+@pytest.mark.parametrize("robot", ["point", "swimmer", "ant", "walker"])
 def test_tape_handoff_two_ranks_equal_the_packed_rollout(torch_cuda, robot):
     """The multi-GPU hand-off on one GPU: two shard engines ("ranks") step with rollout_tape(), exchange the shard
     buffers, and each expands BOTH tapes with expand_tape() on another stream one epoch later (what the all-gather
@@ -898,8 +898,7 @@ def test_tape_handoff_two_ranks_equal_the_packed_rollout(torch_cuda, robot):
     from guardx_amd import Engine
     N, W, T, M, EPOCHS = 192, 2, 50, 60000, 4
     kw = dict(seed=9, num_steps=17, goal_size=2.6)
-    if robot == "swimmer":
-        kw.update(SWIMMER)
+    kw.update({"swimmer": SWIMMER, "ant": ANT, "walker": WALKER}.get(robot, {}))
     full = Engine(task_config(N * W, **kw), n_candidates=M)
     ranks = [Engine(task_config(N, **kw), n_candidates=M, shard=(r, W)) for r in range(W)]
     A = full.action_space.shape[0]
@@ -1041,14 +1040,15 @@ def test_bench_two_ranks_on_one_gpu_rehearsal(torch_cuda):
 
 
 def test_tape_handoff_is_refused_where_it_does_not_apply(torch_cuda):
-    """gx_rollout_tape / gx_expand_tape: robots whose reset_done observation needs a physics step (Ant, Walker) and
-    configurations with the pose history in the observation are GX_ERR_UNSUPPORTED, a rollout before reset() is
-    GX_ERR_STATE, a shard of the wrong size is caught by the Python mirror."""
+    """gx_rollout_tape / gx_expand_tape: configurations with the pose history in the observation are
+    GX_ERR_UNSUPPORTED (every robot is supported since round 3: the Ant / Walker reset_done rows come from the pool's
+    fake-step table), a rollout before reset() is GX_ERR_STATE, a shard of the wrong size is caught by the Python
+    mirror."""
     torch = torch_cuda
     from guardx_amd import Engine
     from guardx_amd._native import GxError, GX_ERR_UNSUPPORTED, GX_ERR_STATE
     acts = torch.zeros(4, 32, 8, device="cuda")
-    for cfg in (task_config(32, seed=1, **ANT), task_config(32, seed=1, observe_vel=True)):
+    for cfg in (task_config(32, seed=1, observe_vel=True), task_config(32, seed=1, observe_vel=True, **ANT)):
         e = Engine(cfg, n_candidates=20000)
         e.reset()
         with pytest.raises(GxError) as ei:
