@@ -740,7 +740,9 @@ static gx_status rollout_impl(gx_engine* e, int32_t T, const float* d_actions, f
         if (st != GX_OK) return st;
         hipEvent_t hold = nullptr;
         if (e->pf_phase1_pending && getenv("GX_NO_OBS_HOLD") == nullptr) { hold = e->pf_phase1; e->pf_phase1_pending = false; }
-        GX_HIP(launch_split_rollout(e->p, r, e->tape, e->obj0, e->tape + nt, e->b, s, hold));
+        // a prefetch sampler is in flight beside this rollout: the one-lane dynamics pass (see SwimmerRobot::kDynLanes)
+        const int lanes = (e->pf_valid && e->prefetch_steps != -1) ? 1 : 4;
+        GX_HIP(launch_split_rollout(e->p, r, e->tape, e->obj0, e->tape + nt, e->b, s, hold, 3, lanes));
     } else if (use_group_path(e)) {   // latency regime: 16 lanes per env
         r.commit = take_commit(e);
         launch_group_rollout(e->p, r, e->b, s);
@@ -817,7 +819,7 @@ extern "C" gx_status gx_rollout_tape(gx_engine* e, int32_t T, const float* d_act
     if (st != GX_OK) return st;
     const size_t nt = (size_t)T * e->p.N * split_tape_width(e->p), no = (size_t)e->p.P * e->p.Npad * 4;
     GX_HIP(launch_split_rollout(e->p, r, d_shard, reinterpret_cast<float4*>(d_shard + nt), d_shard + nt + no, e->b, s,
-                                nullptr, 1));
+                                nullptr, 1, (e->pf_valid && e->prefetch_steps != -1) ? 1 : 4));
     GX_HIP(hipEventRecord(e->keys_ev[slot], s));
     GX_HIP(hipGetLastError());
     e->key[0] = k0; e->key[1] = k1;

@@ -10,6 +10,23 @@
 
 namespace gx {
 
+// value held by lane K of this lane's quad (DPP quad_perm broadcast: a move, no arithmetic)
+template <int K>
+GX_D float quad_bc(float x)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), K * 0x55, 0xf, 0xf, true));
+}
+template <int K>
+GX_D bool quad_bcb(bool x) { return __builtin_amdgcn_mov_dpp(x ? 1 : 0, K * 0x55, 0xf, 0xf, true) != 0; }
+// a per-lane choice between elements of a small register array.  Each operand goes through an empty asm first: left
+// alone, the optimiser turns the select chain into a dynamically indexed load and the array moves to scratch (see
+// pick() in gx_robot_kernels.inl)
+GX_D float opaque(float x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 // ===========================================================================
 // Point (xmls/point.xml): slide-x, slide-y, hinge-z; sphere r=.1 + box .05 at
 // x=.1, density 1 (:5,19-20); damping .01 .01 .005 (:16-18); h=.02 (:3).
@@ -27,6 +44,7 @@ struct PointRobotT {
     static constexpr int kId = kBare ? 4 : 0, NQ = 3, NV = 3, NU = 3, NA = 2, NDYN = 3;
     static constexpr float kH = 0.02f;
     static constexpr float kIo = 2.842182748581224e-05f; // inertia about the hinge axis (enters substep through kInvD3*)
+    static constexpr int kDynLanes = 1; // lanes per env in the dynamics pass of the two-kernel rollout
     // default Goal_Point_8Hazards observation: ctrl[0:3] compass[3:5] glidar[5:21] hlidar[21:37] qpos[37:40] qvel[40:43]
     static constexpr int kD = 43, kOffCtrl = 0, kOffComp = 3, kOffGl = 5, kOffHl = 21, kOffQpos = 37, kOffQvel = 40;
 
@@ -215,9 +233,27 @@ struct SwimmerRobot {
         return true;
     }
 
+    // lanes per env in the dynamics pass of the two-kernel rollout: the four lanes of a quad share one env and split
+    // what is independent in the step -- the three half-angle sincos, the two joint-limit rows, the two unit solves and
+    // the three candidate active sets of the limit QP; everything else they evaluate redundantly (same operations,
+    // same bits).  Every value is produced by the same expression as in the one-lane form and moved, never
+    // re-associated, so the forms agree bit for bit (770 -> 600 instructions on the serial chain of a step: a 200-step
+    // rollout alone 395 -> 322 us).  Used when no layout sampler runs beside the rollout: 125 waves instead of 32 each
+    // take most of a SIMD's issue slots, and with the sampler saturating the vector ALUs the epoch is faster with
+    // the one-lane form (0.581 against 0.595 ms), so gx_rollout picks per launch (SplitArgs::lanes).
+    static constexpr int kDynLanes = 4;
+
     template <bool kQacc, bool kNoNaN = false> // kNoNaN: nothing to gain here (the clamp below passes NaN through by itself)
     GX_D static void substep(float (&q)[NQ], float (&v)[NV], const float (&ctrl)[NU], float (&pose)[4],
                              float (&qacc)[NV])
+    {
+        substep_q<false>(q, v, ctrl, pose, qacc, 0);
+    }
+
+    // kQuad: called by all four lanes of a quad that hold the same env (identical q, v, ctrl); j = lane & 3
+    template <bool kQuad>
+    GX_D static void substep_q(float (&q)[NQ], float (&v)[NV], const float (&ctrl)[NU], float (&pose)[4],
+                               float (&qacc)[NV], int j)
     {
         constexpr float kM = 0.22200588085367876f, kIc = 0.00060383505197098225f, kArm = 0.1f, kGear = 20.0f;
         constexpr float kInvW2 = 9.3234461878793518f, kInvW3 = 9.8671592198756102f;
@@ -225,9 +261,19 @@ struct SwimmerRobot {
         constexpr float kImu = (float)(1.0 / (3.0 * 0.22200588085367876 + 0.1));
         // kinematics: hinge quaternions (half angles) composed down the chain
         float sh1, ch1, sh2, ch2, sh3, ch3;
-        sincos_f(0.5f * q[2], sh1, ch1);
-        sincos_f(0.5f * q[3], sh2, ch2);
-        sincos_f(0.5f * q[4], sh3, ch3);
+        if (kQuad) { // lane j takes joint min(j, 2)
+            const float a0 = opaque(q[2]), a1 = opaque(q[3]), a2 = opaque(q[4]);
+            const float ang = j == 0 ? a0 : (j == 1 ? a1 : a2);
+            float sh, ch;
+            sincos_f(0.5f * ang, sh, ch);
+            sh1 = quad_bc<0>(sh); ch1 = quad_bc<0>(ch);
+            sh2 = quad_bc<1>(sh); ch2 = quad_bc<1>(ch);
+            sh3 = quad_bc<2>(sh); ch3 = quad_bc<2>(ch);
+        } else {
+            sincos_f(0.5f * q[2], sh1, ch1);
+            sincos_f(0.5f * q[3], sh2, ch2);
+            sincos_f(0.5f * q[4], sh3, ch3);
+        }
         const float w1 = ch1, z1 = sh1;
         const float w2 = w1 * ch2 - z1 * sh2, z2 = w1 * sh2 + z1 * ch2;
         const float w3 = w2 * ch3 - z2 * sh3, z3 = w2 * sh3 + z2 * ch3;
@@ -292,32 +338,74 @@ struct SwimmerRobot {
         ldl_solve(F, r0, r1, r2, a);
         // joint limits on phi2, phi3
         float sg2, ar2, R2, sg3, ar3, R3;
-        const bool p2 = limit_row(q[3], v[3], kInvW2, sg2, ar2, R2);
-        const bool p3 = limit_row(q[4], v[4], kInvW3, sg3, ar3, R3);
+        bool p2, p3;
+        if (kQuad) { // lanes 0, 1: phi2's row; lanes 2, 3: phi3's
+            const bool two = j >= 2;
+            float sg, ar, Rr;
+            const float q3_ = opaque(q[3]), q4_ = opaque(q[4]), v3_ = opaque(v[3]), v4_ = opaque(v[4]);
+            const bool pr = limit_row(two ? q4_ : q3_, two ? v4_ : v3_, two ? kInvW3 : kInvW2, sg, ar, Rr);
+            p2 = quad_bcb<0>(pr); sg2 = quad_bc<0>(sg); ar2 = quad_bc<0>(ar); R2 = quad_bc<0>(Rr);
+            p3 = quad_bcb<2>(pr); sg3 = quad_bc<2>(sg); ar3 = quad_bc<2>(ar); R3 = quad_bc<2>(Rr);
+        } else {
+            p2 = limit_row(q[3], v[3], kInvW2, sg2, ar2, R2);
+            p3 = limit_row(q[4], v[4], kInvW3, sg3, ar3, R3);
+        }
         if (p2 || p3) {
             if (!p2) sg2 = 0.0f;
             if (!p3) sg3 = 0.0f;
-            float zc2[3], zc3[3];
-            ldl_solve(F, 0.0f, 1.0f, 0.0f, zc2);
-            ldl_solve(F, 0.0f, 0.0f, 1.0f, zc3);
-            const float A22i = zc2[1], A33i = zc3[2], A23i = zc3[1] * (sg2 * sg3);
+            float A22i, A33i, z31;
+            if (kQuad) { // one unit solve per half of the quad
+                const bool two = j >= 2;
+                float zc[3];
+                ldl_solve(F, 0.0f, two ? 0.0f : 1.0f, two ? 1.0f : 0.0f, zc);
+                A22i = quad_bc<0>(zc[1]); A33i = quad_bc<2>(zc[2]); z31 = quad_bc<2>(zc[1]);
+            } else {
+                float zc2[3], zc3[3];
+                ldl_solve(F, 0.0f, 1.0f, 0.0f, zc2);
+                ldl_solve(F, 0.0f, 0.0f, 1.0f, zc3);
+                A22i = zc2[1]; A33i = zc3[2]; z31 = zc3[1];
+            }
+            const float A23i = z31 * (sg2 * sg3);
             const float E2 = sg2 * a[1] - ar2, E3 = sg3 * a[2] - ar3;
             float f2 = 0.0f, f3 = 0.0f;
-            bool done = false;
-            if (p2 && p3) {
+            if (kQuad) {
+                // the three candidate active sets side by side: lane 0 both rows, lane 1 row 2 alone, lanes 2, 3 row 3
+                // alone; then the one-lane form's order of preference (both, row 2, row 3)
                 const float m22 = R2 + A22i, m33 = R3 + A33i;
                 const float det = m22 * m33 - A23i * A23i;
-                const float g2 = ((-E2) * m33 - A23i * (-E3)) / det;
-                const float g3 = (m22 * (-E3) - A23i * (-E2)) / det;
-                if (g2 > 0.0f && g3 > 0.0f) { f2 = g2; f3 = g3; done = true; }
-            }
-            if (!done && p2) {
-                const float g2 = (-E2) / (R2 + A22i);
-                if (g2 > 0.0f && (!p3 || !(E3 + A23i * g2 < 0.0f))) { f2 = g2; f3 = 0.0f; done = true; }
-            }
-            if (!done && p3) {
-                const float g3 = (-E3) / (R3 + A33i);
-                if (g3 > 0.0f && (!p2 || !(E2 + A23i * g3 < 0.0f))) { f3 = g3; f2 = 0.0f; done = true; }
+                const float nA2 = (-E2) * m33 - A23i * (-E3), nA3 = m22 * (-E3) - A23i * (-E2);
+                const float num1 = j == 0 ? nA2 : (j == 1 ? -E2 : -E3);
+                const float den = j == 0 ? det : (j == 1 ? m22 : m33);
+                const float g1 = num1 / den;     // lane 0: g2 of "both"; lane 1: g2 alone; lanes 2, 3: g3 alone
+                const float gq = nA3 / den;      // lane 0: g3 of "both" (unused elsewhere)
+                const float gA2 = quad_bc<0>(g1), gA3 = quad_bc<0>(gq), gB = quad_bc<1>(g1), gC = quad_bc<2>(g1);
+                bool done = false;
+                if (p2 && p3) {
+                    if (gA2 > 0.0f && gA3 > 0.0f) { f2 = gA2; f3 = gA3; done = true; }
+                }
+                if (!done && p2) {
+                    if (gB > 0.0f && (!p3 || !(E3 + A23i * gB < 0.0f))) { f2 = gB; f3 = 0.0f; done = true; }
+                }
+                if (!done && p3) {
+                    if (gC > 0.0f && (!p2 || !(E2 + A23i * gC < 0.0f))) { f3 = gC; f2 = 0.0f; done = true; }
+                }
+            } else {
+                bool done = false;
+                if (p2 && p3) {
+                    const float m22 = R2 + A22i, m33 = R3 + A33i;
+                    const float det = m22 * m33 - A23i * A23i;
+                    const float g2 = ((-E2) * m33 - A23i * (-E3)) / det;
+                    const float g3 = (m22 * (-E3) - A23i * (-E2)) / det;
+                    if (g2 > 0.0f && g3 > 0.0f) { f2 = g2; f3 = g3; done = true; }
+                }
+                if (!done && p2) {
+                    const float g2 = (-E2) / (R2 + A22i);
+                    if (g2 > 0.0f && (!p3 || !(E3 + A23i * g2 < 0.0f))) { f2 = g2; f3 = 0.0f; done = true; }
+                }
+                if (!done && p3) {
+                    const float g3 = (-E3) / (R3 + A33i);
+                    if (g3 > 0.0f && (!p2 || !(E2 + A23i * g3 < 0.0f))) { f3 = g3; f2 = 0.0f; done = true; }
+                }
             }
             ldl_solve(F, r0, r1 + sg2 * f2, r2 + sg3 * f3, a);
         }

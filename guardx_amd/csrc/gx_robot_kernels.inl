@@ -1329,17 +1329,17 @@ void RobotLaunch<R>::fake_table(const Params& p, const Pool& pl, int nobj_total,
 
 template <class R>
 hipError_t RobotLaunch<R>::split(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, float* entry,
-                                 const DevBuffers& b, hipStream_t s, hipEvent_t hold, int which)
+                                 const DevBuffers& b, hipStream_t s, hipEvent_t hold, int which, int lanes)
 {
     if constexpr (R::kRestFixed) {
         SplitArgs sa;
-        sa.tape = tape; sa.obj0 = obj0; sa.entry = entry;
+        sa.tape = tape; sa.obj0 = obj0; sa.entry = entry; sa.lanes = lanes;
         if (p.P <= 5) return launch_split_p<R, 5>(p, r, sa, b, s, hold, which);
         if (p.P <= 9) return launch_split_p<R, 9>(p, r, sa, b, s, hold, which);
         return launch_split_p<R, 33>(p, r, sa, b, s, hold, which);
     } else { // Ant, Walker: the dynamics pass is the lane-group form of the step
         SplitArgs sa;
-        sa.tape = tape; sa.obj0 = obj0; sa.entry = entry;
+        sa.tape = tape; sa.obj0 = obj0; sa.entry = entry; sa.lanes = lanes;
         if (p.P <= 5) return launch_split_group_p<R, 5>(p, r, sa, b, s, hold, which);
         if (p.P <= 9) return launch_split_group_p<R, 9>(p, r, sa, b, s, hold, which);
         return launch_split_group_p<R, 33>(p, r, sa, b, s, hold, which);

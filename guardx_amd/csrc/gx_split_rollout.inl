@@ -42,6 +42,7 @@ struct SplitArgs {
     float* tape;        // [T][N][kW]
     float4* obj0;       // [P][Npad] snapshot of the layouts at entry (pass 2 reads it for rows with jcur < 0)
     float* entry;       // [N][kE] state at entry (pass 2 needs it for the rows of steps 0 and 1)
+    int lanes;          // lanes per env in pass 1 where the robot offers a choice (R::kDynLanes): 1 or 4
 };
 
 GX_D bool moderate(float x) { return fabsf(x) < 1e18f; } // false for NaN / Inf too
@@ -64,20 +65,27 @@ GX_D void store_row(float* __restrict__ p, const float (&v)[W])
         reinterpret_cast<float4*>(p)[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
 }
 
-template <class R, int BLOCK, int PMAX, bool kDef>
+template <class R, int BLOCK, int PMAX, bool kDef, int LPE = 1>
 __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArgs r, SplitArgs sa,
                                                          float4* __restrict__ dyn, float4* __restrict__ obj)
 {
     using TP = SplitTape<R>;
+    // the serial chain of the epoch: its waves go first wherever they share a SIMD with the layout sampler's (which are
+    // throughput work and fill every issue slot this wave leaves)
+    __builtin_amdgcn_s_setprio(3);
     const Params p = fold_params<R, kDef>(p_in);
     extern __shared__ float4 tile4[];
     float* tile = reinterpret_cast<float*>(tile4); // one obs row per thread: exact NaN-guard evaluation only
+    // LPE lanes per env (4, Swimmer: the lanes of a quad share an env and split the step's independent pieces,
+    // SwimmerRobot::substep_q; they all carry the state, lane 0 of the quad does the stores)
     const int tid = threadIdx.x;
-    const int i = blockIdx.x * BLOCK + tid;
+    const int i = (blockIdx.x * BLOCK + tid) / LPE;
+    const int jq = tid & (LPE - 1);
+    const bool writer = jq == 0;
     if (i >= p.N) return;
     float q[R::NQ], v[R::NV], pose0[4], done0, steps;
     R::load(dyn, p.Npad, i, q, v, pose0, done0, steps);
-    {   // the state at entry, for the rows of steps 0 and 1 in pass 2
+    if (writer) {   // the state at entry, for the rows of steps 0 and 1 in pass 2
         float ev[TP::kE];
 #pragma unroll
         for (int k = 0; k < TP::kE; ++k) ev[k] = 0.f;
@@ -97,7 +105,7 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
     for (int k = 0; k < PMAX; ++k) {
         if (k < p.P) {
             const float4 o4 = obj[(size_t)k * p.Npad + i];
-            sa.obj0[(size_t)k * p.Npad + i] = o4;
+            if (writer) sa.obj0[(size_t)k * p.Npad + i] = o4;
             if (k == 0) { gx = o4.x; gy = o4.y; }
             objs_ok = objs_ok && moderate(o4.x) && moderate(o4.y);
             if (2 * k + 1 < p.nobj) objs_ok = objs_ok && moderate(o4.z) && moderate(o4.w);
@@ -170,7 +178,8 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
         for (int k = 0; k < R::NQ; ++k) qf[k] = q[k];
 #pragma unroll
         for (int k = 0; k < R::NV; ++k) vf[k] = v[k];
-        R::template substep<false, true>(qf, vf, ctrl, pose, qacc);
+        if constexpr (LPE == 4) R::template substep_q<true>(qf, vf, ctrl, pose, qacc, jq);
+        else R::template substep<false, true>(qf, vf, ctrl, pose, qacc);
         float mag = 0.f;
 #pragma unroll
         for (int k = 0; k < R::NQ; ++k) mag = mag + fabsf(qf[k]);
@@ -193,7 +202,10 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
             p_ok = true;   // this step's pose: the kinematics of a moderate qpos
             s_ok = true;   // moderate(mag)
         } else { // rare: the step again, exactly (from the untouched q, v)
-            for (int k = 0; k < p.physics_steps; ++k) R::template substep<false>(q, v, ctrl, pose, qacc);
+            for (int k = 0; k < p.physics_steps; ++k) {
+                if constexpr (LPE == 4) R::template substep_q<true>(q, v, ctrl, pose, qacc, jq);
+                else R::template substep<false>(q, v, ctrl, pose, qacc);
+            }
             // NaN / Inf guard :696-699
             float4 ob[PMAX];
             if (jcur >= 0) { float rx_, ry_; load_layout<PMAX>(p, r.cand_xy, r.nobj_total, jcur, ob, rx_, ry_); }
@@ -248,7 +260,7 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
         rowv[TP::kJcur] = __int_as_float(jcur); rowv[TP::kJaft] = __int_as_float(jaft);
 #pragma unroll
         for (int k = TP::kUsed; k < TP::kW; ++k) rowv[k] = 0.f;
-        store_row<TP::kW>(sa.tape + ((size_t)t * p.N + i) * TP::kW, rowv);
+        if (writer) store_row<TP::kW>(sa.tape + ((size_t)t * p.N + i) * TP::kW, rowv);
 
         // commit the history, then the re-initialisation (the stale pose stays, :731)
 #pragma unroll
@@ -271,8 +283,8 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
 #pragma unroll
         for (int d = 0; d < R::NA; ++d) actl[((abuf * kActBlock + k) * BLOCK + tid) * R::NA + d] = anx[k][d];
     }
-    R::store(dyn, p.Npad, i, q, v, pose0, done0, steps);
-    if (jcur >= 0) { // the layout a reset_done installed becomes the env's layout
+    if (writer) R::store(dyn, p.Npad, i, q, v, pose0, done0, steps);
+    if (writer && jcur >= 0) { // the layout a reset_done installed becomes the env's layout
         float4 ob[PMAX];
         float rx_, ry_;
         load_layout<PMAX>(p, r.cand_xy, r.nobj_total, jcur, ob, rx_, ry_);
@@ -298,6 +310,7 @@ __global__ __launch_bounds__(64) void group_dyn_tape_kernel(Params p_in, Rollout
 {
     using TP = SplitTape<R>;
     constexpr int BT = 64, EPW = BT / kGL; // envs per wave
+    __builtin_amdgcn_s_setprio(3); // see dyn_tape_kernel
     const Params p = fold_params<R, kDef>(p_in);
     __shared__ GroupLds<OPL, BPL, BT> S;
     __shared__ float actl[2][kActBlock][EPW][R::NA];
@@ -642,19 +655,28 @@ static hipError_t launch_split_p(const Params& p, const RolloutArgs& r, const Sp
 {
     hipError_t st = hipSuccess; // of the wait that orders the observation pass behind the sampler: must not be dropped
     constexpr int B1 = 64, B2 = 64;
-    const dim3 g1((p.N + B1 - 1) / B1), g2((unsigned)(((size_t)r.T * p.N + B2 - 1) / B2));
+    const int lpe = (R::kDynLanes == 4 && sa.lanes == 4) ? 4 : 1;
+    const dim3 g1((p.N * lpe + B1 - 1) / B1), g2((unsigned)(((size_t)r.T * p.N + B2 - 1) / B2));
     const size_t lds1 = sizeof(float) * ((size_t)B1 * p.D + 2 * (size_t)kActBlock * B1 * R::NA); // obs rows + two action blocks
     const size_t lds2 = sizeof(float) * (size_t)B2 * (r.obs_stride | 1);
-    if (PMAX == 5 && is_default_layout<R>(p)) {
-        if (which & 1) hipLaunchKernelGGL((dyn_tape_kernel<R, B1, 5, true>), g1, dim3(B1), lds1, s, p, r, sa, b.dyn, b.obj);
-        if (hold) st = hipStreamWaitEvent(s, hold, 0);
-        if (st != hipSuccess) return st;
-        if (which & 2) hipLaunchKernelGGL((obs_tape_kernel<R, B2, 5, true>), g2, dim3(B2), lds2, s, p, r, sa);
-    } else {
-        if (which & 1) hipLaunchKernelGGL((dyn_tape_kernel<R, B1, PMAX, false>), g1, dim3(B1), lds1, s, p, r, sa, b.dyn, b.obj);
-        if (hold) st = hipStreamWaitEvent(s, hold, 0);
-        if (st != hipSuccess) return st;
-        if (which & 2) hipLaunchKernelGGL((obs_tape_kernel<R, B2, PMAX, false>), g2, dim3(B2), lds2, s, p, r, sa);
+    const bool def = PMAX == 5 && is_default_layout<R>(p);
+    if (which & 1) {
+        if constexpr (R::kDynLanes == 4) {
+            if (lpe == 4) {
+                if (def) hipLaunchKernelGGL((dyn_tape_kernel<R, B1, 5, true, 4>), g1, dim3(B1), lds1, s, p, r, sa, b.dyn, b.obj);
+                else hipLaunchKernelGGL((dyn_tape_kernel<R, B1, PMAX, false, 4>), g1, dim3(B1), lds1, s, p, r, sa, b.dyn, b.obj);
+            }
+        }
+        if (lpe == 1) {
+            if (def) hipLaunchKernelGGL((dyn_tape_kernel<R, B1, 5, true, 1>), g1, dim3(B1), lds1, s, p, r, sa, b.dyn, b.obj);
+            else hipLaunchKernelGGL((dyn_tape_kernel<R, B1, PMAX, false, 1>), g1, dim3(B1), lds1, s, p, r, sa, b.dyn, b.obj);
+        }
+    }
+    if (hold) st = hipStreamWaitEvent(s, hold, 0);
+    if (st != hipSuccess) return st;
+    if (which & 2) {
+        if (def) hipLaunchKernelGGL((obs_tape_kernel<R, B2, 5, true>), g2, dim3(B2), lds2, s, p, r, sa);
+        else hipLaunchKernelGGL((obs_tape_kernel<R, B2, PMAX, false>), g2, dim3(B2), lds2, s, p, r, sa);
     }
     return st;
 }

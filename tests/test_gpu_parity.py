@@ -21,7 +21,9 @@ def torch_cuda():
     return torch
 
 
-PATHS = {"thread": 1, "group": 2, "split": 3}   # split: two-kernel rollouts (Point / Swimmer), lane-group steps
+# split: two-kernel rollouts (dynamics tape + observation pass), lane-group steps; split-alone: the same with the layout
+# prefetch off, which selects the dynamics pass's alone-on-the-chip form where a robot has one (Swimmer: a quad per env)
+PATHS = {"thread": 1, "group": 2, "split": 3, "split-alone": 3}
 
 
 def _engines(cfg, oracle, n_candidates=20000, path=None, **kw):
@@ -30,6 +32,8 @@ def _engines(cfg, oracle, n_candidates=20000, path=None, **kw):
     assert E.action_space.shape[0] == E._lib.gx_act_dim(E._h)
     if path is not None:
         E.set_path(PATHS[path])
+        if path == "split-alone":
+            E.set_prefetch(-1)
     O = oracle.OracleEngine(cfg, n_candidates=n_candidates, env_total=E._cfg.env_total,
                             env_offset=E._cfg.env_offset, point_actuators=kw.get('point_actuators', 'mjcf'))
     return E, O
@@ -721,7 +725,7 @@ def test_swimmer_step_parity_random_states(torch_cuda, oracle, N, path):
         assert_state_equal(E.get_state(), O.get_state())
 
 
-@pytest.mark.parametrize("path", ["thread", "group", "split"])
+@pytest.mark.parametrize("path", ["thread", "group", "split", "split-alone"])
 def test_swimmer_rollout_parity(torch_cuda, oracle, path):
     torch = torch_cuda
     N, T = 300, 120
@@ -771,7 +775,7 @@ def test_ant_step_parity_random_states(torch_cuda, oracle, N, path):
         assert_state_equal(E.get_state(), O.get_state())
 
 
-@pytest.mark.parametrize("path", ["thread", "group"])
+@pytest.mark.parametrize("path", ["thread", "group", "split"])
 def test_ant_rollout_parity(torch_cuda, oracle, path):
     torch = torch_cuda
     N, T = 300, 100
@@ -820,7 +824,7 @@ def test_walker_step_parity_random_states(torch_cuda, oracle, N, path):
         assert_state_equal(E.get_state(), O.get_state())
 
 
-@pytest.mark.parametrize("path", ["thread", "group"])
+@pytest.mark.parametrize("path", ["thread", "group", "split"])
 def test_walker_rollout_parity(torch_cuda, oracle, path):
     torch = torch_cuda
     N, T = 300, 100

@@ -1,0 +1,11 @@
+"""Kernel timeline of the last epochs from a rocprofv3 --kernel-trace csv: start / end relative to the first listed kernel.
+    python tools/debug/timeline.py <kernel_trace.csv> [n_last]"""
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+rows = rows[-n:]
+t0 = int(rows[0]["Start_Timestamp"])
+for r in rows:
+    s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
+    print(f"{s/1e3:9.1f} {e/1e3:9.1f} {(e-s)/1e3:8.1f} us  q{r.get('Queue_Id','?'):>3} {r['Kernel_Name'][:70]}")
