@@ -32,7 +32,7 @@ class GxConfig(C.Structure):
         ("robot_goal_min_dist", C.c_float), ("device", C.c_int32),
         ("placements", C.POINTER(C.c_double)),
         ("pillars_num", C.c_int32), ("observe_pillars", C.c_int32), ("pillars_size", C.c_float),
-        ("pad_", C.c_float), ("pillars_keepout", C.c_double),
+        ("robot_rot", C.c_float), ("pillars_keepout", C.c_double),
     ]
 
 

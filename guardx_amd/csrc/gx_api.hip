@@ -249,6 +249,12 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     p.bin_size = (float)((3.14159265358979323846 * 2) / p.bins); // engine.py:880
     p.goal_size = cfg->goal_size;
     p.goal_cut = sqrt_cutoff(cfg->goal_size);
+    {   // robot_rot: rot2quat -> (w, 0, 0, z); the body's x axis in the world is (w^2 - z^2, 2 w z) in fp32
+        const float w = (float)cos(0.5 * (double)cfg->robot_rot), z = (float)sin(0.5 * (double)cfg->robot_rot);
+        p.rot_on = cfg->robot_rot != 0.0f;
+        p.rot_c = w * w - z * z;
+        p.rot_s = 2.0f * (w * z);
+    }
     p.hazards_size = cfg->hazards_size;
     p.pillars_size = cfg->pillars_size;
     p.reward_distance = cfg->reward_distance;

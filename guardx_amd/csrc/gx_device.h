@@ -37,6 +37,11 @@ struct Params {
     int have_last, have_last_last; // None-ness of _last_done / _last_last_done
     int hist_on;                   // observe_vel || observe_acc
     int robot;                     // 0 point, 1 swimmer
+    // 'robot_rot' (engine.py:114,342-345 -> world.py:117): the robot's root body is turned by this angle about z, its
+    // joints with it.  The dynamics are evaluated in the root body's frame (they do not depend on the angle: gravity
+    // is along z, the floor is the plane z = 0) and every pose that leaves a step is turned into the world frame
+    int rot_on;
+    float rot_c, rot_s;            // cos / sin of robot_rot (from the root quaternion: w^2 - z^2, 2 w z)
 };
 
 // ---------------------------------------------------------------------------
@@ -46,6 +51,18 @@ GX_HD float u2f(uint32_t u) { union { uint32_t u; float f; } v; v.u = u; return 
 GX_HD uint32_t f2u(float f) { union { uint32_t u; float f; } v; v.f = f; return v.u; }
 GX_D float nmax(float a, float b) { return (a > b || a != a) ? a : b; }
 GX_D bool notfinite(float v) { return !(fabsf(v) <= 3.4028234663852886e38f); }
+
+// pose (x, y, cos, sin) of the robot body in its root body's frame -> world frame (robot_rot, see Params)
+GX_D void world_pose(const Params& p, float (&pose)[4])
+{
+    if (p.rot_on) {
+        const float x = pose[0], y = pose[1], c = pose[2], s = pose[3];
+        pose[0] = p.rot_c * x - p.rot_s * y;
+        pose[1] = p.rot_s * x + p.rot_c * y;
+        pose[2] = p.rot_c * c - p.rot_s * s;
+        pose[3] = p.rot_s * c + p.rot_c * s;
+    }
+}
 
 // ---------------------------------------------------------------------------
 // sin/cos: 3-term Cody-Waite to [-pi/4, pi/4], minimax polynomials

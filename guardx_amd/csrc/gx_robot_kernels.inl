@@ -143,7 +143,7 @@ static bool is_default_layout(const Params& p)
     return p.nobj == 9 && p.PL == 0 && p.off_pl == -1 && p.bins == 16 && p.D == R::kD && p.off_acc == -1 && p.off_ctrl == R::kOffCtrl &&
            p.off_comp == R::kOffComp && p.off_gl == R::kOffGl && p.off_hl == R::kOffHl &&
            p.off_qpos == R::kOffQpos && p.off_qvel == R::kOffQvel && p.off_vel == -1 && p.lidar_alias == 1 &&
-           p.lidar_max_dist_set == 0 && p.physics_steps == 1 && p.hist_on == 0;
+           p.lidar_max_dist_set == 0 && p.physics_steps == 1 && p.hist_on == 0 && p.rot_on == 0;
 }
 
 template <class R, bool kDef>
@@ -153,7 +153,7 @@ GX_D Params fold_params(Params p)
         p.H = 8; p.PL = 0; p.off_pl = -1; p.nobj = 9; p.P = 5; p.bins = 16; p.D = R::kD;
         p.off_acc = -1; p.off_ctrl = R::kOffCtrl; p.off_comp = R::kOffComp; p.off_gl = R::kOffGl;
         p.off_hl = R::kOffHl; p.off_qpos = R::kOffQpos; p.off_qvel = R::kOffQvel; p.off_vel = -1;
-        p.lidar_alias = 1; p.lidar_max_dist_set = 0; p.physics_steps = 1; p.hist_on = 0;
+        p.lidar_alias = 1; p.lidar_max_dist_set = 0; p.physics_steps = 1; p.hist_on = 0; p.rot_on = 0;
     }
     return p;
 }
@@ -241,6 +241,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p_in, const float* _
 #pragma unroll
     for (int k = 0; k < R::NV; ++k) qacc[k] = 0.f;
     for (int k = 0; k < p.physics_steps; ++k) R::template substep<kQacc>(q, v, ctrl, pose, qacc);
+    world_pose(p, pose);
 
     float vel0 = 0.f, vel1 = 0.f, acc0 = 0.f, acc1 = 0.f;
     if (p.hist_on)
@@ -348,7 +349,8 @@ __global__ __launch_bounds__(BLOCK) void reset_apply_kernel(Params p, int nobj_t
 #pragma unroll
     for (int k = 0; k < R::NU; ++k) ctrl[k] = 0.f;
     R::place(q, rx, ry);
-    const float pose[4] = {rx, ry, 1.0f, 0.0f};
+    float pose[4] = {rx, ry, 1.0f, 0.0f};
+    world_pose(p, pose);
     float* row = tile + tid * p.D;
     build_obs_row<R, PMAX>(p, row, pose, ob, ctrl, q, v, 0.f, 0.f, 0.f, 0.f);
     if (live) {
@@ -412,6 +414,7 @@ __global__ __launch_bounds__(BLOCK) void reset_done_kernel(Params p, int nobj_to
         for (int k = 0; k < R::NU; ++k) ctrl[k] = 0.f;
         R::place(q, rx, ry);
         float pose[4] = {rx, ry, 1.0f, 0.0f};
+        world_pose(p, pose);
         if (R::kRestFixed) {
             build_obs_row<R, PMAX>(p, tile + tid * p.D, pose, ob, ctrl, q, v, 0.f, 0.f, 0.f, 0.f);
         } else { // the fake step moves the robot: its qpos/qvel feed the obs only
@@ -421,6 +424,7 @@ __global__ __launch_bounds__(BLOCK) void reset_done_kernel(Params p, int nobj_to
 #pragma unroll
             for (int k = 0; k < R::NV; ++k) fv[k] = 0.f;
             for (int k = 0; k < p.physics_steps; ++k) R::template substep<false>(fq, fv, ctrl, pose, fa);
+            world_pose(p, pose);
             build_obs_row<R, PMAX>(p, tile + tid * p.D, pose, ob, ctrl, fq, fv, 0.f, 0.f, 0.f, 0.f);
         }
         R::store(dyn, p.Npad, i, q, v, opose, odone, osteps);
@@ -483,6 +487,7 @@ void thread_rollout_kernel(Params p_in, RolloutArgs r,
 #pragma unroll
         for (int k = 0; k < R::NV; ++k) qacc[k] = 0.f;
         for (int k = 0; k < p.physics_steps; ++k) R::template substep<false>(q, v, ctrl, pose, qacc);
+        world_pose(p, pose);
 
         float vel0 = 0.f, vel1 = 0.f, acc0 = 0.f, acc1 = 0.f;
         if (p.hist_on)
@@ -541,6 +546,7 @@ void thread_rollout_kernel(Params p_in, RolloutArgs r,
                 for (int k = 0; k < R::NU; ++k) zc[k] = 0.f;
                 R::place(q, rx, ry);
                 float rpose[4] = {rx, ry, 1.0f, 0.0f};
+                world_pose(p, rpose);
                 if (R::kRestFixed) {
                     build_obs_row<R, PMAX>(p, row, rpose, ob, zc, q, v, 0.f, 0.f, 0.f, 0.f);
                 } else { // the fake step (:719-724) moves the robot: qpos | qvel | pose tabulated with the pool
@@ -627,6 +633,7 @@ __global__ __launch_bounds__(BLOCK) void fake_table_kernel(Params p, int nobj_to
     for (int k = 0; k < R::NU; ++k) ctrl[k] = 0.f;
     R::place(q, rb.x, rb.y);
     for (int k = 0; k < p.physics_steps; ++k) R::template substep<false>(q, v, ctrl, pose, qacc);
+    world_pose(p, pose);
     float* row = fake + (size_t)c * (R::NQ + R::NV + 4);
 #pragma unroll
     for (int k = 0; k < R::NQ; ++k) row[k] = q[k];
@@ -997,6 +1004,7 @@ __global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Par
 #pragma unroll
         for (int k = 0; k < R::NV; ++k) qacc[k] = 0.f;
         for (int k = 0; k < p.physics_steps; ++k) group_substep<R, kQacc>(q, v, ctrl, pose, qacc, l);
+        world_pose(p, pose);
         if (r.stamps && t == tstar) { asm volatile("" ::"v"(pose[0] + pose[3] + q[2])); stamp(r, 4); }
 
         float vel0 = 0.f, vel1 = 0.f, acc0 = 0.f, acc1 = 0.f;
@@ -1108,6 +1116,7 @@ __global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Par
                     ngx = g.x; ngy = g.y; rx = rb.x; ry = rb.y;
                 }
                 float rpose[4] = {rx, ry, 1.0f, 0.0f};
+                world_pose(p, rpose);
                 float fq[R::NQ], fv[R::NV];
 #pragma unroll
                 for (int k = 0; k < R::NQ; ++k) fq[k] = 0.f;

@@ -180,6 +180,7 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
         for (int k = 0; k < R::NV; ++k) vf[k] = v[k];
         if constexpr (LPE == 4) R::template substep_q<true>(qf, vf, ctrl, pose, qacc, jq);
         else R::template substep<false, true>(qf, vf, ctrl, pose, qacc);
+        world_pose(p, pose);
         float mag = 0.f;
 #pragma unroll
         for (int k = 0; k < R::NQ; ++k) mag = mag + fabsf(qf[k]);
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
                 if constexpr (LPE == 4) R::template substep_q<true>(q, v, ctrl, pose, qacc, jq);
                 else R::template substep<false>(q, v, ctrl, pose, qacc);
             }
+            world_pose(p, pose);
             // NaN / Inf guard :696-699
             float4 ob[PMAX];
             if (jcur >= 0) { float rx_, ry_; load_layout<PMAX>(p, r.cand_xy, r.nobj_total, jcur, ob, rx_, ry_); }
@@ -394,6 +396,7 @@ __global__ __launch_bounds__(64) void group_dyn_tape_kernel(Params p_in, Rollout
 #pragma unroll
         for (int k = 0; k < R::NV; ++k) qacc[k] = 0.f;
         group_substep<R, false>(q, v, ctrl, pose, qacc, l);
+        world_pose(p, pose);
 
         // NaN / Inf guard :696-699
         float mag = 0.f;
@@ -578,11 +581,13 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
             next_start<R>(pp, r, sp);
         }
         R::pose_of(sp, pose0);
+        world_pose(p, pose0);
     }
     hist0 = t < 2 ? ev[TP::kEHist] : 2.0f; // number of step() calls before the rollout (only its first rows care)
     const bool have_last = ((int)hist0 + t) >= 1;
     float pose[4], ctrl[R::NU];
     R::pose_of(s, pose);                  // mjx.step = forward(qpos_t); integrate: the returned xpos / xmat are one step stale
+    world_pose(p, pose);
     R::convert_action(pose0, a, ctrl);    // :672-685, PRE-step xmat
 
     float4 ob[PMAX];
@@ -619,6 +624,7 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
         for (int k = 0; k < R::NU; ++k) ctrl[k] = 0.f;
         R::place(q, rx, ry);
         pose[0] = rx; pose[1] = ry; pose[2] = 1.0f; pose[3] = 0.0f;
+        world_pose(p, pose);
         if constexpr (!R::kRestFixed) { // the fake step (:719-724) moves the robot: its qpos / qvel / pose feed this row
             const float* frow = r.fake + (size_t)__float_as_int(rowv[TP::kFidx]) * (R::NQ + R::NV + 4);
 #pragma unroll

@@ -192,8 +192,6 @@ class Engine:
                                       "undefined in the reference (engine.py:773-778)")
         if self.observe_vision:
             raise NotImplementedError("observe_vision is not part of the batched path")
-        if self.robot_rot not in (None, 0, 0.0):
-            raise NotImplementedError("robot_rot other than None/0")
         robot_id, nq, nv, nu, z_height, timestep, (act_lo, act_hi, act_dim) = _ROBOTS[self.robot_base]
         if robot_id == 0 and point_actuators == 'bare':
             robot_id, act_lo, act_hi = 4, -np.inf, np.inf
@@ -331,6 +329,8 @@ class Engine:
         c.observe_pillars = int(bool(self.observe_pillars))
         c.pillars_size = float(self.pillars_size)
         c.pillars_keepout = float(self.pillars_keepout)
+        # engine.py:342-345: None -> random_rot(), which returns 0.0 (engine.py:330-333); else float(robot_rot)
+        c.robot_rot = 0.0 if self.robot_rot is None else float(self.robot_rot)
         c.device = int(self.device_id)
         return c
 

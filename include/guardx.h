@@ -86,7 +86,8 @@ typedef struct gx_config {
     int32_t pillars_num;
     int32_t observe_pillars;
     float pillars_size;
-    float pad_;
+    float robot_rot;            /* 'robot_rot' engine.py:114,342-345: rotation of the robot's root body about z in radians
+                                 * (world.py:117); 0 for None (random_rot() returns 0.0, engine.py:330-333).  Was pad_. */
     double pillars_keepout;
 } gx_config;
 

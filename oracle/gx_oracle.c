@@ -721,7 +721,26 @@ void gxo_ant_probe(const float* q, const float* v, const float* ctrl, float* q2,
 }
 
 #define GX_MAXQ 13
-/* one mjx.step of the configured robot */
+/* 'robot_rot' (engine.py:114,342-345): world.py:117 turns the robot's ROOT body by this angle about z, and its joints
+ * with it (slide axes and hinge are given in the body's frame).  The dynamics do not depend on the angle (gravity is
+ * along z, the floor is z = 0), so the steps are evaluated in the root body's frame and every pose that leaves them --
+ * (x, y, cos, sin) of the robot body -- is turned into the world frame: cos / sin of the angle from the root quaternion
+ * rot2quat(robot_rot) = (w, 0, 0, z) as the body's x axis (w^2 - z^2, 2 w z).  qpos / qvel stay joint coordinates;
+ * layout2qpos writes the layout's robot xy into the slide joints as it is (engine.py:635-638), so a rotated robot
+ * starts at R(robot_rot) . xy -- the reference's behaviour, reproduced. */
+static void world_pose(const gxo_env* e, float pose[4])
+{
+    if (e->cfg.robot_rot == 0.0f) return;
+    const float w = (float)cos(0.5 * (double)e->cfg.robot_rot), z = (float)sin(0.5 * (double)e->cfg.robot_rot);
+    const float rc = w * w - z * z, rs = 2.0f * (w * z);
+    const float x = pose[0], y = pose[1], c = pose[2], s = pose[3];
+    pose[0] = rc * x - rs * y;
+    pose[1] = rs * x + rc * y;
+    pose[2] = rc * c - rs * s;
+    pose[3] = rs * c + rc * s;
+}
+
+/* one mjx.step of the configured robot (pose in the root body's frame: callers go through robot_step_w) */
 static void robot_substep(const gxo_env* e, float* q, float* v, const float* ctrl, float pose[4], float* qacc)
 {
     if (e->cfg.robot == 0) point_substep(q, v, ctrl, pose, qacc, 0);
@@ -729,6 +748,12 @@ static void robot_substep(const gxo_env* e, float* q, float* v, const float* ctr
     else if (e->cfg.robot == 1) swimmer_substep(q, v, ctrl, pose, qacc);
     else if (e->cfg.robot == 2) ant_substep(q, v, ctrl, pose, qacc);
     else legs_substep(&LG_WALKER, q, v, ctrl, pose, qacc);
+}
+/* physics_steps_per_control_step substeps (engine.py:689), the pose they return in the world frame */
+static void robot_step_w(const gxo_env* e, float* q, float* v, const float* ctrl, float pose[4], float* qacc)
+{
+    for (int k = 0; k < e->cfg.physics_steps; ++k) robot_substep(e, q, v, ctrl, pose, qacc);
+    world_pose(e, pose);
 }
 
 /* convert_action engine.py:672-685: Point rotates (a0,0,0) by the PRE-step xmat; others pass through */
@@ -741,10 +766,13 @@ static void convert_action(const gxo_env* e, const float pose0[4], const float* 
 /* pose of the robot body from qpos (mjx.forward kinematics), qpos with zero angles */
 static void pose_of_rest(const gxo_env* e, const float* q, float pose[4])
 {
-    if (e->cfg.robot == 2 || e->cfg.robot == 3) { ant_pose(q, pose); return; } /* ant, walker: x slide, z hinge, body-y slide */
-    float sh, ch;
-    gx_sincos(0.5f * q[2], &sh, &ch);
-    pose[0] = q[0]; pose[1] = q[1]; pose[2] = ch * ch - sh * sh; pose[3] = 2.0f * (ch * sh);
+    if (e->cfg.robot == 2 || e->cfg.robot == 3) ant_pose(q, pose); /* ant, walker: x slide, z hinge, body-y slide */
+    else {
+        float sh, ch;
+        gx_sincos(0.5f * q[2], &sh, &ch);
+        pose[0] = q[0]; pose[1] = q[1]; pose[2] = ch * ch - sh * sh; pose[3] = 2.0f * (ch * sh);
+    }
+    world_pose(e, pose);
 }
 
 /* obs_lidar engine.py:846-900 over `n` objects (xy pairs), pose=(x,y,c,s). */
@@ -885,7 +913,7 @@ int gxo_step(gxo_env* e, const float* action, float* obs, float* reward, float* 
         for (int k = 0; k < nq; ++k) q[k] = e->qpos[(size_t)i * nq + k];
         for (int k = 0; k < nv; ++k) v[k] = e->qvel[(size_t)i * nv + k];
         float pose[4], qacc[GX_MAXQ] = {0, 0, 0, 0, 0};
-        for (int k = 0; k < e->cfg.physics_steps; ++k) robot_substep(e, q, v, ctrl, pose, qacc); /* :689 */
+        robot_step_w(e, q, v, ctrl, pose, qacc); /* :689 */
         /* ego_vel_acc :902-929 */
         float vel[2] = {0, 0}, acc[2] = {0, 0};
         if (e->off_vel >= 0 || e->off_acc >= 0) {
@@ -976,7 +1004,7 @@ int gxo_reset_done(gxo_env* e, float* obs)
         float q[GX_MAXQ], v[GX_MAXQ], pose[4], qacc[GX_MAXQ];
         for (int k = 0; k < e->nq; ++k) q[k] = e->qpos[(size_t)i * e->nq + k];
         for (int k = 0; k < e->nv; ++k) v[k] = 0.0f;
-        for (int k = 0; k < e->cfg.physics_steps; ++k) robot_substep(e, q, v, zero5, pose, qacc);
+        robot_step_w(e, q, v, zero5, pose, qacc);
         build_obs(e, pose, &e->objs[(size_t)i * e->NOBJ * 2], zero5, q, v, zero2, zero2,
                   &obs[(size_t)i * D]); /* :726-729 */
     }

@@ -69,7 +69,7 @@ typedef struct gxo_config {
     int32_t pillars_num;        /* 0 = the reference's task */
     int32_t observe_pillars;
     float pillars_size;
-    float pad_;
+    float robot_rot;   /* engine.py:114,342-345 -> world.py:117; 0 = None */
     double pillars_keepout;
 } gxo_config;
 

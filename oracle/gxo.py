@@ -16,7 +16,7 @@ _LIB_PATH = os.path.join(_HERE, "libgx_oracle.so")
 DEFAULTS = {
     'num_steps': 1000, 'env_num': 1, '_seed': 0,
     'placements_extents': [-2, -2, 2, 2], 'placements_margin': 0.0,
-    'robot_keepout': 0.4, 'robot_base': 'xmls/point.xml',
+    'robot_keepout': 0.4, 'robot_base': 'xmls/point.xml', 'robot_rot': None,
     'observe_goal_lidar': True, 'observe_goal_comp': True, 'observe_hazards': True,
     'observe_qpos': True, 'observe_qvel': True, 'observe_ctrl': True,
     'observe_vel': False, 'observe_acc': False,
@@ -51,7 +51,7 @@ class Config(C.Structure):
         ("robot_goal_min_dist", C.c_float), ("reserved", C.c_int32),
         ("placements", C.POINTER(C.c_double)),
         ("pillars_num", C.c_int32), ("observe_pillars", C.c_int32), ("pillars_size", C.c_float),
-        ("pad_", C.c_float), ("pillars_keepout", C.c_double),
+        ("robot_rot", C.c_float), ("pillars_keepout", C.c_double),
     ]
 
 
@@ -155,6 +155,7 @@ def make_config(config, n_candidates=1_000_000, env_total=None, env_offset=0, po
     c.observe_pillars = int(bool(cfg['observe_pillars']))
     c.pillars_size = float(cfg['pillars_size'])
     c.pillars_keepout = float(cfg['pillars_keepout'])
+    c.robot_rot = 0.0 if cfg.get('robot_rot') is None else float(cfg['robot_rot'])   # engine.py:342-345
     # engine.py:507-531: per-object rectangle from *_locations (a +-keepout box around the point,
     # which the keepout shrink collapses back onto the point) or a single *_placements rectangle
     rows, custom = [], False

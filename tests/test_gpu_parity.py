@@ -270,6 +270,8 @@ def test_variant_configs(torch_cuda, oracle, path, robot):
         dict(lidar_max_dist=3.0, physics_steps_per_control_step=2, lidar_exp_gain=0.5),
         dict(hazards_num=20, goal_size=0.3, hazards_size=0.2, reward_distance=2.0,
              hazards_keepout=0.18, placements_extents=[-3, -3, 3, 3]),
+        dict(robot_rot=0.7),                                      # engine.py:114,342-345 -> world.py:117
+        dict(robot_rot=-2.4, observe_vel=True, hazards_num=5, goal_size=1.5),
     ]
     for v in variants:
         N = 130
@@ -285,9 +287,10 @@ def test_variant_configs(torch_cuda, oracle, path, robot):
             if t % 7 == 6:
                 np.testing.assert_array_equal(E.reset_done().cpu().numpy(), O.reset_done())
         # and a fused stretch on top (group path: persistent kernel with in-kernel reset_done)
-        acts = rng.uniform(-1, 1, (9, N, A)).astype(np.float32)
+        TF = 40 if 'robot_rot' in v else 9
+        acts = rng.uniform(-1, 1, (TF, N, A)).astype(np.float32)
         obs, rew, cost, done = E.rollout(torch.from_numpy(acts).cuda())
-        for t in range(9):
+        for t in range(TF):
             o, r, d, info = O.step(acts[t])
             np.testing.assert_array_equal(obs[t].cpu().numpy(), O.reset_done())
             np.testing.assert_array_equal(rew[t].cpu().numpy(), r)

@@ -402,3 +402,50 @@ def test_pillars_extension_closed_forms(oracle):
     assert (np.linalg.norm(P[:, :, None] - objs[:, None, 1:9], axis=3) >= 0.7 - 1e-6).all()
     assert (np.linalg.norm(P - objs[:, :1], axis=2) >= 0.8 - 1e-6).all()
     assert (np.linalg.norm(P - robot[:, None], axis=2) >= 0.7 - 1e-6).all()
+
+
+@pytest.mark.parametrize("robot", ["point", "swimmer", "ant", "walker"])
+def test_robot_rot_turns_the_world_pose_not_the_joint_dynamics(oracle, robot):
+    """robot_rot (engine.py:114,342-345) turns the robot's root body about z (world.py:117): the joint-space
+    dynamics of the robots whose ctrl is the action do not notice (same qpos / qvel trajectory as robot_rot = 0 until a
+    done differs), the world pose is the unrotated one turned by the angle, layout2qpos still writes the layout's xy
+    into the slide joints (engine.py:635-638), and the compass is the goal vector in the turned body frame."""
+    from helpers import SWIMMER, ANT, WALKER
+    extra = {"point": {}, "swimmer": SWIMMER, "ant": ANT, "walker": WALKER}[robot]
+    A = {"ant": 8, "walker": 10}.get(robot, 2)
+    N, th = 16, 0.9
+    O0 = oracle.OracleEngine(task_config(N, seed=3, num_steps=100, **extra), n_candidates=20000)
+    O1 = oracle.OracleEngine(task_config(N, seed=3, num_steps=100, robot_rot=th, **extra), n_candidates=20000)
+    o0, o1 = O0.reset(), O1.reset()
+    s0, s1 = O0.get_state(), O1.get_state()
+    np.testing.assert_array_equal(s0['qpos'], s1['qpos'])            # same layouts, same joint coordinates
+    c, s = np.cos(th), np.sin(th)
+    R = np.array([[c, -s], [s, c]])
+
+    def check_pose(p0, p1):
+        np.testing.assert_allclose(p1[:, :2], p0[:, :2] @ R.T, atol=2e-6)
+        np.testing.assert_allclose(p1[:, 2], c * p0[:, 2] - s * p0[:, 3], atol=1e-6)
+        np.testing.assert_allclose(p1[:, 3], s * p0[:, 2] + c * p0[:, 3], atol=1e-6)
+    check_pose(s0['pose0'], s1['pose0'])
+    # compass of the rotated engine = goal vector in the turned body frame (obs_compass engine.py:834-844)
+    D = O1.D
+    off = {"point": 3, "swimmer": 2, "ant": 8, "walker": 10}[robot]
+    goal = s1['objs'][:, 0, :]
+    d = goal - s1['pose0'][:, :2]
+    comp = np.stack([d[:, 0] * s1['pose0'][:, 2] + d[:, 1] * s1['pose0'][:, 3],
+                     -d[:, 0] * s1['pose0'][:, 3] + d[:, 1] * s1['pose0'][:, 2]], axis=1)
+    np.testing.assert_allclose(o1[:, off:off + 2], comp, atol=1e-5)
+    assert not np.allclose(o0, o1)
+    rng = np.random.default_rng(0)
+    for t in range(6):
+        a = rng.uniform(-1, 1, (N, A)).astype(np.float32)
+        _, _, d0, _ = O0.step(a)
+        _, _, d1, _ = O1.step(a)
+        if d0.any() or d1.any():
+            break
+        s0, s1 = O0.get_state(), O1.get_state()
+        if robot != "point":                                          # Point: ctrl = xmat . action (engine.py:672-685)
+            np.testing.assert_array_equal(s0['qpos'], s1['qpos'])
+            np.testing.assert_array_equal(s0['qvel'], s1['qvel'])
+            check_pose(s0['pose0'], s1['pose0'])
+    assert t >= 2
