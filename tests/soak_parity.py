@@ -55,9 +55,13 @@ def main():
         E.close()
         print(f"path {path}: 3 x {n_states} single steps compared  ({time.time() - t0:.1f} s)", flush=True)
     # 2. long fused episodes with resets, on both persistent kernels
-    for path in ((2, 1, 3) if robot in ('point', 'swimmer') else (2, 1)):   # 3: two-kernel rollout (light robots)
+    # 3: two-kernel rollout (every robot since round 3); -3: the same with the layout prefetch off, which selects the
+    # dynamics pass's alone-on-the-chip form where a robot has one (Swimmer: a quad of lanes per env)
+    for path in ((2, 1, 3, -3) if robot == 'swimmer' else (2, 1, 3)):
         cfg = task_config(N, seed=7, num_steps=150, goal_size=2.6 if robot == 'point' else 0.8, **extra)
-        E = Engine(cfg, n_candidates=1000000); E.set_path(path)
+        E = Engine(cfg, n_candidates=1000000); E.set_path(abs(path))
+        if path < 0:
+            E.set_prefetch(-1)
         O = gxo.OracleEngine(cfg, n_candidates=1000000)
         np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
         rng = np.random.default_rng(9)

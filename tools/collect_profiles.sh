@@ -37,6 +37,11 @@ pmc step_N4194304 FETCH_SIZE FETCH_SIZE -- $STEP
 pmc step_N4194304 WRITE_SIZE WRITE_SIZE -- $STEP
 pmc thread_rollout_N4194304_K16 FETCH_SIZE FETCH_SIZE -- $FUSE
 pmc thread_rollout_N4194304_K16 WRITE_SIZE WRITE_SIZE -- $FUSE
+for rb in swimmer ant walker; do   # the two-kernel rollout of the other robots (round 3: lane-group dynamics tape for Ant / Walker)
+  RB="python3 tools/profile_step.py --mode rollout --env-num 2000 --launches 200 --robot xmls/$rb.xml"
+  kt ${rb}_rollout_N2000_T200 $RB
+  pmc ${rb}_rollout_N2000_T200 SQ $SQ -- $RB
+done
 kt sampler $RST
 pmc sampler SQ SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_BUSY_CYCLES -- $RST
 kt bench_noextras python3 bench.py --no-cpu-baseline --no-extras
