@@ -104,10 +104,16 @@ class RolloutHandoff:
                 s[0].wait()
 
 
+SHARDED_RESET = None   # guardx_amd.dist.ShardedReset when GX_SHARD_SAMPLER=1 (optional second collective, default off)
+
+
 def run_epochs(env, tapes, epochs, handoff):
     """`epochs` bench steps: reset() + one fused 200-pass rollout each (+ the async hand-off)."""
     for ep in range(epochs):
-        env.reset(check=False)           # the layout_size assert is checked once after the loop
+        if SHARDED_RESET is not None and SHARDED_RESET.env is env:
+            SHARDED_RESET.reset(check=False)
+        else:
+            env.reset(check=False)       # the layout_size assert is checked once after the loop
         acts = tapes[ep % len(tapes)]
         if isinstance(handoff, RolloutHandoff):
             handoff.submit(env.rollout(acts, packed=True)[4])
@@ -583,6 +589,11 @@ def main():
 
     env = make_engine(ENV_NUM, rank, world)
     env.set_prefetch(EP_LEN)
+    global SHARDED_RESET
+    if os.environ.get("GX_SHARD_SAMPLER") == "1":
+        # OPTIONAL, off by default: the 1e6-candidate layout sampler split over the ranks + one small all-gather of the
+        # valid layouts (a second collective; north_star names one).  Same pools, same results.
+        SHARDED_RESET = gxd.ShardedReset(env)
     tapes = [action_tape(EP_LEN, ENV_NUM, 1000 * rank + k, device) for k in range(4)]
     gather = world > 1
     # the hand-off: "tape" (default) all-gathers the 48-B-per-env-step dynamics tape and expands it on every rank,
@@ -659,6 +670,8 @@ def main():
                    "driver": "gx_rollout: two launches per 200-pass epoch (serial dynamics tape, then one thread per "
                              "(step, env) observation row), layout pool of the next epoch prefetched on a side stream",
                    "layout_candidates_per_reset": 1_000_000,
+                   "layout_sampler": ("sharded over the ranks + all-gather of the valid layouts (GX_SHARD_SAMPLER=1)"
+                                      if SHARDED_RESET is not None else "every rank samples all candidates (shared key)"),
                    "point_actuators": "mjcf defaults inherited (DESIGN.md 0.1)"},
     }
     try:   # the 8-GPU hand-off as arithmetic (it cannot be measured on a one-GPU box): bytes on the wire vs the epoch

@@ -274,6 +274,7 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     SampleParams& sp = e->sp;
     e->nobj_total = p.H + p.PL + 2;
     sp.M = cfg->n_candidates;
+    sp.c0 = 0; sp.Mtot = sp.M;
     sp.dbg = nullptr;
     sp.nobj_total = e->nobj_total;
     sp.H = p.H;
@@ -524,6 +525,73 @@ extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
         e->pf_valid = true;
         e->pf_key[0] = k0; e->pf_key[1] = k1;
     }
+    return GX_OK;
+}
+
+// ---- sharded layout sampling (optional, multi-GPU) -------------------------------------------------------------
+// The candidates of reset()'s 1e6-candidate rejection sampler are independent (candidate c uses split(key, 1e6)[c]), so
+// rank r of W can sample candidates [r M / W, (r + 1) M / W) alone, export its valid layouts in candidate order, and
+// after ONE all-gather of the exports (a few MB) every rank installs the same pool the unsharded sampler compacts:
+// the 0.5 ms that bound the epoch are done once per node instead of once per GPU.  A second collective on a path whose
+// north_star allows one (the rollout hand-off): off unless the caller asks for it (guardx_amd.dist.ShardedReset).
+static int shard_target_pool(const gx_engine* e) { return e->have_reset ? (e->cur + 1) % gx_engine::kPools : e->cur; }
+
+extern "C" gx_status gx_sample_shard(gx_engine* e, int32_t shard, int32_t n_shards, float* d_rows, int32_t cap,
+                                     int32_t* d_count, void* stream)
+{
+    if (!e || !d_rows || !d_count || n_shards < 1 || shard < 0 || shard >= n_shards || cap < 1)
+        return fail(GX_ERR_ARG, "gx_sample_shard: bad argument");
+    if (e->pf_valid || e->prefetch_steps != -1)
+        return fail(GX_ERR_STATE, "gx_sample_shard: switch the layout prefetch off first (gx_set_prefetch(e, -1) before the "
+                                  "reset in front of this one): a sharded reset samples on the caller's stream");
+    DeviceGuard guard(e->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int tgt = shard_target_pool(e);
+    GX_HIP(claim_pool(e, tgt, s));
+    SampleParams sp = e->sp;
+    const long long M = e->sp.M;
+    sp.c0 = (int)(M * shard / n_shards);
+    sp.M = (int)(M * (shard + 1) / n_shards) - sp.c0;
+    sp.Mtot = (int)M;
+    sp.k0 = e->key[0]; sp.k1 = e->key[1];
+    sp.dbg = nullptr;
+    if (sp.M < 1) return fail(GX_ERR_ARG, "gx_sample_shard: more shards than candidates");
+    // the flags behind this shard's last candidate, up to the end of its last compaction tile, may be a full-size
+    // sampler's: the ordered compaction reads whole tiles
+    const int tile = sample_compact_tile();
+    const int padded = (sp.M + tile - 1) / tile * tile;
+    if (padded > sp.M) GX_HIP(hipMemsetAsync(e->pools[tgt].cand_ok + sp.M, 0, (size_t)(padded - sp.M), s));
+    GX_HIP(launch_sample(sp, e->pools[tgt], s));
+    launch_pool_export(e->pools[tgt], e->nobj_total, reinterpret_cast<float2*>(d_rows), cap, d_count, s);
+    GX_HIP(hipGetLastError());
+    return GX_OK;
+}
+
+extern "C" gx_status gx_reset_from_shards(gx_engine* e, const float* d_rows_all, const int32_t* d_counts, int32_t n_shards,
+                                          int32_t cap, float* d_obs, void* stream)
+{
+    if (!e || !d_rows_all || !d_counts || !d_obs || n_shards < 1 || cap < 1)
+        return fail(GX_ERR_ARG, "gx_reset_from_shards: bad argument");
+    if (e->pf_valid || e->prefetch_steps != -1) return fail(GX_ERR_STATE, "gx_reset_from_shards: layout prefetch is on");
+    DeviceGuard guard(e->device);
+    hipStream_t s = (hipStream_t)stream;
+    (void)take_commit(e);
+    if (e->have_reset) e->last_interval = e->steps_since_reset;
+    e->steps_since_reset = 0;
+    const int tgt = shard_target_pool(e);
+    if (e->have_reset) GX_HIP(hipEventRecord(e->pool_free[e->cur], s));
+    e->cur = tgt;
+    launch_pool_install(e->pools[tgt], e->nobj_total, n_shards, cap, reinterpret_cast<const float2*>(d_rows_all), d_counts,
+                        e->sp.M, s);
+    launch_fake_table(e->p, e->pools[tgt], e->nobj_total, e->sp.M, s);
+    e->b.pool = e->pools[tgt];
+    uint32_t k[4];
+    layout_keys(e, k);
+    launch_reset_apply(e->p, e->b, e->nobj_total, k[0], k[1], k[2], k[3], d_obs, e->h_layout_size, s);
+    GX_HIP(hipEventRecord(e->layout_ev, s));
+    GX_HIP(hipGetLastError());
+    e->layout_pending = true;
+    e->have_reset = true;
     return GX_OK;
 }
 

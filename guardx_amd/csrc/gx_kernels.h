@@ -10,7 +10,8 @@ namespace gx {
 // layout-sampler parameters (engine.py:546-621); object types: 0 goal, 1 hazard, 2 robot, 3 pillar (synthetic
 // extension); placement order goal, hazards, pillars, robot
 struct SampleParams {
-    int M;          // candidates (engine.py:263)
+    int M;          // candidates sampled by this launch (engine.py:263: all 1e6; a shard: its share of them)
+    int c0, Mtot;   // ... which are candidates c0 .. c0 + M - 1 of the Mtot the reference draws (split(key, Mtot)[c])
     int nobj_total; // goal + hazards + pillars + robot
     int H;          // hazards: objects 1..H; pillars: H+1 .. nobj_total-2
     float lo_x[4], hi_x[4], lo_y[4], hi_y[4]; // by type (hazards / pillars: default rectangle)
@@ -53,6 +54,10 @@ void launch_step(const Params& p, const DevBuffers& b, const float* act, float* 
 int sample_compact_tile(); // candidates per block of the ordered compaction: cand_ok is padded to a multiple of it
 // returns the status of the event record it enqueues (ordering-critical: never dropped)
 hipError_t launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s, hipEvent_t after_phase1 = nullptr);
+// sharded layout sampling: a shard's valid layouts out (candidate order), the gathered shards in as the pool
+void launch_pool_export(const Pool& pl, int nobj_total, float2* rows, int cap, int* count, hipStream_t s);
+void launch_pool_install(const Pool& pl, int nobj_total, int n_shards, int cap, const float2* rows_all, const int* counts,
+                         int M, hipStream_t s);
 void launch_reset_apply(const Params& p, const DevBuffers& b, int nobj_total, uint32_t k10,
                         uint32_t k11, uint32_t k20, uint32_t k21, float* obs, int* host_layout_size,
                         hipStream_t s);

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kSampleBlock) void sample_phase0_kernel(SampleParam
     const int j = blockIdx.x * kSampleBlock + tid;
     const bool live = j < sp.M;
     uint32_t r0, r1;
-    split_at(sp.k0, sp.k1, (uint32_t)sp.M, (uint32_t)(live ? j : 0), r0, r1);
+    split_at(sp.k0, sp.k1, (uint32_t)sp.Mtot, (uint32_t)(sp.c0 + (live ? j : 0)), r0, r1);
     uint32_t n0, n1, g0 = 0, g1 = 0;
     for (int t = 0; t < 10; ++t) { split2(r0, r1, n0, n1, g0, g1); r0 = n0; r1 = n1; }
     float gx, gy;
@@ -386,6 +386,60 @@ __global__ __launch_bounds__(kSampleBlock) void scan_compact_kernel(int M, const
         *layout_size = off;
         n_surv[0] = 0; n_surv[1] = 0; // consumed by phases 1 and 2 of THIS launch_sample, re-armed for the next one
     }
+}
+
+// ---------------------------------------------------------------------------
+// Sharded layout sampling (optional, multi-GPU; gx_sample_shard / gx_reset_from_shards): a rank samples a contiguous
+// range of the 1e6 candidates, EXPORTS its valid layouts in candidate order, the ranks all-gather the exports, and every
+// rank INSTALLS the concatenation -- shard after shard, i.e. in candidate order -- as its pool: the same rows in the
+// same order as the unsharded sampler's compacted list, so layout_size and every randint draw agree.
+// ---------------------------------------------------------------------------
+__global__ void pool_export_kernel(int nobj_total, const int* __restrict__ layout_size, const int* __restrict__ cand_of,
+                                   const float2* __restrict__ cand_xy, float2* __restrict__ rows, int cap,
+                                   int* __restrict__ count)
+{
+    const int L = *layout_size;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count = L; // may exceed cap: the installer reports the overflow
+    const int n = (L < cap ? L : cap) * nobj_total;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const int row = k / nobj_total, o = k - row * nobj_total;
+        rows[k] = cand_xy[(size_t)cand_of[row] * nobj_total + o];
+    }
+}
+
+__global__ void pool_install_kernel(int nobj_total, int n_shards, int cap, const float2* __restrict__ rows_all,
+                                    const int* __restrict__ counts, int M, float2* __restrict__ cand_xy,
+                                    int* __restrict__ cand_of, int* __restrict__ layout_size)
+{
+    // rows in front of shard s: the counts of the shards before it (a handful of them)
+    const int s = blockIdx.y;
+    int off = 0, total = 0, bad = 0;
+    for (int q = 0; q < n_shards; ++q) {
+        const int c = counts[q];
+        if (c > cap || c < 0) bad = q + 1;
+        if (q < s) off += c;
+        total += c;
+    }
+    if (total > M) bad = n_shards + 1;
+    if (blockIdx.x == 0 && s == 0 && threadIdx.x == 0) *layout_size = bad ? -bad : total; // < 0: an export overflowed
+    if (bad) return;
+    const int n = counts[s] * nobj_total;
+    const float2* src = rows_all + (size_t)s * cap * nobj_total;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        cand_xy[(size_t)off * nobj_total + k] = src[k];
+        if (k % nobj_total == 0) cand_of[off + k / nobj_total] = off + k / nobj_total;
+    }
+}
+
+void launch_pool_export(const Pool& pl, int nobj_total, float2* rows, int cap, int* count, hipStream_t s)
+{
+    hipLaunchKernelGGL(pool_export_kernel, dim3(256), dim3(256), 0, s, nobj_total, pl.layout_size, pl.cand_of, pl.cand_xy, rows, cap, count);
+}
+void launch_pool_install(const Pool& pl, int nobj_total, int n_shards, int cap, const float2* rows_all, const int* counts,
+                         int M, hipStream_t s)
+{
+    hipLaunchKernelGGL(pool_install_kernel, dim3(64, n_shards), dim3(256), 0, s, nobj_total, n_shards, cap, rows_all, counts, M,
+                       pl.cand_xy, pl.cand_of, pl.layout_size);
 }
 
 // ---------------------------------------------------------------------------

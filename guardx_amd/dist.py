@@ -147,3 +147,50 @@ def max_over_ranks(value, device):
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+class ShardedReset:
+    """OPTIONAL: reset() with the reference's 1e6-candidate layout sampler split over the ranks.
+
+        sr = ShardedReset(env)         # after init_process_group; env.set_prefetch(-1) is done here
+        obs = sr.reset()               # instead of env.reset()
+
+    The candidates are independent (candidate c draws from split(key, 1e6)[c]), so rank r samples candidates
+    [r 1e6 / W, (r + 1) 1e6 / W) alone (Engine.sample_shard), the ranks all-gather their valid layouts (a few MB: ~2 % of
+    the candidates are valid) and every rank installs the concatenation -- shard after shard, i.e. candidate order -- as
+    its pool (Engine.reset_from_shards): layout_size, pool rows, the observation and every later randint draw are those of
+    the unsharded reset(), bit for bit, and the sampler's 0.5 ms of vector-ALU work is done once per node instead of once
+    per GPU.  It is a SECOND collective (north_star allows one, the rollout hand-off), so nothing uses it unless asked:
+    bench.py with GX_SHARD_SAMPLER=1.  The sampler then runs on the caller's stream in front of the epoch (no prefetch
+    overlap): per epoch 1/W of the sampler + one small all-gather + the install."""
+
+    def __init__(self, env):
+        self.env = env
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.host = dist.is_initialized() and dist.get_backend() != "nccl"
+        env.set_prefetch(-1)
+        cap, dev = env.shard_capacity(self.world), env.device
+        K = int(env.n_layout_objects)
+        self.rows = torch.empty(cap, K, 2, dtype=torch.float32, device=dev)
+        self.count = torch.empty(1, dtype=torch.int32, device=dev)
+        self.rows_all = torch.empty(self.world, cap, K, 2, dtype=torch.float32, device=dev)
+        self.counts = torch.empty(self.world, dtype=torch.int32, device=dev)
+        self.bytes_received = 0
+
+    def reset(self, check=True):
+        env, W = self.env, self.world
+        env.sample_shard(self.rank, W, self.rows, self.count)
+        if W == 1:
+            self.rows_all[0].copy_(self.rows); self.counts.copy_(self.count)
+        elif self.host:   # gloo rehearsal: through host memory
+            ra = torch.empty(self.rows_all.shape, dtype=torch.float32)
+            ca = torch.empty(W, dtype=torch.int32)
+            dist.all_gather_into_tensor(ra.view(-1), self.rows.cpu().view(-1))
+            dist.all_gather_into_tensor(ca, self.count.cpu())
+            self.rows_all.copy_(ra); self.counts.copy_(ca)
+        else:
+            dist.all_gather_into_tensor(self.rows_all.view(-1), self.rows.view(-1))
+            dist.all_gather_into_tensor(self.counts, self.count)
+        self.bytes_received += (W - 1) * (self.rows.numel() * 4 + 4)
+        return env.reset_from_shards(self.rows_all, self.counts, check=check)

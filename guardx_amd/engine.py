@@ -554,6 +554,55 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------
+    # sharded layout sampling (multi-GPU, optional): guardx_amd.dist.ShardedReset drives these two
+    # ------------------------------------------------------------------
+    @property
+    def n_layout_objects(self):
+        """objects of a layout row: goal, hazards, pillars, robot (engine.py:533-544)"""
+        return int(self.hazards_num) + int(self.pillars_num) + 2
+
+    def shard_capacity(self, n_shards):
+        """Rows a shard export holds: an eighth of the shard's candidates (about 2 % of the candidates of the reference's
+        tasks are valid layouts), at least 256."""
+        return max(256, -(-int(self._cfg.n_candidates) // (8 * int(n_shards))))
+
+    def sample_shard(self, shard, n_shards, rows=None, count=None):
+        """Sample candidates [shard M / n, (shard + 1) M / n) of the reset() about to happen (M = n_candidates) and
+        export the valid layouts in candidate order: (rows (cap, K, 2) float32, count (1,) int32), on the current
+        stream.  The layout prefetch must be off (set_prefetch(-1))."""
+        cap, K = self.shard_capacity(n_shards), self.n_layout_objects
+        if rows is None:
+            rows = torch.empty(cap, K, 2, dtype=torch.float32, device=self.device)
+        if count is None:
+            count = torch.empty(1, dtype=torch.int32, device=self.device)
+        assert tuple(rows.shape) == (cap, K, 2) and rows.is_contiguous() and count.dtype == torch.int32
+        _native.check(self._lib.gx_sample_shard(self._h, int(shard), int(n_shards), rows.data_ptr(), cap,
+                                                count.data_ptr(), self._stream()))
+        return rows, count
+
+    def reset_from_shards(self, rows_all, counts, check=True):
+        """reset() with the pool assembled from the all-gathered shard exports (n, cap, K, 2) / (n,): same pool, same
+        observation, same later draws as reset()."""
+        n, cap = int(rows_all.shape[0]), int(rows_all.shape[1])
+        assert rows_all.is_contiguous() and rows_all.dtype == torch.float32 and counts.dtype == torch.int32
+        assert counts.numel() == n and cap == self.shard_capacity(n)
+        obs = self._new(self.env_num, self.obs_flat_size)
+        _native.check(self._lib.gx_reset_from_shards(self._h, rows_all.data_ptr(), counts.data_ptr(), n, cap,
+                                                     obs.data_ptr(), self._stream()))
+        self._rd_obs = None
+        self._obs = obs
+        if check:
+            n_ = C.c_int32()
+            st = self._lib.gx_layout_size(self._h, C.byref(n_))
+            self.layout_size = int(n_.value)
+            if st == _native.GX_ERR_LAYOUT:
+                if self.layout_size < 0:
+                    raise ResamplingError(f"shard {-self.layout_size - 1} exported more than {cap} valid layouts")
+                raise ResamplingError(f"number of valid layout is {self.layout_size} <= env_num {self._cfg.env_total}")
+            _native.check(st)
+        return obs
+
+    # ------------------------------------------------------------------
     # closed-loop fused rollout (policy evaluated inside the kernel)
     # ------------------------------------------------------------------
     @staticmethod

@@ -155,7 +155,7 @@ gx_status gx_rollout(gx_engine* e, int32_t T, const float* d_actions, float* d_o
 gx_status gx_rollout_packed(gx_engine* e, int32_t T, const float* d_actions, float* d_packed, void* stream);
 int32_t gx_packed_width(const gx_engine* e);
 
-/* ---- tape hand-off (multi-GPU; Point / Swimmer) ----------------------------------------------------------
+/* ---- tape hand-off (multi-GPU; every robot) --------------------------------------------------------------
  * The packed row is 4 * (obs_dim + act_dim + 3) bytes per env-step (192 B for Goal_Point_8Hazards); an all-gather of it
  * over xGMI takes longer than the epoch that produced it.  The observation is a function of 80 B of state, so the
  * stepping rank runs only the serial dynamics pass of gx_rollout and hands out that tape; every rank that needs the
@@ -164,8 +164,10 @@ int32_t gx_packed_width(const gx_engine* e);
  * key, engine.py:263), so the pool rows a tape's reset_done events refer to are local on every rank.
  *   d_shard: gx_tape_floats() floats = [ tape | layouts at entry | entry records ], 16-byte aligned; all-gather it as
  *            is.  A tape row is qpos | qvel | action | done | layout row in effect | layout row reset_done installed:
- *            12 floats (48 B) per env-step for the Point, 16 for the Swimmer; the observation pass re-derives the
- *            pose, ctrl and the reward from consecutive rows.  One physics step per control step only.
+ *            12 floats (48 B) per env-step for the Point, 16 for the Swimmer, 36 for the Ant and 40 for the Walker
+ *            (plus, for those two, the row of the pool's fake-step table a reset_done observation is read from); the
+ *            observation pass re-derives the pose, ctrl and the reward from consecutive rows.  One physics step per
+ *            control step and no observe_vel / observe_acc only (GX_ERR_UNSUPPORTED otherwise).
  *   token:   names the layout pool in effect; gx_expand_tape (on any engine of the same configuration and key
  *            history, e.g. the other ranks') must be CALLED before the second gx_reset after the rollout --
  *            the engines keep three pools for that; GX_ERR_STATE afterwards.  The next sampler that reuses the
@@ -175,6 +177,22 @@ gx_status gx_rollout_tape(gx_engine* e, int32_t T, const float* d_actions, float
                           void* stream);
 gx_status gx_expand_tape(gx_engine* e, int32_t T, const float* d_shard, int64_t token, float* d_packed,
                          void* stream);
+
+/* ---- sharded layout sampling (multi-GPU, OPTIONAL: a second collective on the reset path) -----------------
+ * reset()'s rejection sampler (engine.py:433-444, 546-621) draws 1e6 independent candidates (candidate c from
+ * split(key, 1e6)[c]) and keeps the valid ones in candidate order.  With envs sharded over W ranks every rank would
+ * sample all of them.  Instead: rank r calls gx_sample_shard(r, W) for candidates [r 1e6 / W, (r+1) 1e6 / W) of the
+ * reset about to happen, all-gathers the exported rows and counts, and gx_reset_from_shards installs the concatenation
+ * (shard after shard = candidate order) as the pool and re-initialises the envs: layout_size, the pool rows and every
+ * later randint draw equal the unsharded gx_reset's.  The layout prefetch must be off (gx_set_prefetch(e, -1)).
+ *   d_rows:  [cap][goal, hazards.., pillars.., robot][2] floats, this shard's valid layouts in candidate order
+ *   d_count: their number (device int32; may exceed cap, in which case gx_reset_from_shards leaves a negative
+ *            layout_size and the layout check fails)
+ *   d_rows_all / d_counts: the all-gathered [W][cap][..][2] / [W] */
+gx_status gx_sample_shard(gx_engine* e, int32_t shard, int32_t n_shards, float* d_rows, int32_t cap, int32_t* d_count,
+                          void* stream);
+gx_status gx_reset_from_shards(gx_engine* e, const float* d_rows_all, const int32_t* d_counts, int32_t n_shards,
+                               int32_t cap, float* d_obs, void* stream);
 
 /* ---- closed-loop fused rollout with an on-device policy ------------------
  * `ac.step(o)` of MLPActorCritic(hidden_sizes=(64,64), tanh) (safe_rl_libX/trpo/trpo_core.py:110-173)
@@ -223,10 +241,10 @@ gx_status gx_set_prefetch(gx_engine* e, int32_t steps);
 /* prefetched pools used / discarded so far, and the current prediction */
 gx_status gx_prefetch_stats(const gx_engine* e, int32_t* hits, int32_t* misses, int32_t* horizon);
 
-/* Kernel family used by step / rollout: 0 = auto (up to 16384 envs -- Ant 11000, Walker 8192, the measured
- * crossovers -- lane-group kernels, and for rollouts of 8+
- * steps of the Point / Swimmer the two-kernel form -- serial dynamics tape, then one thread per (step, env)
- * observation row; thread-per-env kernels above 16384 envs), 1 = force thread-per-env, 2 = force lane-group,
+/* Kernel family used by step / rollout: 0 = auto (up to 16384 envs -- Ant 27000, Walker 16000, the measured
+ * crossovers -- lane-group kernels, and for rollouts of 8+ steps the two-kernel form -- serial dynamics tape, then one
+ * thread per (step, env) observation row; thread-per-env kernels above those sizes), 1 = force thread-per-env,
+ * 2 = force lane-group,
  * 3 = two-kernel rollouts at any T where supported (lane-group otherwise).
  * Results are bit-identical either way (tests/test_gpu_parity.py). */
 gx_status gx_set_path(gx_engine* e, int32_t mode);

@@ -57,6 +57,10 @@ CASES = [
     ("goal_ant_8hazards_n12_seed4", task_config(12, seed=4, num_steps=40, goal_size=1.0, robot_base='xmls/ant.xml'), 60, 3),
     ("goal_walker_8hazards_n12_seed6",
      task_config(12, seed=6, num_steps=40, goal_size=1.0, robot_base='xmls/walker.xml'), 60, 4),
+    # robot_rot (engine.py:114,342-345 -> world.py:117): the root body turned about z; DESIGN.md section 9
+    ("goal_point_8hazards_n8_rot07", task_config(8, seed=1, num_steps=40, goal_size=1.2, robot_rot=0.7), 60, 5),
+    ("goal_ant_8hazards_n8_rot07",
+     task_config(8, seed=1, num_steps=40, goal_size=1.0, robot_rot=0.7, robot_base='xmls/ant.xml'), 60, 6),
 ]
 
 

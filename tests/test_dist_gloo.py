@@ -188,3 +188,81 @@ def test_single_process_passthrough():
     assert p.shape == (2, 3, 10)
     u = gxd.unpack_rollout(p, 5, 2)
     assert (u['act'] == 1).all() and (u['rew'] == 2).all() and (u['cost'] == 3).all() and (u['done'] == 4).all()
+
+
+class _StubShardEngine:
+    """CPU stand-in with the Engine surface ShardedReset uses: shard r "samples" r + 2 rows whose entries name the
+    shard, the reset and the row; reset_from_shards records what it was handed."""
+
+    def __init__(self, rank):
+        self.rank = rank
+        self.device = torch.device("cpu")
+        self.n_layout_objects = 10
+        self.prefetch = None
+        self.resets = 0
+        self.installed = []
+
+    def set_prefetch(self, steps):
+        self.prefetch = steps
+
+    def shard_capacity(self, n_shards):
+        return 6
+
+    def sample_shard(self, shard, n_shards, rows, count):
+        assert self.prefetch == -1 and shard == self.rank
+        rows.zero_()
+        for k in range(shard + 2):
+            rows[k] = 100.0 * shard + 10.0 * self.resets + k
+        count[0] = shard + 2
+        return rows, count
+
+    def reset_from_shards(self, rows_all, counts, check=True):
+        self.installed.append((rows_all.clone(), counts.clone()))
+        self.resets += 1
+        return torch.full((3,), float(self.resets))
+
+
+def _shard_worker(rank, world, port, q):
+    try:
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                          MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        from guardx_amd import dist as gxd
+        gxd.init_from_env("gloo")
+        env = _StubShardEngine(rank)
+        sr = gxd.ShardedReset(env)
+        for ep in range(3):
+            obs = sr.reset()
+            assert obs[0].item() == ep + 1
+            rows_all, counts = env.installed[-1]
+            assert counts.tolist() == [s + 2 for s in range(world)]
+            for s in range(world):                      # shard after shard = candidate order, on every rank
+                for k in range(s + 2):
+                    assert (rows_all[s, k] == 100.0 * s + 10.0 * ep + k).all(), (rank, ep, s, k)
+                assert (rows_all[s, s + 2:] == 0).all()
+        assert sr.bytes_received == 3 * (world - 1) * (6 * 10 * 2 * 4 + 4)
+        gxd.barrier()
+        if rank == 0:
+            q.put(("ok", None))
+        torch.distributed.destroy_process_group()
+    except Exception as exc:  # noqa: BLE001
+        q.put(("fail", f"rank {rank}: {type(exc).__name__}: {exc}"))
+        raise
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_reset_over_gloo():
+    """guardx_amd.dist.ShardedReset over 2 gloo ranks with a stand-in engine: every rank installs every rank's export,
+    in rank (= candidate) order, reset after reset (the GPU engine's own equality with the unsharded sampler is
+    tests/test_gpu_parity.py::test_sharded_layout_sampler_equals_the_unsharded_reset)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    tag, msg = q.get(timeout=240)
+    assert tag == "ok", msg
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0

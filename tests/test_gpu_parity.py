@@ -1073,3 +1073,50 @@ def test_tape_handoff_is_refused_where_it_does_not_apply(torch_cuda):
     out = e.expand_tape(sh, tok, 4)
     assert out.shape == (4, 32, 48) and torch.isfinite(out).all()
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot,n_shards", [("point", 2), ("point", 8), ("ant", 3)])
+def test_sharded_layout_sampler_equals_the_unsharded_reset(torch_cuda, oracle, robot, n_shards):
+    """gx_sample_shard / gx_reset_from_shards (optional second collective, default off): every shard samples its range
+    of the 1e6-candidate list, the exports are concatenated as an all-gather would, and the installed pool -- layout_size,
+    rows, reset observation, the steps and reset_done draws that follow, the next reset -- equals the unsharded engine's and
+    the checker's."""
+    torch = torch_cuda
+    from guardx_amd import Engine, ResamplingError
+    extra = {"point": {}, "ant": ANT}[robot]
+    A = {"ant": 8}.get(robot, 2)
+    N, M = 96, 200_000
+    cfg = task_config(N, seed=4, num_steps=30, goal_size=1.5, **extra)
+    full, O = _engines(cfg, oracle, n_candidates=M)
+    sh = Engine(cfg, n_candidates=M)
+    with pytest.raises(RuntimeError, match="prefetch"):
+        sh.sample_shard(0, n_shards)                       # refused while the layout prefetch is on
+    sh.set_prefetch(-1)
+    rng = np.random.default_rng(2)
+    for ep in range(3):
+        o_full = full.reset()
+        if ep == 0:                                        # (the checker is not stepped below)
+            np.testing.assert_array_equal(o_full.cpu().numpy(), O.reset())
+        parts = [sh.sample_shard(r, n_shards) for r in range(n_shards)]   # one engine plays every rank in turn
+        rows_all = torch.stack([p[0].clone() for p in parts]); counts = torch.cat([p[1].clone() for p in parts])
+        assert int(counts.sum().item()) == full.layout_size and int(counts.min().item()) > 0
+        o_sh = sh.reset_from_shards(rows_all, counts)
+        assert sh.layout_size == full.layout_size
+        assert torch.equal(o_sh, o_full)
+        np.testing.assert_array_equal(sh.get_pool(64), full.get_pool(64))
+        for t in range(35):                                # crosses the timeout: reset_done draws from the installed pool
+            a = torch.from_numpy(rng.uniform(-1, 1, (N, A)).astype(np.float32)).cuda()
+            og, rg, dg, ig = sh.step(a)
+            of, rf, df, i_f = full.step(a)
+            assert torch.equal(og, of) and torch.equal(dg, df) and torch.equal(ig['cost'], i_f['cost'])
+            assert torch.equal(sh.reset_done(), full.reset_done())
+        acts = torch.from_numpy(rng.uniform(-1, 1, (20, N, A)).astype(np.float32)).cuda()
+        for x, y in zip(sh.rollout(acts), full.rollout(acts)):
+            assert torch.equal(x, y)
+    # an export that does not fit is reported, not installed
+    tiny = torch.zeros(n_shards, sh.shard_capacity(n_shards), sh.n_layout_objects, 2, device='cuda')
+    big = torch.full((n_shards,), sh.shard_capacity(n_shards) + 1, dtype=torch.int32, device='cuda')
+    with pytest.raises(ResamplingError, match="exported more"):
+        sh.reset_from_shards(tiny, big)
+    full.close(); sh.close()
