@@ -180,3 +180,44 @@ def test_point_rests_without_contact_forces():
     d.qvel[0] = 1.0
     mujoco.mj_forward(m, d)
     assert d.nefc == 0
+
+
+@pytest.mark.parametrize("robot", ["point", "ant"])
+def test_robot_rot_world_pose_matches_mujoco(oracle, robot):
+    """robot_rot (engine.py:114,342-345): world.py:117 writes rot2quat(robot_rot) into the robot ROOT body's quat.  With
+    that quaternion on the MJCF's root body MuJoCo's xpos / xmat of the robot body after mj_forward must be the
+    checker's world pose (the root-frame pose turned by the angle) for random joint coordinates,
+    and a few steps under random ctrl must keep the same joint trajectory as the unrotated model."""
+    th = 0.7
+    fname = {"point": "point.xml", "ant": "ant.xml"}[robot]
+    extra = {"point": {}, "ant": ANT}[robot]
+    spec_xml = open(os.path.join(XML_DIR, fname)).read()
+    quat = f'{np.cos(th / 2)} 0 0 {np.sin(th / 2)}'                       # rot2quat (world.py:20-27)
+    assert '<body name="robot"' in spec_xml
+    rotated = spec_xml.replace('<body name="robot"', f'<body name="robot" quat="{quat}"', 1)
+    cwd = os.getcwd()
+    os.chdir(XML_DIR)                                                     # meshes / includes relative to the xml dir
+    try:
+        m = mujoco.MjModel.from_xml_string(rotated)
+    finally:
+        os.chdir(cwd)
+    d = mujoco.MjData(m)
+    rb = m.body('robot').id
+    E = oracle.OracleEngine(task_config(4, robot_rot=th, **extra), n_candidates=4000)
+    E.reset(check=False)
+    rng = np.random.default_rng(1)
+    for trial in range(5):
+        s = E.get_state()
+        q = s['qpos'].copy()
+        q[:, :3] = rng.uniform(-1.5, 1.5, (q.shape[0], 3))
+        s['qpos'][:] = q; s['qvel'][:] = 0; s['hist'] = 2
+        E.set_state(s)
+        A = 8 if robot == "ant" else 2
+        E.step(np.zeros((q.shape[0], A), np.float32))                     # the pose a step returns: kinematics of q
+        pose = E.get_state()['pose0']
+        for i in range(q.shape[0]):
+            d.qpos[:] = 0; d.qpos[:q.shape[1]] = q[i]; d.qvel[:] = 0
+            mujoco.mj_forward(m, d)
+            R = d.xmat[rb].reshape(3, 3)
+            np.testing.assert_allclose(pose[i, :2], d.xpos[rb][:2], atol=5e-6)
+            np.testing.assert_allclose(pose[i, 2:], [R[0, 0], R[1, 0]], atol=5e-6)
