@@ -1,23 +1,26 @@
-// gx_split_rollout.inl -- the fused T-step rollout of the light robots (Point, Swimmer) at small env_num as TWO
-// kernels instead of one persistent lane-group kernel (included by gx_robot_kernels.inl):
+// gx_split_rollout.inl -- the fused T-step rollout at small env_num as TWO kernels instead of one persistent lane-group
+// kernel (included by gx_robot_kernels.inl):
 //
-//   pass 1  dyn_tape_kernel   one thread per env, T steps: convert_action, mjx.step, done / NaN guard / timeout,
-//           reset_done (layout index draw + re-placement) -- everything the NEXT step depends on -- and one SLIM tape
-//           row per (step, env): qpos, qvel after the step, the action, done, the layout row in effect and the layout row
-//           a reset_done installed: 12 floats for the Point (48 B), 16 for the Swimmer.  ~190 instructions per step on
-//           the serial chain.  (Rounds 1-2 also wrote the stepped pose, ctrl and the reward: 20 floats.)
+//   pass 1  the serial chain: convert_action, mjx.step, done / NaN guard / timeout, reset_done (layout index draw +
+//           re-placement) -- everything the NEXT step depends on -- and one SLIM tape row per (step, env): qpos, qvel after
+//           the step, the action, done, the layout row in effect and the layout row a reset_done installed.
+//           dyn_tape_kernel (Point, Swimmer): one thread per env, 12 / 16 floats per row, ~170 instructions per Point step
+//           (the Swimmer also as a quad of lanes per env, SwimmerRobot::substep_q).
+//           group_dyn_tape_kernel (Ant, Walker; round 3): the lane-group form of their step, 16 lanes per env, 36 / 40
+//           floats per row (+ the row of the pool's fake-step table a reset_done observation is read from).
+//           (Rounds 1-2 also wrote the stepped pose, ctrl and the reward into the row.)
 //   pass 2  obs_tape_kernel   one thread per (step, env) tape row: re-derives what pass 1 no longer writes -- the pose
 //           the step returned (kinematics of the qpos the step STARTED from: the previous row's qpos, or the robot
 //           position of the layout the previous row's reset_done installed), the pose before that (for
 //           convert_action -> ctrl and for reward_done's `last`), the reward -- then lidars, compass, cost, the
 //           observation row (of the re-initialised env where reset_done fired) and the reward / cost / done outputs:
 //           400 000 independent rows at env_num = 2000, T = 200, the bandwidth regime of the thread-per-env kernels.
-//           Rows 0 and 1 of an env take the state at entry from a 48-byte entry record pass 1 leaves per env.
+//           Rows 0 and 1 of an env take the state at entry from the entry record pass 1 leaves per env.
 //
 // Same functions, same operation order as step_kernel / reset_done_kernel, hence the same bits
 // (tests/test_gpu_parity.py runs every rollout test on this path too).  Not used when observe_vel / observe_acc
-// need the pose history in the row, for robots whose reset_done observation needs a physics step (Ant, Walker: their
-// dynamics dominate anyway), for the closed-loop policy rollout, or for Engine.step.
+// need the pose history in the row, with more than one physics step per control step, for the closed-loop policy
+// rollout, or for Engine.step.
 //
 // The NaN guard (engine.py:696-699) needs "any observation entry non-finite" in pass 1.  With finite qpos / qvel /
 // ctrl / pose, |position| < 1e18 and finite objects of that size every entry is finite (exp <= 1, alias in [0,1],
