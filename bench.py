@@ -126,7 +126,7 @@ def run_epochs(env, tapes, epochs, handoff):
     env.check_layouts()                  # engine.py:444 for every reset above (one sync)
 
 
-PRECONDITION_MS = 40.0
+PRECONDITION_MS = 60.0
 
 
 def precondition_clocks(device, ms=PRECONDITION_MS):
@@ -135,18 +135,18 @@ def precondition_clocks(device, ms=PRECONDITION_MS):
     DESIGN.md section 6): after >= 50 ms of idle the first ~25 epochs (13 ms) run 10 % -> 0 % slower than the steady
     state whatever ran before the idle gap, and 30 ms of any sustained compute removes that.  The driver's region
     (5 + 20 epochs = 13 ms) would otherwise sit entirely inside the ramp.  The line reports `cold_start` beside."""
-    a = torch.ones(2048, 2048, device=device)
-    b = torch.ones(2048, 2048, device=device)
+    a = torch.ones(4096, 4096, device=device)
+    b = torch.ones(4096, 4096, device=device)
     c = a @ b                                            # library initialisation happens here, outside the busy loop
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     n = 0
     while (time.perf_counter() - t0) * 1e3 < ms:
-        for _ in range(8):
+        for _ in range(4):
             torch.mm(a, b, out=c)
-        n += 8
+        n += 4
         torch.cuda.synchronize()
-    return {"ms": round((time.perf_counter() - t0) * 1e3, 1), "work": f"{n} x fp32 torch.mm 2048^3 (not the workload)"}
+    return {"ms": round((time.perf_counter() - t0) * 1e3, 1), "work": f"{n} x fp32 torch.mm 4096^3 (not the workload)"}
 
 
 def _fresh_engine(env_num):
@@ -569,7 +569,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-precondition", action="store_true",
-                    help="skip the 40 ms of unrelated GPU work before the warm-up epochs (clock ramp, see precondition_clocks)")
+                    help="skip the 60 ms of unrelated GPU work before the warm-up epochs (clock ramp, see precondition_clocks)")
     args = ap.parse_args()
     if args.steps < 1 or args.warmup < 0:
         ap.error("--steps >= 1, --warmup >= 0")
