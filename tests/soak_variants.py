@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Soak over configuration variants (MI355X box): the variants of test_variant_configs, several seeds, 150 steps of
-Engine.step() + reset_done() with timeouts, both kernel families, HIP against the CPU restatement bit for bit.
+Engine.step() + reset_done() with timeouts plus two 48-step fused rollouts, both kernel families and the two-kernel rollout,
+HIP against the CPU restatement bit for bit.
 Exits non-zero on any mismatch.
 
     python tests/soak_variants.py [ant|walker|point|swimmer] [seeds]
@@ -28,6 +29,8 @@ VARIANTS = [
     dict(hazards_num=20, goal_size=0.3, hazards_size=0.2, reward_distance=2.0, hazards_keepout=0.18,
          placements_extents=[-3, -3, 3, 3]),
     dict(pillars_num=8, observe_pillars=True, pillars_keepout=0.3, pillars_size=0.2, placements_extents=[-3, -3, 3, 3]),
+    dict(robot_rot=0.7),
+    dict(robot_rot=-2.4, hazards_num=5, goal_size=1.5),
 ]
 
 
@@ -39,7 +42,7 @@ def main():
     bad, t0, steps = 0, time.time(), 0
     for vi, v in enumerate(VARIANTS):
         for seed in range(seeds):
-            for path in (1, 2):
+            for path in (1, 2, 3):       # 3: the same steps on the lane-group kernels, fused stretches on the two-kernel rollout
                 N = 257
                 cfg = task_config(N, seed=100 + seed, num_steps=40, **v, **extra)
                 E = Engine(cfg, n_candidates=30000); E.set_path(path)
@@ -60,6 +63,19 @@ def main():
                         print(f"MISMATCH variant {vi} seed {seed} path {path} step {t}", flush=True)
                         break
                     steps += N
+                # fused stretches (the two-kernel rollout where the variant allows it, the persistent kernels otherwise)
+                for rep in range(2):
+                    acts = rng.uniform(-1, 1, (48, N, A)).astype(np.float32)
+                    obs, rew, cost, done = (x.cpu().numpy() for x in E.rollout(torch.from_numpy(acts).cuda()))
+                    for t in range(48):
+                        oo, ro, do, io = O.step(acts[t])
+                        oo = O.reset_done()
+                        if not (np.array_equal(obs[t], oo, equal_nan=True) and np.array_equal(rew[t], ro) and
+                                np.array_equal(done[t], do) and np.array_equal(cost[t], io['cost'], equal_nan=True)):
+                            bad += 1
+                            print(f"MISMATCH variant {vi} seed {seed} path {path} fused rep {rep} t {t}", flush=True)
+                            break
+                    steps += 48 * N
                 E.close()
         print(f"variant {vi}: done ({time.time() - t0:.0f} s, {steps} env-steps compared, mismatches so far {bad})", flush=True)
     print("TOTAL MISMATCHES:", bad)
