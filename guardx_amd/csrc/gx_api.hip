@@ -584,6 +584,7 @@ extern "C" gx_status gx_reset_from_shards(gx_engine* e, const float* d_rows_all,
     launch_pool_install(e->pools[tgt], e->nobj_total, n_shards, cap, reinterpret_cast<const float2*>(d_rows_all), d_counts,
                         e->sp.M, s);
     launch_fake_table(e->p, e->pools[tgt], e->nobj_total, e->sp.M, s);
+    GX_HIP(hipEventRecord(e->pool_ready[tgt], s)); // gx_expand_tape on another stream waits for the pool it reads
     e->b.pool = e->pools[tgt];
     uint32_t k[4];
     layout_keys(e, k);
