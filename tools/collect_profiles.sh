@@ -23,7 +23,7 @@ pmc() { # name, counters-label, counters..., -- command...
   rocprofv3 --pmc "${ctrs[@]}" --output-format csv -d /tmp/pmc_${tag}_${name}_$label -- "$@" > $out/${tag}_${name}_pmc_$label.log 2>&1
   python3 tools/pmc_means.py $(find /tmp/pmc_${tag}_${name}_$label -name "*counter_collection.csv" | head -1) > $out/${tag}_${name}_pmc_$label.csv
 }
-ROLL="python3 tools/profile_step.py --mode rollout --env-num 2000 --launches 200"
+ROLL="python3 tools/profile_step.py --mode rollout --env-num 2000 --launches 200 --repeat 20"
 STEP="python3 tools/profile_step.py --mode step --env-num 4194304 --launches 20"
 FUSE="python3 tools/profile_step.py --mode rollout --env-num 4194304 --launches 16"
 RST="python3 tools/profile_reset.py"
@@ -38,7 +38,7 @@ pmc step_N4194304 WRITE_SIZE WRITE_SIZE -- $STEP
 pmc thread_rollout_N4194304_K16 FETCH_SIZE FETCH_SIZE -- $FUSE
 pmc thread_rollout_N4194304_K16 WRITE_SIZE WRITE_SIZE -- $FUSE
 for rb in swimmer ant walker; do   # the two-kernel rollout of the other robots (round 3: lane-group dynamics tape for Ant / Walker)
-  RB="python3 tools/profile_step.py --mode rollout --env-num 2000 --launches 200 --robot xmls/$rb.xml"
+  RB="python3 tools/profile_step.py --mode rollout --env-num 2000 --launches 200 --repeat 10 --robot xmls/$rb.xml"
   kt ${rb}_rollout_N2000_T200 $RB
   pmc ${rb}_rollout_N2000_T200 SQ $SQ -- $RB
 done

@@ -21,6 +21,9 @@ def main():
     ap.add_argument("--launches", type=int, default=20)
     ap.add_argument("--mode", default="step", choices=["step", "rollout"])
     ap.add_argument("--robot", default=None, help="e.g. xmls/ant.xml (default: point)")
+    ap.add_argument("--repeat", type=int, default=1,
+                    help="rollout mode: this many gx_rollout calls after bench.precondition_clocks (a single call from an idle "
+                         "GPU runs inside the firmware's clock ramp: 100-119 us for the same kernel)")
     a = ap.parse_args()
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
@@ -38,7 +41,10 @@ def main():
             env.step(act)
     else:
         acts = bench.action_tape(a.launches, a.env_num, 3, dev, A)
-        env.rollout(acts)
+        if a.repeat > 1:
+            bench.precondition_clocks(dev)   # (also lets the prefetch sampler that reset() started finish first)
+        for _ in range(a.repeat):
+            env.rollout(acts)
     torch.cuda.synchronize()
     print("done", a.env_num, a.launches)
 
