@@ -94,6 +94,22 @@ struct gx_engine {
     int keys_cap[kKeyRing];
     hipEvent_t keys_ev[kKeyRing];
     int keys_next;
+    // ---- sharded layout sampling ----
+    // gx_sample_shard -> gx_reset_from_shards: the pool and key the last shard was sampled for (claim_pool done there)
+    bool rs_sampled = false;
+    int rs_pool = -1;
+    uint32_t rs_key[2] = {0, 0};
+    // piggy-backed form (gx_sample_shard_ahead / gx_install_shards): layout_source 1 = the pool of the next reset() is
+    // installed from the ranks' export blocks, gx_reset launches no prefetch sampler of its own
+    int layout_source = 0;
+    Pool shard_scratch;            // the shard sampler's own working pool (the ring's three are all in use)
+    bool shard_scratch_ok = false;
+    hipEvent_t shard_dep = nullptr, shard_done = nullptr;
+    bool shard_inflight = false;
+    struct ShardJob { int64_t ticket; uint32_t k0, k1; int n_shards, cap; };
+    static const int kJobs = 4;
+    ShardJob jobs[kJobs];          // the last four gx_sample_shard_ahead calls, slot = ticket % kJobs
+    int64_t next_ticket = 1;
 };
 
 // the pending reset_done (if any) is consumed by the launch about to be made / dropped by reset()
@@ -328,6 +344,8 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     e->keys_next = 0;
     for (int i = 0; i < gx_engine::kKeyRing; ++i) { e->h_keys[i] = nullptr; e->keys_cap[i] = 0; e->keys_ev[i] = nullptr; }
     memset(&e->b, 0, sizeof(e->b));
+    memset(&e->shard_scratch, 0, sizeof(e->shard_scratch));
+    memset(e->jobs, 0, sizeof(e->jobs));
 
     const size_t M = (size_t)sp.M;
     hipError_t err = hipSuccess;
@@ -425,6 +443,14 @@ extern "C" gx_status gx_destroy(gx_engine* e)
     if (e->h_layout_size) (void)hipHostFree(e->h_layout_size);
     if (e->layout_ev) (void)hipEventDestroy(e->layout_ev);
     if (e->pf_phase1) (void)hipEventDestroy(e->pf_phase1);
+    if (e->shard_dep) (void)hipEventDestroy(e->shard_dep);
+    if (e->shard_done) (void)hipEventDestroy(e->shard_done);
+    {
+        Pool& pl = e->shard_scratch;
+        void* pb[] = {pl.cand_ok, pl.cand_xy, pl.blk_cnt, pl.cand_of, pl.layout_size, pl.n_surv, pl.surv, pl.surv0};
+        for (void* q : pb)
+            if (q) (void)hipFree(q);
+    }
     delete e;
     return GX_OK;
 }
@@ -499,7 +525,7 @@ extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
     // step() (engine.py:431) -- independent of the data, so it can be computed now
     const int horizon = e->prefetch_steps == -2 ? (e->last_interval > 0 ? e->last_interval : e->cfg.num_steps)
                                                  : e->prefetch_steps;
-    if (horizon >= 0) {
+    if (horizon >= 0 && e->layout_source == 0) {
         uint32_t k0 = e->key[0], k1 = e->key[1];
         for (int t = 0; t < horizon; ++t) {
             uint32_t a0, a1, b0, b1;
@@ -548,6 +574,7 @@ extern "C" gx_status gx_sample_shard(gx_engine* e, int32_t shard, int32_t n_shar
     hipStream_t s = (hipStream_t)stream;
     const int tgt = shard_target_pool(e);
     GX_HIP(claim_pool(e, tgt, s));
+    e->rs_sampled = true; e->rs_pool = tgt; e->rs_key[0] = e->key[0]; e->rs_key[1] = e->key[1];
     SampleParams sp = e->sp;
     const long long M = e->sp.M;
     sp.c0 = (int)(M * shard / n_shards);
@@ -579,6 +606,12 @@ extern "C" gx_status gx_reset_from_shards(gx_engine* e, const float* d_rows_all,
     if (e->have_reset) e->last_interval = e->steps_since_reset;
     e->steps_since_reset = 0;
     const int tgt = shard_target_pool(e);
+    // normally this engine sampled one of the shards itself (gx_sample_shard claimed the pool: tokens of its old
+    // contents expired, the sampler ran behind the last expansion that read them).  If it did not -- or sampled for
+    // another key -- the pool is claimed here, so that an outstanding tape token never names rewritten rows
+    if (!(e->rs_sampled && e->rs_pool == tgt && e->rs_key[0] == e->key[0] && e->rs_key[1] == e->key[1]))
+        GX_HIP(claim_pool(e, tgt, s));
+    e->rs_sampled = false;
     if (e->have_reset) GX_HIP(hipEventRecord(e->pool_free[e->cur], s));
     e->cur = tgt;
     launch_pool_install(e->pools[tgt], e->nobj_total, n_shards, cap, reinterpret_cast<const float2*>(d_rows_all), d_counts,
@@ -593,6 +626,143 @@ extern "C" gx_status gx_reset_from_shards(gx_engine* e, const float* d_rows_all,
     GX_HIP(hipGetLastError());
     e->layout_pending = true;
     e->have_reset = true;
+    return GX_OK;
+}
+
+// ---- piggy-backed form: the shard of a LATER reset travels with the rollout hand-off ---------------------------------
+// The key of reset(k + 2) is known at reset(k) (this key advanced by one split per step(), engine.py:431, the horizon
+// being the learned interval between resets), so rank r samples ITS share of the candidates of reset(k + 2) during
+// epoch k on the side stream, exports the valid rows into the tail of its tape shard, the ONE all-gather of epoch k
+// (which has all of epoch k + 1 to finish) delivers every rank's block, and gx_install_shards turns the blocks into the
+// pool reset(k + 2) takes as a prefetch hit.  A reset whose key has no installed pool samples inline (all candidates),
+// exactly as a prefetch miss does: results never depend on any of this.
+extern "C" gx_status gx_set_layout_source(gx_engine* e, int32_t source)
+{
+    if (!e || source < 0 || source > 1) return fail(GX_ERR_ARG, "gx_set_layout_source: 0 = own sampler, 1 = installed shards");
+    e->layout_source = source;
+    return GX_OK;
+}
+
+static int shard_horizon(const gx_engine* e)
+{
+    return e->prefetch_steps == -2 ? (e->last_interval > 0 ? e->last_interval : e->cfg.num_steps) : e->prefetch_steps;
+}
+
+extern "C" gx_status gx_shard_block_floats(const gx_engine* e, int32_t cap, int64_t* floats)
+{
+    if (!e || cap < 1 || !floats) return fail(GX_ERR_ARG, "gx_shard_block_floats: bad argument");
+    *floats = 4 + (int64_t)cap * e->nobj_total * 2; // count, key, tag | rows: a multiple of 4 floats
+    return GX_OK;
+}
+
+extern "C" gx_status gx_sample_shard_ahead(gx_engine* e, int32_t shard, int32_t n_shards, int32_t resets_ahead,
+                                           float* d_block, int32_t cap, int64_t* ticket, void* stream)
+{
+    if (!e || !d_block || !ticket || n_shards < 1 || shard < 0 || shard >= n_shards || cap < 1 || resets_ahead < 1 || n_shards > 32767)
+        return fail(GX_ERR_ARG, "gx_sample_shard_ahead: bad argument");
+    if (reinterpret_cast<uintptr_t>(d_block) & 15u) return fail(GX_ERR_ARG, "gx_sample_shard_ahead: d_block must be 16-byte aligned");
+    if (!e->have_reset) return fail(GX_ERR_STATE, "gx_sample_shard_ahead before gx_reset");
+    if (e->layout_source != 1)
+        return fail(GX_ERR_STATE, "gx_sample_shard_ahead: gx_set_layout_source(e, 1) first (the engine's own prefetch "
+                                  "sampler and installed shards would fight over the next pool)");
+    const int horizon = shard_horizon(e);
+    if (horizon < 1) return fail(GX_ERR_STATE, "gx_sample_shard_ahead: needs a reset interval (gx_set_prefetch(e, -2) or a fixed one)");
+    const long long adv = (long long)resets_ahead * horizon - e->steps_since_reset;
+    if (adv < 0 || adv > (1 << 24)) return fail(GX_ERR_STATE, "gx_sample_shard_ahead: more steps since the last reset than the horizon covers");
+    DeviceGuard guard(e->device);
+    hipStream_t s = (hipStream_t)stream;
+    const long long M = e->sp.M;
+    SampleParams sp = e->sp;
+    sp.c0 = (int)(M * shard / n_shards);
+    sp.M = (int)(M * (shard + 1) / n_shards) - sp.c0;
+    sp.Mtot = (int)M;
+    sp.dbg = nullptr;
+    if (sp.M < 1) return fail(GX_ERR_ARG, "gx_sample_shard_ahead: more shards than candidates");
+    uint32_t k0 = e->key[0], k1 = e->key[1];
+    for (long long t = 0; t < adv; ++t) {
+        uint32_t a0, a1, b0, b1;
+        split2(k0, k1, a0, a1, b0, b1);
+        k0 = a0; k1 = a1;
+    }
+    sp.k0 = k0; sp.k1 = k1;
+    Pool& pl = e->shard_scratch;
+    if (!e->shard_scratch_ok) { // sized for any shard (n_shards may change): the full candidate count
+        hipError_t err = hipSuccess;
+        auto alloc = [&](void** ptr, size_t bytes) {
+            if (err == hipSuccess) err = hipMalloc(ptr, bytes);
+            if (err == hipSuccess) err = hipMemset(*ptr, 0, bytes);
+        };
+        const size_t Mz = (size_t)M, tile = (size_t)sample_compact_tile();
+        alloc((void**)&pl.cand_ok, (Mz + tile - 1) / tile * tile);
+        alloc((void**)&pl.cand_xy, sizeof(float2) * Mz * e->nobj_total);
+        alloc((void**)&pl.blk_cnt, sizeof(int) * ((Mz + tile - 1) / tile));
+        alloc((void**)&pl.cand_of, sizeof(int) * Mz);
+        alloc((void**)&pl.layout_size, sizeof(int));
+        alloc((void**)&pl.n_surv, 2 * sizeof(int));
+        alloc((void**)&pl.surv, sizeof(uint32_t) * 32 * Mz);
+        alloc((void**)&pl.surv0, sizeof(uint32_t) * 8 * Mz);
+        pl.fake = nullptr;
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&e->shard_dep, hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&e->shard_done, hipEventDisableTiming);
+        if (err != hipSuccess) return fail(GX_ERR_HIP, std::string("gx_sample_shard_ahead: ") + hipGetErrorString(err));
+        e->shard_scratch_ok = true;
+    }
+    hipStream_t side = e->side[0];
+    // behind everything queued on the caller's stream: the block may be the tail of a buffer an earlier collective
+    // read, and the caller ordered its own stream behind that
+    GX_HIP(hipEventRecord(e->shard_dep, s));
+    GX_HIP(hipStreamWaitEvent(side, e->shard_dep, 0));
+    const int tile = sample_compact_tile();
+    const int padded = (sp.M + tile - 1) / tile * tile;
+    if (padded > sp.M) GX_HIP(hipMemsetAsync(pl.cand_ok + sp.M, 0, (size_t)(padded - sp.M), side));
+    GX_HIP(launch_sample(sp, pl, side));
+    launch_pool_export(pl, e->nobj_total, reinterpret_cast<float2*>(d_block + 4), cap, reinterpret_cast<int*>(d_block), side,
+                       reinterpret_cast<uint32_t*>(d_block), k0, k1, (uint32_t)shard | ((uint32_t)n_shards << 16));
+    GX_HIP(hipEventRecord(e->shard_done, side));
+    GX_HIP(hipGetLastError());
+    e->shard_inflight = true;
+    gx_engine::ShardJob& j = e->jobs[e->next_ticket % gx_engine::kJobs];
+    j.ticket = e->next_ticket; j.k0 = k0; j.k1 = k1; j.n_shards = n_shards; j.cap = cap;
+    *ticket = e->next_ticket++;
+    return GX_OK;
+}
+
+// `stream` waits for the export block of the last gx_sample_shard_ahead (call it before handing the block to a collective)
+extern "C" gx_status gx_shard_join(gx_engine* e, void* stream)
+{
+    if (!e) return fail(GX_ERR_ARG, "null engine");
+    if (!e->shard_inflight) return GX_OK;
+    DeviceGuard guard(e->device);
+    GX_HIP(hipStreamWaitEvent((hipStream_t)stream, e->shard_done, 0));
+    return GX_OK;
+}
+
+extern "C" gx_status gx_install_shards(gx_engine* e, int64_t ticket, const float* d_blocks, int64_t stride_floats,
+                                       int32_t n_shards, int32_t cap, void* stream)
+{
+    if (!e || !d_blocks || n_shards < 1 || cap < 1 || stride_floats < 4 + (int64_t)cap * (e ? e->nobj_total : 0) * 2)
+        return fail(GX_ERR_ARG, "gx_install_shards: bad argument");
+    if ((reinterpret_cast<uintptr_t>(d_blocks) & 15u) || (stride_floats & 3))
+        return fail(GX_ERR_ARG, "gx_install_shards: blocks must be 16-byte aligned and a multiple of 4 floats apart");
+    if (!e->have_reset) return fail(GX_ERR_STATE, "gx_install_shards before gx_reset");
+    if (e->layout_source != 1) return fail(GX_ERR_STATE, "gx_install_shards: gx_set_layout_source(e, 1) first");
+    const gx_engine::ShardJob j = e->jobs[(ticket > 0 ? ticket : 0) % gx_engine::kJobs];
+    if (ticket < 1 || j.ticket != ticket)
+        return fail(GX_ERR_STATE, "gx_install_shards: unknown ticket (the engine remembers its last four gx_sample_shard_ahead calls)");
+    if (j.n_shards != n_shards || j.cap != cap)
+        return fail(GX_ERR_STATE, "gx_install_shards: n_shards / cap differ from the gx_sample_shard_ahead call of this ticket");
+    DeviceGuard guard(e->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int tgt = (e->cur + 1) % gx_engine::kPools;
+    GX_HIP(hipStreamWaitEvent(s, e->pool_free[tgt], 0)); // the epoch that drew from this pool has been stepped
+    if (e->pf_valid) GX_HIP(hipStreamWaitEvent(s, e->pool_ready[tgt], 0)); // a sampler / install still writing it finishes first
+    GX_HIP(claim_pool(e, tgt, s));                       // tokens of its old rows expire; behind their last expansion
+    launch_pool_install_blocks(e->pools[tgt], e->nobj_total, n_shards, cap, d_blocks, stride_floats, j.k0, j.k1, e->sp.M, s);
+    launch_fake_table(e->p, e->pools[tgt], e->nobj_total, e->sp.M, s);
+    GX_HIP(hipEventRecord(e->pool_ready[tgt], s));
+    GX_HIP(hipGetLastError());
+    e->pf_valid = true; // the next gx_reset takes it if its key is this one, otherwise it samples inline
+    e->pf_key[0] = j.k0; e->pf_key[1] = j.k1;
     return GX_OK;
 }
 

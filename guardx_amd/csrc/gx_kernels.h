@@ -55,9 +55,15 @@ int sample_compact_tile(); // candidates per block of the ordered compaction: ca
 // returns the status of the event record it enqueues (ordering-critical: never dropped)
 hipError_t launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s, hipEvent_t after_phase1 = nullptr);
 // sharded layout sampling: a shard's valid layouts out (candidate order), the gathered shards in as the pool
-void launch_pool_export(const Pool& pl, int nobj_total, float2* rows, int cap, int* count, hipStream_t s);
+// `hdr`: null, or the 4-word header of a piggy-backed export block whose words 1..3 become (k0, k1, tag)
+void launch_pool_export(const Pool& pl, int nobj_total, float2* rows, int cap, int* count, hipStream_t s,
+                        uint32_t* hdr = nullptr, uint32_t k0 = 0, uint32_t k1 = 0, uint32_t tag = 0);
 void launch_pool_install(const Pool& pl, int nobj_total, int n_shards, int cap, const float2* rows_all, const int* counts,
                          int M, hipStream_t s);
+// the same from n_shards export blocks [count, k0, k1, shard | n_shards << 16 | rows] `stride_floats` apart (the tails of
+// the all-gathered tape shards); blocks sampled for another key / shard / world size are refused (layout_size < 0)
+void launch_pool_install_blocks(const Pool& pl, int nobj_total, int n_shards, int cap, const float* blocks,
+                                long long stride_floats, uint32_t k0, uint32_t k1, int M, hipStream_t s);
 void launch_reset_apply(const Params& p, const DevBuffers& b, int nobj_total, uint32_t k10,
                         uint32_t k11, uint32_t k20, uint32_t k21, float* obs, int* host_layout_size,
                         hipStream_t s);

@@ -59,7 +59,7 @@ def all_gather_rollout(packed, out=None):
 
 
 class TapeHandoff:
-    """Once-per-epoch rollout hand-off by dynamics tape.
+    """Once-per-epoch rollout hand-off by dynamics tape -- the ONE collective of the multi-GPU path.
 
         h = TapeHandoff(env, T)                    # after init_process_group
         per epoch:  env.reset(); h.step(actions)   # = env.rollout_tape + async all-gather + expansion of the
@@ -73,43 +73,97 @@ class TapeHandoff:
     the packed shards would have given it, bit for bit.  The all-gather of epoch k overlaps epoch k+1 entirely:
     its expansion is enqueued during epoch k+1 behind a stream-level wait for the collective, and the engine orders
     the layout sampler that recycles epoch k's pool behind that expansion (three pools), so a slow link slows the
-    epochs down instead of corrupting anything.  On the gloo rehearsal backend the shard goes through host memory."""
+    epochs down instead of corrupting anything.  On the gloo rehearsal backend the shard goes through host memory.
 
-    def __init__(self, env, T, depth=3):
-        self.env, self.T, self.depth = env, int(T), depth
+    sharded_sampler (default: on when the engine supports it): the reference's 1e6-candidate layout sampler
+    (engine.py:433-444; candidate c draws from split(key, 1e6)[c], so the candidates are independent) is split over the
+    ranks WITHOUT a second collective.  The key of reset(k + 2) is known at reset(k), so during epoch k rank r samples
+    candidates [r 1e6 / W, (r + 1) 1e6 / W) of THAT reset on the engine's side stream and its valid rows ride in the tail
+    of the shard buffer; the all-gather of epoch k delivers every rank's block, and while epoch k + 1 runs the blocks
+    are installed -- shard after shard = candidate order -- as the pool reset(k + 2) takes like a prefetch hit:
+    layout_size, pool rows, observations and every later randint draw are the unsharded reset()'s, bit for bit.  A
+    reset without an installed pool (the first two, a changed episode length) samples all candidates inline.
+
+    expand: "all" (default) -- every rank expands every rank's tape (the hand-off contract above); "local" -- only its
+    own; expand_rank(s) then expands rank s's tape of the last gathered epoch on demand (before the next step())."""
+
+    def __init__(self, env, T, depth=3, sharded_sampler=None, expand="all"):
+        assert expand in ("all", "local")
+        self.env, self.T, self.depth, self.expand = env, int(T), depth, expand
         self.world = dist.get_world_size() if dist.is_initialized() else 1
-        self.n = sum(env.tape_floats(self.T))
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.n_tape = sum(env.tape_floats(self.T))
         self.host = dist.is_initialized() and dist.get_backend() != "nccl"
         dev = env.device
-        self.send = [torch.empty(self.n, dtype=torch.float32, device=dev) for _ in range(depth)]
+        if sharded_sampler is None:
+            sharded_sampler = hasattr(env, "sample_shard_ahead")
+        self.sharded = bool(sharded_sampler)
+        self.cap = self.n_block = 0
+        if self.sharded:
+            # rows one block holds: twice this rank's expected share of the valid layouts (binomial: the share's spread
+            # is a few per cent) + slack; an overflow is reported by the reset that would take the pool, never installed
+            size = getattr(env, "layout_size", None)
+            if not size:
+                raise RuntimeError("TapeHandoff(sharded_sampler=True): call env.reset() once first (the size of its "
+                                   "layout pool sizes the export blocks)")
+            self.cap = int(min(-(-int(env._cfg.n_candidates) // self.world), 2 * (-(-int(size) // self.world)) + 1024))
+            self.n_block = env.shard_block_floats(self.cap)
+            env.set_layout_source('shards')
+        pad = (-self.n_tape) % 4 if self.sharded else 0    # the block starts 16-byte aligned
+        self.off_block = self.n_tape + pad
+        self.n = self.off_block + self.n_block             # floats per rank in the collective
+        self.send = [torch.zeros(self.n, dtype=torch.float32, device=dev) for _ in range(depth)]
         self.recv = [torch.empty(self.world * self.n, dtype=torch.float32, device="cpu" if self.host else dev,
                                  pin_memory=self.host and dev.type == "cuda") for _ in range(depth)]
         W = env.obs_flat_size + env.action_space.shape[0] + 3
         self.out = [torch.empty(self.world, self.T, env.env_num, W, dtype=torch.float32, device=dev) for _ in range(2)]
         # the expansion runs on its own stream (a CPU stand-in engine, as in the gloo unit test, has none)
         self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
-        self.pending = None            # (work, slot, token) of the epoch whose tapes are in flight
+        self.pending = None            # (work, slot, token, ticket of the block it carries) of the epoch in flight
+        self.last = None               # (gathered buffer on the device, token) of the last expanded epoch (expand_rank)
         self.k = 0
         self.rollout = None            # the most recently expanded epoch (valid after drain())
         self.bytes_received = 0
+        self.blocks_installed = 0
+        self.deferred = None           # (ticket, gathered buffer) of a block drain() could not install yet
+
+    def close(self):
+        """give the layout sampling back to the engine (its own prefetch)"""
+        if self.sharded:
+            self.env.set_layout_source('own')
+            self.sharded = False
 
     def step(self, actions):
         i = self.k % self.depth
-        shard, token = self.env.rollout_tape(actions, out=self.send[i])
+        buf = self.send[i]
+        ticket = None
+        if self.sharded:               # this rank's candidates of the reset after next, beside the dynamics pass
+            ticket = self.env.sample_shard_ahead(self.rank, self.world, buf[self.off_block:], self.cap, resets_ahead=2)
+        shard, token = self.env.rollout_tape(actions, out=buf[:self.n_tape])
+        if self.sharded:
+            self.env.shard_join()      # the collective below must see the block
         self._expand_pending()         # epoch k-1: its collective has had a whole epoch
         if self.world == 1:
-            work, self.recv[i] = None, shard
+            work, self.recv[i] = None, buf
         else:
-            src = shard.to("cpu") if self.host else shard
+            src = buf.to("cpu") if self.host else buf
             work = dist.all_gather_into_tensor(self.recv[i], src, async_op=True)
             self.bytes_received += (self.world - 1) * self.n * 4
-        self.pending = (work, i, token)
+        self.pending = (work, i, token, ticket)
         self.k += 1
 
-    def _expand_pending(self):
+    def _install(self, ticket, recv):
+        self.env.install_shards(ticket, recv[self.off_block:], self.n, self.world, self.cap)
+        self.blocks_installed += 1
+
+    def _expand_pending(self, install=True):
         if self.pending is None:
+            if install and self.deferred is not None:      # the block a drain() left behind: its reset is the next one
+                with (torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()):
+                    self._install(*self.deferred)
+                self.deferred = None
             return
-        work, i, token = self.pending
+        work, i, token, ticket = self.pending
         self.pending = None
         out = self.out[self.k % 2]
         # no wait for the caller's stream: the buffers are this object's own, and their reuse three epochs later is
@@ -122,12 +176,26 @@ class TapeHandoff:
             recv = self.recv[i]
             if self.host:
                 recv = recv.to(self.env.device, non_blocking=True)
-            for s in range(self.world):
-                self.env.expand_tape(recv[s * self.n:(s + 1) * self.n], token, self.T, out=out[s])
+            if ticket is not None and self.sharded:
+                if install:            # first: the next reset() waits for this pool, not for the expansions
+                    self._install(ticket, recv)
+                else:                  # drain(): the pool slot still holds the NEXT reset's layouts; install after it
+                    self.deferred = (ticket, recv)
+            for s in (range(self.world) if self.expand == "all" else (self.rank,)):
+                self.env.expand_tape(recv[s * self.n:s * self.n + self.n_tape], token, self.T, out=out[s])
         self.rollout = out
+        self.last = (recv, token)
+
+    def expand_rank(self, s):
+        """expand="local": the packed rows of rank s for the epoch `rollout` holds, expanded now on the hand-off's
+        stream (valid until the next step(): the layout pool the tape names is recycled two resets after its rollout)."""
+        recv, token = self.last
+        with (torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()):
+            self.env.expand_tape(recv[s * self.n:s * self.n + self.n_tape], token, self.T, out=self.rollout[s])
+        return self.rollout[s]
 
     def drain(self):
-        self._expand_pending()
+        self._expand_pending(install=False)
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
 

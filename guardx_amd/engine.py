@@ -602,6 +602,43 @@ class Engine:
             _native.check(st)
         return obs
 
+    # ---- the same riding on the tape hand-off (one collective per epoch): guardx_amd.dist.TapeHandoff drives these ----
+    def set_layout_source(self, source):
+        """'own' (default): reset() samples / prefetches all candidates itself.  'shards': the pool of the next reset()
+        is installed from the ranks' export blocks (install_shards); a reset whose key has no installed pool samples
+        inline, so results never depend on the source."""
+        _native.check(self._lib.gx_set_layout_source(self._h, {'own': 0, 'shards': 1}[source]))
+
+    def shard_block_floats(self, cap):
+        n = C.c_int64()
+        _native.check(self._lib.gx_shard_block_floats(self._h, int(cap), C.byref(n)))
+        return int(n.value)
+
+    def sample_shard_ahead(self, shard, n_shards, block, cap, resets_ahead=2):
+        """Sample candidates [shard M / n, (shard + 1) M / n) of the reset() `resets_ahead` resets from now (its key is
+        this key advanced by the learned number of steps between resets) on the engine's side stream and export the
+        valid layouts into `block` (shard_block_floats(cap) floats: count, key, tag | rows).  Returns the ticket
+        install_shards() takes for the blocks of this call (the same number on every rank)."""
+        assert block.is_contiguous() and block.dtype == torch.float32 and block.device == self.device
+        assert block.numel() == self.shard_block_floats(cap)
+        ticket = C.c_int64()
+        _native.check(self._lib.gx_sample_shard_ahead(self._h, int(shard), int(n_shards), int(resets_ahead),
+                                                      block.data_ptr(), int(cap), C.byref(ticket), self._stream()))
+        return int(ticket.value)
+
+    def shard_join(self):
+        """the current stream waits for the block of the last sample_shard_ahead()"""
+        _native.check(self._lib.gx_shard_join(self._h, self._stream()))
+
+    def install_shards(self, ticket, blocks, stride_floats, n_shards, cap):
+        """Assemble the n_shards export blocks of sample_shard_ahead() call `ticket` (shard s at
+        blocks[s * stride_floats:]) into the pool of the reset() they were sampled for, on the current stream; that
+        reset() then takes it like a prefetched pool."""
+        assert blocks.is_contiguous() and blocks.dtype == torch.float32 and blocks.device == self.device
+        assert blocks.numel() >= (int(n_shards) - 1) * int(stride_floats) + self.shard_block_floats(cap)
+        _native.check(self._lib.gx_install_shards(self._h, int(ticket), blocks.data_ptr(), int(stride_floats),
+                                                  int(n_shards), int(cap), self._stream()))
+
     # ------------------------------------------------------------------
     # closed-loop fused rollout (policy evaluated inside the kernel)
     # ------------------------------------------------------------------

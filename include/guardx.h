@@ -194,6 +194,36 @@ gx_status gx_sample_shard(gx_engine* e, int32_t shard, int32_t n_shards, float* 
 gx_status gx_reset_from_shards(gx_engine* e, const float* d_rows_all, const int32_t* d_counts, int32_t n_shards,
                                int32_t cap, float* d_obs, void* stream);
 
+/* ---- the same riding on the rollout hand-off: ONE collective per epoch (the default multi-GPU path since round 4) --
+ * The key of reset(k + 2) is known at reset(k): this key advanced by one split per step() (engine.py:431), the number
+ * of steps between resets being the learned horizon of gx_set_prefetch.  So rank r samples ITS candidates of reset(k + 2)
+ * during epoch k (gx_sample_shard_ahead, on the engine's side stream), the export block -- [count, key0, key1,
+ * shard | n_shards << 16 | rows cap x (goal, hazards.., pillars.., robot) x 2 floats] -- is the tail of the buffer that
+ * carries its dynamics tape, the all-gather of epoch k delivers every rank's block, and gx_install_shards (during epoch
+ * k + 1, on the stream that waited for the collective) assembles them into the pool gx_reset(k + 2) takes exactly like a
+ * prefetch hit.  A reset whose key has no installed pool (the first two, a changed episode length) samples all
+ * candidates inline like a prefetch miss: layouts, observations and every later draw are the reference's either way
+ * (engine.py:433-452).  The sampler's work per GPU is 1/W of the reference's and no second collective exists.
+ *   gx_set_layout_source(e, 1): gx_reset launches no prefetch sampler of its own; 0 (default) restores it.
+ *   gx_shard_block_floats:  floats of one export block of capacity `cap` rows (a multiple of 4).
+ *   gx_sample_shard_ahead:  resets_ahead >= 1 (2 for the pipeline above).  d_block 16-byte aligned.  The sampler starts
+ *                           behind everything already queued on `stream`; gx_shard_join makes `stream` wait for the block
+ *                           (call it before the collective that sends it).
+ *                           *ticket names the call: every rank makes the same calls in the same order, so the
+ *                           ticket of the blocks that arrive with a collective is the local one of that epoch.
+ *   gx_install_shards:      d_blocks = block of shard 0, shard s at d_blocks + s * stride_floats; `ticket` = the
+ *                           gx_sample_shard_ahead call whose key / n_shards / cap these blocks belong to (the engine
+ *                           remembers its last four; GX_ERR_STATE otherwise).  A block of another key, shard or world
+ *                           size, or count > cap, leaves layout_size < 0: the reset that takes the pool fails its
+ *                           layout check (engine.py:444) instead of using it. */
+gx_status gx_set_layout_source(gx_engine* e, int32_t source);
+gx_status gx_shard_block_floats(const gx_engine* e, int32_t cap, int64_t* floats);
+gx_status gx_sample_shard_ahead(gx_engine* e, int32_t shard, int32_t n_shards, int32_t resets_ahead, float* d_block,
+                                int32_t cap, int64_t* ticket, void* stream);
+gx_status gx_shard_join(gx_engine* e, void* stream);
+gx_status gx_install_shards(gx_engine* e, int64_t ticket, const float* d_blocks, int64_t stride_floats, int32_t n_shards,
+                            int32_t cap, void* stream);
+
 /* ---- closed-loop fused rollout with an on-device policy ------------------
  * `ac.step(o)` of MLPActorCritic(hidden_sizes=(64,64), tanh) (safe_rl_libX/trpo/trpo_core.py:110-173)
  * evaluated inside the persistent rollout kernel: per step  a ~ N(mu_net(o), exp(log_std)), logp,

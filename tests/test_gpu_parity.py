@@ -1126,3 +1126,133 @@ def test_sharded_layout_sampler_equals_the_unsharded_reset(torch_cuda, oracle, r
     with pytest.raises(ResamplingError, match="exported more"):
         sh.reset_from_shards(tiny, big)
     full.close(); sh.close()
+
+
+@pytest.mark.parametrize("robot,W", [("point", 2), ("point", 8), ("ant", 3)])
+def test_piggybacked_shard_sampler_equals_the_unsharded_engine(torch_cuda, oracle, robot, W):
+    """The default multi-GPU path on one GPU: W shard engines ("ranks") each sample THEIR candidates of the reset after
+    next beside the dynamics pass (sample_shard_ahead), the export blocks ride in the tail of the tape shards, the
+    "all-gather" (a concatenation here) delivers them one epoch later, and install_shards assembles the pool the reset
+    after that takes like a prefetch hit.  Every reset observation, layout_size, pool rows, the expanded rows of every
+    tape on every rank, reset_done draws included, equal ONE unsharded engine's (which samples all candidates itself)
+    and -- first reset -- the checker's.  No reset after the first samples inline."""
+    torch = torch_cuda
+    from guardx_amd import Engine
+    extra = {"point": {}, "ant": ANT}[robot]
+    N, T, M, EPOCHS = 64, 40, 120_000, 6
+    kw = dict(seed=6, num_steps=T, goal_size=2.6, **extra)
+    full, O = _engines(task_config(N * W, **kw), oracle, n_candidates=M)
+    ranks = [Engine(task_config(N, **kw), n_candidates=M, shard=(r, W)) for r in range(W)]
+    A = full.action_space.shape[0]
+    rng = np.random.default_rng(3)
+    side = torch.cuda.Stream()
+    n_tape = sum(ranks[0].tape_floats(T))
+    off = n_tape + (-n_tape) % 4
+    cap = n_blk = None
+    bufs, pend = [], None            # per epoch: the W "send" buffers; (buffers, tokens, tickets, reference rows)
+    for ep in range(EPOCHS):
+        o_full = full.reset()
+        if ep == 0:
+            np.testing.assert_array_equal(o_full.cpu().numpy(), O.reset())
+        for r, e in enumerate(ranks):
+            assert torch.equal(e.reset(), o_full[r * N:(r + 1) * N]), (ep, r)
+            assert e.layout_size == full.layout_size
+            np.testing.assert_array_equal(e.get_pool(48), full.get_pool(48))
+        if cap is None:
+            cap = 2 * (-(-full.layout_size // W)) + 256
+            n_blk = ranks[0].shard_block_floats(cap)
+            for e in ranks:
+                e.set_layout_source('shards')
+        acts = torch.from_numpy(rng.uniform(-1, 1, (T, N * W, A)).astype(np.float32)).cuda()
+        *_, pk = full.rollout(acts, packed=True)
+        cur = [torch.zeros(off + n_blk, device='cuda') for _ in range(W)]
+        tokens, tickets = [], []
+        for r, e in enumerate(ranks):
+            tickets.append(e.sample_shard_ahead(r, W, cur[r][off:], cap))
+            _, tok = e.rollout_tape(acts[:, r * N:(r + 1) * N].contiguous(), out=cur[r][:n_tape])
+            e.shard_join()
+            tokens.append(tok)
+        assert len(set(tickets)) == 1                        # the same call sequence on every rank
+        if pend is not None:                                 # the previous epoch's collective has "arrived"
+            pbuf, ptok, ptick, pref = pend
+            gathered = torch.cat(pbuf)                       # what all_gather_into_tensor leaves on every rank
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                outs = []
+                for by, e in enumerate(ranks):
+                    e.install_shards(ptick, gathered[off:], off + n_blk, W, cap)
+                    outs.append([e.expand_tape(gathered[s * (off + n_blk):s * (off + n_blk) + n_tape], ptok[s], T)
+                                 for s in range(W)])
+            torch.cuda.current_stream().wait_stream(side)
+            for by in range(W):
+                for s in range(W):
+                    want = pref[:, s * N:(s + 1) * N].contiguous()
+                    assert torch.equal(outs[by][s].view(torch.int32), want.view(torch.int32)), (ep, by, s)
+        pend = (cur, tokens, tickets[0], pk)
+    for e in ranks:
+        hits, misses, horizon = e.prefetch_stats()
+        # reset 0 sampled inline, reset 1 took the pool the engine's own prefetch had started before the switch to
+        # 'shards', every later one an installed pool
+        assert horizon == T and hits == EPOCHS - 1 and misses == 0, (hits, misses)
+        e.check_layouts()
+    # a block of another key / a foreign shard is refused by the reset that would take the pool
+    e = ranks[0]
+    e.reset()                                                # reset EPOCHS: the pool installed in the last epoch
+    e.rollout_tape(acts[:, :N].contiguous())                 # T steps: the key of reset EPOCHS + 1, which the last blocks are for
+    bad = torch.cat(pend[0]).clone()
+    bad[off + 1] = 12345.0                                   # key word of shard 0's block
+    e.install_shards(pend[2], bad[off:], off + n_blk, W, cap)
+    from guardx_amd import ResamplingError
+    with pytest.raises(ResamplingError):
+        e.reset()
+    from guardx_amd._native import GxError, GX_ERR_STATE
+    with pytest.raises(GxError) as ei:
+        e.install_shards(pend[2] + 100, bad[off:], off + n_blk, W, cap)
+    assert ei.value.status == GX_ERR_STATE
+    full.close()
+    for e in ranks:
+        e.close()
+
+
+@pytest.mark.parametrize("expand", ["all", "local"])
+def test_tape_handoff_with_piggybacked_sampler_pipeline(torch_cuda, expand):
+    """guardx_amd.dist.TapeHandoff as bench.py drives it at N > 1, in a world of one (the whole candidate list is this
+    rank's shard; no collective): the blocks sampled two resets ahead are installed one epoch later, a drain() in the
+    middle (bench.py drains after its warm-up epochs) defers the install it cannot make yet, and every reset from the
+    third on is a hit.  Rows, observations and pool sizes equal a twin engine's that samples for itself."""
+    torch = torch_cuda
+    from guardx_amd import Engine
+    from guardx_amd.dist import TapeHandoff
+    N, T, M = 300, 50, 150_000
+    cfg = task_config(N, seed=8, num_steps=T, goal_size=2.9)
+    a, b = Engine(cfg, n_candidates=M), Engine(cfg, n_candidates=M)
+    assert torch.equal(a.reset(), b.reset())
+    h = TapeHandoff(a, T, sharded_sampler=True, expand=expand)
+    assert h.sharded and h.cap < M
+    rng = np.random.default_rng(12)
+    prev = None
+    for ep in range(8):
+        acts = torch.from_numpy(rng.uniform(-1, 1, (T, N, 2)).astype(np.float32)).cuda()
+        if ep:
+            assert torch.equal(a.reset(check=False), b.reset(check=False)), ep
+        h.step(acts)
+        *_, pk = b.rollout(acts, packed=True)
+        if ep >= 1:
+            torch.cuda.current_stream().wait_stream(h.stream)
+            assert torch.equal(h.rollout[0], prev)
+        prev = pk
+        if ep == 3:
+            h.drain()
+            assert torch.equal(h.rollout[0], prev) and h.deferred is not None
+    h.drain()
+    assert torch.equal(h.rollout[0], prev)
+    if expand == "local":
+        assert torch.equal(h.expand_rank(0), prev)
+    a.check_layouts(); b.check_layouts()
+    hits, misses, _ = a.prefetch_stats()
+    # reset 1 took the engine's own prefetch (started before the switch to 'shards'), resets 2..7 installed pools
+    assert hits == 7 and misses == 0 and h.blocks_installed == 7, (hits, misses, h.blocks_installed)
+    h.close()
+    assert torch.equal(a.reset(), b.reset())                 # back on its own sampler, still in step
+    assert torch.equal(a.reset(), b.reset())
+    a.close(); b.close()
