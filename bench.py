@@ -104,16 +104,10 @@ class RolloutHandoff:
                 s[0].wait()
 
 
-SHARDED_RESET = None   # guardx_amd.dist.ShardedReset when GX_SHARD_SAMPLER=1 (optional second collective, default off)
-
-
 def run_epochs(env, tapes, epochs, handoff):
     """`epochs` bench steps: reset() + one fused 200-pass rollout each (+ the async hand-off)."""
     for ep in range(epochs):
-        if SHARDED_RESET is not None and SHARDED_RESET.env is env:
-            SHARDED_RESET.reset(check=False)
-        else:
-            env.reset(check=False)       # the layout_size assert is checked once after the loop
+        env.reset(check=False)           # the layout_size assert is checked once after the loop
         acts = tapes[ep % len(tapes)]
         if isinstance(handoff, RolloutHandoff):
             handoff.submit(env.rollout(acts, packed=True)[4])
@@ -522,6 +516,21 @@ def api_loop_rate(env, tape, steps):
     return env.env_num * steps / (time.perf_counter() - t0)
 
 
+def api_loop_summary(env, tape, reps=5, steps=2000):
+    """the default Engine (out_ring=0: step() outputs are never overwritten, engine.py:495) and the opt-in ring of 8
+    reused output sets, side by side"""
+    from guardx_amd import Engine
+    rates = sorted(api_loop_rate(env, tape, steps) for _ in range(reps))
+    ring = Engine(env._ctor_config, **dict(env._ctor_kwargs, out_ring=8))
+    ring.set_prefetch(EP_LEN)
+    r8 = sorted(api_loop_rate(ring, tape, steps) for _ in range(reps))
+    ring.close()
+    return {"value": round(rates[reps // 2], 1), "best": round(rates[-1], 1), "out_ring": 0,
+            "out_ring_8": {"value": round(r8[reps // 2], 1), "best": round(r8[-1], 1)},
+            "unit": "env-steps/s", "note": f"median (and best) of {reps} runs of {steps} step()+reset_done() pairs incl. "
+                                           "a reset() every 200"}
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this process has not
     touched the GPU), one per GPU, rendezvous on 127.0.0.1, relay rank 0's line, fail if any rank fails."""
@@ -589,30 +598,23 @@ def main():
 
     env = make_engine(ENV_NUM, rank, world)
     env.set_prefetch(EP_LEN)
-    global SHARDED_RESET
-    if os.environ.get("GX_SHARD_SAMPLER") == "1":
-        # OPTIONAL, off by default: the 1e6-candidate layout sampler split over the ranks + one small all-gather of the
-        # valid layouts (a second collective; north_star names one).  Same pools, same results.
-        SHARDED_RESET = gxd.ShardedReset(env)
     tapes = [action_tape(EP_LEN, ENV_NUM, 1000 * rank + k, device) for k in range(4)]
     gather = world > 1
     # the hand-off: "tape" (default) all-gathers the 48-B-per-env-step dynamics tape and expands it on every rank,
     # "packed" all-gathers the 192-B packed rows (what round 1 did; GX_HANDOFF=packed to compare)
     mode = os.environ.get("GX_HANDOFF", "tape")
-    handoff = None
-    if gather:
-        if mode == "tape":
-            try:
-                handoff = gxd.TapeHandoff(env, EP_LEN)
-            except Exception as exc:  # noqa: BLE001 - same code on every rank, so every rank falls back together
-                print(f"bench.py: tape hand-off unavailable ({type(exc).__name__}: {exc}); using the packed rows",
-                      file=sys.stderr)
-                mode = "packed"
-        if mode != "tape":
-            handoff = RolloutHandoff(world)
+    if gather and mode == "tape":
+        env.reset()                      # sizes the export blocks of the sharded sampler (layout_size)
 
-    def timed_region():
-        run_epochs(env, tapes, args.warmup, handoff)
+    def make_handoff(sharded, expand):
+        if not gather:
+            return None
+        if mode != "tape":
+            return RolloutHandoff(world)
+        return gxd.TapeHandoff(env, EP_LEN, sharded_sampler=sharded, expand=expand)
+
+    def timed_region(handoff, warmup):
+        run_epochs(env, tapes, warmup, handoff)
         gxd.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -621,36 +623,48 @@ def main():
         gxd.barrier()
         return gxd.max_over_ranks(time.perf_counter() - t0, device)
 
+    def leg(sharded, expand, warmup):
+        h = make_handoff(sharded, expand)
+        t = timed_region(h, warmup)
+        if hasattr(h, "close"):
+            h.close()                    # the engine samples for itself again
+        return t, h
+
+    # `value` at N > 1: the tape hand-off with the layout sampler sharded over the ranks (each rank samples 1/N of the
+    # candidates of the reset after next, the rows ride on the tape all-gather: still ONE collective per epoch) and every
+    # rank expanding every rank's tape
     precond = None if args.no_precondition else precondition_clocks(device)
-    dt = timed_region()
+    dt, handoff = leg(True, "all", args.warmup)
 
     env_steps = ENV_NUM * world * EP_LEN * args.steps
     value = env_steps / dt
     stepping_only = None
+    legs = None
     if gather:
-        # the same epochs without the hand-off: what the sharded stepping alone sustains (no collective on the
-        # data path), so the cost of the mandated all-gather can be read off the two numbers
-        gxd.barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        run_epochs(env, tapes, args.steps, None)
-        torch.cuda.synchronize()
-        gxd.barrier()
-        dt1 = gxd.max_over_ranks(time.perf_counter() - t1, device)
+        w2 = max(3, args.warmup)         # a change of the layout source costs up to two inline samplers
         W = env.obs_flat_size + 2 + 3
-        stepping_only = {"value": round(env_steps / dt1, 1), "unit": "env-steps/s",
-                         "ms_per_step": round(dt1 / args.steps * 1e3, 6),
-                         "handoff_ms_per_epoch_exposed": round((dt - dt1) / args.steps * 1e3, 6),
-                         "handoff": mode,
-                         "handoff_bytes_received_per_rank_per_epoch":
-                             int((world - 1) * (handoff.n if mode == "tape" else EP_LEN * ENV_NUM * W) * 4),
-                         "packed_rows_bytes_per_rank_per_epoch": int(EP_LEN * ENV_NUM * W * 4),
-                         "note": "same epochs with the rollout hand-off switched off (two-kernel gx_rollout); `value` "
-                                 "above includes the hand-off: asynchronous all-gather of the dynamics tape, 3 in "
-                                 "flight, and the observation pass over all ranks' tapes on every rank"
-                                 if mode == "tape" else
-                                 "same epochs with the rollout hand-off switched off; `value` above includes it "
-                                 "(asynchronous all-gather of the packed rows, 3 gathered buffers in flight)"}
+
+        def rate(t):
+            return {"value": round(env_steps / t, 1), "unit": "env-steps/s", "ms_per_step": round(t / args.steps * 1e3, 6)}
+        # the same epochs without the hand-off: what the sharded stepping alone sustains (no collective on the
+        # data path, every rank samples all candidates for itself)
+        dt1 = timed_region(None, w2)
+        stepping_only = dict(rate(dt1),
+                             handoff_ms_per_epoch_exposed=round((dt - dt1) / args.steps * 1e3, 6), handoff=mode,
+                             handoff_bytes_received_per_rank_per_epoch=int(
+                                 (world - 1) * (handoff.n if mode == "tape" else EP_LEN * ENV_NUM * W) * 4),
+                             packed_rows_bytes_per_rank_per_epoch=int(EP_LEN * ENV_NUM * W * 4),
+                             note="same epochs with the rollout hand-off switched off (two-kernel gx_rollout, every rank "
+                                  "samples all 1e6 layout candidates itself); `value` above includes the hand-off")
+        if mode == "tape":
+            dt2, _ = leg(False, "all", w2)
+            dt3, _ = leg(True, "local", w2)
+            legs = {"unsharded_sampler": dict(rate(dt2), note="the round-3 default: tape hand-off, every rank expands every "
+                                              "tape, every rank samples all 1e6 layout candidates itself"),
+                    "local_expand": dict(rate(dt3), note="as `value`, but a rank expands only its own tape; the other "
+                                         "ranks' tapes are held and expanded on demand (TapeHandoff.expand_rank)"),
+                    "warmup_epochs_each": w2,
+                    "note": "`value` = sharded sampler + expand all; all legs: same engine, same epochs, one collective per epoch"}
     line = {
         "metric": "env-steps/sec", "value": round(value, 1), "unit": "env-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -670,12 +684,14 @@ def main():
                    "driver": "gx_rollout: two launches per 200-pass epoch (serial dynamics tape, then one thread per "
                              "(step, env) observation row), layout pool of the next epoch prefetched on a side stream",
                    "layout_candidates_per_reset": 1_000_000,
-                   "layout_sampler": ("sharded over the ranks + all-gather of the valid layouts (GX_SHARD_SAMPLER=1)"
-                                      if SHARDED_RESET is not None else "every rank samples all candidates (shared key)"),
+                   "layout_sampler": ("sharded over the ranks: each samples 1/N of the candidates of the reset after next, the "
+                                      "valid rows ride in the tail of its tape shard (no second collective)"
+                                      if getattr(handoff, "sharded_used", False) else
+                                      "every rank samples all candidates (shared key)"),
                    "point_actuators": "mjcf defaults inherited (DESIGN.md 0.1)"},
     }
     try:   # the 8-GPU hand-off as arithmetic (it cannot be measured on a one-GPU box): bytes on the wire vs the epoch
-        shard_bytes = int(sum(env.tape_floats(EP_LEN))) * 4
+        shard_bytes = int(handoff.n if hasattr(handoff, "n") else sum(env.tape_floats(EP_LEN))) * 4
         line["handoff_model"] = {
             "shard_bytes_per_rank_per_epoch": shard_bytes,
             "packed_rows_bytes_per_rank_per_epoch": int(EP_LEN * ENV_NUM * (env.obs_flat_size + 2 + 3) * 4),
@@ -683,7 +699,8 @@ def main():
             "allgather_ms_at_8_gpus_310GBps": round(7 * shard_bytes / 310e9 * 1e3, 4),
             "ms_per_step_this_run": round(dt / args.steps * 1e3, 4),
             "note": "one async all-gather of the dynamics tape per epoch (48 B per env-step: qpos, qvel, action, done, "
-                    "two layout-row indices), overlapped with the following epoch; 310 GB/s = a realistic all-gather bus "
+                    "two layout-row indices; at N > 1 plus the rank's export block of valid layouts, ~0.5 MB), overlapped "
+                    "with the following epoch; 310 GB/s = a realistic all-gather bus "
                     "bandwidth over 7 xGMI links (537 GB/s peak per direction); arithmetic, not a measurement"}
     except Exception as exc:  # noqa: BLE001
         line["handoff_model"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
@@ -691,9 +708,9 @@ def main():
                                           "firmware clock ramp (13 ms on this pool) is not inside the timed region; "
                                           "`cold_start` below is the same W + K epochs after 1 s of idle without it")
                                      if precond else None)
-    if precond and world == 1:
+    if precond:
         time.sleep(1.0)
-        dtc = timed_region()
+        dtc, _ = leg(True, "all", args.warmup)
         line["cold_start"] = {"value": round(env_steps / dtc, 1), "unit": "env-steps/s",
                               "ms_per_step": round(dtc / args.steps * 1e3, 6),
                               "note": "same W warm-up + K timed epochs started from an idle GPU (1 s sleep), no preconditioning"}
@@ -701,6 +718,8 @@ def main():
         line["warning"] = f"timed region {dt*1e3:.2f} ms < 10 ms: use more --steps for a meaningful rate"
     if stepping_only is not None:
         line["stepping_only"] = stepping_only
+    if legs is not None:
+        line["legs"] = legs
     if rank == 0:
         try:
             line["roofline"] = roofline_rollout(ENV_NUM, EP_LEN, 30, device)
@@ -717,8 +736,8 @@ def main():
             # bandwidth regime: the thread-per-env step kernel at 2^22 envs
             extra("roofline_large_batch", lambda: roofline_step(1 << 22, 30, device))
             extra("large_batch_fused", lambda: large_batch_fused(1 << 22, 32, device))
-            # host-bound (one ctypes call per step): best of three, the box's host cores are shared with other tenants
-            extra("api_step_loop_env_steps_per_s", lambda: round(max(api_loop_rate(env, tapes[0], 2000) for _ in range(3)), 1))
+            # host-bound (one ctypes call per step; the box's host cores are shared with other tenants): median of five
+            extra("api_step_loop_env_steps_per_s", lambda: api_loop_summary(env, tapes[0]))
             extra("epoch_breakdown", lambda: epoch_breakdown(device))
             extra("closed_loop_policy_env_steps_per_s", lambda: round(closed_loop_rate(device), 1))
             extra("reset_done_heavy", lambda: reset_done_heavy(device))

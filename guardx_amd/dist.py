@@ -75,7 +75,7 @@ class TapeHandoff:
     the layout sampler that recycles epoch k's pool behind that expansion (three pools), so a slow link slows the
     epochs down instead of corrupting anything.  On the gloo rehearsal backend the shard goes through host memory.
 
-    sharded_sampler (default: on when the engine supports it): the reference's 1e6-candidate layout sampler
+    sharded_sampler (default: on at world > 1): the reference's 1e6-candidate layout sampler
     (engine.py:433-444; candidate c draws from split(key, 1e6)[c], so the candidates are independent) is split over the
     ranks WITHOUT a second collective.  The key of reset(k + 2) is known at reset(k), so during epoch k rank r samples
     candidates [r 1e6 / W, (r + 1) 1e6 / W) of THAT reset on the engine's side stream and its valid rows ride in the tail
@@ -95,9 +95,10 @@ class TapeHandoff:
         self.n_tape = sum(env.tape_floats(self.T))
         self.host = dist.is_initialized() and dist.get_backend() != "nccl"
         dev = env.device
-        if sharded_sampler is None:
-            sharded_sampler = hasattr(env, "sample_shard_ahead")
+        if sharded_sampler is None:    # a world of one has nobody to share the sampler with
+            sharded_sampler = hasattr(env, "sample_shard_ahead") and self.world > 1
         self.sharded = bool(sharded_sampler)
+        self.sharded_used = self.sharded   # (close() clears `sharded`)
         self.cap = self.n_block = 0
         if self.sharded:
             # rows one block holds: twice this rank's expected share of the valid layouts (binomial: the share's spread
@@ -143,14 +144,19 @@ class TapeHandoff:
         if self.sharded:
             self.env.shard_join()      # the collective below must see the block
         self._expand_pending()         # epoch k-1: its collective has had a whole epoch
-        if self.world == 1:
-            work, self.recv[i] = None, buf
-        else:
-            src = buf.to("cpu") if self.host else buf
-            work = dist.all_gather_into_tensor(self.recv[i], src, async_op=True)
-            self.bytes_received += (self.world - 1) * self.n * 4
+        work = self._gather(i, buf)
         self.pending = (work, i, token, ticket)
         self.k += 1
+
+    def _gather(self, i, buf):
+        """the ONE collective of the epoch: every rank's [tape | layouts | entry records | shard block] into recv[i]"""
+        if self.world == 1:
+            self.recv[i] = buf
+            return None
+        src = buf.to("cpu") if self.host else buf
+        work = dist.all_gather_into_tensor(self.recv[i], src, async_op=True)
+        self.bytes_received += (self.world - 1) * self.n * 4
+        return work
 
     def _install(self, ticket, recv):
         self.env.install_shards(ticket, recv[self.off_block:], self.n, self.world, self.cap)

@@ -266,3 +266,117 @@ def test_two_rank_sharded_reset_over_gloo():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+
+
+class _StubShardAheadEngine(_StubEngine):
+    """_StubEngine + the surface of the piggy-backed sharded sampler: the "block" a rank samples at call c names
+    (rank, c); install_shards records what arrived with which ticket and whether a reset separates consecutive
+    installs (an install must not clobber the pool the NEXT reset still has to take)."""
+
+    def __init__(self, rank, N, D):
+        super().__init__(rank, N, D)
+        self.layout_size = 40
+        self._cfg = type("Cfg", (), {"n_candidates": 1000})()
+        self.source = 'own'
+        self.calls = 0
+        self.joined = 0
+        self.installs = []
+        self.resets = 0
+        self.installs_since_reset = 0
+
+    def set_layout_source(self, source):
+        self.source = source
+
+    def shard_block_floats(self, cap):
+        return 4 + cap * 10 * 2
+
+    def sample_shard_ahead(self, shard, n_shards, block, cap, resets_ahead=2):
+        assert self.source == 'shards' and shard == self.rank and resets_ahead == 2
+        assert block.numel() == self.shard_block_floats(cap)
+        self.calls += 1
+        block.fill_(100.0 * shard + self.calls)
+        return self.calls
+
+    def shard_join(self):
+        self.joined += 1
+
+    def reset(self):
+        self.resets += 1
+        self.installs_since_reset = 0
+
+    def install_shards(self, ticket, blocks, stride, n_shards, cap):
+        self.installs_since_reset += 1
+        assert self.installs_since_reset == 1, "two installs between resets: the second overwrites a pool not yet taken"
+        nb = self.shard_block_floats(cap)
+        self.installs.append((ticket, [float(blocks[s * stride]) for s in range(n_shards)],
+                              all(bool((blocks[s * stride:s * stride + nb] == blocks[s * stride]).all()) for s in range(n_shards))))
+
+
+def _shard_ahead_worker(rank, world, port, q):
+    try:
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                          MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        from guardx_amd import dist as gxd
+        gxd.init_from_env("gloo")
+        T, N, D = 3, 5, 6
+        env = _StubShardAheadEngine(rank, N, D)
+        h = gxd.TapeHandoff(env, T, expand="local")
+        assert h.sharded and env.source == 'shards'
+        assert h.cap == 500             # min(M / W, 2 L / W + 1024)
+        assert h.n % 4 == 0 and h.off_block % 4 == 0
+        acts = torch.zeros(T, N, 2)
+        n_tape = sum(env.tape_floats(T))
+        for ep in range(7):
+            env.reset()
+            h.step(acts)
+            if ep >= 1 and ep != 4:     # the previous epoch's OWN tape has been expanded (expand="local")
+                ramp = torch.arange(n_tape, dtype=torch.float32) + 1000.0 * rank + 10000.0 * (ep - 1)
+                want = ramp[:T * N * 4].reshape(T, N, 4).sum(-1, keepdim=True) + float(77 + ep)
+                assert torch.equal(h.rollout[rank], want.expand(T, N, D + 5)), (rank, ep)
+            if ep == 3:
+                h.drain()               # bench.py drains between its warm-up and its timed epochs
+                assert h.deferred is not None
+                other = 1 - rank        # on demand: the other rank's tape of the epoch just drained
+                ramp = torch.arange(n_tape, dtype=torch.float32) + 1000.0 * other + 10000.0 * 3
+                want = ramp[:T * N * 4].reshape(T, N, 4).sum(-1, keepdim=True) + float(77 + 4)
+                assert torch.equal(h.expand_rank(other), want.expand(T, N, D + 5))
+        h.drain()
+        # blocks of call c (sampled during epoch c - 1) are installed during epoch c -- one per reset, never two --
+        # with every rank's block in rank order; the drain after epoch 3 defers block 4 to epoch 4's step
+        assert env.joined == 7 and env.calls == 7
+        assert [t for t, _, _ in env.installs] == [1, 2, 3, 4, 5, 6]
+        for t, firsts, uniform in env.installs:
+            assert firsts == [100.0 * s + t for s in range(world)] and uniform, (rank, t, firsts)
+        assert h.bytes_received == 7 * (world - 1) * h.n * 4
+        h.close()
+        assert env.source == 'own'
+        gxd.barrier()
+        if rank == 0:
+            q.put(("ok", None))
+        torch.distributed.destroy_process_group()
+    except Exception as exc:  # noqa: BLE001
+        import traceback
+        q.put(("fail", f"rank {rank}: {traceback.format_exc()}"))
+        raise
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_tape_handoff_with_piggybacked_shard_blocks_over_gloo():
+    """The default N > 1 hand-off over 2 gloo ranks with a stand-in engine: each rank's export block of the reset after
+    next travels in the tail of its tape shard, ONE all_gather_into_tensor per epoch; one epoch later every rank
+    installs both blocks (rank order = candidate order) under the ticket of that epoch -- before the expansions, exactly
+    one install between consecutive resets, a drain() deferring the install it may not make yet; expand="local" expands
+    the own tape only and any other on demand.  (The GPU engine's equality with the unsharded sampler:
+    tests/test_gpu_parity.py::test_piggybacked_shard_sampler_equals_the_unsharded_engine.)"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_ahead_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    tag, msg = q.get(timeout=240)
+    assert tag == "ok", msg
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0

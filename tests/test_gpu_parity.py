@@ -1018,27 +1018,24 @@ def test_sampler_grid_stride_iterations(torch_cuda, oracle, monkeypatch):
         E.close()
 
 
-@pytest.mark.parametrize("sharded_sampler", [False, True])
-def test_bench_two_ranks_on_one_gpu_rehearsal(torch_cuda, sharded_sampler):
-    """(sharded_sampler: the same with GX_SHARD_SAMPLER=1 -- each rank samples half of the candidates, the valid layouts are
-    all-gathered, also over gloo.)
-    bench.py's N > 1 path end to end on this box: `--gpus 2` with no launcher starts two rank processes itself;
+def test_bench_two_ranks_on_one_gpu_rehearsal(torch_cuda):
+    """bench.py's N > 1 path end to end on this box: `--gpus 2` with no launcher starts two rank processes itself;
     both share GPU 0 and talk over gloo (RCCL refuses two ranks on one device), shards staged through host memory.
     What is checked is the plumbing the 8-GPU run depends on -- spawn, rendezvous, barrier, max-over-ranks timing, the
-    tape hand-off ring with both ranks expanding both tapes, the stepping-only re-run, ONE JSON line from rank 0 --
-    not the rate (gloo through host memory is two orders of magnitude slower than xGMI)."""
+    tape hand-off ring with the layout sampler sharded over the two ranks (each samples half of the candidates of the
+    reset after next, the rows ride on the tape all-gather, also over gloo), every leg the line reports at N > 1
+    (`value`, stepping_only, unsharded_sampler, local_expand, cold_start), the deferred layout check of every leg, ONE
+    JSON line from rank 0 -- not the rate (gloo through host memory is two orders of magnitude slower than xGMI)."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GX_BENCH_FORCE_DEVICE="0", GX_DIST_BACKEND="gloo", GX_BENCH_SPAWN_TIMEOUT="400")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GX_SHARD_SAMPLER"):
+    env = dict(os.environ, GX_BENCH_FORCE_DEVICE="0", GX_DIST_BACKEND="gloo", GX_BENCH_SPAWN_TIMEOUT="500")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    if sharded_sampler:
-        env["GX_SHARD_SAMPLER"] = "1"
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                          "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+                          "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -1048,8 +1045,9 @@ def test_bench_two_ranks_on_one_gpu_rehearsal(torch_cuda, sharded_sampler):
     so = line["stepping_only"]
     assert so["handoff"] == "tape" and so["value"] > line["value"]
     assert so["handoff_bytes_received_per_rank_per_epoch"] < so["packed_rows_bytes_per_rank_per_epoch"] / 2
-    assert "roofline" in line
-    assert line["config"]["layout_sampler"].startswith("sharded" if sharded_sampler else "every rank")
+    assert "roofline" in line and line["cold_start"]["value"] > 0
+    assert line["config"]["layout_sampler"].startswith("sharded")
+    assert line["legs"]["unsharded_sampler"]["value"] > 0 and line["legs"]["local_expand"]["value"] > 0
 
 
 def test_tape_handoff_is_refused_where_it_does_not_apply(torch_cuda):
