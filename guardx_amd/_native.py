@@ -69,6 +69,7 @@ SYMBOLS = {
     "gx_tape_floats": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "gx_rollout_tape": (C.c_int, [C.c_void_p, C.c_int32, _FP, _FP, C.POINTER(C.c_int64), C.c_void_p]),
     "gx_expand_tape": (C.c_int, [C.c_void_p, C.c_int32, _FP, C.c_int64, _FP, C.c_void_p]),
+    "gx_expand_tapes": (C.c_int, [C.c_void_p, C.c_int32, _FP, C.c_int64, C.c_int32, C.c_int64, _FP, C.c_int64, C.c_void_p]),
     "gx_sample_shard": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _FP, C.c_int32, _FP, C.c_void_p]),
     "gx_reset_from_shards": (C.c_int, [C.c_void_p, _FP, _FP, C.c_int32, C.c_int32, _FP, C.c_void_p]),
     "gx_set_layout_source": (C.c_int, [C.c_void_p, C.c_int32]),

@@ -1074,13 +1074,14 @@ extern "C" gx_status gx_rollout_tape(gx_engine* e, int32_t T, const float* d_act
     return GX_OK;
 }
 
-extern "C" gx_status gx_expand_tape(gx_engine* e, int32_t T, const float* d_shard, int64_t token, float* d_packed,
-                                    void* stream)
+static gx_status expand_impl(gx_engine* e, int32_t T, const float* d_shards, int64_t stride_floats, int32_t n_shards,
+                             int64_t token, float* d_packed, int64_t packed_stride_floats, void* stream)
 {
-    if (!e || !d_shard || !d_packed || T < 1) return fail(GX_ERR_ARG, "bad argument");
+    if (!e || !d_shards || !d_packed || T < 1 || n_shards < 1 || n_shards > 65535) return fail(GX_ERR_ARG, "bad argument");
     if (!split_rollout_supported(e->p))
         return fail(GX_ERR_UNSUPPORTED, "tape hand-off: needs a task without observe_vel / observe_acc and one physics step per control step");
-    if (reinterpret_cast<uintptr_t>(d_shard) & 15u) return fail(GX_ERR_ARG, "d_shard must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(d_shards) & 15u) || (n_shards > 1 && (stride_floats & 3)))
+        return fail(GX_ERR_ARG, "d_shard must be 16-byte aligned (and the shards a multiple of 4 floats apart)");
     const int pi = (int)(token & 0xff);
     if (pi < 0 || pi >= gx_engine::kPools || (uint32_t)(token >> 8) != e->pool_gen[pi])
         return fail(GX_ERR_STATE, "gx_expand_tape: the layout pool of this tape has been resampled (expand a tape "
@@ -1093,19 +1094,36 @@ extern "C" gx_status gx_expand_tape(gx_engine* e, int32_t T, const float* d_shar
     r.T = T; r.do_reset = 1; r.nobj_total = e->nobj_total;
     r.cand_xy = e->pools[pi].cand_xy; r.n_rows = e->sp.M; r.fake = e->pools[pi].fake;
     const size_t nt = (size_t)T * e->p.N * split_tape_width(e->p), no = (size_t)e->p.P * e->p.Npad * 4;
+    if (n_shards > 1 && ((size_t)stride_floats < nt + no + (size_t)e->p.N * split_entry_width(e->p) ||
+                         (size_t)packed_stride_floats < (size_t)T * e->p.N * W))
+        return fail(GX_ERR_ARG, "gx_expand_tapes: the strides are smaller than one shard / one packed rollout");
     r.act = nullptr; // the tape rows carry the actions
     r.obs = d_packed; r.act_out = d_packed + e->p.D;
     r.rew = d_packed + e->p.D + e->na; r.cost = r.rew + 1; r.done = r.rew + 2;
     r.obs_stride = W; r.sc_stride = W;
     // the pool must be complete on this stream (it is when the tape's rank has stepped, but this may be another stream)
     GX_HIP(hipStreamWaitEvent(s, e->pool_ready[pi], 0));
-    GX_HIP(launch_split_rollout(e->p, r, const_cast<float*>(d_shard),
-                                reinterpret_cast<float4*>(const_cast<float*>(d_shard) + nt),
-                                const_cast<float*>(d_shard) + nt + no, e->b, s, nullptr, 2));
+    GX_HIP(launch_split_rollout(e->p, r, const_cast<float*>(d_shards),
+                                reinterpret_cast<float4*>(const_cast<float*>(d_shards) + nt),
+                                const_cast<float*>(d_shards) + nt + no, e->b, s, nullptr, 2, 1, n_shards, stride_floats,
+                                packed_stride_floats));
     GX_HIP(hipEventRecord(e->expand_ev[pi], s));
     e->expand_pending[pi] = true;
     GX_HIP(hipGetLastError());
     return GX_OK;
+}
+
+extern "C" gx_status gx_expand_tape(gx_engine* e, int32_t T, const float* d_shard, int64_t token, float* d_packed,
+                                    void* stream)
+{
+    return expand_impl(e, T, d_shard, 0, 1, token, d_packed, 0, stream);
+}
+
+// the observation pass over the shards of ALL ranks in one launch (the all-gathered buffer as it is)
+extern "C" gx_status gx_expand_tapes(gx_engine* e, int32_t T, const float* d_shards, int64_t stride_floats, int32_t n_shards,
+                                     int64_t token, float* d_packed, int64_t packed_stride_floats, void* stream)
+{
+    return expand_impl(e, T, d_shards, stride_floats, n_shards, token, d_packed, packed_stride_floats, stream);
 }
 
 extern "C" gx_status gx_rollout_policy(gx_engine* e, int32_t T, const gx_policy* pol, const float* d_obs0,

@@ -113,9 +113,11 @@ int split_entry_width(const Params& p);  // floats per env of the entry record (
 // returns the status of the stream-ordering calls it makes (the kernels' own launch errors surface in hipGetLastError)
 // `lanes`: lanes per env in the dynamics pass where the robot has both forms (Swimmer: 4 = the quad form, faster alone;
 // 1 = faster beside a running layout sampler)
+// `n_shards` > 1 (observation pass only): one launch over n_shards shard buffers `shard_stride` floats apart (tape, obj0
+// and entry all move by it), packed outputs `out_stride` floats apart
 hipError_t launch_split_rollout(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, float* entry,
                                 const DevBuffers& b, hipStream_t s, hipEvent_t hold = nullptr, int which = 3,
-                                int lanes = 1);
+                                int lanes = 1, int n_shards = 1, long long shard_stride = 0, long long out_stride = 0);
 // install the reset_done recorded in b.rd_j (pending commit) for consumers other than the lane-group kernels
 void launch_commit_pending(const Params& p, const DevBuffers& b, int nobj_total, int n_rows, hipStream_t s);
 // fill Pool::fake for the valid layouts of a freshly sampled pool (no-op for robots whose rest state is a fixed point)
@@ -137,7 +139,8 @@ struct RobotLaunch {
     static void commit_pending(const Params& p, const DevBuffers& b, int nobj_total, int n_rows, hipStream_t s);
     static void fake_table(const Params& p, const Pool& pl, int nobj_total, int M, hipStream_t s);
     static hipError_t split(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, float* entry,
-                            const DevBuffers& b, hipStream_t s, hipEvent_t hold, int which, int lanes);
+                            const DevBuffers& b, hipStream_t s, hipEvent_t hold, int which, int lanes, int n_shards,
+                            long long shard_stride, long long out_stride);
     static int split_width();
     static int split_entry_width();
 };

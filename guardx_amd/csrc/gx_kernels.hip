@@ -604,13 +604,14 @@ int split_entry_width(const Params& p)
     return 0;
 }
 hipError_t launch_split_rollout(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, float* entry,
-                                const DevBuffers& b, hipStream_t s, hipEvent_t hold, int which, int lanes)
+                                const DevBuffers& b, hipStream_t s, hipEvent_t hold, int which, int lanes, int n_shards,
+                                long long shard_stride, long long out_stride)
 {
-    if (p.robot == SwimmerRobot::kId) return RobotLaunch<SwimmerRobot>::split(p, r, tape, obj0, entry, b, s, hold, which, lanes);
-    if (p.robot == PointBareRobot::kId) return RobotLaunch<PointBareRobot>::split(p, r, tape, obj0, entry, b, s, hold, which, lanes);
-    if (p.robot == PointRobot::kId) return RobotLaunch<PointRobot>::split(p, r, tape, obj0, entry, b, s, hold, which, lanes);
-    if (p.robot == AntRobot::kId) return RobotLaunch<AntRobot>::split(p, r, tape, obj0, entry, b, s, hold, which, lanes);
-    if (p.robot == WalkerRobot::kId) return RobotLaunch<WalkerRobot>::split(p, r, tape, obj0, entry, b, s, hold, which, lanes);
+    if (p.robot == SwimmerRobot::kId) return RobotLaunch<SwimmerRobot>::split(p, r, tape, obj0, entry, b, s, hold, which, lanes, n_shards, shard_stride, out_stride);
+    if (p.robot == PointBareRobot::kId) return RobotLaunch<PointBareRobot>::split(p, r, tape, obj0, entry, b, s, hold, which, lanes, n_shards, shard_stride, out_stride);
+    if (p.robot == PointRobot::kId) return RobotLaunch<PointRobot>::split(p, r, tape, obj0, entry, b, s, hold, which, lanes, n_shards, shard_stride, out_stride);
+    if (p.robot == AntRobot::kId) return RobotLaunch<AntRobot>::split(p, r, tape, obj0, entry, b, s, hold, which, lanes, n_shards, shard_stride, out_stride);
+    if (p.robot == WalkerRobot::kId) return RobotLaunch<WalkerRobot>::split(p, r, tape, obj0, entry, b, s, hold, which, lanes, n_shards, shard_stride, out_stride);
     return hipErrorNotSupported;
 }
 

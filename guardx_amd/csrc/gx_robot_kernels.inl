@@ -1338,20 +1338,20 @@ void RobotLaunch<R>::fake_table(const Params& p, const Pool& pl, int nobj_total,
 
 template <class R>
 hipError_t RobotLaunch<R>::split(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, float* entry,
-                                 const DevBuffers& b, hipStream_t s, hipEvent_t hold, int which, int lanes)
+                                 const DevBuffers& b, hipStream_t s, hipEvent_t hold, int which, int lanes, int n_shards,
+                                 long long shard_stride, long long out_stride)
 {
+    SplitArgs sa;
+    sa.tape = tape; sa.obj0 = obj0; sa.entry = entry; sa.lanes = lanes;
+    sa.shard_stride = shard_stride; sa.out_stride = out_stride;
     if constexpr (R::kRestFixed) {
-        SplitArgs sa;
-        sa.tape = tape; sa.obj0 = obj0; sa.entry = entry; sa.lanes = lanes;
-        if (p.P <= 5) return launch_split_p<R, 5>(p, r, sa, b, s, hold, which);
-        if (p.P <= 9) return launch_split_p<R, 9>(p, r, sa, b, s, hold, which);
-        return launch_split_p<R, 33>(p, r, sa, b, s, hold, which);
+        if (p.P <= 5) return launch_split_p<R, 5>(p, r, sa, b, s, hold, which, n_shards);
+        if (p.P <= 9) return launch_split_p<R, 9>(p, r, sa, b, s, hold, which, n_shards);
+        return launch_split_p<R, 33>(p, r, sa, b, s, hold, which, n_shards);
     } else { // Ant, Walker: the dynamics pass is the lane-group form of the step
-        SplitArgs sa;
-        sa.tape = tape; sa.obj0 = obj0; sa.entry = entry; sa.lanes = lanes;
-        if (p.P <= 5) return launch_split_group_p<R, 5>(p, r, sa, b, s, hold, which);
-        if (p.P <= 9) return launch_split_group_p<R, 9>(p, r, sa, b, s, hold, which);
-        return launch_split_group_p<R, 33>(p, r, sa, b, s, hold, which);
+        if (p.P <= 5) return launch_split_group_p<R, 5>(p, r, sa, b, s, hold, which, n_shards);
+        if (p.P <= 9) return launch_split_group_p<R, 9>(p, r, sa, b, s, hold, which, n_shards);
+        return launch_split_group_p<R, 33>(p, r, sa, b, s, hold, which, n_shards);
     }
 }
 template <class R>

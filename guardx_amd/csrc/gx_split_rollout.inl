@@ -46,6 +46,9 @@ struct SplitArgs {
     float4* obj0;       // [P][Npad] snapshot of the layouts at entry (pass 2 reads it for rows with jcur < 0)
     float* entry;       // [N][kE] state at entry (pass 2 needs it for the rows of steps 0 and 1)
     int lanes;          // lanes per env in pass 1 where the robot offers a choice (R::kDynLanes): 1 or 4
+    // pass 2 over several shards in ONE launch (gx_expand_tapes; blockIdx.y = shard): floats between the buffers of
+    // consecutive shards (tape, obj0 and entry all move by it) and between their packed outputs
+    long long shard_stride, out_stride;
 };
 
 GX_D bool moderate(float x) { return fabsf(x) < 1e18f; } // false for NaN / Inf too
@@ -535,6 +538,12 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
     extern __shared__ float4 tile4[];
     float* tile = reinterpret_cast<float*>(tile4);
     const int tid = threadIdx.x;
+    if (blockIdx.y) { // another rank's shard of the gathered buffer (one launch expands them all)
+        const size_t so = (size_t)blockIdx.y * (size_t)sa.shard_stride;
+        sa.tape += so; sa.entry += so;
+        sa.obj0 = reinterpret_cast<float4*>(reinterpret_cast<float*>(sa.obj0) + so);
+        r.obs += (size_t)blockIdx.y * (size_t)sa.out_stride;
+    }
     const size_t G = (size_t)r.T * p.N;
     const size_t g0 = (size_t)blockIdx.x * BLOCK, g = g0 + tid;
     const bool live = g < G;
@@ -660,12 +669,12 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
 // different ranks: gx_rollout_tape / gx_expand_tape)
 template <class R, int PMAX>
 static hipError_t launch_split_p(const Params& p, const RolloutArgs& r, const SplitArgs& sa, const DevBuffers& b, hipStream_t s,
-                                hipEvent_t hold, int which)
+                                hipEvent_t hold, int which, int n_shards = 1)
 {
     hipError_t st = hipSuccess; // of the wait that orders the observation pass behind the sampler: must not be dropped
     constexpr int B1 = 64, B2 = 64;
     const int lpe = (R::kDynLanes == 4 && sa.lanes == 4) ? 4 : 1;
-    const dim3 g1((p.N * lpe + B1 - 1) / B1), g2((unsigned)(((size_t)r.T * p.N + B2 - 1) / B2));
+    const dim3 g1((p.N * lpe + B1 - 1) / B1), g2((unsigned)(((size_t)r.T * p.N + B2 - 1) / B2), n_shards);
     const size_t lds1 = sizeof(float) * ((size_t)B1 * p.D + 2 * (size_t)kActBlock * B1 * R::NA); // obs rows + two action blocks
     const size_t lds2 = sizeof(float) * (size_t)B2 * (r.obs_stride | 1);
     const bool def = PMAX == 5 && is_default_layout<R>(p);
@@ -693,11 +702,11 @@ static hipError_t launch_split_p(const Params& p, const RolloutArgs& r, const Sp
 // the same for the robots whose dynamics pass is the lane-group kernel (Ant, Walker)
 template <class R, int PMAX>
 static hipError_t launch_split_group_p(const Params& p, const RolloutArgs& r, const SplitArgs& sa, const DevBuffers& b,
-                                       hipStream_t s, hipEvent_t hold, int which)
+                                       hipStream_t s, hipEvent_t hold, int which, int n_shards = 1)
 {
     hipError_t st = hipSuccess;
     constexpr int B2 = 64;
-    const dim3 g1((p.N + 3) / 4), g2((unsigned)(((size_t)r.T * p.N + B2 - 1) / B2));
+    const dim3 g1((p.N + 3) / 4), g2((unsigned)(((size_t)r.T * p.N + B2 - 1) / B2), n_shards);
     const size_t lds2 = sizeof(float) * (size_t)B2 * (r.obs_stride | 1);
     if (which & 1) {
 #define GX_GDYN_LAUNCH(OPL, BPL, DEF) \

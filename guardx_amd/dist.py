@@ -87,11 +87,13 @@ class TapeHandoff:
     expand: "all" (default) -- every rank expands every rank's tape (the hand-off contract above); "local" -- only its
     own; expand_rank(s) then expands rank s's tape of the last gathered epoch on demand (before the next step())."""
 
-    def __init__(self, env, T, depth=3, sharded_sampler=None, expand="all"):
+    def __init__(self, env, T, depth=3, sharded_sampler=None, expand="all", _play=None):
         assert expand in ("all", "local")
         self.env, self.T, self.depth, self.expand = env, int(T), depth, expand
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
+        if _play is not None:          # (rank, world) played without a process group: tools/rehearse_rank.py, which
+            self.rank, self.world = _play   # overrides _gather()
         self.n_tape = sum(env.tape_floats(self.T))
         self.host = dist.is_initialized() and dist.get_backend() != "nccl"
         dev = env.device
@@ -187,8 +189,11 @@ class TapeHandoff:
                     self._install(ticket, recv)
                 else:                  # drain(): the pool slot still holds the NEXT reset's layouts; install after it
                     self.deferred = (ticket, recv)
-            for s in (range(self.world) if self.expand == "all" else (self.rank,)):
-                self.env.expand_tape(recv[s * self.n:s * self.n + self.n_tape], token, self.T, out=out[s])
+            if self.expand == "all" and self.world > 1 and hasattr(self.env, "expand_tapes"):
+                self.env.expand_tapes(recv, self.n, self.world, token, self.T, out)   # every rank's tape, one launch
+            else:
+                for s in (range(self.world) if self.expand == "all" else (self.rank,)):
+                    self.env.expand_tape(recv[s * self.n:s * self.n + self.n_tape], token, self.T, out=out[s])
         self.rollout = out
         self.last = (recv, token)
 

@@ -553,6 +553,17 @@ class Engine:
                                                self._stream()))
         return out
 
+    def expand_tapes(self, shards, stride_floats, n_shards, token, T, out):
+        """expand_tape() over the shards of n_shards ranks in ONE launch: shard s at shards[s * stride_floats:] (the
+        all-gathered buffer as it is), its rows into out[s]; out is (n_shards, T, N, D + A + 3)."""
+        N, W, T = self.env_num, self.obs_flat_size + self.action_space.shape[0] + 3, int(T)
+        assert shards.is_contiguous() and shards.dtype == torch.float32 and shards.device == self.device
+        assert shards.numel() >= (int(n_shards) - 1) * int(stride_floats) + sum(self.tape_floats(T))
+        assert tuple(out.shape) == (int(n_shards), T, N, W) and out.is_contiguous() and out.device == self.device
+        _native.check(self._lib.gx_expand_tapes(self._h, T, shards.data_ptr(), int(stride_floats), int(n_shards),
+                                                int(token), out.data_ptr(), T * N * W, self._stream()))
+        return out
+
     # ------------------------------------------------------------------
     # sharded layout sampling (multi-GPU, optional): guardx_amd.dist.ShardedReset drives these two
     # ------------------------------------------------------------------

@@ -177,6 +177,12 @@ gx_status gx_rollout_tape(gx_engine* e, int32_t T, const float* d_actions, float
                           void* stream);
 gx_status gx_expand_tape(gx_engine* e, int32_t T, const float* d_shard, int64_t token, float* d_packed,
                          void* stream);
+/* The same over the shards of n_shards ranks in ONE launch: shard s at d_shards + s * stride_floats (the all-gathered
+ * buffer as it is; a multiple of 4 floats), its packed rows at d_packed + s * packed_stride_floats.  Eight separate
+ * 400 000-row launches each pay their own ramp and tail; one 3.2 M-row launch runs at the rate of the large-batch
+ * step kernel. */
+gx_status gx_expand_tapes(gx_engine* e, int32_t T, const float* d_shards, int64_t stride_floats, int32_t n_shards,
+                          int64_t token, float* d_packed, int64_t packed_stride_floats, void* stream);
 
 /* ---- sharded layout sampling (multi-GPU, OPTIONAL: a second collective on the reset path) -----------------
  * reset()'s rejection sampler (engine.py:433-444, 546-621) draws 1e6 independent candidates (candidate c from

@@ -1181,11 +1181,16 @@ def test_piggybacked_shard_sampler_equals_the_unsharded_engine(torch_cuda, oracl
                     e.install_shards(ptick, gathered[off:], off + n_blk, W, cap)
                     outs.append([e.expand_tape(gathered[s * (off + n_blk):s * (off + n_blk) + n_tape], ptok[s], T)
                                  for s in range(W)])
+                assert len(set(ptok)) == 1                   # same pool ring position and generation on every rank
+                fused = ranks[ep % W].expand_tapes(gathered, off + n_blk, W, ptok[0], T,
+                                                   torch.empty(W, T, N, pref.shape[-1], device='cuda'))
             torch.cuda.current_stream().wait_stream(side)
             for by in range(W):
                 for s in range(W):
                     want = pref[:, s * N:(s + 1) * N].contiguous()
                     assert torch.equal(outs[by][s].view(torch.int32), want.view(torch.int32)), (ep, by, s)
+            for s in range(W):                               # all shards in ONE launch: the same rows
+                assert torch.equal(fused[s].view(torch.int32), outs[0][s].view(torch.int32)), (ep, s)
         pend = (cur, tokens, tickets[0], pk)
     for e in ranks:
         hits, misses, horizon = e.prefetch_stats()
