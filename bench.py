@@ -125,7 +125,7 @@ PRECONDITION_MS = 60.0
 
 def precondition_clocks(device, ms=PRECONDITION_MS):
     """Keep the GPU busy for `ms` with work that is NOT the workload (fp32 torch.mm), so that the firmware's clock /
-    power ramp is over when the W warm-up epochs start.  Measured on this pool (tools/debug/cold_start_probe.py,
+    power ramp is over when the W warm-up epochs start.  Measured on this pool (tools/history/debug/cold_start_probe.py,
     DESIGN.md section 6): after >= 50 ms of idle the first ~25 epochs (13 ms) run 10 % -> 0 % slower than the steady
     state whatever ran before the idle gap, and 30 ms of any sustained compute removes that.  The driver's region
     (5 + 20 epochs = 13 ms) would otherwise sit entirely inside the ramp.  The line reports `cold_start` beside."""
@@ -399,7 +399,7 @@ def valu_issue_floor():
     n, why = _evidence("epoch_valu_instructions")
     if n is None:
         return {"note": "no counter evidence: " + why}
-    ns = 1.73   # profiles/r02_probe_threefry_chain.log: 110 ns per 63.5-instruction Threefry block per SIMD
+    ns = 1.73   # profiles/history/r02_probe_threefry_chain.log: 110 ns per 63.5-instruction Threefry block per SIMD
     return {"wave_instructions_per_epoch": round(n), "ns_per_wave_instruction_per_simd": ns, "simds": 1024,
             "issue_floor_us": round(n * ns * 1e-9 / 1024 * 1e6, 1),
             "note": "NOT measured in this run: SQ_INSTS_VALU of every kernel of one epoch (profiles/r03_sampler_pmc_SQ.csv, "

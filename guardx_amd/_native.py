@@ -127,8 +127,29 @@ def load():
     if got != want:
         raise ImportError(f"{LIB_PATH} was built from other sources (library {got}, tree {want}); "
                           "run `python -m guardx_amd.build`")
+    _warn_if_unprofiled_compiler(lib)
     _lib = lib
     return lib
+
+
+def _warn_if_unprofiled_compiler(lib):
+    """The parity soak and the committed profiles were taken on one hipcc (profiles/<round>_build_id.txt, line 2); the
+    lane-group kernels are known to be sensitive to the compiler (guardx_amd/build.py).  A library built by another one
+    is not refused -- the parity tests are the judge -- but it says so once."""
+    import glob
+    import warnings
+    ids = sorted(glob.glob(os.path.join(os.path.dirname(_HERE), "profiles", "r[0-9][0-9]_build_id.txt")))
+    if not ids:
+        return
+    try:
+        lines = open(ids[-1]).read().splitlines()
+    except OSError:
+        return
+    have = lib.gx_build_compiler().decode()
+    if len(lines) > 1 and lines[1].strip() and have != "unknown" and lines[1].strip() != have:
+        warnings.warn(f"libguardx_hip.so was built with [{have}]; the parity soak and profiles of {os.path.basename(ids[-1])} "
+                      f"were taken with [{lines[1].strip()}]: run `pytest -m gpu` and tests/soak_parity.py on this build",
+                      RuntimeWarning, stacklevel=3)
 
 
 class GxError(RuntimeError):

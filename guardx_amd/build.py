@@ -22,16 +22,14 @@ SOURCES = ["gx_api.hip", "gx_kernels.hip", "gx_gae.hip", "gx_kernels_point.hip",
 HEADERS = ["gx_device.h", "gx_robot.h", "gx_robot_ant.h", "gx_robot_ant_group.h", "gx_robot_legs.h", "gx_robot_legs_group.h", "gx_policy.h", "gx_kernels.h", "gx_robot_kernels.inl",
            "gx_split_rollout.inl", os.path.join("..", "..", "include", "guardx.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
-# No per-source flags any more.  History: LLVM's inter-procedural register allocation (on by default for amdgcn at
-# -O3) let a noinline callee use, without saving them, the VGPRs in whose lanes the CALLER parks spilled SGPRs (exec
-# masks, v254/v255): after the call the masks are garbage and masked-off lanes store through garbage addresses (found
-# with rocgdb on group_rollout_kernel<WalkerRobot,5,4,...> when it had TWO call sites of the step:
-# HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION in the observation-row stores right after the second substep_call), and
-# the Ant / Walker translation units were built with -mllvm -enable-ipra=0.  Since reset_done's fake step is tabulated
-# with the layout pool (Pool::fake) every kernel has ONE call site of the step: the Ant's steps are inlined (no call
-# at all); the Walker's lane-group step stays a call (inlining it miscompiles, gx_robot_legs_group.h) and is built
-# with IPRA again -- every parity test and the soak pass, and it is 18 % faster than with the callee saving its
-# callee-saved registers.
+# No per-source flags.  History: LLVM's inter-procedural register allocation (on by default for
+# amdgcn at -O3) lets a noinline callee use, without saving them, the VGPRs in whose lanes the CALLER parks spilled SGPRs
+# (exec masks, v254/v255): after the call the masks are garbage and masked-off lanes store through garbage addresses
+# (found with rocgdb in round 2 on group_rollout_kernel<WalkerRobot,...> with two call sites of the step; again in round
+# 3 with ONE call site once the callee grew).  The cure that held: no call at all.  reset_done's fake step is tabulated
+# with the layout pool (Pool::fake), so every kernel steps in one place, and both the Ant's and the Walker's lane-group
+# steps are always_inline (gx_robot_ant_group.h, gx_robot_legs_group.h:substep_call); tests/test_native_abi.py asserts
+# that no lane-group kernel contains an s_swappc_b64.
 PER_SOURCE_FLAGS = {}
 
 
@@ -51,9 +49,11 @@ _COMPILER = None
 
 
 def compiler_id():
-    """`hipcc --version` in one line (HIP version + clang version): part of the build identity, because at least one
-    kernel here depends on what a particular compiler does (the Walker's lane-group step must stay a call:
-    inlining it miscompiles, gx_robot_legs_group.h) -- a different compiler is a different build."""
+    """`hipcc --version` in one line (HIP version + clang version): part of the build identity, because the kernels
+    here are sensitive to what a particular compiler does (hipcc 7.2 miscompiled the CALL form of the Ant's / Walker's
+    lane-group step -- the callee clobbered the caller's SGPR-spill VGPRs -- and is worked around by inlining it,
+    gx_robot_legs_group.h; the soak and the parity suite were run on this compiler) -- a different compiler is a
+    different build."""
     global _COMPILER
     if _COMPILER is None:
         try:

@@ -122,7 +122,7 @@ static int take_commit(gx_engine* e)
 }
 
 // env_num at which the lane-group form of a step beats the thread-per-env form.  Measured crossovers of the two
-// families (fused step incl. reset_done, tools/debug/legs_large.py, round 3 -- after the legs' lanes stopped
+// families (fused step incl. reset_done, tools/history/debug/legs_large.py, round 3 -- after the legs' lanes stopped
 // replicating work): Point / Swimmer 16384 envs; Ant ~27 k (lane-group 38.6 us at 24576 against ~44 us of the serial
 // step); Walker ~16 k (61.6 us at 16384 against 60.7 us)
 static bool in_group_regime(const gx_engine* e)
@@ -504,7 +504,7 @@ extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
         GX_HIP(claim_pool(e, e->cur, s));
         e->sp.k0 = e->key[0];
         e->sp.k1 = e->key[1];
-        // per-wave stamps of sample_phase2 (tools/debug/sampler_waves.py): only on request, the buffer must hold
+        // per-wave stamps of sample_phase2 (tools/history/debug/sampler_waves.py): only on request, the buffer must hold
         // 65536 + 4 * 16384 words -- the other stamp tools pass much smaller ones
         e->sp.dbg = (e->stamps && getenv("GX_SAMPLER_STAMPS")) ? e->stamps + 65536 : nullptr;
         GX_HIP(launch_sample(e->sp, e->pools[e->cur], s));

@@ -107,7 +107,8 @@ class Engine:
       emit_qacc     fill info['obs']['qacc'] (engine.py:763-764); costs one more output array
       out_ring      0 (default): the tensors step() returns are never written again, as in the reference
                     (engine.py:495 hands out fresh buffers; trpo.py:529 mutates the obs it keeps in place) -- they
-                    are views of a slab allocated once per 32 calls and released when the last view dies.
+                    are views of a slab of at most 64 MB (up to 256 calls' outputs) allocated in one piece and released
+                    when the last view dies.
                     k > 0: opt-in ring of k preallocated output sets, a tensor is overwritten k step() calls
                     after it was returned (for callers that copy what they keep, trpo.py:58-64; saves the slab
                     allocations)
@@ -164,7 +165,11 @@ class Engine:
         'pillars_size': 0.2, 'observe_pillars': False,
     }
 
-    _SLAB_STEPS = 32     # step() outputs are carved out of one allocation per 32 calls
+    # step() outputs are carved out of one allocation per `k` calls, k sized by BYTES: as many output sets as fit
+    # _SLAB_BYTES, at most _SLAB_STEPS, at least one (env_num = 2000: 85 sets of 0.75 MB; 2^22 Point envs: one 1.6 GB set
+    # per call, as if every step allocated its own outputs).  A tensor a caller retains keeps at most one slab alive.
+    _SLAB_BYTES = 64 << 20
+    _SLAB_STEPS = 256
 
     def __init__(self, config={}, *, n_candidates=1_000_000, shard=None, emit_qacc=True, point_actuators='mjcf',
                  out_ring=0):
@@ -403,13 +408,22 @@ class Engine:
         self.layout_size = int(n.value)
         return self.layout_size
 
+    def _slab_floats(self):
+        """floats of one set of step() outputs (obs, obs_rd, reward, cost, done, qacc), every piece 16-byte aligned"""
+        N, D, nv = self.env_num, self.obs_flat_size, self.robot.nv
+        Dp, Np = (D + 3) // 4 * 4, (N + 3) // 4 * 4
+        return 2 * N * Dp + 3 * Np + Np * nv
+
+    def _slab_steps(self):
+        return max(1, min(self._SLAB_STEPS, self._SLAB_BYTES // (4 * self._slab_floats())))
+
     def _out_slab(self, k):
         """`k` sets of step() outputs carved out of ONE allocation: per set (obs, obs_rd, reward, cost, done, qacc,
         device addresses).  The views of a slab are made with six unbind() calls, not 6 k slicing operations."""
         N, D, nv = self.env_num, self.obs_flat_size, self.robot.nv
         Dp = (D + 3) // 4 * 4                      # keep every piece 16-byte aligned
         Np = (N + 3) // 4 * 4
-        per = 2 * N * Dp + 3 * Np + Np * nv
+        per = self._slab_floats()
         flat = torch.empty(k, per, dtype=torch.float32, device=self.device)
         o = 0
         obs = flat[:, o:o + N * D].view(k, N, D).unbind(0); o += N * Dp
@@ -441,7 +455,7 @@ class Engine:
             # out_ring == 0 (default): a NEW slab -- tensors already handed out are never written again
             # (engine.py:495 returns fresh buffers); out_ring > 0: wrap around and reuse the ring
             if not self._out_ring or not self._slab:
-                self._slab = self._out_slab(self._out_ring or self._SLAB_STEPS)
+                self._slab = self._out_slab(self._out_ring or self._slab_steps())
             i = 0
         self._slab_i = i + 1
         obs, obs_rd, reward, cost, done, qacc, p = self._slab[i]

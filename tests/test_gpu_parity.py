@@ -353,14 +353,16 @@ def test_step_speculates_reset_done_without_installing_it(torch_cuda, oracle, ro
 
 def test_step_outputs_are_never_overwritten_by_default(torch_cuda):
     """Ownership (engine.py:495 returns fresh buffers): with the default out_ring=0 every tensor
-    step() / reset_done() handed out keeps its values however many calls follow (across slab boundaries: 32 calls
-    per slab); the opt-in ring of k sets overwrites a tensor exactly k calls later."""
+    step() / reset_done() handed out keeps its values however many calls follow (across slab boundaries: here 32
+    calls per slab); the opt-in ring of k sets overwrites a tensor exactly k calls later."""
     torch = torch_cuda
     from guardx_amd import Engine
     N = 130
     gen = torch.Generator(device='cuda').manual_seed(3)
     acts = torch.rand(80, N, 2, device='cuda', generator=gen) * 2 - 1
     env = Engine(task_config(N, seed=2, num_steps=9, goal_size=2.8), n_candidates=30000)
+    assert env._slab_steps() == 256                              # small outputs: the step cap binds, not the 64 MB
+    env._SLAB_STEPS = 32
     env.reset()
     kept, copies = [], []
     for t in range(80):
@@ -386,6 +388,30 @@ def test_step_outputs_are_never_overwritten_by_default(torch_cuda):
     again = ring.step(acts[8])[0]
     assert again.data_ptr() == first.data_ptr() and not torch.equal(first, snap)   # ... and reused by call k
     ring.close()
+
+
+def test_step_output_slab_is_sized_by_bytes(torch_cuda):
+    """the slab step() carves its outputs from holds as many output sets as fit 64 MB (at most 256, at
+    least one) -- at 2^20 Point envs one 394 MB set per call, not 32 of them in one 12.6 GB allocation."""
+    torch = torch_cuda
+    from guardx_amd import Engine
+    small = Engine(task_config(2000, seed=1), n_candidates=30000)
+    assert small._slab_steps() == (64 << 20) // (4 * small._slab_floats()) == 89
+    small.close()
+    N = 1 << 20
+    env = Engine(task_config(N, seed=1), n_candidates=30000)
+    assert env._slab_steps() == 1
+    env.reset(check=False)                                       # (pool smaller than env_num: drawn with replacement)
+    act = torch.zeros(N, 2, device='cuda')
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    out = env.step(act)
+    torch.cuda.synchronize()
+    grown = torch.cuda.max_memory_allocated() - base
+    assert grown <= 1.25 * 4 * env._slab_floats(), grown         # one output set (+ allocator rounding)
+    assert out[0].shape == (N, env.obs_flat_size)
+    env.close()
 
 
 def test_step_reset_done_above_the_group_limit(torch_cuda, oracle):

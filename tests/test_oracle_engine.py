@@ -449,3 +449,78 @@ def test_robot_rot_turns_the_world_pose_not_the_joint_dynamics(oracle, robot):
             np.testing.assert_array_equal(s0['qvel'], s1['qvel'])
             check_pose(s0['pose0'], s1['pose0'])
     assert t >= 2
+
+
+def test_point_solve_single_step_error_against_float64(oracle):
+    """Independent bound on the arithmetic of the Point's 3x3 solve (round 3 replaced the division by the fp32
+    Schur complement Io - (b*b + d*d)/m with a multiplication by the reciprocal of its exact value -- b^2 + d^2 is the
+    model constant (m xc)^2 -- in checker and kernels together).  Reference here: the SAME forces (fp32, the checker's
+    own sincos) solved in float64 with a dense 3x3 solve.  On 40 000 random states, servo-saturated and not:
+      * the checker's step (get_state after one step) IS the fp32 reciprocal form restated below, bit for bit;
+      * its single-step error against float64 is a few ulp of the result and not larger than the error of the
+        round-2 division form on the same states (both restated here in numpy fp32).
+    The 60-step trajectories of the two forms nevertheless separate (2e-4 in obs): the hinge's velocity servo is
+    unstable at h = 0.02 and amplifies ANY last-bit difference, which is why the 1e-5 bar is
+    stated per step from a common state (tests/test_golden.py replays the reference step by step)."""
+    f = np.float32
+    N = 40_000
+    rng = np.random.default_rng(17)
+    cfg = task_config(N, seed=1)
+    E = oracle.OracleEngine(cfg, n_candidates=3000)
+    E.reset(check=False)
+    s = random_state(N, 8, rng, done_frac=0.0)
+    s['qvel'][: N // 2] *= f(0.05)                    # half of the states in the unsaturated servo regime
+    s['hist'] = 2
+    E.set_state(s)
+    act = rng.uniform(-1.5, 1.5, (N, 2)).astype(f)
+    q, v = s['qpos'].copy(), s['qvel'].copy()
+    _, _, _, info = E.step(act)
+    st = E.get_state()
+
+    # the forces exactly as the checker forms them (fp32, its sincos)
+    sh, ch, _, _ = oracle.math_probe(f(0.5) * q[:, 2], np.zeros(N, f))
+    c, sn = ch * ch - sh * sh, f(2.0) * (ch * sh)
+    a0 = s['pose0'][:, 2] * act[:, 0], s['pose0'][:, 3] * act[:, 0]
+    ctrl = np.stack([a0[0], a0[1], act[:, 1]], 1).astype(f)
+    MXC, DXY, DT, G, H = f(0.0001), f(0.01), f(0.005), f(0.3), f(0.02)
+    m64, io64 = 0.005188790204786391, 2.842182748581224e-05
+    b, d = -(MXC * sn), MXC * c
+    w2 = v[:, 2] * v[:, 2]
+
+    def actu(u, vel):
+        u = np.clip(u, f(-1), f(1))
+        return G * np.clip(u - f(1.0) * (G * vel), f(-0.05), f(0.05))
+    fx = (-(DXY * v[:, 0]) - (-(d * w2))) + actu(ctrl[:, 0], v[:, 0])
+    fy = (-(DXY * v[:, 1]) - (b * w2)) + actu(ctrl[:, 1], v[:, 1])
+    ft = (-(DT * v[:, 2]) - f(0.0)) + actu(ctrl[:, 2], v[:, 2])
+    t = b * fx + d * fy
+
+    def solve32(ia, num_d3, recip):
+        y3 = ft - t * ia
+        q3 = y3 * recip if recip is not None else y3 / (num_d3 - (b * b + d * d) * ia)
+        return np.stack([(fx - b * q3) * ia, (fy - d * q3) * ia, q3], 1)
+    iaA = f(1.0 / (m64 + 0.02 * 0.01))
+    idA = f(1.0 / ((io64 + 0.02 * 0.005) - (1.0e-4 * 1.0e-4) / (m64 + 0.02 * 0.01)))
+    qa_rec = solve32(iaA, None, idA)
+    qa_div = solve32(iaA, f(io64 + 0.02 * 0.005), None)
+    # float64 dense solve of (M + h D) qa = f with the same fp32 forces and fp32 (b, d)
+    Mi = np.zeros((N, 3, 3))
+    Mi[:, 0, 0] = Mi[:, 1, 1] = m64 + 0.02 * 0.01
+    Mi[:, 2, 2] = io64 + 0.02 * 0.005
+    Mi[:, 0, 2] = Mi[:, 2, 0] = b.astype(np.float64)
+    Mi[:, 1, 2] = Mi[:, 2, 1] = d.astype(np.float64)
+    rhs = np.stack([fx, fy, ft], 1).astype(np.float64)
+    qa64 = np.linalg.solve(Mi, rhs[..., None])[..., 0]
+
+    v_rec = (v + H * qa_rec).astype(f)
+    np.testing.assert_array_equal(st['qvel'], v_rec)                       # the checker IS the reciprocal form
+    np.testing.assert_array_equal(st['qpos'], (q + H * v_rec).astype(f))
+    scale = np.abs(qa64) + 1e-3 * np.abs(qa64).max(axis=1, keepdims=True)
+    e_rec = np.abs(qa_rec - qa64) / scale
+    e_div = np.abs(qa_div - qa64) / scale
+    assert e_rec.max() < 4e-6 and e_div.max() < 4e-6, (e_rec.max(), e_div.max())
+    assert np.sqrt((e_rec ** 2).mean()) <= 1.25 * np.sqrt((e_div ** 2).mean()) + 1e-9
+    # one step from a common state: far inside the 1e-5 bar, in either form
+    v64 = v.astype(np.float64) + 0.02 * qa64
+    assert np.abs(v_rec - v64).max() < 2e-6 * max(1.0, np.abs(v64).max())
+    assert np.abs((v + H * qa_div).astype(f) - v64).max() < 2e-6 * max(1.0, np.abs(v64).max())
