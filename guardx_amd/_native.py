@@ -62,6 +62,8 @@ SYMBOLS = {
     "gx_layout_size_min": (C.c_int, [C.c_void_p, _I32P]),
     "gx_step": (C.c_int, [C.c_void_p, _FP, _FP, _FP, _FP, _FP, _FP, C.c_void_p]),
     "gx_step_rd": (C.c_int, [C.c_void_p, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _I32P, C.c_void_p]),
+    "gx_step_set_floats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "gx_step_slab": (C.c_int, [C.c_void_p, _FP, _FP, C.c_int32, C.c_int32, _I32P, C.c_void_p]),
     "gx_reset_done_commit": (C.c_int, [C.c_void_p]),
     "gx_reset_done": (C.c_int, [C.c_void_p, _FP, _FP, C.c_void_p]),
     "gx_rollout_packed": (C.c_int, [C.c_void_p, C.c_int32, _FP, _FP, C.c_void_p]),

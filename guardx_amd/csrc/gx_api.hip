@@ -881,6 +881,32 @@ extern "C" gx_status gx_step_rd(gx_engine* e, const float* d_action, float* d_ob
     return step_impl(e, d_action, d_obs, d_reward, d_cost, d_done, d_qacc, d_obs_rd, speculated, stream);
 }
 
+// ---- step() outputs addressed inside a caller-owned slab: one pointer + a slot index per call -------------------------
+// An unmodified learner drives Engine.step() once per control step (trpo.py:479-547) and must be handed tensors nobody
+// overwrites later (engine.py:495).  The Python host carves them out of one allocation per ~100 calls; passing SIX
+// addresses per call through ctypes is a third of that call's host time at env_num = 2000.  Layout of one output set
+// (floats; Dp = D rounded up to 4, Np = env_num rounded up to 4, every piece 16-byte aligned):
+//   obs [N][D] (at 0) | obs_rd [N][D] (at N*Dp) | reward [N] (at 2*N*Dp) | cost [N] (+Np) | done [N] (+2*Np) | qacc [N][nv] (+3*Np)
+extern "C" gx_status gx_step_set_floats(const gx_engine* e, int64_t* floats)
+{
+    if (!e || !floats) return fail(GX_ERR_ARG, "null argument");
+    const int64_t N = e->p.N, Dp = (e->p.D + 3) / 4 * 4, Np = (N + 3) / 4 * 4;
+    *floats = 2 * N * Dp + 3 * Np + Np * e->nv;
+    return GX_OK;
+}
+
+extern "C" gx_status gx_step_slab(gx_engine* e, const float* d_action, float* d_slab, int32_t slot, int32_t flags,
+                                  int32_t* speculated, void* stream)
+{
+    if (!e || !d_slab || slot < 0 || !speculated) return fail(GX_ERR_ARG, "gx_step_slab: bad argument");
+    if (reinterpret_cast<uintptr_t>(d_slab) & 15u) return fail(GX_ERR_ARG, "gx_step_slab: d_slab must be 16-byte aligned");
+    const int64_t N = e->p.N, Dp = (e->p.D + 3) / 4 * 4, Np = (N + 3) / 4 * 4;
+    float* b = d_slab + (size_t)slot * (size_t)(2 * N * Dp + 3 * Np + Np * e->nv);
+    float* rew = b + 2 * N * Dp;
+    return step_impl(e, d_action, b, rew, rew + Np, rew + 2 * Np, (flags & 1) ? rew + 3 * Np : nullptr,
+                     (flags & 2) ? b + N * Dp : nullptr, speculated, stream);
+}
+
 extern "C" gx_status gx_reset_done_commit(gx_engine* e)
 {
     if (!e) return fail(GX_ERR_ARG, "null engine");

@@ -57,7 +57,8 @@ class _LazyObsDict(dict):
             for k, s in slices.items():
                 dict.__setitem__(self, k, obs[:, s])
             if qacc is not None:
-                dict.__setitem__(self, 'qacc', qacc)
+                flat, i, lo, n, nv = qacc      # the step's qacc lives in the output slab: viewed only when asked for
+                dict.__setitem__(self, 'qacc', flat[i, lo:lo + n * nv].view(n, nv))
 
     def __getitem__(self, k):
         self._fill()
@@ -94,6 +95,61 @@ class _LazyObsDict(dict):
     def __repr__(self):
         self._fill()
         return dict.__repr__(self)
+
+
+class _StepInfo(dict):
+    """The `info` dict of step() (engine.py:693-695: {'cost': ..., 'obs': {...}}).  'cost' is there from the start -- the
+    learners read it every step (trpo.py:484) --, 'obs' (the per-key views, which only render() reads) is built on first
+    use: step() + reset_done() is host bound at env_num = 2000 and every Python object made per call counts."""
+    __slots__ = ('_src',)
+
+    def _fill(self):
+        src = self._src
+        if src is not None:
+            self._src = None
+            dict.__setitem__(self, 'obs', _LazyObsDict(*src))
+
+    def __missing__(self, k):
+        self._fill()
+        return dict.__getitem__(self, k)       # KeyError for anything but 'obs', as a plain dict
+
+    def __iter__(self):
+        self._fill()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._fill()
+        return dict.__len__(self)
+
+    def __contains__(self, k):
+        self._fill()
+        return dict.__contains__(self, k)
+
+    def keys(self):
+        self._fill()
+        return dict.keys(self)
+
+    def items(self):
+        self._fill()
+        return dict.items(self)
+
+    def values(self):
+        self._fill()
+        return dict.values(self)
+
+    def get(self, k, default=None):
+        self._fill()
+        return dict.get(self, k, default)
+
+    def __repr__(self):
+        self._fill()
+        return dict.__repr__(self)
+
+    def __eq__(self, other):
+        self._fill()
+        return dict.__eq__(self, other)
+
+    __hash__ = None
 
 
 class Engine:
@@ -227,10 +283,13 @@ class Engine:
 
         self._act_shape = torch.Size((int(self.env_num), act_dim))
         self._out_ring = max(0, int(out_ring))
-        self._slab, self._slab_i = [], 0
+        self._slab, self._slab_i = None, 0
+        self._per_set = self._slab_floats()
         self._speculate = os.environ.get("GX_NO_SPECULATE", "0") != "1"
+        # bit 0: write qacc; bit 1: speculate reset_done in the step launch (off: two-launch form, debugging / A-B timing)
+        self._step_flags = (1 if self.emit_qacc else 0) | (2 if self._speculate else 0)
         # the per-step entry points, looked up once (step() + reset_done() is host-bound at env_num = 2000)
-        self._gx_step_rd, self._gx_step = self._lib.gx_step_rd, self._lib.gx_step
+        self._gx_step_slab = self._lib.gx_step_slab
         self._gx_commit = self._lib.gx_reset_done_commit
         self._raw_stream = torch._C._cuda_getCurrentRawStream
         self._dev_index = self.device.index
@@ -409,21 +468,23 @@ class Engine:
         return self.layout_size
 
     def _slab_floats(self):
-        """floats of one set of step() outputs (obs, obs_rd, reward, cost, done, qacc), every piece 16-byte aligned"""
-        N, D, nv = self.env_num, self.obs_flat_size, self.robot.nv
-        Dp, Np = (D + 3) // 4 * 4, (N + 3) // 4 * 4
-        return 2 * N * Dp + 3 * Np + Np * nv
+        """floats of one set of step() outputs (obs, obs_rd, reward, cost, done, qacc), every piece 16-byte aligned:
+        the layout gx_step_slab addresses (include/guardx.h)"""
+        n = C.c_int64()
+        _native.check(self._lib.gx_step_set_floats(self._h, C.byref(n)))
+        return int(n.value)
 
     def _slab_steps(self):
         return max(1, min(self._SLAB_STEPS, self._SLAB_BYTES // (4 * self._slab_floats())))
 
     def _out_slab(self, k):
-        """`k` sets of step() outputs carved out of ONE allocation: per set (obs, obs_rd, reward, cost, done, qacc,
-        device addresses).  The views of a slab are made with six unbind() calls, not 6 k slicing operations."""
+        """`k` sets of step() outputs carved out of ONE allocation: (obs, obs_rd, reward, cost, done, qacc) tuples of k
+        views each -- six unbind() calls, not 6 k slicing operations -- and the base address; the kernel addresses set i
+        itself (gx_step_slab), so no per-set pointer objects are made."""
         N, D, nv = self.env_num, self.obs_flat_size, self.robot.nv
         Dp = (D + 3) // 4 * 4                      # keep every piece 16-byte aligned
         Np = (N + 3) // 4 * 4
-        per = self._slab_floats()
+        per = self._per_set
         flat = torch.empty(k, per, dtype=torch.float32, device=self.device)
         o = 0
         obs = flat[:, o:o + N * D].view(k, N, D).unbind(0); o += N * Dp
@@ -431,16 +492,9 @@ class Engine:
         rew = flat[:, o:o + N].unbind(0); o += Np
         cost = flat[:, o:o + N].unbind(0); o += Np
         done = flat[:, o:o + N].unbind(0); o += Np
-        qacc = flat[:, o:o + N * nv].view(k, N, nv).unbind(0) if self.emit_qacc else (None,) * k
-        base, off_rd, off_r, off_q = flat.data_ptr(), 4 * N * Dp, 8 * N * Dp, 4 * (2 * N * Dp + 3 * Np)
-        slots = []
-        vp = C.c_void_p       # ready-made ctypes arguments: no int -> c_void_p conversion per step() call
-        for i in range(k):
-            b = base + 4 * per * i
-            ptrs = (vp(b), vp(b + off_r), vp(b + off_r + 4 * Np), vp(b + off_r + 8 * Np),
-                    vp(b + off_q) if self.emit_qacc else None, vp(b + off_rd))
-            slots.append((obs[i], obs_rd[i], rew[i], cost[i], done[i], qacc[i], ptrs))
-        return slots
+        # qacc (engine.py:763-764; not part of the flat observation) is viewed on demand: (slab, set, offset, N, nv)
+        return (obs, obs_rd, rew, cost, done, (flat, o) if self.emit_qacc and self._qacc_in_info else None,
+                flat.data_ptr(), k)
 
     def step(self, action):
         """One control step for every env (engine.py:469-495).  No auto-reset.  The same launch also
@@ -451,25 +505,23 @@ class Engine:
                 and a.device == self.device and a.is_contiguous() and not a.requires_grad):
             a = self._as_action(action)
         i = self._slab_i
-        if i >= len(self._slab):
+        slab = self._slab
+        if slab is None or i >= slab[7]:
             # out_ring == 0 (default): a NEW slab -- tensors already handed out are never written again
             # (engine.py:495 returns fresh buffers); out_ring > 0: wrap around and reuse the ring
-            if not self._out_ring or not self._slab:
-                self._slab = self._out_slab(self._out_ring or self._slab_steps())
+            if not self._out_ring or slab is None:
+                slab = self._slab = self._out_slab(self._out_ring or self._slab_steps())
             i = 0
         self._slab_i = i + 1
-        obs, obs_rd, reward, cost, done, qacc, p = self._slab[i]
-        stream = self._raw_stream(self._dev_index)
-        if self._speculate:
-            st = self._gx_step_rd(self._h, a.data_ptr(), p[0], p[1], p[2], p[3], p[4], p[5], self._spec_ref, stream)
-        else:   # two-launch form (step, then reset_done on demand): debugging / A-B timing only
-            self._spec.value = 0
-            st = self._gx_step(self._h, a.data_ptr(), p[0], p[1], p[2], p[3], p[4], stream)
+        st = self._gx_step_slab(self._h, a.data_ptr(), slab[6], i, self._step_flags, self._spec_ref,
+                                self._raw_stream(self._dev_index))
         if st:
             _native.check(st)
-        self._rd_obs = obs_rd if self._spec.value else None
-        info = {'cost': cost,
-                'obs': _LazyObsDict(obs, self._obs_slices, qacc if self._qacc_in_info else None)}
+        obs, reward, cost, done = slab[0][i], slab[2][i], slab[3][i], slab[4][i]
+        self._rd_obs = slab[1][i] if self._spec.value else None
+        info = _StepInfo(cost=cost)
+        q = slab[5]
+        info._src = (obs, self._obs_slices, None if q is None else (q[0], i, q[1], self.env_num, self.robot.nv))
         self._obs, self._reward, self._done, self._info = obs, reward, done, info
         return obs, reward, done, info
 

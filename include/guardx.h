@@ -133,6 +133,16 @@ gx_status gx_step(gx_engine* e, const float* d_action, float* d_obs, float* d_re
  * thread-per-env kernels (env_num > 16384): d_obs_rd is then left unwritten and the caller uses gx_reset_done. */
 gx_status gx_step_rd(gx_engine* e, const float* d_action, float* d_obs, float* d_reward, float* d_cost,
                      float* d_done, float* d_qacc, float* d_obs_rd, int32_t* speculated, void* stream);
+/* gx_step / gx_step_rd with the outputs addressed inside ONE caller-owned allocation ("slab") of consecutive output sets:
+ * set `slot` starts at d_slab + slot * gx_step_set_floats() floats (d_slab 16-byte aligned) and holds, every piece 16-byte
+ * aligned (Dp = obs_dim rounded up to 4, Np = env_num rounded up to 4):
+ *   obs [N][D] at 0 | obs_rd [N][D] at N*Dp | reward [N] at 2*N*Dp | cost [N] at +Np | done [N] at +2*Np | qacc [N][nv] at +3*Np
+ * flags: bit 0 = write qacc, bit 1 = also evaluate obs_rd (= gx_step_rd; *speculated as there).  The host hands out
+ * views of a set and never reuses it (engine.py:495 returns fresh buffers); one pointer and an index per call instead
+ * of six addresses is what the learner-driven step()+reset_done() loop needs at env_num = 2000, where it is host bound. */
+gx_status gx_step_set_floats(const gx_engine* e, int64_t* floats);
+gx_status gx_step_slab(gx_engine* e, const float* d_action, float* d_slab, int32_t slot, int32_t flags,
+                       int32_t* speculated, void* stream);
 /* Engine.reset_done for the step just made through gx_step_rd (speculated == 1): host-only, idempotent.
  * GX_ERR_STATE if the last hot-path call was anything else. */
 gx_status gx_reset_done_commit(gx_engine* e);

@@ -1285,3 +1285,123 @@ def test_tape_handoff_with_piggybacked_sampler_pipeline(torch_cuda, expand):
     assert torch.equal(a.reset(), b.reset())                 # back on its own sampler, still in step
     assert torch.equal(a.reset(), b.reset())
     a.close(); b.close()
+
+
+# ---------------------------------------------------------------------------
+# streams and devices (SURVEY 8b "Threading / streams"): every gx_* call runs on torch's CURRENT stream of the engine's
+# device; the prefetch sampler runs on the engine's own side stream, ordered by events
+# ---------------------------------------------------------------------------
+def test_step_reset_done_rollout_on_a_side_stream(torch_cuda, oracle):
+    """reset / step / reset_done / rollout issued under torch.cuda.stream(side) -- with the actions produced on that
+    stream and the results consumed on it, no device-wide synchronisation in between -- equal the checker's, across three
+    epochs with the pool prefetch hitting (the sampler on the engine's own stream is ordered behind / in front of work
+    on a stream that is NOT the default one)."""
+    torch = torch_cuda
+    N, T = 256, 40
+    E, O = _engines(task_config(N, seed=31, num_steps=T, goal_size=2.7), oracle, n_candidates=60000)
+    side = torch.cuda.Stream()
+    rng = np.random.default_rng(7)
+    with torch.cuda.stream(side):
+        for ep in range(3):
+            np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
+            assert E.layout_size == O.layout_size
+            steps = []
+            for t in range(12):
+                a = rng.uniform(-1, 1, (N, 2)).astype(np.float32)
+                ad = torch.from_numpy(a).to('cuda', non_blocking=True) * 1.0       # produced on `side`
+                steps.append((E.step(ad), E.reset_done(), a))
+            for out, rd, a in steps:                                               # consumed on `side`, in order
+                _cmp_step(out, O.step(a))
+                np.testing.assert_array_equal(rd.cpu().numpy(), O.reset_done())
+            acts = rng.uniform(-1, 1, (T - 12, N, 2)).astype(np.float32)
+            og, rg, cg, dg = E.rollout(torch.from_numpy(acts).to('cuda', non_blocking=True))
+            for t in range(T - 12):
+                oo, ro, do, io = O.step(acts[t])
+                o2 = O.reset_done()
+                np.testing.assert_array_equal(og[t].cpu().numpy(), o2)
+                np.testing.assert_array_equal(dg[t].cpu().numpy(), do)
+                np.testing.assert_array_equal(rg[t].cpu().numpy(), ro)
+                np.testing.assert_array_equal(cg[t].cpu().numpy(), io['cost'])
+    hits, misses, _ = E.prefetch_stats()
+    assert hits == 2 and misses == 0
+    E.close()
+
+
+def test_two_engines_interleaved_on_two_streams(torch_cuda, oracle):
+    """Two engines (different seeds) in one process, each driven on its own stream, calls interleaved on the host, three
+    epochs with prefetch hits: per engine the pool ring (in use | being prefetched | referenced by a tape in flight), its
+    side stream and the pool_ready / pool_free / expand events are its own -- results equal each engine's checker, the
+    tape of epoch k expanded during epoch k + 1 on the OTHER engine's stream included."""
+    torch = torch_cuda
+    from guardx_amd import Engine
+    N, T, M = 192, 30, 50000
+    cfgs = [task_config(N, seed=41, num_steps=T, goal_size=2.6), task_config(N, seed=42, num_steps=T, goal_size=2.6, **SWIMMER)]
+    pairs = [_engines(c, oracle, n_candidates=M) for c in cfgs]
+    twins = [Engine(c, n_candidates=M) for c in cfgs]            # for the tape expansion reference (packed rows)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    rng = np.random.default_rng(9)
+    pending = [None, None]
+    for ep in range(3):
+        acts = [torch.from_numpy(rng.uniform(-1, 1, (T, N, 2)).astype(np.float32)).cuda() for _ in range(2)]
+        torch.cuda.synchronize()
+        obs = [None, None]
+        for k in (0, 1):                                          # reset both, then roll both: launches interleave
+            with torch.cuda.stream(streams[k]):
+                obs[k] = pairs[k][0].reset(check=False)
+        outs = [None, None]
+        for k in (1, 0):
+            with torch.cuda.stream(streams[k]):
+                if pending[k] is not None:                        # epoch ep-1's tape, expanded on the OTHER stream
+                    with torch.cuda.stream(streams[1 - k]):
+                        streams[1 - k].wait_stream(streams[k])
+                        sh, tok, want = pending[k]
+                        got = pairs[k][0].expand_tape(sh, tok, T)
+                        pending[k] = (got, want)
+                sh, tok = pairs[k][0].rollout_tape(acts[k])
+                outs[k] = (sh, tok)
+        torch.cuda.synchronize()
+        for k in (0, 1):
+            E, O = pairs[k]
+            np.testing.assert_array_equal(obs[k].cpu().numpy(), O.reset())
+            assert torch.equal(twins[k].reset(check=False), obs[k])
+            *_, pk = twins[k].rollout(acts[k], packed=True)
+            if pending[k] is not None:
+                got, want = pending[k]
+                assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (ep, k)
+            pending[k] = (outs[k][0], outs[k][1], pk)
+            a = acts[k].cpu().numpy()
+            for t in range(T):
+                _, _, d, _ = O.step(a[t]); O.reset_done()
+            np.testing.assert_array_equal(pk[-1, :, -1].cpu().numpy(), d)         # last done column of the packed rows
+            st, so = E.get_state(), O.get_state()
+            assert_state_equal(st, so)
+    for k in (0, 1):
+        E = pairs[k][0]
+        E.check_layouts()
+        assert E.prefetch_stats()[:2] == (2, 0)
+        E.close(); twins[k].close()
+
+
+def test_engine_on_a_second_device_while_the_first_is_current(torch_cuda, oracle):
+    """Engine(device_id=1) created and driven while cuda:0 is the current device (every gx_* call switches to the handle's
+    device and back): results equal the checker's; tensors live on cuda:1.  Skipped on a one-GPU box."""
+    torch = torch_cuda
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two HIP devices")
+    from guardx_amd import Engine
+    torch.cuda.set_device(0)
+    N = 128
+    cfg = task_config(N, seed=5, num_steps=30, goal_size=2.5, device_id=1)
+    E = Engine(cfg, n_candidates=30000)
+    O = oracle.OracleEngine(cfg, n_candidates=30000)
+    assert torch.cuda.current_device() == 0
+    o = E.reset()
+    assert o.device == torch.device('cuda', 1) and torch.cuda.current_device() == 0
+    np.testing.assert_array_equal(o.cpu().numpy(), O.reset())
+    rng = np.random.default_rng(1)
+    for t in range(35):
+        a = rng.uniform(-1, 1, (N, 2)).astype(np.float32)
+        _cmp_step(E.step(torch.from_numpy(a).to('cuda:1')), O.step(a))
+        np.testing.assert_array_equal(E.reset_done().cpu().numpy(), O.reset_done())
+    assert torch.cuda.current_device() == 0
+    E.close()

@@ -40,3 +40,19 @@ t(lambda: lib.gx_step(env._h, act.data_ptr(), obs.data_ptr(), r.data_ptr(), c.da
 t(lambda: lib.gx_reset_done(env._h, obs.data_ptr(), obs.data_ptr(), st), "raw gx_reset_done ctypes call")
 t(lambda: lib.gx_obs_dim(env._h), "trivial ctypes call")
 t(lambda: act.data_ptr(), "data_ptr()")
+
+# the pair an unmodified learner drives, by output ownership mode (round 4: slab sized by bytes)
+from guardx_amd import Engine
+tape = bench.action_tape(bench.EP_LEN, 2000, 0, dev)
+for ring, slab in ((0, 256), (0, 32), (8, 256)):
+    e2 = bench.make_engine(2000, 0, 1)
+    e2._out_ring = ring
+    e2._SLAB_STEPS = slab
+    e2.set_prefetch(bench.EP_LEN)
+    rates = sorted(bench.api_loop_rate(e2, tape, 2000) for _ in range(5))
+    print(f"api loop out_ring={ring} slab cap {slab}: median {rates[2]/1e6:.1f} M  best {rates[-1]/1e6:.1f} M env-steps/s  "
+          f"({2000/rates[2]*1e6:.2f} us per step()+reset_done() pair)   slab steps {e2._slab_steps()}")
+    t(lambda: e2.step(act), "  step() alone, outputs dropped")
+    keep = []
+    t(lambda: keep.append(e2.step(act)[0]) or (len(keep) > 400 and keep.clear()), "  step() alone, outputs kept (400)")
+    e2.close()
