@@ -407,15 +407,16 @@ def valu_issue_floor():
                     "SIMDs; compare with the headline ms_per_step"}
 
 
-def closed_loop_rate(device, epochs=50):
-    """reset() + ONE rollout_policy launch per epoch: the (64,64)-tanh actor-critic of
-    trpo_core.py:110-173 (random init) evaluated inside the persistent kernel."""
+def closed_loop_rate(device, epochs=50, hidden=64):
+    """reset() + rollout_policy per epoch: the (h, h)-tanh actor-critic of trpo_core.py:110-173 (random init) evaluated on
+    device.  h = 64 (the reference default): ONE launch per 200-step rollout; wider networks
+    (trpo.py:606 --hid): two launches per control step."""
     from guardx_amd import Engine
     env = make_engine(ENV_NUM, 0, 1)
     D = env.obs_flat_size
     torch.manual_seed(0)
-    mk = lambda out: torch.nn.Sequential(torch.nn.Linear(D, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64),  # noqa: E731
-                                         torch.nn.Tanh(), torch.nn.Linear(64, out))
+    mk = lambda out: torch.nn.Sequential(torch.nn.Linear(D, hidden), torch.nn.Tanh(), torch.nn.Linear(hidden, hidden),  # noqa: E731
+                                         torch.nn.Tanh(), torch.nn.Linear(hidden, out))
     params = Engine.pack_actor_critic(mu_net=mk(2), v_net=mk(1), log_std=torch.full((2,), -0.5)).to(device)
 
     def epoch():
@@ -740,6 +741,8 @@ def main():
             extra("api_step_loop_env_steps_per_s", lambda: api_loop_summary(env, tapes[0]))
             extra("epoch_breakdown", lambda: epoch_breakdown(device))
             extra("closed_loop_policy_env_steps_per_s", lambda: round(closed_loop_rate(device), 1))
+            extra("closed_loop_policy_wider_env_steps_per_s",
+                  lambda: {f"hidden_{h}": round(closed_loop_rate(device, 20, h), 1) for h in (128, 256)})
             extra("reset_done_heavy", lambda: reset_done_heavy(device))
             extra("other_robots", lambda: other_robots(device))
         if world == 1 and not args.no_cpu_baseline:

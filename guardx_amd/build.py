@@ -17,7 +17,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB = os.path.join(LIB_DIR, "libguardx_hip.so")
 # one translation unit per robot (gx_robot_kernels.inl instantiated for it), compiled in parallel
-SOURCES = ["gx_api.hip", "gx_kernels.hip", "gx_gae.hip", "gx_kernels_point.hip", "gx_kernels_point_bare.hip", "gx_kernels_swimmer.hip",
+SOURCES = ["gx_api.hip", "gx_kernels.hip", "gx_gae.hip", "gx_policy_step.hip", "gx_kernels_point.hip", "gx_kernels_point_bare.hip", "gx_kernels_swimmer.hip",
            "gx_kernels_ant.hip", "gx_kernels_walker.hip"]
 HEADERS = ["gx_device.h", "gx_robot.h", "gx_robot_ant.h", "gx_robot_ant_group.h", "gx_robot_legs.h", "gx_robot_legs_group.h", "gx_policy.h", "gx_kernels.h", "gx_robot_kernels.inl",
            "gx_split_rollout.inl", os.path.join("..", "..", "include", "guardx.h")]

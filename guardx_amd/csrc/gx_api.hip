@@ -94,6 +94,10 @@ struct gx_engine {
     int keys_cap[kKeyRing];
     hipEvent_t keys_ev[kKeyRing];
     int keys_next;
+    // step-wise policy rollout (hidden widths beyond the fused kernel's): transposed weights, current observation
+    float* pol_wt = nullptr;
+    size_t pol_wt_cap = 0;
+    float* pol_cur = nullptr;
     // ---- sharded layout sampling ----
     // gx_sample_shard -> gx_reset_from_shards: the pool and key the last shard was sampled for (claim_pool done there)
     bool rs_sampled = false;
@@ -422,7 +426,7 @@ extern "C" gx_status gx_destroy(gx_engine* e)
     if (!e) return GX_OK;
     DeviceGuard guard(e->device);
     (void)hipDeviceSynchronize();
-    void* bufs[] = {e->b.dyn, e->b.obj, e->b.hist, e->b.rd_j, e->haz_bounds, e->tape, e->obj0};
+    void* bufs[] = {e->b.dyn, e->b.obj, e->b.hist, e->b.rd_j, e->haz_bounds, e->tape, e->obj0, e->pol_wt, e->pol_cur};
     for (void* q : bufs)
         if (q) (void)hipFree(q);
     for (int i = 0; i < gx_engine::kPools; ++i) {
@@ -1152,6 +1156,68 @@ extern "C" gx_status gx_expand_tapes(gx_engine* e, int32_t T, const float* d_sha
     return expand_impl(e, T, d_shards, stride_floats, n_shards, token, d_packed, packed_stride_floats, stream);
 }
 
+// Hidden widths whose weights do not fit the fused kernel's LDS (128, 256; also 64 with gx_set_policy_impl(e, 3), as a
+// cross-check): per control step one policy launch over all envs (gx_policy_step.hip) and the ordinary fused
+// step + reset_done launch -- the loop of oracle/gx_oracle.c:gxo_rollout_policy, the arithmetic of the fused kernel.
+static gx_status rollout_policy_stepwise(gx_engine* e, int32_t T, const gx_policy* pol, const float* d_obs0, float* d_obs_in,
+                                         float* d_act, float* d_logp, float* d_val, float* d_mu, float* d_reward,
+                                         float* d_cost, float* d_done, float* d_obs_last, float* d_val_last, float* d_logstd,
+                                         void* stream)
+{
+    const int H = pol->hidden;
+    if (!policy_step_supported(H))
+        return fail(GX_ERR_UNSUPPORTED, "gx_rollout_policy: hidden_sizes must be (64, 64), (128, 128), (192, 192) or (256, 256)");
+    if ((e->na & 1) || e->na > 16) return fail(GX_ERR_UNSUPPORTED, "gx_rollout_policy: needs an even action width <= 16");
+    if (reinterpret_cast<uintptr_t>(d_act) & 7u) return fail(GX_ERR_ARG, "gx_rollout_policy: d_act must be 8-byte aligned");
+    DeviceGuard guard(e->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int N = e->p.N, D = e->p.D, A = e->na;
+    const size_t need = (size_t)policy_step_wt_floats(D, H);
+    if (need > e->pol_wt_cap) {
+        GX_HIP(hipStreamSynchronize(s));
+        if (e->pol_wt) (void)hipFree(e->pol_wt);
+        e->pol_wt = nullptr; e->pol_wt_cap = 0;
+        GX_HIP(hipMalloc((void**)&e->pol_wt, sizeof(float) * need));
+        e->pol_wt_cap = need;
+    }
+    if (!e->pol_cur) GX_HIP(hipMalloc((void**)&e->pol_cur, sizeof(float) * (size_t)N * D));
+    int slot; uint32_t k0, k1;
+    gx_status st = stage_rollout_keys(e, T, slot, k0, k1);
+    if (st != GX_OK) return st;
+    launch_policy_transpose(pol->d_params, e->pol_wt, D, A, H, s);
+    GX_HIP(hipMemcpyAsync(e->pol_cur, d_obs0, sizeof(float) * (size_t)N * D, hipMemcpyDeviceToDevice, s));
+    const bool group = use_group_path(e);
+    if (!group) { st = flush_pending(e, s); if (st != GX_OK) return st; }
+    for (int32_t t = 0; t < T; ++t) {
+        const size_t tn = (size_t)t * N;
+        launch_policy_step(H, pol->d_params, e->pol_wt, e->pol_cur, pol->seed[0], pol->seed[1], e->policy_steps + (uint32_t)t, N, D,
+                           A, e->p.env_offset, 0, d_obs_in + tn * D, d_act + tn * A, d_mu + tn * A, d_logp + tn, d_val + tn,
+                           nullptr, d_logstd, s);
+        RolloutArgs r;
+        fill_rollout_args(e, r, 1, slot);
+        r.keys = e->h_keys[slot] + t;          // this step's reset_done key (engine.py:431,447,500)
+        r.act = d_act + tn * A;
+        r.obs = e->pol_cur;                    // the post-reset_done observation feeds the next policy step (trpo.py:547)
+        r.rew = d_reward + tn; r.cost = d_cost + tn; r.done = d_done + tn; r.qacc = nullptr;
+        if (group) {
+            r.commit = t == 0 ? take_commit(e) : 0;
+            launch_group_rollout(e->p, r, e->b, s);
+        } else {
+            launch_thread_rollout(e->p, r, e->b, s);
+        }
+        if (e->hist < 2) e->hist++;
+    }
+    launch_policy_step(H, pol->d_params, e->pol_wt, e->pol_cur, pol->seed[0], pol->seed[1], 0u, N, D, A, e->p.env_offset, 1,
+                       nullptr, nullptr, nullptr, nullptr, d_val_last, d_obs_last, nullptr, s);
+    e->last_policy = false; // (the open-loop kernels ran: the prefetch sampler keeps its back-to-back chain)
+    GX_HIP(hipEventRecord(e->keys_ev[slot], s));
+    GX_HIP(hipGetLastError());
+    e->key[0] = k0; e->key[1] = k1;
+    e->steps_since_reset += T;
+    e->policy_steps += (uint32_t)T;
+    return GX_OK;
+}
+
 extern "C" gx_status gx_rollout_policy(gx_engine* e, int32_t T, const gx_policy* pol, const float* d_obs0,
                                        float* d_obs_in, float* d_act, float* d_logp, float* d_val,
                                        float* d_mu, float* d_reward, float* d_cost, float* d_done,
@@ -1163,8 +1229,9 @@ extern "C" gx_status gx_rollout_policy(gx_engine* e, int32_t T, const gx_policy*
     if (pol->struct_size != (int32_t)sizeof(gx_policy) || !pol->d_params)
         return fail(GX_ERR_ARG, "gx_policy.struct_size mismatch or null parameters");
     if (!e->have_reset) return fail(GX_ERR_STATE, "gx_rollout_policy before gx_reset");
-    if (pol->hidden != kPolHd)
-        return fail(GX_ERR_UNSUPPORTED, "gx_rollout_policy: hidden_sizes must be (64, 64) (the reference default)");
+    if (pol->hidden != kPolHd || e->policy_impl == 3)
+        return rollout_policy_stepwise(e, T, pol, d_obs0, d_obs_in, d_act, d_logp, d_val, d_mu, d_reward, d_cost, d_done,
+                                       d_obs_last, d_val_last, d_logstd, stream);
     if (!policy_rollout_supported(e->p) || (e->na & 1) || e->na > 16 || e->p.N > 65536)
         return fail(GX_ERR_UNSUPPORTED, "gx_rollout_policy: needs hazards_num <= 15, lidar_num_bins <= 16, env_num <= 65536");
     const int impl = e->policy_impl == 1 ? 1 : 2; // auto = MFMA
@@ -1197,7 +1264,7 @@ extern "C" gx_status gx_rollout_policy(gx_engine* e, int32_t T, const gx_policy*
 
 extern "C" gx_status gx_set_policy_impl(gx_engine* e, int32_t impl)
 {
-    if (!e || impl < 0 || impl > 2) return fail(GX_ERR_ARG, "gx_set_policy_impl: 0 auto, 1 VALU, 2 MFMA");
+    if (!e || impl < 0 || impl > 3) return fail(GX_ERR_ARG, "gx_set_policy_impl: 0 auto, 1 VALU, 2 MFMA, 3 step-wise");
     e->policy_impl = impl;
     return GX_OK;
 }

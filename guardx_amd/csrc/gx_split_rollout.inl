@@ -53,6 +53,8 @@ struct SplitArgs {
 
 GX_D bool moderate(float x) { return fabsf(x) < 1e18f; } // false for NaN / Inf too
 constexpr int kActBlock = 16; // steps whose actions the dynamics pass fetches at once
+constexpr int kObsGridCap = 3072; // one-wave workgroups of a ONE-shard observation launch (measured: 47.1 -> 44.2 us at 400 000 rows; a launch over
+                                  // several shards is fastest uncapped: 32.5 us per shard at 8 shards)
 
 template <int W>
 GX_D void load_row(const float* __restrict__ p, float (&v)[W])
@@ -254,6 +256,11 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
             const float2 g = rowp[0], rb = rowp[r.nobj_total - 1];
             nq0 = rb.x; nq1 = rb.y;
             gx = g.x; gy = g.y;
+            // The loads of this RARE branch must have landed before it ends: otherwise the compiler guards the next
+            // step's first touch of these registers with an s_waitcnt vmcnt(3) on the COMMON path -- and the memory
+            // counter is in order, so that wait also covers the tape stores of the step before the previous one: a
+            // store round trip on the serial chain of almost every step, for a load that almost never happened.
+            asm volatile("" : "+v"(nq0), "+v"(nq1), "+v"(gx), "+v"(gy));
         }
 
         // tape row
@@ -530,6 +537,20 @@ GX_D void next_start(const float (&rowv)[SplitTape<R>::kW], const RolloutArgs& r
     }
 }
 
+// LDS tile hand-over inside a workgroup: a single wave executes its LDS operations in program order, so only the
+// compiler has to keep the order (wave-scope fence over the LDS address space: no instruction, no wait for global stores)
+template <int BLOCK>
+GX_D void tile_sync()
+{
+    if (BLOCK == 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    } else {
+        __syncthreads();
+    }
+}
+
 template <class R, int BLOCK, int PMAX, bool kDef>
 __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArgs r, SplitArgs sa)
 {
@@ -545,17 +566,24 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
         r.obs += (size_t)blockIdx.y * (size_t)sa.out_stride;
     }
     const size_t G = (size_t)r.T * p.N;
-    const size_t g0 = (size_t)blockIdx.x * BLOCK, g = g0 + tid;
-    const bool live = g < G;
-    const size_t gg = live ? g : 0;
-    const int i = (int)(gg % (size_t)p.N);
-    const int t = (int)(gg / (size_t)p.N);
     const int RS = r.obs_stride;
     const bool packed = r.act_out != nullptr;
     // LDS row stride: RS + 1 when RS is a multiple of 4 floats (48 for the Point's packed rows: 64 rows on 4 banks,
     // 16-way conflicts on every row write); other widths conflict 2-way at worst and keep the contiguous tile
     const int LS = (RS & 3) ? RS : RS + 1;
     float* row = tile + tid * LS;
+    // GRID-STRIDE over the 64-row tiles (round 4).  With one tile per workgroup every wave of a launch goes through the same
+    // three phases at about the same time -- tape loads, ~1 800 VALU instructions, a 12 KB burst of row stores; with a
+    // capped grid (obs_grid) a wave's stores of tile k drain while it computes tile k + 1 (single-wave workgroups: the LDS
+    // tile is reused behind a wave-scope fence, which -- unlike __syncthreads -- does not wait for the stores to be
+    // acknowledged).  Measured gain at 400 000 rows: 6 % (47.1 -> 44.2 us with 3072 workgroups); a launch over several
+    // shards already has that overlap between its tiles and is fastest uncapped.
+    for (size_t g0 = (size_t)blockIdx.x * BLOCK; g0 < G; g0 += (size_t)gridDim.x * BLOCK) {
+    const size_t g = g0 + tid;
+    const bool live = g < G;
+    const size_t gg = live ? g : 0;
+    const int i = (int)(gg % (size_t)p.N);
+    const int t = (int)(gg / (size_t)p.N);
 
     float rowv[TP::kW], ev[TP::kE];
     load_row<TP::kW>(sa.tape + gg * TP::kW, rowv);
@@ -655,7 +683,7 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
     } else if (live) {
         r.rew[g] = rw; r.cost[g] = cs; r.done[g] = dn;
     }
-    __syncthreads();
+    tile_sync<BLOCK>();
     const size_t left = G - g0;
     const int nrow = left < (size_t)BLOCK ? (int)left : BLOCK;
     if (LS == RS) flush_tile<BLOCK>(tile, r.obs + g0 * RS, nrow * RS);
@@ -663,6 +691,21 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
     else {
         for (int k = tid; k < nrow * RS; k += BLOCK) { const int rw_ = k / RS; r.obs[g0 * RS + k] = tile[rw_ * LS + (k - rw_ * RS)]; }
     }
+    tile_sync<BLOCK>(); // the tile is rewritten by the next iteration
+    }
+}
+
+// workgroups of the observation pass per shard: enough to fill the chip a few waves deep, few enough that every wave
+// takes several tiles in turn (GX_OBS_GRID_CAP: experiments)
+static unsigned obs_grid(size_t rows, int block, int n_shards)
+{
+    static const int forced = [] { const char* e = getenv("GX_OBS_GRID_CAP"); return e ? atoi(e) : 0; }();
+    const size_t tiles = (rows + block - 1) / block;
+    if (forced <= 0 && n_shards > 1) return (unsigned)tiles;
+    size_t cap = forced > 0 ? (size_t)forced : (size_t)kObsGridCap;
+    cap = (cap + n_shards - 1) / n_shards;
+    if (cap < 1) cap = 1;
+    return (unsigned)(tiles < cap ? tiles : cap);
 }
 
 // which: bit 0 = the dynamics pass, bit 1 = the observation pass (gx_rollout: both; the tape hand-off runs them on
@@ -674,7 +717,7 @@ static hipError_t launch_split_p(const Params& p, const RolloutArgs& r, const Sp
     hipError_t st = hipSuccess; // of the wait that orders the observation pass behind the sampler: must not be dropped
     constexpr int B1 = 64, B2 = 64;
     const int lpe = (R::kDynLanes == 4 && sa.lanes == 4) ? 4 : 1;
-    const dim3 g1((p.N * lpe + B1 - 1) / B1), g2((unsigned)(((size_t)r.T * p.N + B2 - 1) / B2), n_shards);
+    const dim3 g1((p.N * lpe + B1 - 1) / B1), g2(obs_grid((size_t)r.T * p.N, B2, n_shards), n_shards);
     const size_t lds1 = sizeof(float) * ((size_t)B1 * p.D + 2 * (size_t)kActBlock * B1 * R::NA); // obs rows + two action blocks
     const size_t lds2 = sizeof(float) * (size_t)B2 * (r.obs_stride | 1);
     const bool def = PMAX == 5 && is_default_layout<R>(p);
@@ -706,7 +749,7 @@ static hipError_t launch_split_group_p(const Params& p, const RolloutArgs& r, co
 {
     hipError_t st = hipSuccess;
     constexpr int B2 = 64;
-    const dim3 g1((p.N + 3) / 4), g2((unsigned)(((size_t)r.T * p.N + B2 - 1) / B2), n_shards);
+    const dim3 g1((p.N + 3) / 4), g2(obs_grid((size_t)r.T * p.N, B2, n_shards), n_shards);
     const size_t lds2 = sizeof(float) * (size_t)B2 * (r.obs_stride | 1);
     if (which & 1) {
 #define GX_GDYN_LAUNCH(OPL, BPL, DEF) \

@@ -719,27 +719,39 @@ class Engine:
     # ------------------------------------------------------------------
     # closed-loop fused rollout (policy evaluated inside the kernel)
     # ------------------------------------------------------------------
+    POLICY_HIDDEN = (64, 128, 192, 256)
+
     @staticmethod
     def pack_actor_critic(ac=None, *, mu_net=None, v_net=None, log_std=None, device=None):
-        """Flatten MLPActorCritic(hidden_sizes=(64,64), tanh) weights (trpo_core.py:110-164) into the
-        layout gx_rollout_policy expects.  `ac` needs .pi.mu_net, .pi.log_std, .v.v_net
-        (nn.Sequential of Linear/Tanh/Linear/Tanh/Linear[/Identity]); or pass the three pieces."""
+        """Flatten MLPActorCritic(hidden_sizes=(h, h), tanh) weights (trpo_core.py:110-164; h = 64 is the reference
+        default, trpo.py:606-607 --hid / --l) into the layout gx_rollout_policy expects.  `ac` needs .pi.mu_net,
+        .pi.log_std, .v.v_net (nn.Sequential of Linear/Tanh/Linear/Tanh/Linear[/Identity]); or pass the three pieces."""
         if ac is not None:
             mu_net, v_net, log_std = ac.pi.mu_net, ac.v.v_net, ac.pi.log_std
-        parts = []
+        parts, widths = [], set()
         for net in (mu_net, v_net):
             lin = [m for m in net if isinstance(m, torch.nn.Linear)]
-            if len(lin) != 3 or lin[0].out_features != 64 or lin[1].out_features != 64:
-                raise NotImplementedError("rollout_policy supports hidden_sizes=(64, 64) (the reference default)")
+            if len(lin) != 3 or lin[0].out_features != lin[1].out_features or lin[1].in_features != lin[0].out_features:
+                raise NotImplementedError("rollout_policy supports two hidden layers of equal width (--l 2)")
+            widths.add(lin[0].out_features)
             for m in lin:
                 parts += [m.weight.detach().reshape(-1), m.bias.detach().reshape(-1)]
+        if len(widths) != 1 or widths.pop() not in Engine.POLICY_HIDDEN:
+            raise NotImplementedError(f"rollout_policy supports hidden_sizes (h, h) with h in {Engine.POLICY_HIDDEN}, "
+                                      "the same for actor and critic")
         parts.append(torch.as_tensor(log_std).detach().reshape(-1))
         flat = torch.cat([t.to(torch.float32) for t in parts])
         return flat.to(device) if device is not None else flat
 
+    @staticmethod
+    def _policy_floats(D, A, h):
+        return 2 * (h * D + h + h * h + h) + (A + 1) * h + (A + 1) + A
+
     def rollout_policy(self, params, T, obs0=None, noise_seed=(0, 0)):
-        """T x (ac.step -> env.step -> reset_done) in ONE kernel launch (trpo.py:466-547 with the
-        actor-critic of trpo_core.py:110-173 evaluated on device).  `params` = pack_actor_critic(ac).
+        """T x (ac.step -> env.step -> reset_done) on device (trpo.py:466-547 with the actor-critic of
+        trpo_core.py:110-173 evaluated there).  `params` = pack_actor_critic(ac); the hidden width is read off its
+        size.  h = 64: ONE kernel launch for the whole rollout; h = 128 / 192 / 256 (the weights do not fit the fused
+        kernel's LDS): two launches per control step, same results.
         Returns a dict of time-major tensors: obs (T,N,D) [what the policy saw], act, mu (T,N,A),
         logp, val, rew, cost, done (T,N), plus obs_last (N,D), val_last (N,), logstd (A,)."""
         if obs0 is None:
@@ -750,18 +762,19 @@ class Engine:
         params = params.to(device=self.device, dtype=torch.float32).contiguous()
         obs0 = obs0.to(device=self.device, dtype=torch.float32).contiguous()
         assert tuple(obs0.shape) == (N, D)
+        hidden = next((h for h in self.POLICY_HIDDEN if self._policy_floats(D, A, h) == params.numel()), None)
+        if hidden is None:
+            raise ValueError(f"params has {params.numel()} floats; expected one of "
+                             f"{[self._policy_floats(D, A, h) for h in self.POLICY_HIDDEN]} (hidden {self.POLICY_HIDDEN})")
         self._rd_obs = None
         out = dict(obs=self._new(T, N, D), act=self._new(T, N, A), logp=self._new(T, N), val=self._new(T, N),
                    mu=self._new(T, N, A), rew=self._new(T, N), cost=self._new(T, N), done=self._new(T, N),
                    obs_last=self._new(N, D), val_last=self._new(N), logstd=self._new(A))
         pol = _native.GxPolicy()
         pol.struct_size = C.sizeof(_native.GxPolicy)
-        pol.hidden = 64
+        pol.hidden = hidden
         pol.d_params = params.data_ptr()
         pol.seed[0], pol.seed[1] = int(noise_seed[0]) & 0xFFFFFFFF, int(noise_seed[1]) & 0xFFFFFFFF
-        expect = 2 * (64 * D + 64 + 64 * 64 + 64) + (A + 1) * 64 + (A + 1) + A
-        if params.numel() != expect:
-            raise ValueError(f"params has {params.numel()} floats, expected {expect}")
         _native.check(self._lib.gx_rollout_policy(
             self._h, T, C.byref(pol), obs0.data_ptr(), out['obs'].data_ptr(), out['act'].data_ptr(),
             out['logp'].data_ptr(), out['val'].data_ptr(), out['mu'].data_ptr(), out['rew'].data_ptr(),
@@ -772,7 +785,8 @@ class Engine:
         return out
 
     def set_policy_impl(self, impl):
-        """rollout_policy hidden layers: 0 auto, 1 VALU fmaf chains, 2 fp32 MFMA tiles (same bits)."""
+        """rollout_policy hidden layers at width 64: 0 auto, 1 VALU fmaf chains, 2 fp32 MFMA tiles, 3 the step-wise form
+        the wider networks use (same bits)."""
         _native.check(self._lib.gx_set_policy_impl(self._h, int(impl)))
 
     def set_prefetch(self, steps):

@@ -251,7 +251,9 @@ gx_status gx_install_shards(gx_engine* e, int64_t ticket, const float* d_blocks,
  * d_obs_last[N][D], d_val_last[N] = o_T and V(o_T) for the bootstrap; d_logstd[A] = log(std). */
 typedef struct gx_policy {
     int32_t struct_size;   /* sizeof(gx_policy) */
-    int32_t hidden;        /* 64 */
+    int32_t hidden;        /* 64 (the reference default, trpo.py:606 --hid): one fused launch; 128, 192, 256: the weights
+                            * do not fit the fused kernel's LDS -- two launches per control step (policy over all envs,
+                            * then the fused step + reset_done), same arithmetic, same results as the checker */
     const float* d_params; /* device pointer, layout above */
     uint32_t seed[2];
 } gx_policy;
@@ -260,7 +262,8 @@ gx_status gx_rollout_policy(gx_engine* e, int32_t T, const gx_policy* pol, const
                             float* d_reward, float* d_cost, float* d_done, float* d_obs_last,
                             float* d_val_last, float* d_logstd, void* stream);
 /* How the two hidden layers are evaluated: 0 auto (= 2), 1 VALU fmaf chains with one wave per
- * workgroup, 2 v_mfma_f32_16x16x4_f32 tiles with 16 envs per workgroup.  Bit-identical results. */
+ * workgroup, 2 v_mfma_f32_16x16x4_f32 tiles with 16 envs per workgroup, 3 the step-wise form the wider networks use
+ * (two launches per control step; available at hidden = 64 as a cross-check).  Bit-identical results. */
 gx_status gx_set_policy_impl(gx_engine* e, int32_t impl);
 gx_status gx_math_probe2(int32_t n, const float* d_x, float* d_log, float* d_tanh, void* stream);
 

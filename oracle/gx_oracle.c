@@ -1059,34 +1059,38 @@ int gxo_get_pool(const gxo_env* e, float* pool, int32_t max_rows)
 /* ------------------------------------------------------------------ */
 /* closed-loop rollout with an on-device policy      */
 /* `ac.step(o)` of safe_rl_libX/trpo/trpo_core.py:110-173 for           */
-/* MLPActorCritic(hidden_sizes=(64,64), tanh): Gaussian actor with a    */
+/* MLPActorCritic(hidden_sizes=(hd,hd), tanh): Gaussian actor with a    */
 /* state-independent log_std, MLP critic.  The noise is our own         */
 /* counter-based stream (the reference uses torch's global generator).  */
 /* params: pi{W1[Hd][D] b1 W2[Hd][Hd] b2 W3[A][Hd] b3} v{.. W3[1][Hd] b3} log_std[A] */
 /* ------------------------------------------------------------------ */
-#define POL_HD 64
+#define POL_HD_MAX 256
 
-static void mlp_forward(const float* w, const float* x, int D, int Out, float* out)
+/* hd = hidden width: 64 (the reference default, trpo.py:606 --hid), 128 or 256 (any multiple of 64 up to POL_HD_MAX).
+ * Hidden units: one sequential fmaf chain over the inputs each.  Output layer: 16 partial sums -- partial l takes the
+ * units 64 c + 4 l + j (c = 0 .. hd/64 - 1, j = 0 .. 3) in that order -- folded by a butterfly (xor 8, 4, 2, 1): the
+ * order in which the 16 lanes that own an env combine their shares in the kernels (gx_policy.h, gx_policy_step.hip). */
+static void mlp_forward(const float* w, const float* x, int D, int Out, int hd, float* out)
 {
-    const float *W1 = w, *b1 = W1 + POL_HD * D, *W2 = b1 + POL_HD, *b2 = W2 + POL_HD * POL_HD;
-    const float *W3 = b2 + POL_HD, *b3 = W3 + Out * POL_HD;
-    float h1[POL_HD], h2[POL_HD];
-    for (int j = 0; j < POL_HD; ++j) {
+    const float *W1 = w, *b1 = W1 + hd * D, *W2 = b1 + hd, *b2 = W2 + hd * hd;
+    const float *W3 = b2 + hd, *b3 = W3 + Out * hd;
+    float h1[POL_HD_MAX], h2[POL_HD_MAX];
+    for (int j = 0; j < hd; ++j) {
         float acc = b1[j];
         for (int k = 0; k < D; ++k) acc = fmaf(x[k], W1[j * D + k], acc);
         h1[j] = gx_tanh(acc);
     }
-    for (int j = 0; j < POL_HD; ++j) {
+    for (int j = 0; j < hd; ++j) {
         float acc = b2[j];
-        for (int k = 0; k < POL_HD; ++k) acc = fmaf(h1[k], W2[j * POL_HD + k], acc);
+        for (int k = 0; k < hd; ++k) acc = fmaf(h1[k], W2[j * hd + k], acc);
         h2[j] = gx_tanh(acc);
     }
     for (int o = 0; o < Out; ++o) {
-        /* 16 lane partials over units 4l..4l+3, then a butterfly (xor 8,4,2,1) */
         float pl[16], ql[16];
         for (int l = 0; l < 16; ++l) {
             float pp = 0.0f;
-            for (int c = 0; c < 4; ++c) pp = fmaf(h2[4 * l + c], W3[o * POL_HD + 4 * l + c], pp);
+            for (int c = 0; 64 * c < hd; ++c)
+                for (int j = 0; j < 4; ++j) pp = fmaf(h2[64 * c + 4 * l + j], W3[o * hd + 64 * c + 4 * l + j], pp);
             pl[l] = pp;
         }
         for (int off = 8; off >= 1; off >>= 1) {
@@ -1097,7 +1101,7 @@ static void mlp_forward(const float* w, const float* x, int D, int Out, float* o
     }
 }
 
-static int mlp_size(int D, int Out) { return POL_HD * D + POL_HD + POL_HD * POL_HD + POL_HD + Out * POL_HD + Out; }
+static int mlp_size(int D, int Out, int hd) { return hd * D + hd + hd * hd + hd + Out * hd + Out; }
 
 /* two standard normals from one Threefry block keyed by `seed`, counter (global env, step*16+pair) */
 static void normal_pair(const uint32_t seed[2], uint32_t env, uint32_t ctr, float* z0, float* z1)
@@ -1118,11 +1122,11 @@ int gxo_rollout_policy(gxo_env* e, int32_t T, int32_t hidden, const float* param
                        float* mu_out, float* rew, float* cost, float* done, float* obs_last, float* val_last,
                        float* logstd_out)
 {
-    if (hidden != POL_HD) return GXO_ERR_UNSUPPORTED;
-    const int N = e->N, D = e->D, A = e->na;
+    if (hidden < 64 || hidden > POL_HD_MAX || (hidden & 63)) return GXO_ERR_UNSUPPORTED;
+    const int N = e->N, D = e->D, A = e->na, hd = hidden;
     const float* wpi = params;
-    const float* wv = params + mlp_size(D, A);
-    const float* log_std = wv + mlp_size(D, 1);
+    const float* wv = params + mlp_size(D, A, hd);
+    const float* log_std = wv + mlp_size(D, 1, hd);
     float std[16], lstd[16];
     for (int d = 0; d < A; ++d) { std[d] = gx_exp(log_std[d]); lstd[d] = gx_log(std[d]); logstd_out[d] = lstd[d]; }
     float* cur = (float*)malloc((size_t)N * D * 4);
@@ -1134,8 +1138,8 @@ int gxo_rollout_policy(gxo_env* e, int32_t T, int32_t hidden, const float* param
         memcpy(&obs_in[(size_t)t * N * D], cur, (size_t)N * D * 4);
         for (int i = 0; i < N; ++i) {
             float m[16], v1[1], z[16];
-            mlp_forward(wpi, &cur[(size_t)i * D], D, A, m);
-            mlp_forward(wv, &cur[(size_t)i * D], D, 1, v1);
+            mlp_forward(wpi, &cur[(size_t)i * D], D, A, hd, m);
+            mlp_forward(wv, &cur[(size_t)i * D], D, 1, hd, v1);
             for (int pr = 0; 2 * pr < A; ++pr)
                 normal_pair(seed, (uint32_t)(e->cfg.env_offset + i), (t0 + (uint32_t)t) * 16u + (uint32_t)pr,
                             &z[2 * pr], &z[2 * pr + 1]);
@@ -1160,7 +1164,7 @@ int gxo_rollout_policy(gxo_env* e, int32_t T, int32_t hidden, const float* param
     memcpy(obs_last, cur, (size_t)N * D * 4);
     for (int i = 0; i < N; ++i) {
         float v1[1];
-        mlp_forward(wv, &cur[(size_t)i * D], D, 1, v1);
+        mlp_forward(wv, &cur[(size_t)i * D], D, 1, hd, v1);
         val_last[i] = v1[0];
     }
     free(cur); free(nxt); free(a_t); free(qa);

@@ -227,7 +227,7 @@ class OracleEngine:
         assert rc == 0, rc
         return obs
 
-    def rollout_policy(self, params, T, obs0, noise_seed=(0, 0), t0=0):
+    def rollout_policy(self, params, T, obs0, noise_seed=(0, 0), t0=0, hidden=64):
         N, D, A = self.N, self.D, self.na
         params = np.ascontiguousarray(params, np.float32)
         obs0 = np.ascontiguousarray(obs0, np.float32)
@@ -237,7 +237,7 @@ class OracleEngine:
                    cost=np.empty((T, N), f), done=np.empty((T, N), f), obs_last=np.empty((N, D), f),
                    val_last=np.empty(N, f), logstd=np.empty(A, f))
         seed = (C.c_uint32 * 2)(int(noise_seed[0]), int(noise_seed[1]))
-        rc = self.L.gxo_rollout_policy(self.h, T, 64, _fp(params), seed, t0, _fp(obs0), *[_fp(out[k]) for k in
+        rc = self.L.gxo_rollout_policy(self.h, T, int(hidden), _fp(params), seed, t0, _fp(obs0), *[_fp(out[k]) for k in
                                        ('obs', 'act', 'logp', 'val', 'mu', 'rew', 'cost', 'done', 'obs_last',
                                         'val_last', 'logstd')])
         assert rc == 0, rc

@@ -6,16 +6,17 @@ import pytest
 from helpers import task_config, assert_state_equal, SWIMMER, ANT, WALKER
 
 
-def _torch_ac(D, A, seed=0):
+def _torch_ac(D, A, seed=0, hidden=64):
     import torch
     torch.manual_seed(seed)
-    mk = lambda out: torch.nn.Sequential(torch.nn.Linear(D, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64),   # noqa: E731
-                                         torch.nn.Tanh(), torch.nn.Linear(64, out), torch.nn.Identity())
+    h = hidden
+    mk = lambda out: torch.nn.Sequential(torch.nn.Linear(D, h), torch.nn.Tanh(), torch.nn.Linear(h, h),   # noqa: E731
+                                         torch.nn.Tanh(), torch.nn.Linear(h, out), torch.nn.Identity())
     mu_net, v_net = mk(A), mk(1)
     for net in (mu_net, v_net):           # livelier than the default init so tanh is exercised
         for m in net:
             if isinstance(m, torch.nn.Linear):
-                torch.nn.init.normal_(m.weight, std=0.5)
+                torch.nn.init.normal_(m.weight, std=0.5 * (64 / h) ** 0.5 if m.in_features == h else 0.5)
                 torch.nn.init.normal_(m.bias, std=0.3)
     log_std = torch.tensor([-0.5, -0.3, -0.7, -0.1, -0.9, -0.4, -0.6, -0.2, -0.8, -0.35][:A])
     return mu_net, v_net, log_std
@@ -32,17 +33,20 @@ def test_log_tanh_accuracy(oracle):
     assert th[0] == -1 and th[-1] == 1 and oracle.math_probe2(np.array([0.0], np.float32))[1][0] == 0
 
 
-def test_oracle_policy_matches_torch_and_noise_is_standard_normal(oracle):
-    """oracle MLP / logp against torch (fp32, different summation order -> 1e-5), noise statistics"""
+@pytest.mark.parametrize("hidden", [64, 128, 256])
+def test_oracle_policy_matches_torch_and_noise_is_standard_normal(oracle, hidden):
+    """oracle MLP / logp against torch (fp32, different summation order -> 1e-5), noise statistics -- at the reference's
+    default width and at the wider networks its command line offers (trpo.py:606-607 --hid)"""
     import torch
     from guardx_amd import Engine
     N, T = 256, 40
     cfg = task_config(N, seed=1, num_steps=T)
     O = oracle.OracleEngine(cfg, n_candidates=30000)
     o0 = O.reset()
-    mu_net, v_net, log_std = _torch_ac(43, 2)
+    mu_net, v_net, log_std = _torch_ac(43, 2, hidden=hidden)
     params = Engine.pack_actor_critic(mu_net=mu_net, v_net=v_net, log_std=log_std).numpy()
-    out = O.rollout_policy(params, T, o0, noise_seed=(7, 9))
+    assert params.size == Engine._policy_floats(43, 2, hidden)
+    out = O.rollout_policy(params, T, o0, noise_seed=(7, 9), hidden=hidden)
     obs = torch.from_numpy(out['obs'])
     with torch.no_grad():
         mu_t, v_t = mu_net(obs), v_net(obs).squeeze(-1)
@@ -118,3 +122,74 @@ def test_policy_rollout_parity(oracle, robot, impl):
     for k in ('obs', 'act', 'rew', 'done', 'obs_last'):
         np.testing.assert_array_equal(g3[k].cpu().numpy(), o3[k], err_msg=k)
     assert_state_equal(E.get_state(), O.get_state())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot,hidden", [("point", 128), ("point", 256), ("swimmer", 192), ("ant", 128), ("walker", 256),
+                                          ("point", 64), ("ant", 64)])
+def test_policy_rollout_other_widths_parity(oracle, robot, hidden):
+    """hidden_sizes (h, h) beyond the fused kernel's 64 (trpo.py:606-607 --hid): the step-wise form (two launches per
+    control step, gx_policy_step.hip) equals the checker bit for bit -- every output, the state afterwards, a second call
+    that continues the noise stream; at h = 64 (gx_set_policy_impl(3)) it also equals the FUSED kernel's outputs."""
+    import torch
+    from guardx_amd import Engine
+    N, T = 203, 40
+    extra = {"point": {}, "swimmer": SWIMMER, "ant": ANT, "walker": WALKER}[robot]
+    cfg = task_config(N, seed=3, num_steps=25, goal_size=0.9, **extra)
+    E = Engine(cfg, n_candidates=40000)
+    if hidden == 64:
+        E.set_policy_impl(3)
+    O = oracle.OracleEngine(cfg, n_candidates=40000)
+    og, oo = E.reset(), O.reset()
+    np.testing.assert_array_equal(og.cpu().numpy(), oo)
+    D, A = E.obs_flat_size, E.action_space.shape[0]
+    mu_net, v_net, log_std = _torch_ac(D, A, seed=5, hidden=hidden)
+    params = Engine.pack_actor_critic(mu_net=mu_net, v_net=v_net, log_std=log_std)
+    g = E.rollout_policy(params.cuda(), T, noise_seed=(11, 13))
+    o = O.rollout_policy(params.numpy(), T, oo, noise_seed=(11, 13), hidden=hidden)
+    assert o['done'].sum() > 0
+    keys = ('obs', 'act', 'mu', 'logp', 'val', 'rew', 'cost', 'done', 'obs_last', 'val_last', 'logstd')
+    for k in keys:
+        np.testing.assert_array_equal(g[k].cpu().numpy(), o[k], err_msg=k)
+    assert_state_equal(E.get_state(), O.get_state())
+    g2 = E.rollout_policy(params.cuda(), 7, noise_seed=(11, 13))
+    o2 = O.rollout_policy(params.numpy(), 7, o['obs_last'], noise_seed=(11, 13), t0=T, hidden=hidden)
+    for k in keys:
+        np.testing.assert_array_equal(g2[k].cpu().numpy(), o2[k], err_msg=k)
+    # the ordinary API lines up afterwards, reset_done speculated by step() included
+    act = np.zeros((N, A), np.float32)
+    og3, _, dg3, _ = E.step(torch.from_numpy(act).cuda())
+    oo3, _, do3, _ = O.step(act)
+    np.testing.assert_array_equal(og3.cpu().numpy(), oo3)
+    rd_g, rd_o = E.reset_done(), O.reset_done()
+    np.testing.assert_array_equal(rd_g.cpu().numpy(), rd_o)
+    g3 = E.rollout_policy(params.cuda(), 5, obs0=rd_g, noise_seed=(11, 13))
+    o3 = O.rollout_policy(params.numpy(), 5, rd_o, noise_seed=(11, 13), t0=T + 7, hidden=hidden)
+    for k in ('obs', 'act', 'rew', 'done', 'obs_last'):
+        np.testing.assert_array_equal(g3[k].cpu().numpy(), o3[k], err_msg=k)
+    assert_state_equal(E.get_state(), O.get_state())
+    if hidden == 64:                       # the fused kernel on a twin engine: same bits
+        F = Engine(cfg, n_candidates=40000)
+        F.reset()
+        f = F.rollout_policy(params.cuda(), T, noise_seed=(11, 13))
+        for k in keys:
+            assert torch.equal(f[k], g[k]), k
+        F.close()
+    E.close()
+
+
+@pytest.mark.gpu
+def test_policy_rollout_width_errors():
+    import torch
+    from guardx_amd import Engine
+    E = Engine(task_config(16, seed=1), n_candidates=20000)
+    E.reset()
+    with pytest.raises(ValueError, match="expected one of"):
+        E.rollout_policy(torch.zeros(1234), 3)
+    mk = lambda h1, h2: torch.nn.Sequential(torch.nn.Linear(43, h1), torch.nn.Tanh(), torch.nn.Linear(h1, h2),   # noqa: E731
+                                            torch.nn.Tanh(), torch.nn.Linear(h2, 2))
+    with pytest.raises(NotImplementedError):
+        Engine.pack_actor_critic(mu_net=mk(64, 32), v_net=mk(64, 32), log_std=torch.zeros(2))
+    with pytest.raises(NotImplementedError):
+        Engine.pack_actor_critic(mu_net=mk(96, 96), v_net=mk(96, 96), log_std=torch.zeros(2))
+    E.close()

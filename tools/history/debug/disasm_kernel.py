@@ -1,7 +1,7 @@
 """Disassemble the kernels of libguardx_hip.so whose mangled name contains every given substring:
     python tools/debug/disasm_kernel.py dyn_tape_kernel PointRobot Lb1E > /tmp/dyn.s"""
 import os, subprocess, sys, tempfile
-root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tools"))
 import kernel_descriptors as kd
 from guardx_amd import _native
