@@ -502,6 +502,24 @@ def reset_done_heavy(device, epochs=50):
             "config": "Goal_Point_8Hazards env_num=2000, goal_size=2.9, num_steps=60 (timeouts), 200-step epochs"}
 
 
+def multi_gpu_rehearsal(device, world=8, epochs=30):
+    """This GPU plays rank 0 of `world` in the default N > 1 epoch (tools/rehearse_rank.py): everything a rank does per
+    epoch -- 1/world of the layout sampler for the reset after next, its dynamics pass, the install of every rank's
+    export block, the observation pass over all (or only its own) tapes -- with device copies standing in for the
+    all-gather.  Measured GPU time of a rank's epoch + the link as arithmetic = the predicted weak-scaling efficiency
+    (an 8-GPU node is the driver's to run)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import rehearse_rank as rr
+    one = rr.single("xmls/point.xml", epochs, 6, device)
+    out = {"world": world, "one_gpu_own_sampler": one,
+           "note": "NOT an 8-GPU measurement: one GPU playing rank 0 of 8; the xGMI transfer enters as bytes / bandwidth"}
+    for expand in ("all", "local"):
+        r = rr.rehearse(world, "xmls/point.xml", epochs, 6, expand, device)
+        r["model"] = rr.model(one, r, world)
+        out["expand_" + expand] = r
+    return out
+
+
 def api_loop_rate(env, tape, steps):
     """Python-driven Engine.step()/reset_done() loop (what an unmodified learner drives)."""
     torch.cuda.synchronize()
@@ -642,7 +660,7 @@ def main():
     stepping_only = None
     legs = None
     if gather:
-        w2 = max(3, args.warmup)         # a change of the layout source costs up to two inline samplers
+        w2 = max(4, args.warmup)         # a change of the layout source costs up to three inline samplers
         W = env.obs_flat_size + 2 + 3
 
         def rate(t):
@@ -744,6 +762,7 @@ def main():
             extra("closed_loop_policy_wider_env_steps_per_s",
                   lambda: {f"hidden_{h}": round(closed_loop_rate(device, 20, h), 1) for h in (128, 256)})
             extra("reset_done_heavy", lambda: reset_done_heavy(device))
+            extra("multi_gpu_rehearsal", lambda: multi_gpu_rehearsal(device))
             extra("other_robots", lambda: other_robots(device))
         if world == 1 and not args.no_cpu_baseline:
             try:

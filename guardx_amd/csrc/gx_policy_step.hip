@@ -56,6 +56,37 @@ struct PolicyStepArgs {
     float* logstd;        // [A], written by workgroup 0 in mode 0
 };
 
+// acc[e] = fmaf(x[k][e], w[k], acc[e]) for k = 0 .. K-1 (ascending: one sequential chain per env), the weights of unit
+// `u` fetched kWB at a time and one block AHEAD of the arithmetic: a plain loop waits one L2 round trip per k (the
+// compiler does not hoist the loads of a run-time-length loop): 172 round trips per launch at H = 128.
+constexpr int kWB = 16;
+template <int E>
+GX_D void chain_layer(float (&acc)[E], const float* __restrict__ wt, int H, int u, const float* xk, int K)
+{
+    static_assert(E == 8, "two float4 reads per k");
+    float w[kWB], wn[kWB];
+#pragma unroll
+    for (int i = 0; i < kWB; ++i) w[i] = i < K ? wt[(size_t)i * H + u] : 0.0f;
+#pragma unroll 1 // (K = H is a compile-time constant at the second layer: fully unrolled, every load of the layer is
+                 // hoisted to the top and the kernel spills 9 KB per thread)
+    for (int k0 = 0; k0 < K; k0 += kWB) {
+#pragma unroll
+        for (int i = 0; i < kWB; ++i) wn[i] = (k0 + kWB + i) < K ? wt[(size_t)(k0 + kWB + i) * H + u] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < kWB; ++i) {
+            if (k0 + i < K) {
+                const float4 xa = *reinterpret_cast<const float4*>(xk + (k0 + i) * E);
+                const float4 xb = *reinterpret_cast<const float4*>(xk + (k0 + i) * E + 4);
+                const float ww = w[i];
+                acc[0] = fmaf(xa.x, ww, acc[0]); acc[1] = fmaf(xa.y, ww, acc[1]); acc[2] = fmaf(xa.z, ww, acc[2]); acc[3] = fmaf(xa.w, ww, acc[3]);
+                acc[4] = fmaf(xb.x, ww, acc[4]); acc[5] = fmaf(xb.y, ww, acc[5]); acc[6] = fmaf(xb.z, ww, acc[6]); acc[7] = fmaf(xb.w, ww, acc[7]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kWB; ++i) w[i] = wn[i];
+    }
+}
+
 template <int H>
 __global__ __launch_bounds__(2 * H) void policy_step_kernel(PolicyStepArgs a)
 {
@@ -93,12 +124,7 @@ __global__ __launch_bounds__(2 * H) void policy_step_kernel(PolicyStepArgs a)
         const float bb = b1[u];
 #pragma unroll
         for (int e = 0; e < E; ++e) acc[e] = bb;
-        for (int k = 0; k < D; ++k) {
-            const float w = wt1[k * H + u];
-            const float4 xa = *reinterpret_cast<const float4*>(xs + k * E), xb = *reinterpret_cast<const float4*>(xs + k * E + 4);
-            acc[0] = fmaf(xa.x, w, acc[0]); acc[1] = fmaf(xa.y, w, acc[1]); acc[2] = fmaf(xa.z, w, acc[2]); acc[3] = fmaf(xa.w, w, acc[3]);
-            acc[4] = fmaf(xb.x, w, acc[4]); acc[5] = fmaf(xb.y, w, acc[5]); acc[6] = fmaf(xb.z, w, acc[6]); acc[7] = fmaf(xb.w, w, acc[7]);
-        }
+        chain_layer<E>(acc, wt1, H, u, xs, D);
         float* hp = h1 + ((size_t)net * H + u) * E;
         *reinterpret_cast<float4*>(hp) = make_float4(tanh_f(acc[0]), tanh_f(acc[1]), tanh_f(acc[2]), tanh_f(acc[3]));
         *reinterpret_cast<float4*>(hp + 4) = make_float4(tanh_f(acc[4]), tanh_f(acc[5]), tanh_f(acc[6]), tanh_f(acc[7]));
@@ -109,13 +135,7 @@ __global__ __launch_bounds__(2 * H) void policy_step_kernel(PolicyStepArgs a)
 #pragma unroll
         for (int e = 0; e < E; ++e) acc[e] = bb;
         const float* hin = h1 + (size_t)net * H * E;
-#pragma unroll 4
-        for (int k = 0; k < H; ++k) {
-            const float w = wt2[k * H + u];
-            const float4 xa = *reinterpret_cast<const float4*>(hin + k * E), xb = *reinterpret_cast<const float4*>(hin + k * E + 4);
-            acc[0] = fmaf(xa.x, w, acc[0]); acc[1] = fmaf(xa.y, w, acc[1]); acc[2] = fmaf(xa.z, w, acc[2]); acc[3] = fmaf(xa.w, w, acc[3]);
-            acc[4] = fmaf(xb.x, w, acc[4]); acc[5] = fmaf(xb.y, w, acc[5]); acc[6] = fmaf(xb.z, w, acc[6]); acc[7] = fmaf(xb.w, w, acc[7]);
-        }
+        chain_layer<E>(acc, wt2, H, u, hin, H);
         float* hp = h2 + ((size_t)net * H + u) * E;
         *reinterpret_cast<float4*>(hp) = make_float4(tanh_f(acc[0]), tanh_f(acc[1]), tanh_f(acc[2]), tanh_f(acc[3]));
         *reinterpret_cast<float4*>(hp + 4) = make_float4(tanh_f(acc[4]), tanh_f(acc[5]), tanh_f(acc[6]), tanh_f(acc[7]));

@@ -77,12 +77,13 @@ class TapeHandoff:
 
     sharded_sampler (default: on at world > 1): the reference's 1e6-candidate layout sampler
     (engine.py:433-444; candidate c draws from split(key, 1e6)[c], so the candidates are independent) is split over the
-    ranks WITHOUT a second collective.  The key of reset(k + 2) is known at reset(k), so during epoch k rank r samples
-    candidates [r 1e6 / W, (r + 1) 1e6 / W) of THAT reset on the engine's side stream and its valid rows ride in the tail
-    of the shard buffer; the all-gather of epoch k delivers every rank's block, and while epoch k + 1 runs the blocks
-    are installed -- shard after shard = candidate order -- as the pool reset(k + 2) takes like a prefetch hit:
-    layout_size, pool rows, observations and every later randint draw are the unsharded reset()'s, bit for bit.  A
-    reset without an installed pool (the first two, a changed episode length) samples all candidates inline.
+    ranks WITHOUT a second collective.  The key of a later reset is known now (this key advanced by one split per
+    step(), engine.py:431), so once epoch k's tape is on its way rank r samples candidates [r 1e6 / W, (r + 1) 1e6 / W)
+    of reset(k + 3) on the engine's side stream, into the tail of the buffer that will carry epoch k + 1's tape; the
+    all-gather of epoch k + 1 delivers every rank's block, and while epoch k + 2 runs the blocks are installed -- shard
+    after shard = candidate order -- as the pool reset(k + 3) takes like a prefetch hit: layout_size, pool rows,
+    observations and every later randint draw are the unsharded reset()'s, bit for bit.  A reset without an installed
+    pool (the first three, a changed episode length) samples all candidates inline.
 
     expand: "all" (default) -- every rank expands every rank's tape (the hand-off contract above); "local" -- only its
     own; expand_rank(s) then expands rank s's tape of the last gathered epoch on demand (before the next step())."""
@@ -129,6 +130,8 @@ class TapeHandoff:
         self.bytes_received = 0
         self.blocks_installed = 0
         self.deferred = None           # (ticket, gathered buffer) of a block drain() could not install yet
+        self.works = [None] * depth    # the collective that last read send[i]
+        self.next_ticket = None        # ticket of the block being sampled into the next send buffer's tail
 
     def close(self):
         """give the layout sampling back to the engine (its own prefetch)"""
@@ -139,16 +142,24 @@ class TapeHandoff:
     def step(self, actions):
         i = self.k % self.depth
         buf = self.send[i]
-        ticket = None
-        if self.sharded:               # this rank's candidates of the reset after next, beside the dynamics pass
-            ticket = self.env.sample_shard_ahead(self.rank, self.world, buf[self.off_block:], self.cap, resets_ahead=2)
         shard, token = self.env.rollout_tape(actions, out=buf[:self.n_tape])
-        if self.sharded:
-            self.env.shard_join()      # the collective below must see the block
+        ticket, self.next_ticket = self.next_ticket, None   # the block sampled into this buffer's tail during the last step
+        if ticket is not None:
+            self.env.shard_join()      # the collective below must see the block (it was finished long ago)
         self._expand_pending()         # epoch k-1: its collective has had a whole epoch
         work = self._gather(i, buf)
+        self.works[i] = work
         self.pending = (work, i, token, ticket)
         self.k += 1
+        if self.sharded:
+            # The block that will travel with the NEXT epoch's tape: this rank's candidates of the reset three resets
+            # from now, sampled from here on -- beside this epoch's collective and the expansions, not beside the next
+            # dynamics pass (the serial chain of the epoch) and never in front of a collective that has to wait for it.
+            j = self.k % self.depth
+            if self.works[j] is not None:
+                self.works[j].wait()   # the collective that last read send[j] (two epochs ago)
+            self.next_ticket = self.env.sample_shard_ahead(self.rank, self.world, self.send[j][self.off_block:], self.cap,
+                                                           resets_ahead=3)
 
     def _gather(self, i, buf):
         """the ONE collective of the epoch: every rank's [tape | layouts | entry records | shard block] into recv[i]"""

@@ -291,7 +291,7 @@ class _StubShardAheadEngine(_StubEngine):
         return 4 + cap * 10 * 2
 
     def sample_shard_ahead(self, shard, n_shards, block, cap, resets_ahead=2):
-        assert self.source == 'shards' and shard == self.rank and resets_ahead == 2
+        assert self.source == 'shards' and shard == self.rank and resets_ahead == 3
         assert block.numel() == self.shard_block_floats(cap)
         self.calls += 1
         block.fill_(100.0 * shard + self.calls)
@@ -341,10 +341,11 @@ def _shard_ahead_worker(rank, world, port, q):
                 want = ramp[:T * N * 4].reshape(T, N, 4).sum(-1, keepdim=True) + float(77 + 4)
                 assert torch.equal(h.expand_rank(other), want.expand(T, N, D + 5))
         h.drain()
-        # blocks of call c (sampled during epoch c - 1) are installed during epoch c -- one per reset, never two --
-        # with every rank's block in rank order; the drain after epoch 3 defers block 4 to epoch 4's step
-        assert env.joined == 7 and env.calls == 7
-        assert [t for t, _, _ in env.installs] == [1, 2, 3, 4, 5, 6]
+        # the block of call c (sampled right after epoch c - 1's tape went out) travels with epoch c's tape and is installed
+        # during epoch c + 1 -- one install per reset, never two -- with every rank's block in rank order; the drain after
+        # epoch 3 defers block 3 to epoch 4's step, the final drain leaves block 6 uninstalled
+        assert env.joined == 6 and env.calls == 7
+        assert [t for t, _, _ in env.installs] == [1, 2, 3, 4, 5]
         for t, firsts, uniform in env.installs:
             assert firsts == [100.0 * s + t for s in range(world)] and uniform, (rank, t, firsts)
         assert h.bytes_received == 7 * (world - 1) * h.n * 4
@@ -362,8 +363,9 @@ def _shard_ahead_worker(rank, world, port, q):
 
 @pytest.mark.timeout(300)
 def test_two_rank_tape_handoff_with_piggybacked_shard_blocks_over_gloo():
-    """The default N > 1 hand-off over 2 gloo ranks with a stand-in engine: each rank's export block of the reset after
-    next travels in the tail of its tape shard, ONE all_gather_into_tensor per epoch; one epoch later every rank
+    """The default N > 1 hand-off over 2 gloo ranks with a stand-in engine: each rank's export block of a later reset
+    (sampled as soon as the previous tape is on its way) travels in the tail of its tape shard, ONE
+    all_gather_into_tensor per epoch; one epoch later every rank
     installs both blocks (rank order = candidate order) under the ticket of that epoch -- before the expansions, exactly
     one install between consecutive resets, a drain() deferring the install it may not make yet; expand="local" expands
     the own tape only and any other on demand.  (The GPU engine's equality with the unsharded sampler:

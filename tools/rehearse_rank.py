@@ -58,7 +58,8 @@ class RehearsalHandoff(TapeHandoff):
             recv[:self.n].copy_(buf, non_blocking=True)
             for s in range(1, self.world):
                 recv[s * self.n:s * self.n + self.n_tape].copy_(buf[:self.n_tape], non_blocking=True)
-                recv[s * self.n + self.off_block:(s + 1) * self.n].copy_(self.blocks[self.epoch][s], non_blocking=True)
+                if self.blocks[self.epoch][s] is not None:
+                    recv[s * self.n + self.off_block:(s + 1) * self.n].copy_(self.blocks[self.epoch][s], non_blocking=True)
             work = _CopyWork(self.comm)
         self.epoch += 1
         self.bytes_received += (self.world - 1) * self.n * 4
@@ -79,16 +80,16 @@ def other_ranks_blocks(world, robot, epochs, tapes, cap):
     twin.reset()
     twin.set_layout_source('shards')
     nb = twin.shard_block_floats(cap)
-    out = []
+    out = [[None] * world]            # epoch 0 carries no block (TapeHandoff samples the first one after its first tape)
     for ep in range(epochs):
         if ep:
             twin.reset(check=False)
-        row = [None]
-        for s in range(1, world):
-            blk = torch.zeros(nb, device=twin.device)
-            twin.sample_shard_ahead(s, world, blk, cap)
-            row.append(blk)
         twin.rollout_tape(tapes[ep % len(tapes)])
+        row = [None]
+        for s in range(1, world):     # what rank s samples at the end of its step(ep): travels with the tape of ep + 1
+            blk = torch.zeros(nb, device=twin.device)
+            twin.sample_shard_ahead(s, world, blk, cap, resets_ahead=3)
+            row.append(blk)
         out.append(row)
     twin.shard_join()
     torch.cuda.synchronize()
@@ -168,7 +169,9 @@ def main():
     device = torch.device("cuda", torch.cuda.current_device())
     bench.precondition_clocks(device)
     one = single(args.robot, args.epochs, args.warmup, device)
+    from guardx_amd import _native
     res = {"what": f"one GPU playing rank 0 of {args.world} (tools/rehearse_rank.py): GPU time of a rank's epoch, no link",
+           "library_build": _native.load().gx_build_id().decode(),
            "robot": args.robot, "world": args.world, "epochs": args.epochs,
            "one_gpu_own_sampler": one}
     for expand in ("all", "local"):
