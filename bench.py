@@ -325,7 +325,11 @@ def cpu_baseline(epochs_all=8, epochs_1t=1):
     rng = np.random.RandomState(0)
     acts = rng.uniform(-1, 1, (EP_LEN, ENV_NUM, 2)).astype(np.float32)
     L = gxo.lib()
-    ncores = int(L.gxo_get_threads())
+    visible = int(L.gxo_get_threads())
+    share = cpu_share()
+    # a GPU box shows all of its host's hardware threads but grants this job a share of them (cgroup quota): more
+    # OpenMP threads than the share only time-slice (round 3 timed 128 threads on what was a 16-CPU share)
+    ncores = max(1, min(visible, share)) if share else visible
 
     def run(threads, epochs):
         L.gxo_set_threads(threads)
@@ -353,11 +357,37 @@ def cpu_baseline(epochs_all=8, epochs_1t=1):
             "stepping_only_all_cores": round(sa, 1), "stepping_only_1thread": round(s1, 1),
             "reset_s_all_cores": round(ra, 3), "reset_s_1thread": round(r1, 3),
             "threads": {"reset_phase": ncores, "step_phase": ncores},
+            "host": {"hardware_threads_visible": visible, "cpu_share_of_this_job": share},
             "sample": f"{epochs_all} epochs on {ncores} threads ({wa:.1f} s) and {epochs_1t} epoch on 1 thread "
                       f"({w1:.1f} s): {EP_LEN} steps x {ENV_NUM} envs incl. reset() over 1e6 layout candidates "
                       "and reset_done()",
             "note": "CPU restatement (oracle/, gcc -O2 -fopenmp), not the reference's XLA:CPU program; "
                     "a reported baseline, not the optimisation target"}
+
+
+def cpu_share():
+    """CPUs this process may actually use: the cgroup quota (v2 cpu.max, v1 cfs quota) and the affinity mask, or None"""
+    n = None
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:  # noqa: BLE001
+        pass
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: None if t.split()[0] == "max" else float(t.split()[0]) / float(t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", None)):
+        try:
+            txt = open(path).read().strip()
+            if parse is None:
+                q = float(txt)
+                per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip())
+                v = None if q <= 0 else q / per
+            else:
+                v = parse(txt)
+            if v:
+                n = int(min(n, max(1, round(v)))) if n else int(max(1, round(v)))
+            break
+        except Exception:  # noqa: BLE001
+            continue
+    return n
 
 
 def epoch_breakdown(device):
