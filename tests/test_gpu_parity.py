@@ -1406,3 +1406,95 @@ def test_engine_on_a_second_device_while_the_first_is_current(torch_cuda, oracle
         np.testing.assert_array_equal(E.reset_done().cpu().numpy(), O.reset_done())
     assert torch.cuda.current_device() == 0
     E.close()
+
+
+def test_config4_default_path_eight_ranks_full_size(torch_cuda, oracle):
+    """BASELINE config 4 at full size through the DEFAULT multi-GPU path, on one GPU: eight Engine(env_num=2000,
+    shard=(r, 8)), each behind its own guardx_amd.dist.TapeHandoff (sharded sampler over 1e6 candidates -- 125 000 per
+    rank --, tape hand-off, one launch expanding all eight tapes), with an in-process stand-in for the ONE collective per
+    epoch (the eight send buffers concatenated, delivered an epoch later, as all_gather_into_tensor leaves them).  Every
+    reset observation, the pool and its size, and the expanded rows of all 16 000 envs on every rank equal ONE
+    16 000-env engine that samples all candidates itself; that engine's first reset equals the checker's.  From the
+    fourth reset on no rank samples inline."""
+    torch = torch_cuda
+    from guardx_amd import Engine
+    from guardx_amd.dist import TapeHandoff
+    N, W, T, M, EPOCHS = 2000, 8, 30, 1_000_000, 6
+    kw = dict(seed=5, num_steps=T, goal_size=2.9)
+    full, O = _engines(task_config(N * W, **kw), oracle, n_candidates=M)
+    ranks = [Engine(task_config(N, **kw), n_candidates=M, shard=(r, W)) for r in range(W)]
+    o_full = full.reset()
+    np.testing.assert_array_equal(o_full.cpu().numpy(), O.reset())
+    for r, e in enumerate(ranks):
+        assert torch.equal(e.reset(), o_full[r * N:(r + 1) * N]) and e.layout_size == full.layout_size > N * W
+        e.set_prefetch(T)
+
+    class Wire:
+        """what the eight ranks' all_gather_into_tensor calls of one epoch leave on every rank"""
+        def __init__(self):
+            self.bufs = {}
+        def put(self, ep, r, buf):
+            self.bufs.setdefault(ep, [None] * W)[r] = buf
+        def gathered(self, ep):
+            return torch.cat(self.bufs.pop(ep))
+    wire = Wire()
+
+    class InProcess(TapeHandoff):
+        def __init__(self, env, rank):
+            super().__init__(env, T, sharded_sampler=True, expand="all", _play=(rank, W))
+            self.ep = 0
+        def _gather(self, i, buf):
+            wire.put(self.ep, self.rank, buf)
+            ep, self.ep = self.ep, self.ep + 1
+            me = self
+
+            class Work:                     # "wait" = the collective of that epoch is complete: every rank has put
+                def wait(self_inner):
+                    if me.recv[i].numel() != W * me.n or not getattr(self_inner, "done", False):
+                        me.recv[i] = gathered[ep]
+                        self_inner.done = True
+            return Work()
+    hs = [InProcess(e, r) for r, e in enumerate(ranks)]
+    assert len({h.cap for h in hs}) == 1 and hs[0].n % 4 == 0
+    gathered = {}
+    rng = np.random.default_rng(8)
+    prev = None
+    sizes = [full.layout_size]
+    for ep in range(EPOCHS):
+        acts = torch.from_numpy(rng.uniform(-1, 1, (T, N * W, 2)).astype(np.float32)).cuda()
+        if ep:
+            o_full = full.reset()
+            sizes.append(full.layout_size)
+            for r, e in enumerate(ranks):
+                assert torch.equal(e.reset(check=False), o_full[r * N:(r + 1) * N]), (ep, r)
+        *_, pk = full.rollout(acts, packed=True)
+        # every rank steps (its tape + the block sampled for a later reset go "on the wire") ...
+        for r, h in enumerate(hs):
+            h.pending_before = h.pending
+            h.pending = None                                   # (expanded below, once the epoch's wire is complete)
+            h.step(acts[:, r * N:(r + 1) * N].contiguous())
+        gathered[ep] = wire.gathered(ep)
+        # ... and expands / installs the PREVIOUS epoch's gathered buffer, as TapeHandoff.step does one epoch late
+        if prev is not None:
+            for r, h in enumerate(hs):
+                cur, h.pending = h.pending, h.pending_before
+                h._expand_pending()
+                h.pending = cur
+                torch.cuda.current_stream().wait_stream(h.stream)
+                for s in range(W):
+                    assert torch.equal(h.rollout[s].view(torch.int32),
+                                       prev[:, s * N:(s + 1) * N].contiguous().view(torch.int32)), (ep, r, s)
+        prev = pk
+    torch.cuda.synchronize()
+    for r, e in enumerate(ranks):
+        hits, misses, _ = e.prefetch_stats()
+        # reset 1: the engine's own prefetch (started before the hand-off took over); reset 2: inline (no pool announced);
+        # resets 3 .. EPOCHS - 1: installed pools
+        assert hits == EPOCHS - 2 and misses == 0, (r, hits, misses)
+        assert e.check_layouts() == min(sizes)                  # the smallest pool of all its resets = the big engine's
+        np.testing.assert_array_equal(e.get_pool(32), full.get_pool(32))
+    for h in hs:
+        h.close()
+    full.close()
+    for e in ranks:
+        e.close()
