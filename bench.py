@@ -432,8 +432,8 @@ def valu_issue_floor():
     ns = 1.73   # profiles/history/r02_probe_threefry_chain.log: 110 ns per 63.5-instruction Threefry block per SIMD
     return {"wave_instructions_per_epoch": round(n), "ns_per_wave_instruction_per_simd": ns, "simds": 1024,
             "issue_floor_us": round(n * ns * 1e-9 / 1024 * 1e6, 1),
-            "note": "NOT measured in this run: SQ_INSTS_VALU of every kernel of one epoch (profiles/r03_sampler_pmc_SQ.csv, "
-                    "r03_rollout_N2000_T200_pmc_SQ.csv) x the measured issue cost of the sampler's own Threefry code / 1024 "
+            "note": "NOT measured in this run: SQ_INSTS_VALU of every kernel of one epoch (profiles/r04_sampler_pmc_SQ.csv, "
+                    "r04_rollout_N2000_T200_pmc_SQ.csv) x the measured issue cost of the sampler's own Threefry code / 1024 "
                     "SIMDs; compare with the headline ms_per_step"}
 
 

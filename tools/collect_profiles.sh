@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collect every rocprofv3 summary bench.py / DESIGN.md quote, on the GPU box (through gpurun, from the repo root):
-#   tools/collect_profiles.sh r03      -> gpurun_out/r03_*.csv, r03_build_id.txt  (copy them into profiles/)
+#   tools/collect_profiles.sh r04      -> gpurun_out/r04_*.csv, r04_build_id.txt  (copy them into profiles/)
 # Counter passes are separate runs with --pmc only (no --kernel-trace/--stats mixed in).
 set -e
-tag=${1:-r03}
+tag=${1:-r04}
 out=$PWD/gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
@@ -45,5 +45,11 @@ done
 kt sampler $RST
 pmc sampler SQ SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_BUSY_CYCLES -- $RST
 kt bench_noextras python3 bench.py --no-cpu-baseline --no-extras
+# round 4: one GPU playing rank 0 of 8 in the default multi-GPU epoch (per-kernel times of a rank's epoch), the step-wise
+# policy kernels of the wider networks, the 18-object sampler of the synthetic config 5
+kt rehearsal_rank0_of_8 python3 tools/rehearse_rank.py --world 8 --epochs 30
+kt policy_widths python3 tools/bench_policy_widths.py
+kt sampler_config5 python3 tools/profile_reset.py --task Ant_8Hazards_8Pillars_synthetic
+pmc sampler_config5 SQ SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_BUSY_CYCLES -- python3 tools/profile_reset.py --task Ant_8Hazards_8Pillars_synthetic
 rm -f $out/${tag}_*_kt.log $out/${tag}_*_pmc_*.log
 ls $out/${tag}_* | wc -l

@@ -2,7 +2,7 @@
 # One gx_rollout call (env_num=2000, T=200) under rocprofv3: kernel times, then the PMC passes (separate runs).
 #   tools/prof_rollout.sh <tag> [pmc]   -> gpurun_out/<tag>_rollout_N2000_T200_kernel_stats.csv [+ _pmc_*.csv]
 set -e
-tag=${1:-r03}
+tag=${1:-r04}
 out=$PWD/gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp

@@ -2,7 +2,7 @@
 # Sampler / rollout kernel times on the GPU box (run through gpurun from the repo root):
 #   tools/prof_sampler.sh <tag>   -> gpurun_out/<tag>_sampler_kernel_stats.csv, <tag>_bench_noextras.json, ...
 set -e
-tag=${1:-r03}
+tag=${1:-r04}
 out=$PWD/gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
