@@ -154,36 +154,6 @@ def _warn_if_unprofiled_compiler(lib):
                       RuntimeWarning, stacklevel=3)
 
 
-_fast = False   # not tried yet
-
-
-def fast():
-    """The CPython shim for the per-step calls (csrc/gx_pyfast.c) bound to the loaded library, or None when it cannot be
-    built or loaded here (GX_NO_FAST=1 switches it off) -- the callers then use ctypes for the same entry points."""
-    global _fast
-    if _fast is not False:
-        return _fast
-    _fast = None
-    if os.environ.get("GX_NO_FAST") == "1":
-        return None
-    try:
-        import importlib.machinery
-        import importlib.util
-        from . import build as _build
-        path = _build.build_fast()
-        if path is None:
-            return None
-        loader = importlib.machinery.ExtensionFileLoader("_gxfast", path)
-        mod = importlib.util.module_from_spec(importlib.util.spec_from_loader("_gxfast", loader))
-        loader.exec_module(mod)
-        lib = load()
-        mod.bind(C.cast(lib.gx_step_slab, C.c_void_p).value, C.cast(lib.gx_reset_done_commit, C.c_void_p).value)
-        _fast = mod
-    except Exception:  # noqa: BLE001 - an accelerator of the binding, never a requirement
-        _fast = None
-    return _fast
-
-
 class GxError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__(f"guardx status {status}: {msg}")

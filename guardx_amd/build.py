@@ -163,55 +163,6 @@ def _build_locked(force, verbose, jobs):
     return LIB
 
 
-# ---- the CPython shim for the per-step calls (csrc/gx_pyfast.c): plain gcc, no GPU code ---------------------------------
-def fast_path():
-    import sysconfig
-    return os.path.join(LIB_DIR, "_gxfast" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
-
-
-def _fast_id():
-    import hashlib
-    import sysconfig
-    with open(os.path.join(CSRC, "gx_pyfast.c"), "rb") as f:
-        return hashlib.sha256(f.read() + (sysconfig.get_config_var("EXT_SUFFIX") or "").encode()).hexdigest()[:24]
-
-
-def build_fast(force=False, verbose=False):
-    """Build guardx_amd/lib/_gxfast<EXT_SUFFIX> with the C compiler; returns its path or None (no compiler / headers:
-    the Engine then calls the same entry points through ctypes)."""
-    import fcntl
-    import sysconfig
-    out, tag = fast_path(), fast_path() + ".id"
-    os.makedirs(LIB_DIR, exist_ok=True)
-    with open(LOCK_FILE, "w") as lock:
-        fcntl.flock(lock, fcntl.LOCK_EX)
-        try:
-            try:
-                have = open(tag).read().strip()
-            except OSError:
-                have = None
-            if not force and os.path.exists(out) and have == _fast_id():
-                return out
-            inc = sysconfig.get_paths()["include"]
-            if not os.path.exists(os.path.join(inc, "Python.h")):
-                return None
-            tmp = out + ".tmp.%d" % os.getpid()
-            cmd = [os.environ.get("CC", "gcc"), "-O2", "-shared", "-fPIC", "-I" + inc, os.path.join(CSRC, "gx_pyfast.c"), "-o", tmp]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            try:
-                subprocess.check_call(cmd)
-            except (OSError, subprocess.CalledProcessError):
-                return None
-            os.replace(tmp, out)
-            with open(tag, "w") as f:
-                f.write(_fast_id())
-            return out
-        finally:
-            fcntl.flock(lock, fcntl.LOCK_UN)
-
-
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print("build id", built_id())
-    print(build_fast(force="--force" in sys.argv, verbose=True))

@@ -159,18 +159,3 @@ def test_lane_group_steps_contain_no_call():
                 calls[n] = asm.count("s_swappc_b64")
     assert sum("WalkerRobot" in n for n in calls) >= 4 and sum("AntRobot" in n for n in calls) >= 4, sorted(calls)
     assert set(calls.values()) == {0}, {k: v for k, v in calls.items() if v}
-
-
-def test_fast_call_shim_builds_and_binds():
-    """csrc/gx_pyfast.c: the CPython shim the Engine uses for its two per-step calls.  It carries no arithmetic -- it calls
-    gx_step_slab / gx_reset_done_commit of the loaded library through their addresses -- and the Engine works without it
-    (ctypes).  Here: it builds with the C compiler of this box, loads, binds, and rejects a malformed call."""
-    from guardx_amd import _native, build as gx_build
-    path = gx_build.build_fast()
-    if path is None:
-        pytest.skip("no C compiler / Python.h on this box: the Engine uses ctypes")
-    assert os.path.exists(path)
-    mod = _native.fast()
-    assert mod is not None and {"bind", "step_slab", "reset_done_commit"} <= set(dir(mod))
-    with pytest.raises(TypeError):
-        mod.step_slab(1, 2, 3)
