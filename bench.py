@@ -534,20 +534,28 @@ def reset_done_heavy(device, epochs=50):
 
 def multi_gpu_rehearsal(device, world=8, epochs=30):
     """This GPU plays rank 0 of `world` in the default N > 1 epoch (tools/rehearse_rank.py): everything a rank does per
-    epoch -- 1/world of the layout sampler for the reset after next, its dynamics pass, the install of every rank's
-    export block, the observation pass over all (or only its own) tapes -- with device copies standing in for the
-    all-gather.  Measured GPU time of a rank's epoch + the link as arithmetic = the predicted weak-scaling efficiency
-    (an 8-GPU node is the driver's to run)."""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import rehearse_rank as rr
-    one = rr.single("xmls/point.xml", epochs, 6, device)
-    out = {"world": world, "one_gpu_own_sampler": one,
-           "note": "NOT an 8-GPU measurement: one GPU playing rank 0 of 8; the xGMI transfer enters as bytes / bandwidth"}
-    for expand in ("all", "local"):
-        r = rr.rehearse(world, "xmls/point.xml", epochs, 6, expand, device)
-        r["model"] = rr.model(one, r, world)
-        out["expand_" + expand] = r
-    return out
+    epoch -- 1/world of the layout sampler for a later reset, its dynamics pass, the install of every rank's export
+    block, the observation pass over all (or only its own) tapes -- with device copies standing in for the all-gather.
+    Measured GPU time of a rank's epoch + the link as arithmetic = the predicted weak-scaling efficiency (an 8-GPU node
+    is the driver's to run).  Run in a FRESH process, as a rank is: inside this one -- a dozen engines and their streams
+    created and destroyed by the other extras -- the same rehearsal measures 0.72-0.74 ms per epoch instead of 0.48
+    (HIP assigns streams to hardware queues in creation order; a rank process creates its engine and hand-off first)."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "rehearsal.json")
+        env = dict(os.environ)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        env["HIP_VISIBLE_DEVICES"] = env.get("HIP_VISIBLE_DEVICES", str(device.index if device.index is not None else 0))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rehearse_rank.py"), "--world", str(world),
+                            "--epochs", str(epochs), "--json", out], env=env, capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            raise RuntimeError("tools/rehearse_rank.py failed: " + r.stderr[-300:])
+        with open(out) as f:
+            res = json.load(f)
+    res["note"] = ("NOT an 8-GPU measurement: one GPU playing rank 0 of 8 in a fresh process; the xGMI transfer enters as "
+                   "bytes / bandwidth (model)")
+    return res
 
 
 def api_loop_rate(env, tape, steps):

@@ -58,6 +58,16 @@ def all_gather_rollout(packed, out=None):
     return out
 
 
+_HANDOFF_STREAMS = {}
+
+
+def _handoff_stream(dev):
+    key = (dev.type, dev.index)
+    if key not in _HANDOFF_STREAMS:
+        _HANDOFF_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _HANDOFF_STREAMS[key]
+
+
 class TapeHandoff:
     """Once-per-epoch rollout hand-off by dynamics tape -- the ONE collective of the multi-GPU path.
 
@@ -121,8 +131,10 @@ class TapeHandoff:
                                  pin_memory=self.host and dev.type == "cuda") for _ in range(depth)]
         W = env.obs_flat_size + env.action_space.shape[0] + 3
         self.out = [torch.empty(self.world, self.T, env.env_num, W, dtype=torch.float32, device=dev) for _ in range(2)]
-        # the expansion runs on its own stream (a CPU stand-in engine, as in the gloo unit test, has none)
-        self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        # the expansion runs on its own stream (a CPU stand-in engine, as in the gloo unit test, has none): ONE per device
+        # and process, shared by successive hand-offs (bench.py makes one per leg) -- HIP multiplexes a process's
+        # streams onto a few hardware queues in creation order, and every extra stream is a chance of an alias
+        self.stream = _handoff_stream(dev) if dev.type == "cuda" else None
         self.pending = None            # (work, slot, token, ticket of the block it carries) of the epoch in flight
         self.last = None               # (gathered buffer on the device, token) of the last expanded epoch (expand_rank)
         self.k = 0
