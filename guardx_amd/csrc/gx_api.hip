@@ -1187,12 +1187,13 @@ static gx_status rollout_policy_stepwise(gx_engine* e, int32_t T, const gx_polic
     launch_policy_transpose(pol->d_params, e->pol_wt, D, A, H, s);
     GX_HIP(hipMemcpyAsync(e->pol_cur, d_obs0, sizeof(float) * (size_t)N * D, hipMemcpyDeviceToDevice, s));
     const bool group = use_group_path(e);
+    const bool valu = e->policy_impl == 1; // gx_set_policy_impl(e, 1): fmaf chains; otherwise the MFMA tiles
     if (!group) { st = flush_pending(e, s); if (st != GX_OK) return st; }
     for (int32_t t = 0; t < T; ++t) {
         const size_t tn = (size_t)t * N;
         launch_policy_step(H, pol->d_params, e->pol_wt, e->pol_cur, pol->seed[0], pol->seed[1], e->policy_steps + (uint32_t)t, N, D,
                            A, e->p.env_offset, 0, d_obs_in + tn * D, d_act + tn * A, d_mu + tn * A, d_logp + tn, d_val + tn,
-                           nullptr, d_logstd, s);
+                           nullptr, d_logstd, s, valu);
         RolloutArgs r;
         fill_rollout_args(e, r, 1, slot);
         r.keys = e->h_keys[slot] + t;          // this step's reset_done key (engine.py:431,447,500)
@@ -1208,7 +1209,7 @@ static gx_status rollout_policy_stepwise(gx_engine* e, int32_t T, const gx_polic
         if (e->hist < 2) e->hist++;
     }
     launch_policy_step(H, pol->d_params, e->pol_wt, e->pol_cur, pol->seed[0], pol->seed[1], 0u, N, D, A, e->p.env_offset, 1,
-                       nullptr, nullptr, nullptr, nullptr, d_val_last, d_obs_last, nullptr, s);
+                       nullptr, nullptr, nullptr, nullptr, d_val_last, d_obs_last, nullptr, s, valu);
     e->last_policy = false; // (the open-loop kernels ran: the prefetch sampler keeps its back-to-back chain)
     GX_HIP(hipEventRecord(e->keys_ev[slot], s));
     GX_HIP(hipGetLastError());

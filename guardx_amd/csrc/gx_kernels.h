@@ -148,10 +148,11 @@ struct RobotLaunch {
 bool policy_step_supported(int H);
 int policy_step_wt_floats(int D, int H);
 void launch_policy_transpose(const float* params, float* wt, int D, int A, int H, hipStream_t s);
+// valu: sequential fmaf chains on the vector ALUs instead of v_mfma_f32_16x16x4_f32 tiles (same bits)
 // mode 0: ac.step for one time step (obs -> obs_in, act, mu, logp, val); mode 1: critic only (val -> val_last, obs_last)
 void launch_policy_step(int H, const float* params, const float* wt, const float* obs, uint32_t seed0, uint32_t seed1,
                         uint32_t tnoise, int N, int D, int A, int env_offset, int mode, float* obs_in, float* act, float* mu,
-                        float* logp, float* val, float* obs_last, float* logstd, hipStream_t s);
+                        float* logp, float* val, float* obs_last, float* logstd, hipStream_t s, bool valu = false);
 bool policy_rollout_supported(const Params& p);
 size_t policy_lds_bytes(const Params& p, int impl);
 void launch_math_probe2(int n, const float* x, float* lg, float* th, hipStream_t s);

@@ -125,12 +125,14 @@ def test_policy_rollout_parity(oracle, robot, impl):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("robot,hidden", [("point", 128), ("point", 256), ("swimmer", 192), ("ant", 128), ("walker", 256),
-                                          ("point", 64), ("ant", 64)])
-def test_policy_rollout_other_widths_parity(oracle, robot, hidden):
+@pytest.mark.parametrize("robot,hidden,impl", [("point", 128, "mfma"), ("point", 128, "valu"), ("point", 256, "mfma"),
+                                               ("swimmer", 192, "mfma"), ("ant", 128, "mfma"), ("walker", 256, "valu"),
+                                               ("walker", 256, "mfma"), ("point", 64, "mfma"), ("ant", 64, "mfma")])
+def test_policy_rollout_other_widths_parity(oracle, robot, hidden, impl):
     """hidden_sizes (h, h) beyond the fused kernel's 64 (trpo.py:606-607 --hid): the step-wise form (two launches per
-    control step, gx_policy_step.hip) equals the checker bit for bit -- every output, the state afterwards, a second call
-    that continues the noise stream; at h = 64 (gx_set_policy_impl(3)) it also equals the FUSED kernel's outputs."""
+    control step, gx_policy_step.hip; hidden layers as v_mfma_f32_16x16x4_f32 tiles by default, as fmaf chains with
+    gx_set_policy_impl(1)) equals the checker bit for bit -- every output, the state afterwards, a second call that
+    continues the noise stream; at h = 64 (gx_set_policy_impl(3)) it also equals the FUSED kernel's outputs."""
     import torch
     from guardx_amd import Engine
     N, T = 203, 40
@@ -139,6 +141,8 @@ def test_policy_rollout_other_widths_parity(oracle, robot, hidden):
     E = Engine(cfg, n_candidates=40000)
     if hidden == 64:
         E.set_policy_impl(3)
+    elif impl == "valu":
+        E.set_policy_impl(1)
     O = oracle.OracleEngine(cfg, n_candidates=40000)
     og, oo = E.reset(), O.reset()
     np.testing.assert_array_equal(og.cpu().numpy(), oo)

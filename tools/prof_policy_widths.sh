@@ -1,4 +1,4 @@
-cd /tmp && export TMPDIR=/tmp
+cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kt_pw
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_pw -- python3 $GRAFT_REPO_ROOT/tools/bench_policy_widths.py > $GRAFT_REPO_ROOT/gpurun_out/pw.log 2>&1
 python3 - <<'PY'
 import csv, glob
