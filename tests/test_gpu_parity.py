@@ -1450,9 +1450,7 @@ def test_config4_default_path_eight_ranks_full_size(torch_cuda, oracle):
 
             class Work:                     # "wait" = the collective of that epoch is complete: every rank has put
                 def wait(self_inner):
-                    if me.recv[i].numel() != W * me.n or not getattr(self_inner, "done", False):
-                        me.recv[i] = gathered[ep]
-                        self_inner.done = True
+                    me.recv[i] = gathered[ep]
             return Work()
     hs = [InProcess(e, r) for r, e in enumerate(ranks)]
     assert len({h.cap for h in hs}) == 1 and hs[0].n % 4 == 0
@@ -1468,18 +1466,13 @@ def test_config4_default_path_eight_ranks_full_size(torch_cuda, oracle):
             for r, e in enumerate(ranks):
                 assert torch.equal(e.reset(check=False), o_full[r * N:(r + 1) * N]), (ep, r)
         *_, pk = full.rollout(acts, packed=True)
-        # every rank steps (its tape + the block sampled for a later reset go "on the wire") ...
+        # every rank steps: its tape + the block sampled for a later reset go "on the wire", and -- as in the real
+        # pipeline -- it expands / installs the PREVIOUS epoch's gathered buffer, whose collective is complete by now
         for r, h in enumerate(hs):
-            h.pending_before = h.pending
-            h.pending = None                                   # (expanded below, once the epoch's wire is complete)
             h.step(acts[:, r * N:(r + 1) * N].contiguous())
         gathered[ep] = wire.gathered(ep)
-        # ... and expands / installs the PREVIOUS epoch's gathered buffer, as TapeHandoff.step does one epoch late
         if prev is not None:
             for r, h in enumerate(hs):
-                cur, h.pending = h.pending, h.pending_before
-                h._expand_pending()
-                h.pending = cur
                 torch.cuda.current_stream().wait_stream(h.stream)
                 for s in range(W):
                     assert torch.equal(h.rollout[s].view(torch.int32),
