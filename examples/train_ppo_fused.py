@@ -7,7 +7,10 @@ The learners of safe_rl_libX drive `env.step()` themselves and stay drop-in on `
 this script shows what a learner gains when it hands the collection loop to the device instead.
 It also serves as a sanity check of the environment semantics: the return must go up.
 
-    python examples/train_ppo_fused.py [--epochs 30] [--env-num 2000]
+    python examples/train_ppo_fused.py [--epochs 30] [--env-num 2000] [--hid 64]
+
+--hid: hidden width of actor and critic (trpo.py:606; 64, 128, 192 or 256 -- at 64 the collection phase is one launch,
+wider networks take two launches per control step, guardx_amd/csrc/gx_policy_step.hip).
 """
 import argparse
 import os
@@ -35,6 +38,7 @@ def main():
     ap.add_argument("--env-num", type=int, default=2000)
     ap.add_argument("--task", default="Goal_Point_8Hazards")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--hid", type=int, default=64, choices=Engine.POLICY_HIDDEN)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.manual_seed(args.seed)
@@ -42,7 +46,7 @@ def main():
     cfg = dict(configuration(args.task), env_num=args.env_num, _seed=args.seed, num_steps=T)
     env = Engine(cfg)
     D, A = env.obs_flat_size, env.action_space.shape[0]
-    mu_net, v_net = mlp([D, 64, 64, A]).to(dev), mlp([D, 64, 64, 1]).to(dev)
+    mu_net, v_net = mlp([D, args.hid, args.hid, A]).to(dev), mlp([D, args.hid, args.hid, 1]).to(dev)
     log_std = nn.Parameter(torch.full((A,), -0.5, device=dev))
     pi_opt = torch.optim.Adam(list(mu_net.parameters()) + [log_std], lr=3e-4)
     v_opt = torch.optim.Adam(v_net.parameters(), lr=1e-3)
