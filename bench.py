@@ -754,6 +754,8 @@ def main():
             "packed_rows_bytes_per_rank_per_epoch": int(EP_LEN * ENV_NUM * (env.obs_flat_size + 2 + 3) * 4),
             "received_per_rank_at_8_gpus_bytes": 7 * shard_bytes,
             "allgather_ms_at_8_gpus_310GBps": round(7 * shard_bytes / 310e9 * 1e3, 4),
+            "note_n1": "at N = 1 no hand-off runs; the shard here is the bare tape -- at N > 1 each rank's block of valid "
+                       "layouts (~0.5 MB) rides in its tail",
             "ms_per_step_this_run": round(dt / args.steps * 1e3, 4),
             "note": "one async all-gather of the dynamics tape per epoch (48 B per env-step: qpos, qvel, action, done, "
                     "two layout-row indices; at N > 1 plus the rank's export block of valid layouts, ~0.5 MB), overlapped "
@@ -801,6 +803,17 @@ def main():
                   lambda: {f"hidden_{h}": round(closed_loop_rate(device, 20, h), 1) for h in (128, 256)})
             extra("reset_done_heavy", lambda: reset_done_heavy(device))
             extra("multi_gpu_rehearsal", lambda: multi_gpu_rehearsal(device))
+            mg = line.get("multi_gpu_rehearsal", {})
+            if "expand_all" in mg and isinstance(line.get("handoff_model"), dict):   # the prediction next to the byte count
+                line["handoff_model"]["predicted_at_8_gpus"] = {
+                    "rank_epoch_ms_measured_on_one_gpu": mg["expand_all"]["ms_per_epoch"],
+                    "one_gpu_epoch_ms": mg["one_gpu_own_sampler"]["ms_per_epoch"],
+                    "weak_scaling_efficiency_at_310GBps": mg["expand_all"]["model"]["at_310GBps"]["weak_scaling_efficiency"],
+                    "weak_scaling_efficiency_at_200GBps": mg["expand_all"]["model"]["at_200GBps"]["weak_scaling_efficiency"],
+                    "bytes_received_per_rank_per_epoch": mg["expand_all"]["bytes_received_per_epoch"],
+                    "note": "from `multi_gpu_rehearsal` (this GPU playing rank 0 of 8 in the default N > 1 epoch, fresh "
+                            "process): GPU time of a rank's epoch measured, the link as bytes / bandwidth; efficiency = "
+                            "one-GPU epoch / max(rank epoch, all-gather time)"}
             extra("other_robots", lambda: other_robots(device))
         if world == 1 and not args.no_cpu_baseline:
             try:
