@@ -657,7 +657,7 @@ def main():
     env.set_prefetch(EP_LEN)
     tapes = [action_tape(EP_LEN, ENV_NUM, 1000 * rank + k, device) for k in range(4)]
     gather = world > 1
-    # the hand-off: "tape" (default) all-gathers the 48-B-per-env-step dynamics tape and expands it on every rank,
+    # the hand-off: "tape" (default) all-gathers the 40-B-per-env-step dynamics tape and expands it on every rank,
     # "packed" all-gathers the 192-B packed rows (what round 1 did; GX_HANDOFF=packed to compare)
     mode = os.environ.get("GX_HANDOFF", "tape")
     if gather and mode == "tape":
@@ -757,7 +757,7 @@ def main():
             "note_n1": "at N = 1 no hand-off runs; the shard here is the bare tape -- at N > 1 each rank's block of valid "
                        "layouts (~0.5 MB) rides in its tail",
             "ms_per_step_this_run": round(dt / args.steps * 1e3, 4),
-            "note": "one async all-gather of the dynamics tape per epoch (48 B per env-step: qpos, qvel, action, done, "
+            "note": "one async all-gather of the dynamics tape per epoch (40 B per env-step: qpos, qvel, action, done, "
                     "two layout-row indices; at N > 1 plus the rank's export block of valid layouts, ~0.5 MB), overlapped "
                     "with the following epoch; 310 GB/s = a realistic all-gather bus "
                     "bandwidth over 7 xGMI links (537 GB/s peak per direction); arithmetic, not a measurement"}

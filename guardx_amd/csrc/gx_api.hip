@@ -135,6 +135,13 @@ static bool in_group_regime(const gx_engine* e)
     return e->p.N <= limit;
 }
 
+// floats of the dynamics tape of a T-step rollout, rounded up so that what follows it in a shard buffer (the layout
+// snapshot, float4 planes) stays 16-byte aligned: a tape row is 10 floats for the Point
+static size_t tape_floats_padded(const gx_engine* e, int32_t T)
+{
+    return ((size_t)T * e->p.N * split_tape_width(e->p) + 3) / 4 * 4;
+}
+
 // fused rollouts at small env_num: two kernels (a serial dynamics tape, then one thread per
 // (step, env) row) instead of the persistent lane-group kernel, from 8 steps up
 static bool use_split_rollout(const gx_engine* e, int T)
@@ -1001,7 +1008,7 @@ static gx_status rollout_impl(gx_engine* e, int32_t T, const float* d_actions, f
     r.act_out = d_act_out; r.obs_stride = obs_stride; r.sc_stride = sc_stride;
     e->last_policy = false;
     if (use_split_rollout(e, T)) { // light robots, small env_num: dynamics tape + one thread per (step, env) row
-        const size_t nt = (size_t)T * e->p.N * split_tape_width(e->p);
+        const size_t nt = tape_floats_padded(e, T);
         const size_t need = nt + (size_t)e->p.N * split_entry_width(e->p); // [tape | entry records]
         if (need > e->tape_cap) {
             GX_HIP(hipStreamSynchronize(s));            // an earlier launch may still read the old tape
@@ -1054,7 +1061,7 @@ extern "C" gx_status gx_rollout_packed(gx_engine* e, int32_t T, const float* d_a
 extern "C" int32_t gx_packed_width(const gx_engine* e) { return e ? e->p.D + e->na + 3 : -1; }
 
 // ---------------------------------------------------------------------------------------------------------------
-// tape hand-off: the rank that steps the envs runs only the serial dynamics pass and hands out its tape (48 B per
+// tape hand-off: the rank that steps the envs runs only the serial dynamics pass and hands out its tape (40 B per
 // env-step for the Point -- qpos, qvel, action, done, two layout-row indices -- instead of the 192 B packed row);
 // whoever needs the rollout -- every rank, after ONE all-gather of the tapes -- runs the observation pass on it, which
 // re-derives pose, ctrl and reward.  Every rank samples the same layout pools (the key is shared, engine.py:263), so
@@ -1066,7 +1073,7 @@ extern "C" gx_status gx_tape_floats(const gx_engine* e, int32_t T, int64_t* tape
     if (!e || T < 1 || !tape || !obj0 || !entry) return fail(GX_ERR_ARG, "bad argument");
     if (!split_rollout_supported(e->p))
         return fail(GX_ERR_UNSUPPORTED, "tape hand-off: needs a task without observe_vel / observe_acc and one physics step per control step");
-    *tape = (int64_t)T * e->p.N * split_tape_width(e->p);
+    *tape = (int64_t)tape_floats_padded(e, T);
     *obj0 = (int64_t)e->p.P * e->p.Npad * 4;
     *entry = (int64_t)e->p.N * split_entry_width(e->p);
     return GX_OK;
@@ -1092,7 +1099,7 @@ extern "C" gx_status gx_rollout_tape(gx_engine* e, int32_t T, const float* d_act
     e->last_policy = false;
     st = flush_pending(e, s);
     if (st != GX_OK) return st;
-    const size_t nt = (size_t)T * e->p.N * split_tape_width(e->p), no = (size_t)e->p.P * e->p.Npad * 4;
+    const size_t nt = tape_floats_padded(e, T), no = (size_t)e->p.P * e->p.Npad * 4;
     GX_HIP(launch_split_rollout(e->p, r, d_shard, reinterpret_cast<float4*>(d_shard + nt), d_shard + nt + no, e->b, s,
                                 nullptr, 1, (e->pf_valid && e->prefetch_steps != -1) ? 1 : 4));
     GX_HIP(hipEventRecord(e->keys_ev[slot], s));
@@ -1123,7 +1130,7 @@ static gx_status expand_impl(gx_engine* e, int32_t T, const float* d_shards, int
     const int W = e->p.D + e->na + 3;
     r.T = T; r.do_reset = 1; r.nobj_total = e->nobj_total;
     r.cand_xy = e->pools[pi].cand_xy; r.n_rows = e->sp.M; r.fake = e->pools[pi].fake;
-    const size_t nt = (size_t)T * e->p.N * split_tape_width(e->p), no = (size_t)e->p.P * e->p.Npad * 4;
+    const size_t nt = tape_floats_padded(e, T), no = (size_t)e->p.P * e->p.Npad * 4;
     if (n_shards > 1 && ((size_t)stride_floats < nt + no + (size_t)e->p.N * split_entry_width(e->p) ||
                          (size_t)packed_stride_floats < (size_t)T * e->p.N * W))
         return fail(GX_ERR_ARG, "gx_expand_tapes: the strides are smaller than one shard / one packed rollout");

@@ -4,7 +4,7 @@
 //   pass 1  the serial chain: convert_action, mjx.step, done / NaN guard / timeout, reset_done (layout index draw +
 //           re-placement) -- everything the NEXT step depends on -- and one SLIM tape row per (step, env): qpos, qvel after
 //           the step, the action, done, the layout row in effect and the layout row a reset_done installed.
-//           dyn_tape_kernel (Point, Swimmer): one thread per env, 12 / 16 floats per row, ~170 instructions per Point step
+//           dyn_tape_kernel (Point, Swimmer): one thread per env, 10 / 14 floats per row, ~170 instructions per Point step
 //           (the Swimmer also as a quad of lanes per env, SwimmerRobot::substep_q).
 //           group_dyn_tape_kernel (Ant, Walker; round 3): the lane-group form of their step, 16 lanes per env, 36 / 40
 //           floats per row (+ the row of the pool's fake-step table a reset_done observation is read from).
@@ -32,13 +32,21 @@ namespace gx {
 
 template <class R>
 struct SplitTape {
-    // kFidx (Ant, Walker): row of Pool::fake (= index into the compacted layout list) of the layout a reset_done installed
-    static constexpr int kQ = 0, kV = kQ + R::NQ, kAct = kV + R::NV, kDone = kAct + R::NA, kJcur = kDone + 1,
-                         kJaft = kJcur + 1, kFidx = kJaft + 1, kUsed = kFidx + (R::kRestFixed ? 0 : 1),
-                         kW = (kUsed + 3) / 4 * 4;
+    // One row per (step, env): qpos | qvel after the step | the action | the layout row in effect (-1: the layout at
+    // entry) | kCode: done and reset_done in one word -- -1: the step did not finish the env; -2: it did, and no layout
+    // was installed (no reset_done in this launch, or an empty pool); j >= 0: it did, and reset_done installed layout row j
+    // | kFidx (Ant, Walker): row of Pool::fake (= index into the compacted layout list) of that layout.
+    // Round 4: `done` rode in a word of its own and the row was padded to 16 bytes (Point: 12 floats); now 10 floats =
+    // 40 B (Swimmer 14, Ant 34, Walker 40) -- this is what the multi-GPU hand-off puts on the wire, 400 000 rows per
+    // rank and epoch.  Rows are 8-byte aligned (kW is even).
+    static constexpr int kQ = 0, kV = kQ + R::NQ, kAct = kV + R::NV, kJcur = kAct + R::NA, kCode = kJcur + 1,
+                         kFidx = kCode + 1, kUsed = kFidx + (R::kRestFixed ? 0 : 1), kW = (kUsed + 1) / 2 * 2;
     // entry record of an env: qpos at entry | the stale pose (x, y, cos, sin) | done0 | number of step() calls so far
     static constexpr int kEQ = 0, kEPose = R::NQ, kEDone = kEPose + 4, kEHist = kEDone + 1, kE = (kEHist + 1 + 3) / 4 * 4;
     static_assert(!R::kRestFixed || kE == 12, "entry record of the light robots: 12 floats (include/guardx.h)");
+    GX_D static int code(float dn, int jaft) { return dn > 0.0f ? (jaft >= 0 ? jaft : -2) : -1; }
+    GX_D static float done_of(int c) { return c != -1 ? 1.0f : 0.0f; }
+    GX_D static int jaft_of(int c) { return c >= 0 ? c : -1; }
 };
 
 struct SplitArgs {
@@ -56,21 +64,38 @@ constexpr int kActBlock = 16; // steps whose actions the dynamics pass fetches a
 constexpr int kObsGridCap = 3072; // one-wave workgroups of a ONE-shard observation launch (measured: 47.1 -> 44.2 us at 400 000 rows; a launch over
                                   // several shards is fastest uncapped: 32.5 us per shard at 8 shards)
 
+// rows of W floats, W even: 16-byte pieces and, for W % 4 == 2, one 8-byte piece.  Tape rows start on 8-byte boundaries
+// only (kW = 10 for the Point), so the 16-byte accesses are declared with 8-byte alignment (the hardware takes a dwordx4
+// at any dword address; the compiler must not be told more than is true); entry records are 16-byte aligned rows of 12.
+typedef float gx_f4u __attribute__((ext_vector_type(4), aligned(8)));
+typedef float gx_f2u __attribute__((ext_vector_type(2), aligned(8)));
 template <int W>
 GX_D void load_row(const float* __restrict__ p, float (&v)[W])
 {
+    static_assert(W % 2 == 0, "even row width");
 #pragma unroll
     for (int k = 0; k < W / 4; ++k) {
-        const float4 t4 = reinterpret_cast<const float4*>(p)[k];
+        const gx_f4u t4 = *reinterpret_cast<const gx_f4u*>(p + 4 * k);
         v[4 * k] = t4.x; v[4 * k + 1] = t4.y; v[4 * k + 2] = t4.z; v[4 * k + 3] = t4.w;
+    }
+    if (W % 4) {
+        const gx_f2u t2 = *reinterpret_cast<const gx_f2u*>(p + W - 2);
+        v[W - 2] = t2.x; v[W - 1] = t2.y;
     }
 }
 template <int W>
 GX_D void store_row(float* __restrict__ p, const float (&v)[W])
 {
+    static_assert(W % 2 == 0, "even row width");
 #pragma unroll
-    for (int k = 0; k < W / 4; ++k)
-        reinterpret_cast<float4*>(p)[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    for (int k = 0; k < W / 4; ++k) {
+        gx_f4u t4; t4.x = v[4 * k]; t4.y = v[4 * k + 1]; t4.z = v[4 * k + 2]; t4.w = v[4 * k + 3];
+        *reinterpret_cast<gx_f4u*>(p + 4 * k) = t4;
+    }
+    if (W % 4) {
+        gx_f2u t2; t2.x = v[W - 2]; t2.y = v[W - 1];
+        *reinterpret_cast<gx_f2u*>(p + W - 2) = t2;
+    }
 }
 
 template <class R, int BLOCK, int PMAX, bool kDef, int LPE = 1>
@@ -271,8 +296,7 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
         for (int k = 0; k < R::NV; ++k) rowv[TP::kV + k] = v[k];
 #pragma unroll
         for (int k = 0; k < R::NA; ++k) rowv[TP::kAct + k] = a[k];
-        rowv[TP::kDone] = dn;
-        rowv[TP::kJcur] = __int_as_float(jcur); rowv[TP::kJaft] = __int_as_float(jaft);
+        rowv[TP::kJcur] = __int_as_float(jcur); rowv[TP::kCode] = __int_as_float(TP::code(dn, jaft));
 #pragma unroll
         for (int k = TP::kUsed; k < TP::kW; ++k) rowv[k] = 0.f;
         if (writer) store_row<TP::kW>(sa.tape + ((size_t)t * p.N + i) * TP::kW, rowv);
@@ -482,8 +506,7 @@ __global__ __launch_bounds__(64) void group_dyn_tape_kernel(Params p_in, Rollout
             for (int k = 0; k < R::NV; ++k) rowv[TP::kV + k] = v[k];
 #pragma unroll
             for (int k = 0; k < R::NA; ++k) rowv[TP::kAct + k] = a[k];
-            rowv[TP::kDone] = dn;
-            rowv[TP::kJcur] = __int_as_float(jcur); rowv[TP::kJaft] = __int_as_float(jaft);
+            rowv[TP::kJcur] = __int_as_float(jcur); rowv[TP::kCode] = __int_as_float(TP::code(dn, jaft));
             rowv[TP::kFidx] = __int_as_float(fidx);
 #pragma unroll
             for (int k = TP::kUsed; k < TP::kW; ++k) rowv[k] = 0.f;
@@ -525,7 +548,7 @@ template <class R>
 GX_D void next_start(const float (&rowv)[SplitTape<R>::kW], const RolloutArgs& r, float (&s)[R::NQ])
 {
     using TP = SplitTape<R>;
-    const int jaft = __float_as_int(rowv[TP::kJaft]);
+    const int jaft = TP::jaft_of(__float_as_int(rowv[TP::kCode]));
     if (jaft >= 0 && jaft < r.n_rows) {
         const float2 rb = r.cand_xy[(size_t)jaft * r.nobj_total + r.nobj_total - 1];
 #pragma unroll
@@ -594,8 +617,8 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
     for (int k = 0; k < R::NV; ++k) v[k] = rowv[TP::kV + k];
 #pragma unroll
     for (int k = 0; k < R::NA; ++k) a[k] = rowv[TP::kAct + k];
-    const float dn = rowv[TP::kDone];
-    const int jcur = __float_as_int(rowv[TP::kJcur]), jaft = __float_as_int(rowv[TP::kJaft]);
+    const float dn = TP::done_of(__float_as_int(rowv[TP::kCode]));
+    const int jcur = __float_as_int(rowv[TP::kJcur]), jaft = TP::jaft_of(__float_as_int(rowv[TP::kCode]));
 
     // what the step started from (s), the stale pose it found (pose0) and the done flag before it
     float s[R::NQ], pose0[4], last_done, hist0;
@@ -610,7 +633,7 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
         float prev[TP::kW];
         load_row<TP::kW>(sa.tape + (gg - (size_t)p.N) * TP::kW, prev);
         next_start<R>(prev, r, s);
-        last_done = prev[TP::kDone];
+        last_done = TP::done_of(__float_as_int(prev[TP::kCode]));
         float sp[R::NQ]; // what the PREVIOUS step started from: its pose is this step's stale pose (reset_done keeps it, :731)
         if (t == 1) {
 #pragma unroll
