@@ -1491,3 +1491,34 @@ def test_config4_default_path_eight_ranks_full_size(torch_cuda, oracle):
     full.close()
     for e in ranks:
         e.close()
+
+
+@pytest.mark.parametrize("robot,N,T", [("point", 37, 9), ("swimmer", 51, 7), ("ant", 13, 5), ("walker", 9, 3)])
+def test_tape_rows_odd_sizes(torch_cuda, robot, N, T):
+    """Tape rows are 10 / 14 / 34 / 40 floats (8-byte aligned, not 16): with an odd number of rows the tape is rounded up
+    to a multiple of 4 floats so that the layout snapshot behind it stays 16-byte aligned.  rollout_tape + expand_tape
+    (own stream, one and three "ranks" in one launch) equal rollout(packed=True) bit for bit at such sizes."""
+    torch = torch_cuda
+    from guardx_amd import Engine
+    extra = {"point": {}, "swimmer": SWIMMER, "ant": ANT, "walker": WALKER}[robot]
+    cfg = task_config(N, seed=11, num_steps=1, goal_size=2.7, **extra)      # (the timeout fires on step num_steps + 2)
+    a, b = Engine(cfg, n_candidates=30000), Engine(cfg, n_candidates=30000)
+    A = a.action_space.shape[0]
+    assert (N * T) % 2 == 1
+    tape, lay, ent = a.tape_floats(T)
+    width = {"point": 10, "swimmer": 14, "ant": 34, "walker": 40}[robot]
+    assert tape == (N * T * width + 3) // 4 * 4 and tape % 4 == 0
+    rng = np.random.default_rng(3)
+    for ep in range(2):
+        assert torch.equal(a.reset(), b.reset())
+        acts = torch.from_numpy(rng.uniform(-1, 1, (T, N, A)).astype(np.float32)).cuda()
+        sh, tok = a.rollout_tape(acts)
+        *_, pk = b.rollout(acts, packed=True)
+        assert pk[..., -1].sum().item() > 0                      # timeouts: reset_done rows in the tape
+        assert torch.equal(a.expand_tape(sh, tok, T).view(torch.int32), pk.view(torch.int32))
+        n = sh.numel()
+        three = torch.cat([sh, sh, sh])
+        out = a.expand_tapes(three, n, 3, tok, T, torch.empty(3, T, N, pk.shape[-1], device='cuda'))
+        for s in range(3):
+            assert torch.equal(out[s].view(torch.int32), pk.view(torch.int32)), s
+    a.close(); b.close()
