@@ -263,7 +263,8 @@ class ShardedReset:
     its pool (Engine.reset_from_shards): layout_size, pool rows, the observation and every later randint draw are those of
     the unsharded reset(), bit for bit, and the sampler's 0.5 ms of vector-ALU work is done once per node instead of once
     per GPU.  It is a SECOND collective (north_star allows one, the rollout hand-off), so nothing uses it unless asked:
-    bench.py with GX_SHARD_SAMPLER=1.  The sampler then runs on the caller's stream in front of the epoch (no prefetch
+    a caller without a rollout hand-off (with one, TapeHandoff shards the sampler on the hand-off's own collective).  The
+    sampler then runs on the caller's stream in front of the epoch (no prefetch
     overlap): per epoch 1/W of the sampler + one small all-gather + the install."""
 
     def __init__(self, env):
