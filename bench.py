@@ -496,6 +496,30 @@ def other_robots(device, epochs=50):
                      "ms_per_epoch": round(dt / epochs * 1e3, 4)}
         if label:
             out[name]["label"] = label
+        # the same epochs through the hand-off pipeline in a world of one: the observation pass of epoch k runs on the
+        # hand-off's stream during epoch k + 1 (packed rows one epoch late) instead of behind the dynamics pass -- what
+        # a rank of the multi-GPU run does; it pays where the dynamics chain, not the sampler, bounds the epoch
+        try:
+            from guardx_amd.dist import TapeHandoff
+            env = Engine(cfg)
+            h = TapeHandoff(env, EP_LEN, sharded_sampler=False)
+
+            def epoch_p():
+                env.reset(check=False)
+                h.step(tape)
+            epoch_p(); epoch_p()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(epochs):
+                epoch_p()
+            h.drain()
+            torch.cuda.synchronize()
+            dtp = time.perf_counter() - t0
+            env.check_layouts()
+            env.close()
+            out[name]["pipelined_env_steps_per_s"] = round(ENV_NUM * EP_LEN * epochs / dtp, 1)
+        except Exception as exc:  # noqa: BLE001
+            out[name]["pipelined_env_steps_per_s"] = f"{type(exc).__name__}: {exc}"[:120]
     return out
 
 
