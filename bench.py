@@ -128,7 +128,21 @@ def precondition_clocks(device, ms=PRECONDITION_MS):
     power ramp is over when the W warm-up epochs start.  Measured on this pool (tools/history/debug/cold_start_probe.py,
     DESIGN.md section 6): after >= 50 ms of idle the first ~25 epochs (13 ms) run 10 % -> 0 % slower than the steady
     state whatever ran before the idle gap, and 30 ms of any sustained compute removes that.  The driver's region
-    (5 + 20 epochs = 13 ms) would otherwise sit entirely inside the ramp.  The line reports `cold_start` beside."""
+    (5 + 20 epochs = 13 ms) would otherwise sit entirely inside the ramp.  The line reports `cold_start` beside.
+    (GX_PRECONDITION=int / GX_PRECONDITION_MS: experiments with another kind and length of filler work.)"""
+    ms = float(os.environ.get("GX_PRECONDITION_MS", ms))
+    kind = os.environ.get("GX_PRECONDITION", "mm")
+    if kind == "int":
+        x = torch.arange(1 << 24, device=device, dtype=torch.int32)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 0
+        while (time.perf_counter() - t0) * 1e3 < ms:
+            for _ in range(8):
+                x.mul_(1664525).add_(1013904223)
+            n += 8
+            torch.cuda.synchronize()
+        return {"ms": round((time.perf_counter() - t0) * 1e3, 1), "work": f"{n} x int32 multiply-add over 2^24 elements (not the workload)"}
     a = torch.ones(4096, 4096, device=device)
     b = torch.ones(4096, 4096, device=device)
     c = a @ b                                            # library initialisation happens here, outside the busy loop
