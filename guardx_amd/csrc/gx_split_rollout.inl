@@ -224,96 +224,127 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
         const float mx = pose[0] - pose0[0], my = pose[1] - pose0[1];
         const float gdx = gx - pose[0], gdy = gy - pose[1];
         const float d2 = gdx * gdx + gdy * gdy;                 // dist2()'s radicand
-        const bool ordinary = objs_ok && s_ok && p_ok && p.physics_steps == 1 && moderate(mag) &&
-                              (mx * mx + my * my) < 0.9f && d2 < 1e8f;
-        float dn;
-        if (ordinary) {
+        // (bitwise, not short-circuit: five compares and four scalar ANDs instead of nested exec-mask regions)
+        const bool ordinary = (int)objs_ok & (int)s_ok & (int)p_ok & (int)(p.physics_steps == 1) & (int)moderate(mag) &
+                              (int)((mx * mx + my * my) < 0.9f) & (int)(d2 < 1e8f);
+        // COMMON STEP vs GENERAL STEP (round 4).  Almost every step of almost every wave is ordinary, finishes no env
+        // (no goal reached, no timeout) and so re-initialises nothing.  The per-lane branches for the other cases -- the
+        // exact redo, done, the reset_done draw, the re-placement -- cost this serial chain an exec-mask save / restore
+        // and a taken jump over kilobytes of cold code each, every step (stubbing the dynamics showed 86 of the Point's
+        // 114 us per 200 steps in this wrapper, not in the step).  One wave-uniform test now selects a branch-free
+        // commit; any lane that needs more sends the whole wave through the general code below (same results).
+        const bool rare = (int)!ordinary | (int)(d2 < p.goal_cut) | (int)(steps > p.num_steps_f);
+        if (__builtin_expect(__ballot(rare) == 0ull, 1)) {
 #pragma unroll
             for (int k = 0; k < R::NQ; ++k) q[k] = qf[k];
 #pragma unroll
             for (int k = 0; k < R::NV; ++k) v[k] = vf[k];
-            dn = d2 < p.goal_cut ? 1.0f : 0.0f;
-            p_ok = true;   // this step's pose: the kinematics of a moderate qpos
-            s_ok = true;   // moderate(mag)
-        } else { // rare: the step again, exactly (from the untouched q, v)
-            for (int k = 0; k < p.physics_steps; ++k) {
-                if constexpr (LPE == 4) R::template substep_q<true>(q, v, ctrl, pose, qacc, jq);
-                else R::template substep<false>(q, v, ctrl, pose, qacc);
+            p_ok = true; s_ok = true;
+            steps = steps + 1.0f;                       // :493 (done == 0)
+            float rowv[TP::kW];
+#pragma unroll
+            for (int k = 0; k < R::NQ; ++k) rowv[TP::kQ + k] = q[k];
+#pragma unroll
+            for (int k = 0; k < R::NV; ++k) rowv[TP::kV + k] = v[k];
+#pragma unroll
+            for (int k = 0; k < R::NA; ++k) rowv[TP::kAct + k] = a[k];
+            rowv[TP::kJcur] = __int_as_float(jcur); rowv[TP::kCode] = __int_as_float(-1);
+#pragma unroll
+            for (int k = TP::kUsed; k < TP::kW; ++k) rowv[k] = 0.f;
+            if (writer) store_row<TP::kW>(sa.tape + ((size_t)t * p.N + i) * TP::kW, rowv);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pose0[k] = pose[k];
+            done0 = 0.0f;
+        } else {
+            float dn;
+            if (ordinary) {
+#pragma unroll
+                for (int k = 0; k < R::NQ; ++k) q[k] = qf[k];
+#pragma unroll
+                for (int k = 0; k < R::NV; ++k) v[k] = vf[k];
+                dn = d2 < p.goal_cut ? 1.0f : 0.0f;
+                p_ok = true;   // this step's pose: the kinematics of a moderate qpos
+                s_ok = true;   // moderate(mag)
+            } else { // rare: the step again, exactly (from the untouched q, v)
+                for (int k = 0; k < p.physics_steps; ++k) {
+                    if constexpr (LPE == 4) R::template substep_q<true>(q, v, ctrl, pose, qacc, jq);
+                    else R::template substep<false>(q, v, ctrl, pose, qacc);
+                }
+                world_pose(p, pose);
+                // NaN / Inf guard :696-699
+                float4 ob[PMAX];
+                if (jcur >= 0) { float rx_, ry_; load_layout<PMAX>(p, r.cand_xy, r.nobj_total, jcur, ob, rx_, ry_); }
+                else {
+#pragma unroll
+                    for (int k = 0; k < PMAX; ++k)
+                        ob[k] = (k < p.P) ? sa.obj0[(size_t)k * p.Npad + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                const bool bad = build_obs_row<R, PMAX>(p, row, pose, ob, ctrl, q, v, 0.f, 0.f, 0.f, 0.f);
+                // the done half of reward_done :787-802 (the reward itself is pass 2's)
+                const float dg = dist2(gx, gy, pose[0], pose[1]);
+                float last = dg;
+                if (have_last && !(last_done > 0.0f)) last = dist2(gx, gy, pose0[0], pose0[1]);
+                const float dd = last - dg;
+                dn = dg < p.goal_size ? 1.0f : 0.0f;
+                if (fabsf(dd) > 1.0f) dn = 1.0f;
+                if (bad) dn = 1.0f;                    // :696-699
+                float m1 = 0.f;
+#pragma unroll
+                for (int k = 0; k < R::NQ; ++k) m1 = m1 + fabsf(q[k]);
+#pragma unroll
+                for (int k = 0; k < R::NV; ++k) m1 = m1 + fabsf(v[k]);
+                p_ok = moderate(fabsf(pose[2]) + fabsf(pose[3]));
+                s_ok = moderate(m1);
             }
-            world_pose(p, pose);
-            // NaN / Inf guard :696-699
-            float4 ob[PMAX];
-            if (jcur >= 0) { float rx_, ry_; load_layout<PMAX>(p, r.cand_xy, r.nobj_total, jcur, ob, rx_, ry_); }
-            else {
-#pragma unroll
-                for (int k = 0; k < PMAX; ++k)
-                    ob[k] = (k < p.P) ? sa.obj0[(size_t)k * p.Npad + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (steps > p.num_steps_f) dn = 1.0f;      // :492
+            steps = dn > 0.0f ? 0.0f : steps + 1.0f;   // :493
+
+            // reset_done :497-505 for the env that just finished: the draw and the re-placement
+            int jaft = -1;
+            float nq0 = 0.f, nq1 = 0.f;
+            if (r.do_reset && dn > 0.0f && L > 0) {
+                const uint4 kk = r.keys ? r.keys[t] : r.key0;
+                const uint32_t idx = randint_at(kk.x, kk.y, kk.z, kk.w, (uint32_t)p.env_total, (uint32_t)L,
+                                                (uint32_t)(p.env_offset + i));
+                jaft = r.cand_of[idx];
+                const float2* rowp = r.cand_xy + (size_t)jaft * r.nobj_total;
+                const float2 g = rowp[0], rb = rowp[r.nobj_total - 1];
+                nq0 = rb.x; nq1 = rb.y;
+                gx = g.x; gy = g.y;
+                // The loads of this RARE branch must have landed before it ends: otherwise the compiler guards the next
+                // step's first touch of these registers with an s_waitcnt vmcnt(3) on the COMMON path -- and the memory
+                // counter is in order, so that wait also covers the tape stores of the step before the previous one: a
+                // store round trip on the serial chain of almost every step, for a load that almost never happened.
+                asm volatile("" : "+v"(nq0), "+v"(nq1), "+v"(gx), "+v"(gy));
             }
-            const bool bad = build_obs_row<R, PMAX>(p, row, pose, ob, ctrl, q, v, 0.f, 0.f, 0.f, 0.f);
-            // the done half of reward_done :787-802 (the reward itself is pass 2's)
-            const float dg = dist2(gx, gy, pose[0], pose[1]);
-            float last = dg;
-            if (have_last && !(last_done > 0.0f)) last = dist2(gx, gy, pose0[0], pose0[1]);
-            const float dd = last - dg;
-            dn = dg < p.goal_size ? 1.0f : 0.0f;
-            if (fabsf(dd) > 1.0f) dn = 1.0f;
-            if (bad) dn = 1.0f;                    // :696-699
-            float m1 = 0.f;
-#pragma unroll
-            for (int k = 0; k < R::NQ; ++k) m1 = m1 + fabsf(q[k]);
-#pragma unroll
-            for (int k = 0; k < R::NV; ++k) m1 = m1 + fabsf(v[k]);
-            p_ok = moderate(fabsf(pose[2]) + fabsf(pose[3]));
-            s_ok = moderate(m1);
-        }
-        if (steps > p.num_steps_f) dn = 1.0f;      // :492
-        steps = dn > 0.0f ? 0.0f : steps + 1.0f;   // :493
 
-        // reset_done :497-505 for the env that just finished: the draw and the re-placement
-        int jaft = -1;
-        float nq0 = 0.f, nq1 = 0.f;
-        if (r.do_reset && dn > 0.0f && L > 0) {
-            const uint4 kk = r.keys ? r.keys[t] : r.key0;
-            const uint32_t idx = randint_at(kk.x, kk.y, kk.z, kk.w, (uint32_t)p.env_total, (uint32_t)L,
-                                            (uint32_t)(p.env_offset + i));
-            jaft = r.cand_of[idx];
-            const float2* rowp = r.cand_xy + (size_t)jaft * r.nobj_total;
-            const float2 g = rowp[0], rb = rowp[r.nobj_total - 1];
-            nq0 = rb.x; nq1 = rb.y;
-            gx = g.x; gy = g.y;
-            // The loads of this RARE branch must have landed before it ends: otherwise the compiler guards the next
-            // step's first touch of these registers with an s_waitcnt vmcnt(3) on the COMMON path -- and the memory
-            // counter is in order, so that wait also covers the tape stores of the step before the previous one: a
-            // store round trip on the serial chain of almost every step, for a load that almost never happened.
-            asm volatile("" : "+v"(nq0), "+v"(nq1), "+v"(gx), "+v"(gy));
-        }
+            // tape row
+            float rowv[TP::kW];
+#pragma unroll
+            for (int k = 0; k < R::NQ; ++k) rowv[TP::kQ + k] = q[k];
+#pragma unroll
+            for (int k = 0; k < R::NV; ++k) rowv[TP::kV + k] = v[k];
+#pragma unroll
+            for (int k = 0; k < R::NA; ++k) rowv[TP::kAct + k] = a[k];
+            rowv[TP::kJcur] = __int_as_float(jcur); rowv[TP::kCode] = __int_as_float(TP::code(dn, jaft));
+#pragma unroll
+            for (int k = TP::kUsed; k < TP::kW; ++k) rowv[k] = 0.f;
+            if (writer) store_row<TP::kW>(sa.tape + ((size_t)t * p.N + i) * TP::kW, rowv);
 
-        // tape row
-        float rowv[TP::kW];
+            // commit the history, then the re-initialisation (the stale pose stays, :731)
 #pragma unroll
-        for (int k = 0; k < R::NQ; ++k) rowv[TP::kQ + k] = q[k];
+            for (int k = 0; k < 4; ++k) pose0[k] = pose[k];
+            done0 = dn;
+            if (jaft >= 0) {
 #pragma unroll
-        for (int k = 0; k < R::NV; ++k) rowv[TP::kV + k] = v[k];
+                for (int k = 0; k < R::NQ; ++k) q[k] = 0.f;
 #pragma unroll
-        for (int k = 0; k < R::NA; ++k) rowv[TP::kAct + k] = a[k];
-        rowv[TP::kJcur] = __int_as_float(jcur); rowv[TP::kCode] = __int_as_float(TP::code(dn, jaft));
-#pragma unroll
-        for (int k = TP::kUsed; k < TP::kW; ++k) rowv[k] = 0.f;
-        if (writer) store_row<TP::kW>(sa.tape + ((size_t)t * p.N + i) * TP::kW, rowv);
-
-        // commit the history, then the re-initialisation (the stale pose stays, :731)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) pose0[k] = pose[k];
-        done0 = dn;
-        if (jaft >= 0) {
-#pragma unroll
-            for (int k = 0; k < R::NQ; ++k) q[k] = 0.f;
-#pragma unroll
-            for (int k = 0; k < R::NV; ++k) v[k] = 0.f;
-            R::place(q, nq0, nq1);
-            jcur = jaft;
-            objs_ok = cfg_ok; // pool rows lie inside the placement extents
-            s_ok = true;      // ... and so does the robot, at rest
+                for (int k = 0; k < R::NV; ++k) v[k] = 0.f;
+                R::place(q, nq0, nq1);
+                jcur = jaft;
+                objs_ok = cfg_ok; // pool rows lie inside the placement extents
+                s_ok = true;      // ... and so does the robot, at rest
+            }
         }
     }
     abuf ^= 1; // park the next block's actions
