@@ -177,15 +177,25 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
     // results either way, the serial chain is ~45 instructions shorter.
     //   s_ok: qpos, qvel at the start of the step are finite and < 1e18 (so is the pose the step returns, and its
     //         velocity-servo term cannot be NaN);  p_ok: the stale pose's cos / sin are finite (ctrl = pose0 * action)
-    bool s_ok, p_ok;
+    // (round 4: one flag for both -- a common step starts with it set and leaves it set, so the serial chain carries
+    // no flag updates at all; only the general step below recomputes it)
+    // WAVE MASKS, not per-lane bools: the flags live as 64-bit lane masks in scalar registers (one ballot each), the
+    // tests of a step are ballots ANDed on the scalar unit, and one scalar compare decides "every lane had a common
+    // step".  (As per-lane bools the compiler kept merging them under the exec mask at the end of every step: ~20
+    // scalar and vector instructions on the serial chain for flags that almost never change.)
+    typedef unsigned long long mask_t;
+    const mask_t live_m = __builtin_amdgcn_ballot_w64(true);
+    const int lane_id = tid & 63;
+    mask_t objs_m = __builtin_amdgcn_ballot_w64(objs_ok), sp_m;
     {
         float m0 = fabsf(pose0[2]) + fabsf(pose0[3]), m1 = 0.f;
 #pragma unroll
         for (int k = 0; k < R::NQ; ++k) m1 = m1 + fabsf(q[k]);
 #pragma unroll
         for (int k = 0; k < R::NV; ++k) m1 = m1 + fabsf(v[k]);
-        s_ok = moderate(m1); p_ok = moderate(m0);
+        sp_m = __builtin_amdgcn_ballot_w64(moderate(m1)) & __builtin_amdgcn_ballot_w64(moderate(m0));
     }
+    const mask_t phys1_m = p.physics_steps == 1 ? ~0ull : 0ull;
 #pragma unroll 1
     for (int tb = 0; tb < r.T; tb += kActBlock) { // blocks of kActBlock steps (two loops: the block's addresses are
                                                   // computed once per block, not carried through every step)
@@ -195,8 +205,9 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
             if (tb + kActBlock + k < r.T) load_action<R>(r.act, (size_t)(tb + kActBlock + k) * p.N + i, anx[k]);
     }
     const int kend = r.T - tb < kActBlock ? r.T - tb : kActBlock;
-#pragma unroll 1
-    for (int kb = 0; kb < kend; ++kb) {
+    // (two steps per trip: the stepped state of the first is the start of the second in place -- a one-step loop copies
+    // every loop-carried register back at the end of each step, ~30 moves on the serial chain)
+    auto step1 = [&](const int kb) __attribute__((always_inline)) {
         const int t = tb + kb;
         float a[R::NA];
 #pragma unroll
@@ -224,23 +235,23 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
         const float mx = pose[0] - pose0[0], my = pose[1] - pose0[1];
         const float gdx = gx - pose[0], gdy = gy - pose[1];
         const float d2 = gdx * gdx + gdy * gdy;                 // dist2()'s radicand
-        // (bitwise, not short-circuit: five compares and four scalar ANDs instead of nested exec-mask regions)
-        const bool ordinary = (int)objs_ok & (int)s_ok & (int)p_ok & (int)(p.physics_steps == 1) & (int)moderate(mag) &
-                              (int)((mx * mx + my * my) < 0.9f) & (int)(d2 < 1e8f);
+        // (five compares into scalar lane masks and scalar ANDs)
+        const mask_t ord_m = objs_m & sp_m & phys1_m & __builtin_amdgcn_ballot_w64(moderate(mag)) &
+                             __builtin_amdgcn_ballot_w64((mx * mx + my * my) < 0.9f) & __builtin_amdgcn_ballot_w64(d2 < 1e8f);
         // COMMON STEP vs GENERAL STEP (round 4).  Almost every step of almost every wave is ordinary, finishes no env
         // (no goal reached, no timeout) and so re-initialises nothing.  The per-lane branches for the other cases -- the
         // exact redo, done, the reset_done draw, the re-placement -- cost this serial chain an exec-mask save / restore
         // and a taken jump over kilobytes of cold code each, every step (stubbing the dynamics showed 86 of the Point's
         // 114 us per 200 steps in this wrapper, not in the step).  One wave-uniform test now selects a branch-free
         // commit; any lane that needs more sends the whole wave through the general code below (same results).
-        const bool rare = (int)!ordinary | (int)(d2 < p.goal_cut) | (int)(steps > p.num_steps_f);
-        if (__builtin_expect(__ballot(rare) == 0ull, 1)) {
+        const mask_t rare_m = (~ord_m & live_m) | __builtin_amdgcn_ballot_w64(d2 < p.goal_cut) |
+                              __builtin_amdgcn_ballot_w64(steps > p.num_steps_f);
+        if (__builtin_expect(rare_m == 0ull, 1)) {
 #pragma unroll
             for (int k = 0; k < R::NQ; ++k) q[k] = qf[k];
 #pragma unroll
             for (int k = 0; k < R::NV; ++k) v[k] = vf[k];
-            p_ok = true; s_ok = true;
-            steps = steps + 1.0f;                       // :493 (done == 0)
+            steps = steps + 1.0f;                       // :493 (done == 0); the flag masks stay as they are
             float rowv[TP::kW];
 #pragma unroll
             for (int k = 0; k < R::NQ; ++k) rowv[TP::kQ + k] = q[k];
@@ -256,6 +267,9 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
             for (int k = 0; k < 4; ++k) pose0[k] = pose[k];
             done0 = 0.0f;
         } else {
+            const bool ordinary = (ord_m >> lane_id) & 1ull;
+            bool sp_ok;
+            objs_ok = (objs_m >> lane_id) & 1ull;
             float dn;
             if (ordinary) {
 #pragma unroll
@@ -263,8 +277,7 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
 #pragma unroll
                 for (int k = 0; k < R::NV; ++k) v[k] = vf[k];
                 dn = d2 < p.goal_cut ? 1.0f : 0.0f;
-                p_ok = true;   // this step's pose: the kinematics of a moderate qpos
-                s_ok = true;   // moderate(mag)
+                sp_ok = true;  // this step's pose: the kinematics of a moderate qpos; the state: moderate(mag)
             } else { // rare: the step again, exactly (from the untouched q, v)
                 for (int k = 0; k < p.physics_steps; ++k) {
                     if constexpr (LPE == 4) R::template substep_q<true>(q, v, ctrl, pose, qacc, jq);
@@ -293,8 +306,7 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
                 for (int k = 0; k < R::NQ; ++k) m1 = m1 + fabsf(q[k]);
 #pragma unroll
                 for (int k = 0; k < R::NV; ++k) m1 = m1 + fabsf(v[k]);
-                p_ok = moderate(fabsf(pose[2]) + fabsf(pose[3]));
-                s_ok = moderate(m1);
+                sp_ok = (int)moderate(fabsf(pose[2]) + fabsf(pose[3])) & (int)moderate(m1);
             }
             if (steps > p.num_steps_f) dn = 1.0f;      // :492
             steps = dn > 0.0f ? 0.0f : steps + 1.0f;   // :493
@@ -343,10 +355,17 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
                 R::place(q, nq0, nq1);
                 jcur = jaft;
                 objs_ok = cfg_ok; // pool rows lie inside the placement extents
-                s_ok = true;      // ... and so does the robot, at rest
+                // ... and so does the robot, at rest; the stale pose is the one just checked
+                sp_ok = moderate(fabsf(pose[2]) + fabsf(pose[3]));
             }
+            objs_m = __builtin_amdgcn_ballot_w64(objs_ok);
+            sp_m = __builtin_amdgcn_ballot_w64(sp_ok);
         }
-    }
+    };
+    int kb = 0;
+#pragma unroll 1
+    for (; kb + 1 < kend; kb += 2) { step1(kb); step1(kb + 1); }
+    if (kb < kend) step1(kb);
     abuf ^= 1; // park the next block's actions
 #pragma unroll
     for (int k = 0; k < kActBlock; ++k)
