@@ -67,10 +67,14 @@ GX_D void world_pose(const Params& p, float (&pose)[4])
 // ---------------------------------------------------------------------------
 // sin/cos: 3-term Cody-Waite to [-pi/4, pi/4], minimax polynomials
 // ---------------------------------------------------------------------------
+// kFinite: the caller guarantees |x| <= 2^24 (so x is not NaN either): the same bits without the two guards -- five
+// instructions, two of them on the dependency chain (the dynamics pass of the two-kernel rollout, which verifies the
+// guarantee after the step and redoes the step with the guarded form otherwise)
+template <bool kFinite = false>
 GX_D void sincos_f(float x, float& s, float& c)
 {
     const float x0 = x;
-    if (!(fabsf(x) <= 16777216.0f)) x = x * 0.0f;
+    if (!kFinite && !(fabsf(x) <= 16777216.0f)) x = x * 0.0f;
     const float k = rintf(x * 0.6366197466850281f);
     float r = fmaf(-k, 1.5707963705062866f, x);
     r = fmaf(-k, -4.371138828673793e-08f, r);
@@ -87,7 +91,7 @@ GX_D void sincos_f(float x, float& s, float& c)
     float cc = (q & 1) ? S : C;
     if (q == 1 || q == 2) cc = -cc;
     if (q >= 2) ss = -ss;
-    if (x0 != x0) { ss = x0; cc = x0; }
+    if (!kFinite && x0 != x0) { ss = x0; cc = x0; }
     s = ss;
     c = cc;
 }

@@ -74,10 +74,11 @@ struct PointRobotT {
 
     // xpos / xmat of the robot body for qpos `q` (mjx kinematics: hinge quaternion through the half angle): what a step
     // that STARTS from q returns as its (one step stale) pose -- substep computes exactly this
+    template <bool kFinite = false> // kFinite: |q[2]| <= 2^25 guaranteed (sincos_f)
     GX_D static void pose_of(const float (&q)[NQ], float (&pose)[4])
     {
         float sh, ch;
-        sincos_f(0.5f * q[2], sh, ch);
+        sincos_f<kFinite>(0.5f * q[2], sh, ch);
         pose[0] = q[0]; pose[1] = q[1]; pose[2] = ch * ch - sh * sh; pose[3] = 2.0f * (ch * sh);
     }
 
@@ -112,7 +113,7 @@ struct PointRobotT {
         constexpr float kMxc = 0.0001f, kDxy = 0.01f, kDt = 0.005f;
         constexpr float kInvM = (float)(1.0 / 0.005188790204786391);
         constexpr float kInvA = (float)(1.0 / (0.005188790204786391 + 0.02 * 0.01));
-        pose_of(q, pose);
+        pose_of<kNoNaN>(q, pose); // (kNoNaN: the dynamics pass, whose state sums are below kStateLimit = 2^24)
         const float c = pose[2], sn = pose[3];
         const float b = -(kMxc * sn), d = kMxc * c;
         const float w2 = v[2] * v[2];

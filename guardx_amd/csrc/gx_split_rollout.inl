@@ -60,6 +60,9 @@ struct SplitArgs {
 };
 
 GX_D bool moderate(float x) { return fabsf(x) < 1e18f; } // false for NaN / Inf too
+// the dynamics pass's bound on the sum of |qpos|, |qvel| (and |action|) of a state a common step may start from: 2^24,
+// so that every angle in it is within the range the unguarded sincos_f<true> reduces exactly like the guarded one
+GX_D bool state_ok(float sum) { return fabsf(sum) < 16777216.0f; }
 constexpr int kActBlock = 16; // steps whose actions the dynamics pass fetches at once
 constexpr int kObsGridCap = 3072; // one-wave workgroups of a ONE-shard observation launch (measured: 47.1 -> 44.2 us at 400 000 rows; a launch over
                                   // several shards is fastest uncapped: 32.5 us per shard at 8 shards)
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
         for (int k = 0; k < R::NQ; ++k) m1 = m1 + fabsf(q[k]);
 #pragma unroll
         for (int k = 0; k < R::NV; ++k) m1 = m1 + fabsf(v[k]);
-        sp_m = __builtin_amdgcn_ballot_w64(moderate(m1)) & __builtin_amdgcn_ballot_w64(moderate(m0));
+        sp_m = __builtin_amdgcn_ballot_w64(state_ok(m1)) & __builtin_amdgcn_ballot_w64(moderate(m0));
     }
     const mask_t phys1_m = p.physics_steps == 1 ? ~0ull : 0ull;
 #pragma unroll 1
@@ -225,18 +228,29 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
         if constexpr (LPE == 4) R::template substep_q<true>(qf, vf, ctrl, pose, qacc, jq);
         else R::template substep<false, true>(qf, vf, ctrl, pose, qacc);
         world_pose(p, pose);
-        float mag = 0.f;
+        // sum of magnitudes of the stepped state and the action, as a tree (it only feeds a bound: any order will do,
+        // and the chain from the last velocity to the branch is three additions long instead of eight)
+        float mag;
+        {
+            float term[R::NQ + R::NV + R::NA];
 #pragma unroll
-        for (int k = 0; k < R::NQ; ++k) mag = mag + fabsf(qf[k]);
+            for (int k = 0; k < R::NQ; ++k) term[k] = fabsf(qf[k]);
 #pragma unroll
-        for (int k = 0; k < R::NV; ++k) mag = mag + fabsf(vf[k]);
+            for (int k = 0; k < R::NV; ++k) term[R::NQ + k] = fabsf(vf[k]);
 #pragma unroll
-        for (int k = 0; k < R::NA; ++k) mag = mag + fabsf(a[k]);
+            for (int k = 0; k < R::NA; ++k) term[R::NQ + R::NV + k] = fabsf(a[k]);
+            constexpr int n = R::NQ + R::NV + R::NA;
+#pragma unroll
+            for (int w = 1; w < n; w *= 2)
+#pragma unroll
+                for (int k = 0; k + w < n; k += 2 * w) term[k] = term[k] + term[k + w];
+            mag = term[0];
+        }
         const float mx = pose[0] - pose0[0], my = pose[1] - pose0[1];
         const float gdx = gx - pose[0], gdy = gy - pose[1];
         const float d2 = gdx * gdx + gdy * gdy;                 // dist2()'s radicand
         // (five compares into scalar lane masks and scalar ANDs)
-        const mask_t ord_m = objs_m & sp_m & phys1_m & __builtin_amdgcn_ballot_w64(moderate(mag)) &
+        const mask_t ord_m = objs_m & sp_m & phys1_m & __builtin_amdgcn_ballot_w64(state_ok(mag)) &
                              __builtin_amdgcn_ballot_w64((mx * mx + my * my) < 0.9f) & __builtin_amdgcn_ballot_w64(d2 < 1e8f);
         // COMMON STEP vs GENERAL STEP (round 4).  Almost every step of almost every wave is ordinary, finishes no env
         // (no goal reached, no timeout) and so re-initialises nothing.  The per-lane branches for the other cases -- the
@@ -306,7 +320,7 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
                 for (int k = 0; k < R::NQ; ++k) m1 = m1 + fabsf(q[k]);
 #pragma unroll
                 for (int k = 0; k < R::NV; ++k) m1 = m1 + fabsf(v[k]);
-                sp_ok = (int)moderate(fabsf(pose[2]) + fabsf(pose[3])) & (int)moderate(m1);
+                sp_ok = (int)moderate(fabsf(pose[2]) + fabsf(pose[3])) & (int)state_ok(m1);
             }
             if (steps > p.num_steps_f) dn = 1.0f;      // :492
             steps = dn > 0.0f ? 0.0f : steps + 1.0f;   // :493
@@ -356,7 +370,7 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
                 jcur = jaft;
                 objs_ok = cfg_ok; // pool rows lie inside the placement extents
                 // ... and so does the robot, at rest; the stale pose is the one just checked
-                sp_ok = moderate(fabsf(pose[2]) + fabsf(pose[3]));
+                sp_ok = (int)moderate(fabsf(pose[2]) + fabsf(pose[3])) & (int)state_ok(fabsf(nq0) + fabsf(nq1));
             }
             objs_m = __builtin_amdgcn_ballot_w64(objs_ok);
             sp_m = __builtin_amdgcn_ballot_w64(sp_ok);
