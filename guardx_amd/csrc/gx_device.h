@@ -259,6 +259,23 @@ GX_HD uint32_t randint_at(uint32_t k10, uint32_t k11, uint32_t k20, uint32_t k21
 // ---------------------------------------------------------------------------
 struct LidarTerms { int bin; float sensor, a1, a2; };
 
+// x / bin_size for the default 16 bins WITHOUT the division (round 4).  bin_size = fl(2 pi / 16) = 0x1.921fb6p-2 is a
+// constant; with inv = fl(1 / bin_size) = 0x1.45f306p+1
+//     q0 = x * inv;   r = fma(-q0, bin_size, x);   q = fma(r, inv, q0)
+// is the correctly rounded quotient -- bit for bit what the checker's `/` gives -- for EVERY fp32 x with
+// 2^-100 <= |x| <= 2 pi (and for +0, NaN): three instructions instead of the compiler's ten-instruction IEEE division
+// sequence, twice per lidar object.  That is not a heuristic: tests/test_div_bin_size.py (CPU, gcc) compares the two over
+// all 1.1e9 such x, both signs.  Below 2^-100 the residual underflows and the identity fails for 0.4 % of the inputs
+// (and -0 comes out +0): lidar_terms keeps the true division for any wave that holds such an angle.
+constexpr int kDivFastBins = 16;
+constexpr float kBinSize16 = 0x1.921fb6p-2f, kInvBinSize16 = 0x1.45f306p+1f;
+constexpr uint32_t kDivFastMinBits = 0x0D800000u; // 2^-100
+GX_D float div_bin16(float x)
+{
+    const float q0 = x * kInvBinSize16;
+    return fmaf(fmaf(-q0, kBinSize16, x), kInvBinSize16, q0);
+}
+
 GX_D LidarTerms lidar_terms(const Params& p, float ox, float oy, const float (&pose)[4])
 {
     const float dx = ox - pose[0], dy = oy - pose[1];
@@ -267,16 +284,30 @@ GX_D LidarTerms lidar_terms(const Params& p, float ox, float oy, const float (&p
     const float dist = sqrtf(zx * zx + zy * zy);
     float ang = atan2_f(zy, zx);
     if (ang < 0.0f) ang = ang + 6.2831854820251465f;
-    const float q = ang / p.bin_size;
     const int B = p.bins;
     LidarTerms t;
-    if (!(q >= 0.0f)) t.bin = 0;
-    else if (q >= (float)B) t.bin = B;
-    else t.bin = (int)q;
-    const float bin_angle = p.bin_size * (float)t.bin;
     if (!p.lidar_max_dist_set) t.sensor = exp_f(p.neg_gain * dist);
     else t.sensor = nmax(0.0f, p.lidar_max_dist - dist) / p.lidar_max_dist;
-    const float alias = (ang - bin_angle) / p.bin_size;
+    // every lane's angle is NaN or in [2^-100, 2 pi] (as a signed integer its pattern is then >= that of 2^-100; zeros,
+    // -0 and anything smaller or negative compare below): both divisions by bin_size through div_bin16.  One
+    // wave-uniform branch (the empty asm keeps the compiler from evaluating both sides and selecting).
+    float q, alias;
+    if (p.bins == kDivFastBins && __builtin_amdgcn_ballot_w64((int)f2u(ang) < (int)kDivFastMinBits) == 0ull) {
+        q = div_bin16(ang);
+        if (!(q >= 0.0f)) t.bin = 0;
+        else if (q >= (float)B) t.bin = B;
+        else t.bin = (int)q;
+        // (ang - bin_angle is 0, or at least an ulp of an angle >= bin_size in magnitude, or the angle itself in bin 0)
+        alias = div_bin16(ang - kBinSize16 * (float)t.bin);
+    } else {
+        asm volatile("; lidar_terms: true division");
+        q = ang / p.bin_size;
+        if (!(q >= 0.0f)) t.bin = 0;
+        else if (q >= (float)B) t.bin = B;
+        else t.bin = (int)q;
+        const float bin_angle = p.bin_size * (float)t.bin;
+        alias = (ang - bin_angle) / p.bin_size;
+    }
     t.a1 = alias * t.sensor;
     t.a2 = (1.0f - alias) * t.sensor;
     return t;
