@@ -1522,3 +1522,39 @@ def test_tape_rows_odd_sizes(torch_cuda, robot, N, T):
         for s in range(3):
             assert torch.equal(out[s].view(torch.int32), pk.view(torch.int32)), s
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("path", ["thread", "group", "split"])
+def test_lidar_angles_at_and_below_the_fast_division_bound(torch_cuda, oracle, path):
+    """lidar_terms divides by bin_size without a division (div_bin16, proved exact for 2^-100 <= |x| <= 2 pi by
+    tests/test_div_bin_size.py) and keeps the true division for any wave that holds an angle of exactly 0 or below the
+    bound.  Objects dead ahead of a robot with heading 0 (angle +0), a hair to the left (angles 1e-38, 1e-33 -- denormal
+    and tiny quotients) and just above the bound (2^-99) sit in some envs of a wave, ordinary layouts in the others:
+    observations, cost and reward equal the checker's bit for bit on every kernel family."""
+    torch = torch_cuda
+    N = 200
+    E, O = _engines(task_config(N, seed=3), oracle, n_candidates=30000, path=path)
+    E.reset(); O.reset()
+    rng = np.random.default_rng(17)
+    s = random_state(N, 8, rng)
+    special = np.arange(0, N, 3)
+    s['qpos'][special] = np.array([0.5, 0.0, 0.0], np.float32)          # heading 0: cos = 1, sin = 0 exactly
+    s['qvel'][special] = 0.0
+    s['pose0'][special] = np.array([0.5, 0.0, 1.0, 0.0], np.float32)
+    for n, e in enumerate(special):
+        dy = [0.0, 1e-38, 1e-33, 2.0 ** -99, 2.0 ** -101][n % 5]
+        s['objs'][e, 0] = (1.5, dy)                                     # goal
+        s['objs'][e, 1] = (2.5, dy)                                     # hazards 0, 1 (one in front of the other)
+        s['objs'][e, 2] = (0.75, 0.0)
+    E.set_state(s); O.set_state(s)
+    act = np.zeros((N, 2), np.float32)
+    _cmp_step(E.step(torch.from_numpy(act).cuda()), O.step(act))
+    E.set_state(s); O.set_state(s)
+    acts = np.zeros((8, N, 2), np.float32)
+    obs, rew, cost, done = E.rollout(torch.from_numpy(acts).cuda())
+    for t in range(8):
+        o, r, d, info = O.step(acts[t])
+        np.testing.assert_array_equal(obs[t].cpu().numpy(), O.reset_done())
+        np.testing.assert_array_equal(rew[t].cpu().numpy(), r)
+        np.testing.assert_array_equal(cost[t].cpu().numpy(), info['cost'])
+    assert_state_equal(E.get_state(), O.get_state())
