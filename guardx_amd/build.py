@@ -30,7 +30,18 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++
 # with the layout pool (Pool::fake), so every kernel steps in one place, and both the Ant's and the Walker's lane-group
 # steps are always_inline (gx_robot_ant_group.h, gx_robot_legs_group.h:substep_call); tests/test_native_abi.py asserts
 # that no lane-group kernel contains an s_swappc_b64.
-PER_SOURCE_FLAGS = {}
+# Round 4: LLVM's "max-ilp" machine-scheduling strategy for the translation units of the robots whose dynamics pass is
+# ONE wave per SIMD (the serial chains of the Point and the Swimmer).  A lone wave issues a dependent vector instruction
+# every ~5.75 cycles and an independent one every 4 (tools/probes/chain_clock_probe.hip); the default strategy schedules
+# for occupancy / register pressure, this one interleaves independent instructions and halves the s_nop hazard fillers
+# (538 -> 291 in the Point's dynamics pass).  Same instructions, same arithmetic, other order: results are bit-identical
+# (the parity suite and the soaks run on it).  Same-box A/B: Point dynamics pass 91 -> 86.5 us, observation pass 33.6 ->
+# 32.9 us, Swimmer dynamics pass 459 -> 420 us per 200 steps.  NOT for gx_kernels.hip: the layout sampler's phases are
+# 2.4 % faster alone with it (554 -> 541 us) but the epoch, where they share every SIMD with other waves, is 2 % slower
+# (0.517 -> 0.527 ms, 774 -> 759 M env-steps/s on one box); and not for the Ant's / Walker's lane-group kernels, which do
+# not gain (1272 -> 1280, 2350 -> 2370 us).
+_MAX_ILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+PER_SOURCE_FLAGS = {"gx_kernels_point.hip": _MAX_ILP, "gx_kernels_point_bare.hip": _MAX_ILP, "gx_kernels_swimmer.hip": _MAX_ILP}
 
 
 def _extra(src):
