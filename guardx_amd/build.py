@@ -18,6 +18,7 @@ OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB = os.path.join(LIB_DIR, "libguardx_hip.so")
 # one translation unit per robot (gx_robot_kernels.inl instantiated for it), compiled in parallel
 SOURCES = ["gx_api.hip", "gx_kernels.hip", "gx_gae.hip", "gx_policy_step.hip", "gx_kernels_point.hip", "gx_kernels_point_bare.hip", "gx_kernels_swimmer.hip",
+           "gx_kernels_point_split.hip", "gx_kernels_point_bare_split.hip", "gx_kernels_swimmer_split.hip",
            "gx_kernels_ant.hip", "gx_kernels_walker.hip"]
 HEADERS = ["gx_device.h", "gx_robot.h", "gx_robot_ant.h", "gx_robot_ant_group.h", "gx_robot_legs.h", "gx_robot_legs_group.h", "gx_policy.h", "gx_kernels.h", "gx_robot_kernels.inl",
            "gx_split_rollout.inl", os.path.join("..", "..", "include", "guardx.h")]
@@ -30,8 +31,9 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++
 # with the layout pool (Pool::fake), so every kernel steps in one place, and both the Ant's and the Walker's lane-group
 # steps are always_inline (gx_robot_ant_group.h, gx_robot_legs_group.h:substep_call); tests/test_native_abi.py asserts
 # that no lane-group kernel contains an s_swappc_b64.
-# Round 4: LLVM's "max-ilp" machine-scheduling strategy for the translation units of the robots whose dynamics pass is
-# ONE wave per SIMD (the serial chains of the Point and the Swimmer).  A lone wave issues a dependent vector instruction
+# Round 4: LLVM's "max-ilp" machine-scheduling strategy for the translation units that hold the two-kernel rollout of the
+# robots whose dynamics pass is ONE wave per SIMD (the serial chains of the Point and the Swimmer; everything else of
+# those robots -- step, reset, the closed-loop policy rollout, which lost 2.5 % with it -- keeps the default).  A lone wave issues a dependent vector instruction
 # every ~5.75 cycles and an independent one every 4 (tools/probes/chain_clock_probe.hip); the default strategy schedules
 # for occupancy / register pressure, this one interleaves independent instructions and halves the s_nop hazard fillers
 # (538 -> 291 in the Point's dynamics pass).  Same instructions, same arithmetic, other order: results are bit-identical
@@ -41,7 +43,8 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++
 # (0.517 -> 0.527 ms, 774 -> 759 M env-steps/s on one box); and not for the Ant's / Walker's lane-group kernels, which do
 # not gain (1272 -> 1280, 2350 -> 2370 us).
 _MAX_ILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
-PER_SOURCE_FLAGS = {"gx_kernels_point.hip": _MAX_ILP, "gx_kernels_point_bare.hip": _MAX_ILP, "gx_kernels_swimmer.hip": _MAX_ILP}
+PER_SOURCE_FLAGS = {"gx_kernels_point_split.hip": _MAX_ILP, "gx_kernels_point_bare_split.hip": _MAX_ILP,
+                    "gx_kernels_swimmer_split.hip": _MAX_ILP}
 
 
 def _extra(src):

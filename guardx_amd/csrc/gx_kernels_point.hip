@@ -1,6 +1,7 @@
-// gx_kernels_point.hip -- instantiates the step / reset / rollout kernels for PointRobot.
+// gx_kernels_point.hip -- instantiates the step / reset / rollout kernels for PointRobot
+// (all but the two-kernel rollout: gx_kernels_point_split.hip).
 #include "gx_robot_kernels.inl"
 
 namespace gx {
-template struct RobotLaunch<PointRobot>;
+GX_INSTANTIATE_REST(PointRobot)
 } // namespace gx

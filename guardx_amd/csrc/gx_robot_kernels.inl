@@ -1403,3 +1403,25 @@ void RobotLaunch<R>::policy(const Params& p, const RolloutArgs& r, const PolicyA
 }
 
 } // namespace gx
+
+// Explicit instantiation in two parts (guardx_amd/build.py compiles them with different scheduling strategies): the
+// two-kernel rollout -- whose dynamics pass is one wave per SIMD -- and everything else of a robot.
+#define GX_INSTANTIATE_SPLIT(R)                                                                                          \
+    template hipError_t RobotLaunch<R>::split(const Params&, const RolloutArgs&, float*, float4*, float*, const DevBuffers&, \
+                                              hipStream_t, hipEvent_t, int, int, int, long long, long long);          \
+    template int RobotLaunch<R>::split_width();                                                                          \
+    template int RobotLaunch<R>::split_entry_width();
+#define GX_INSTANTIATE_REST(R)                                                                                           \
+    template void RobotLaunch<R>::step(const Params&, const DevBuffers&, const float*, float*, float*, float*, float*,   \
+                                       float*, hipStream_t);                                                             \
+    template void RobotLaunch<R>::reset_apply(const Params&, const DevBuffers&, int, uint32_t, uint32_t, uint32_t,       \
+                                              uint32_t, float*, int*, hipStream_t);                                      \
+    template void RobotLaunch<R>::reset_done(const Params&, const DevBuffers&, int, uint32_t, uint32_t, uint32_t,        \
+                                             uint32_t, const float*, float*, hipStream_t);                               \
+    template void RobotLaunch<R>::group(const Params&, const RolloutArgs&, const DevBuffers&, hipStream_t);              \
+    template void RobotLaunch<R>::thread_rollout(const Params&, const RolloutArgs&, const DevBuffers&, hipStream_t);     \
+    template void RobotLaunch<R>::policy(const Params&, const RolloutArgs&, const PolicyArgs&, const DevBuffers&, int,   \
+                                         hipStream_t);                                                                   \
+    template void RobotLaunch<R>::commit_pending(const Params&, const DevBuffers&, int, int, hipStream_t);               \
+    template void RobotLaunch<R>::fake_table(const Params&, const Pool&, int, int, hipStream_t);
+
