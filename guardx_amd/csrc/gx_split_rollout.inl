@@ -418,9 +418,15 @@ __global__ __launch_bounds__(64) void group_dyn_tape_kernel(Params p_in, Rollout
     __shared__ GroupLds<OPL, BPL, BT> S;
     __shared__ float actl[2][kActBlock][EPW][R::NA];
     const int lane = threadIdx.x, l = lane & (kGL - 1), g = lane >> 4;
-    const int env = blockIdx.x * EPW + g;
-    const bool live = env < p.N;
-    const int e = live ? env : 0;
+    // envs of this wave: 4, or -- sa.lanes = 1 | 2, chosen by the launcher while the waves still fit one per SIMD --
+    // fewer: the Newton loop of the step runs until the LAST env of the wave has converged, and the maximum over one or
+    // two envs is smaller than over four.  The other groups of lanes repeat the envs of the first (same data, same trip
+    // counts, no stores).
+    const int epw = (sa.lanes == 1 || sa.lanes == 2) ? sa.lanes : EPW;
+    const int env = blockIdx.x * epw + (g & (epw - 1));
+    const bool twin = env < p.N;            // computes (a group beyond epw repeats its twin's env, reset_done included)
+    const bool live = twin && g < epw;       // ... and stores
+    const int e = twin ? env : 0;
     const bool writer = live && l == 0;
 
     float q[R::NQ], v[R::NV], pose0[4], done0, steps;
@@ -551,7 +557,7 @@ __global__ __launch_bounds__(64) void group_dyn_tape_kernel(Params p_in, Rollout
         // reset_done :497-505 for the env that just finished: the draw and the re-placement
         int jaft = -1, fidx = 0;
         float nq0 = 0.f, nq1 = 0.f;
-        if (r.do_reset && live && dn > 0.0f && L > 0) {
+        if (r.do_reset && twin && dn > 0.0f && L > 0) {
             const uint4 kk = r.keys ? r.keys[t] : r.key0;
             const uint32_t idx = randint_at(kk.x, kk.y, kk.z, kk.w, (uint32_t)p.env_total, (uint32_t)L,
                                             (uint32_t)(p.env_offset + env));
@@ -836,11 +842,22 @@ static hipError_t launch_split_group_p(const Params& p, const RolloutArgs& r, co
 {
     hipError_t st = hipSuccess;
     constexpr int B2 = 64;
-    const dim3 g1((p.N + 3) / 4), g2(obs_grid((size_t)r.T * p.N, B2, n_shards), n_shards);
+    // Envs per wave: as few as still leave one wave per SIMD (1024 on the chip) -- one up to 1024 envs, two up to 2048,
+    // four beyond.  A wave runs the step's data-dependent loops (the active-set Newton iterations above all) until its
+    // LAST env is done, and it issues nearly every slot it gets (two waves on one SIMD take 1.97x the time of one), so
+    // fewer envs per wave is faster exactly as long as the waves do not have to share SIMDs.  Ant, 200 steps, round 4:
+    // 2000 envs 1262 us (4 per wave) -> 1205 us (2); 1000 envs 1131 us (1); Walker 2361 -> 2279 us.
+    // (GX_GROUP_EPW = 1 | 2 | 4: experiments.)
+    static const int epw_forced = [] { const char* e = getenv("GX_GROUP_EPW"); return e ? atoi(e) : 0; }();
+    const int epw = epw_forced == 1 || epw_forced == 2 || epw_forced == 4 ? epw_forced
+                                                                         : (p.N <= 1024 ? 1 : ((p.N + 1) / 2 <= 1024 ? 2 : 4));
+    SplitArgs sg = sa;
+    sg.lanes = epw;
+    const dim3 g1((p.N + epw - 1) / epw), g2(obs_grid((size_t)r.T * p.N, B2, n_shards), n_shards);
     const size_t lds2 = sizeof(float) * (size_t)B2 * (r.obs_stride | 1);
     if (which & 1) {
 #define GX_GDYN_LAUNCH(OPL, BPL, DEF) \
-    hipLaunchKernelGGL((group_dyn_tape_kernel<R, OPL, BPL, DEF>), g1, dim3(64), 0, s, p, r, sa, b.dyn, b.obj)
+    hipLaunchKernelGGL((group_dyn_tape_kernel<R, OPL, BPL, DEF>), g1, dim3(64), 0, s, p, r, sg, b.dyn, b.obj)
         if (is_default_layout<R>(p)) GX_GDYN_LAUNCH(1, 1, true);
         else if (p.nobj <= 16 && p.bins <= 16) GX_GDYN_LAUNCH(1, 1, false);
         else if (p.nobj <= 32 && p.bins <= 16) GX_GDYN_LAUNCH(2, 1, false);
