@@ -43,8 +43,12 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++
 # (0.517 -> 0.527 ms, 774 -> 759 M env-steps/s on one box); and not for the Ant's / Walker's lane-group kernels, which do
 # not gain (1272 -> 1280, 2350 -> 2370 us).
 _MAX_ILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+# The Ant's lane-group step without the SLP vectorizer: its packed-fp32 forms (v_pk_mul_f32 / v_pk_add_f32, 340 in the
+# step loop) cost more register shuffles than they save issue slots there -- 1231 -> 1152 us per 200 steps of 2000 envs
+# (same-box A/B).  The Walker's is indifferent (2269 -> 2252 / 2274 us) and keeps the default; the Point's dynamics pass
+# is 3 % SLOWER without it (87.0 -> 89.3 us).
 PER_SOURCE_FLAGS = {"gx_kernels_point_split.hip": _MAX_ILP, "gx_kernels_point_bare_split.hip": _MAX_ILP,
-                    "gx_kernels_swimmer_split.hip": _MAX_ILP}
+                    "gx_kernels_swimmer_split.hip": _MAX_ILP, "gx_kernels_ant.hip": ["-fno-slp-vectorize"]}
 
 
 def _extra(src):
