@@ -38,7 +38,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++
 # for occupancy / register pressure, this one interleaves independent instructions and halves the s_nop hazard fillers
 # (538 -> 291 in the Point's dynamics pass).  Same instructions, same arithmetic, other order: results are bit-identical
 # (the parity suite and the soaks run on it).  Same-box A/B: Point dynamics pass 91 -> 86.5 us, observation pass 33.6 ->
-# 32.9 us, Swimmer dynamics pass 459 -> 420 us per 200 steps.  NOT for gx_kernels.hip: the layout sampler's phases are
+# 32.9 us, Swimmer dynamics pass 459 - 467 -> 451 us per 200 steps.  NOT for gx_kernels.hip: the layout sampler's phases are
 # 2.4 % faster alone with it (554 -> 541 us) but the epoch, where they share every SIMD with other waves, is 2 % slower
 # (0.517 -> 0.527 ms, 774 -> 759 M env-steps/s on one box); and not for the Ant's / Walker's lane-group kernels, which do
 # not gain (1272 -> 1280, 2350 -> 2370 us).
