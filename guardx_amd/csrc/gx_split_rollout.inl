@@ -848,9 +848,13 @@ static hipError_t launch_split_group_p(const Params& p, const RolloutArgs& r, co
     // fewer envs per wave is faster exactly as long as the waves do not have to share SIMDs.  Ant, 200 steps, round 4:
     // 2000 envs 1262 us (4 per wave) -> 1205 us (2); 1000 envs 1131 us (1); Walker 2361 -> 2279 us.
     // (GX_GROUP_EPW = 1 | 2 | 4: experiments.)
+    // ... and only ALONE on the chip (sa.lanes == 4: no layout sampler of this engine in flight, as for the Swimmer's
+    // quad form): beside the sampler the four-env waves leave it half of the SIMDs to itself -- Ant epoch 1.53 -> 1.46 ms
+    // (262 -> 274 M env-steps/s), the 18-object config 5 2.79 -> 2.67 ms with four.
     static const int epw_forced = [] { const char* e = getenv("GX_GROUP_EPW"); return e ? atoi(e) : 0; }();
-    const int epw = epw_forced == 1 || epw_forced == 2 || epw_forced == 4 ? epw_forced
-                                                                         : (p.N <= 1024 ? 1 : ((p.N + 1) / 2 <= 1024 ? 2 : 4));
+    const int epw = epw_forced == 1 || epw_forced == 2 || epw_forced == 4
+                        ? epw_forced
+                        : (sa.lanes != 4 ? 4 : (p.N <= 1024 ? 1 : ((p.N + 1) / 2 <= 1024 ? 2 : 4)));
     SplitArgs sg = sa;
     sg.lanes = epw;
     const dim3 g1((p.N + epw - 1) / epw), g2(obs_grid((size_t)r.T * p.N, B2, n_shards), n_shards);

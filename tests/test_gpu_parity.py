@@ -22,7 +22,8 @@ def torch_cuda():
 
 
 # split: two-kernel rollouts (dynamics tape + observation pass), lane-group steps; split-alone: the same with the layout
-# prefetch off, which selects the dynamics pass's alone-on-the-chip form where a robot has one (Swimmer: a quad per env)
+# prefetch off, which selects the dynamics pass's alone-on-the-chip form where a robot has one (Swimmer: a quad per env;
+# Ant / Walker: one or two envs per wave instead of four)
 PATHS = {"thread": 1, "group": 2, "split": 3, "split-alone": 3}
 
 
@@ -804,7 +805,7 @@ def test_ant_step_parity_random_states(torch_cuda, oracle, N, path):
         assert_state_equal(E.get_state(), O.get_state())
 
 
-@pytest.mark.parametrize("path", ["thread", "group", "split"])
+@pytest.mark.parametrize("path", ["thread", "group", "split", "split-alone"])
 def test_ant_rollout_parity(torch_cuda, oracle, path):
     torch = torch_cuda
     N, T = 300, 100
@@ -853,7 +854,7 @@ def test_walker_step_parity_random_states(torch_cuda, oracle, N, path):
         assert_state_equal(E.get_state(), O.get_state())
 
 
-@pytest.mark.parametrize("path", ["thread", "group", "split"])
+@pytest.mark.parametrize("path", ["thread", "group", "split", "split-alone"])
 def test_walker_rollout_parity(torch_cuda, oracle, path):
     torch = torch_cuda
     N, T = 300, 100
