@@ -56,8 +56,9 @@ def main():
         print(f"path {path}: 3 x {n_states} single steps compared  ({time.time() - t0:.1f} s)", flush=True)
     # 2. long fused episodes with resets, on both persistent kernels
     # 3: two-kernel rollout (every robot since round 3); -3: the same with the layout prefetch off, which selects the
-    # dynamics pass's alone-on-the-chip form where a robot has one (Swimmer: a quad of lanes per env)
-    for path in ((2, 1, 3, -3) if robot == 'swimmer' else (2, 1, 3)):
+    # dynamics pass's alone-on-the-chip form where a robot has one (Swimmer: a quad of lanes per env; Ant / Walker: one or
+    # two envs per wave -- the soak's N decides -- instead of four)
+    for path in ((2, 1, 3) if robot == 'point' else (2, 1, 3, -3)):
         cfg = task_config(N, seed=7, num_steps=150, goal_size=2.6 if robot == 'point' else 0.8, **extra)
         E = Engine(cfg, n_candidates=1000000); E.set_path(abs(path))
         if path < 0:
