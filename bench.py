@@ -694,7 +694,9 @@ def main():
     env = make_engine(ENV_NUM, rank, world)
     env.set_prefetch(EP_LEN)
     tapes = [action_tape(EP_LEN, ENV_NUM, 1000 * rank + k, device) for k in range(4)]
-    gather = world > 1
+    import torch.distributed as tdist
+    forced = gxd.forced_dist() and tdist.is_initialized()   # GX_FORCE_DIST=1: the N > 1 path over a one-rank group
+    gather = world > 1 or forced
     # the hand-off: "tape" (default) all-gathers the 40-B-per-env-step dynamics tape and expands it on every rank,
     # "packed" all-gathers the 192-B packed rows (what round 1 did; GX_HANDOFF=packed to compare)
     mode = os.environ.get("GX_HANDOFF", "tape")
@@ -811,6 +813,11 @@ def main():
         line["cold_start"] = {"value": round(env_steps / dtc, 1), "unit": "env-steps/s",
                               "ms_per_step": round(dtc / args.steps * 1e3, 6),
                               "note": "same W warm-up + K timed epochs started from an idle GPU (1 s sleep), no preconditioning"}
+    if forced:
+        line["forced_dist"] = {"backend": tdist.get_backend(), "world_size": world,
+                               "note": "GX_FORCE_DIST=1: the N > 1 path (process group, barrier, max-over-ranks, tape hand-off "
+                                       "with the collective issued, sharded sampler, all-tapes expansion) over a group of "
+                                       "this many ranks -- a code-path run, not a scaling measurement"}
     if dt < 0.010:
         line["warning"] = f"timed region {dt*1e3:.2f} ms < 10 ms: use more --steps for a meaningful rate"
     if stepping_only is not None:
@@ -861,10 +868,8 @@ def main():
         print(json.dumps(line), flush=True)
     gxd.barrier()
     env.close()
-    if world > 1:
-        import torch.distributed as dist
-        if dist.is_initialized():
-            dist.destroy_process_group()
+    if tdist.is_initialized():
+        tdist.destroy_process_group()
 
 
 if __name__ == "__main__":

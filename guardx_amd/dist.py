@@ -12,7 +12,21 @@ import os
 import torch
 import torch.distributed as dist
 
+_GX_ERR_STATE = 5   # include/guardx.h:37 (= guardx_amd._native.GX_ERR_STATE; not imported: a CPU stand-in engine has no library)
+
 ROLLOUT_FIELDS = ("obs", "act", "rew", "cost", "done")
+
+
+def forced_dist():
+    """GX_FORCE_DIST=1: a world of ONE rank still forms a process group and issues every collective of the N > 1 path
+    (RCCL on a GPU) instead of short-circuiting it -- the whole multi-GPU code path on a one-GPU box
+    (tests/test_rccl_one_rank.py, `GX_FORCE_DIST=1 python bench.py --gpus 1`)."""
+    return os.environ.get("GX_FORCE_DIST", "0") == "1"
+
+
+def _collective():
+    """do the collectives of this process run? (a group exists and has company, or is forced)"""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or forced_dist())
 
 
 def init_from_env(backend=None):
@@ -20,7 +34,7 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or forced_dist()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -47,7 +61,7 @@ def unpack_rollout(packed, obs_dim, act_dim):
 
 def all_gather_rollout(packed, out=None):
     """All-gather the per-rank packed shard -> (world, T, N, W).  World size 1: a view."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _collective():
         return packed.unsqueeze(0)
     world = dist.get_world_size()
     shape = tuple(packed.shape)
@@ -96,20 +110,26 @@ class TapeHandoff:
     pool (the first three, a changed episode length) samples all candidates inline.
 
     expand: "all" (default) -- every rank expands every rank's tape (the hand-off contract above); "local" -- only its
-    own; expand_rank(s) then expands rank s's tape of the last gathered epoch on demand (before the next step())."""
+    own; expand_rank(s) then expands rank s's tape of the last gathered epoch on demand (before the next step()).
 
-    def __init__(self, env, T, depth=3, sharded_sampler=None, expand="all", _play=None):
+    force_collective (default: GX_FORCE_DIST=1): a world of one issues the collective, shards the sampler "over" its one
+    rank and expands through the all-ranks launch, i.e. runs the N > 1 path as it is instead of the short cuts."""
+
+    def __init__(self, env, T, depth=3, sharded_sampler=None, expand="all", _play=None, force_collective=None):
         assert expand in ("all", "local")
         self.env, self.T, self.depth, self.expand = env, int(T), depth, expand
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         if _play is not None:          # (rank, world) played without a process group: tools/rehearse_rank.py, which
             self.rank, self.world = _play   # overrides _gather()
+        if force_collective is None:
+            force_collective = forced_dist() and dist.is_initialized()
+        self.collective = self.world > 1 or bool(force_collective)
         self.n_tape = sum(env.tape_floats(self.T))
         self.host = dist.is_initialized() and dist.get_backend() != "nccl"
         dev = env.device
         if sharded_sampler is None:    # a world of one has nobody to share the sampler with
-            sharded_sampler = hasattr(env, "sample_shard_ahead") and self.world > 1
+            sharded_sampler = hasattr(env, "sample_shard_ahead") and self.collective
         self.sharded = bool(sharded_sampler)
         self.sharded_used = self.sharded   # (close() clears `sharded`)
         self.cap = self.n_block = 0
@@ -144,12 +164,34 @@ class TapeHandoff:
         self.deferred = None           # (ticket, gathered buffer) of a block drain() could not install yet
         self.works = [None] * depth    # the collective that last read send[i]
         self.next_ticket = None        # ticket of the block being sampled into the next send buffer's tail
+        self.shard_skips = 0           # epochs whose block was not sampled (the engine refused: see step())
+        self.closed = False
 
     def close(self):
-        """give the layout sampling back to the engine (its own prefetch)"""
+        """Give the layout sampling back to the engine (its own prefetch) and order the CURRENT stream behind everything
+        this object still has in flight on streams torch's allocator does not know of -- the collectives that read
+        send[] / write recv[], the expansion on the hand-off's stream, the shard sampler the last step() queued into a
+        send buffer's tail on the engine's side stream -- so that the buffers may go back to the allocator."""
+        if self.closed:
+            return
+        self.closed = True
+        self.drain()
+        for w in self.works:
+            if w is not None:
+                w.wait()
+        self.works = [None] * self.depth
+        if self.sharded_used and hasattr(self.env, "shard_join") and getattr(self.env, "_h", True) is not None:
+            self.env.shard_join()      # the current stream waits for shard_done
+        self.next_ticket = self.deferred = None
         if self.sharded:
             self.env.set_layout_source('own')
             self.sharded = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown / the engine is gone: nothing left to order
+            pass
 
     def step(self, actions):
         i = self.k % self.depth
@@ -170,12 +212,22 @@ class TapeHandoff:
             j = self.k % self.depth
             if self.works[j] is not None:
                 self.works[j].wait()   # the collective that last read send[j] (two epochs ago)
-            self.next_ticket = self.env.sample_shard_ahead(self.rank, self.world, self.send[j][self.off_block:], self.cap,
-                                                           resets_ahead=3)
+            try:
+                self.next_ticket = self.env.sample_shard_ahead(self.rank, self.world, self.send[j][self.off_block:],
+                                                               self.cap, resets_ahead=3)
+            except RuntimeError as exc:
+                # The engine has no horizon to sample for (prefetch switched off, or more steps since the last reset
+                # than three intervals cover): a state every rank shares, so every rank skips this block alike and the
+                # reset it was meant for samples inline.  Raising here -- after this epoch's collective was issued --
+                # would leave the other ranks waiting in the next one.
+                if getattr(exc, "status", None) != _GX_ERR_STATE:
+                    raise
+                self.next_ticket = None
+                self.shard_skips += 1
 
     def _gather(self, i, buf):
         """the ONE collective of the epoch: every rank's [tape | layouts | entry records | shard block] into recv[i]"""
-        if self.world == 1:
+        if not self.collective:
             self.recv[i] = buf
             return None
         src = buf.to("cpu") if self.host else buf
@@ -212,7 +264,7 @@ class TapeHandoff:
                     self._install(ticket, recv)
                 else:                  # drain(): the pool slot still holds the NEXT reset's layouts; install after it
                     self.deferred = (ticket, recv)
-            if self.expand == "all" and self.world > 1 and hasattr(self.env, "expand_tapes"):
+            if self.expand == "all" and self.collective and hasattr(self.env, "expand_tapes"):
                 self.env.expand_tapes(recv, self.n, self.world, token, self.T, out)   # every rank's tape, one launch
             else:
                 for s in (range(self.world) if self.expand == "all" else (self.rank,)):
@@ -235,7 +287,7 @@ class TapeHandoff:
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _collective():
         if dist.get_backend() == "nccl":   # name the device: RCCL otherwise guesses it from the rank
             dist.barrier(device_ids=[torch.cuda.current_device()])
         else:
@@ -246,7 +298,7 @@ def max_over_ranks(value, device):
     if dist.is_initialized() and dist.get_backend() != "nccl":
         device = "cpu"                      # gloo rehearsal
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _collective():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -284,7 +336,7 @@ class ShardedReset:
     def reset(self, check=True):
         env, W = self.env, self.world
         env.sample_shard(self.rank, W, self.rows, self.count)
-        if W == 1:
+        if W == 1 and not _collective():
             self.rows_all[0].copy_(self.rows); self.counts.copy_(self.count)
         elif self.host:   # gloo rehearsal: through host memory
             ra = torch.empty(self.rows_all.shape, dtype=torch.float32)

@@ -382,3 +382,59 @@ def test_two_rank_tape_handoff_with_piggybacked_shard_blocks_over_gloo():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+
+
+def _forced_one_rank_worker(port, q):
+    try:
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                          GX_FORCE_DIST="1")
+        from guardx_amd import dist as gxd
+        r, _, w = gxd.init_from_env("gloo")
+        assert (r, w) == (0, 1) and torch.distributed.is_initialized() and gxd._collective()
+        T, N, D = 3, 5, 6
+        env = _StubShardAheadEngine(0, N, D)
+        h = gxd.TapeHandoff(env, T)                     # forced: collective + sharded sampler + host staging (gloo)
+        assert h.collective and h.sharded and h.host and h.world == 1 and h.cap == 1000
+        acts = torch.zeros(T, N, 2)
+        n_tape = sum(env.tape_floats(T))
+        for ep in range(5):
+            env.reset()
+            h.step(acts)
+            assert h.pending[0] is not None              # a real Work object: the all-gather was issued
+            if ep >= 1:
+                ramp = torch.arange(n_tape, dtype=torch.float32) + 10000.0 * (ep - 1)
+                want = ramp[:T * N * 4].reshape(T, N, 4).sum(-1, keepdim=True) + float(77 + ep)
+                assert torch.equal(h.rollout[0], want.expand(T, N, D + 5)), ep
+        h.drain()
+        assert [t for t, _, _ in env.installs] == [1, 2, 3] and env.calls == 5
+        h.close()
+        assert env.source == 'own' and h.next_ticket is None and env.joined == 5   # 4 in step() + close()
+        x = torch.arange(6, dtype=torch.float32).reshape(1, 2, 3)
+        g = gxd.all_gather_rollout(x)
+        assert g.data_ptr() != x.data_ptr() and torch.equal(g[0], x)
+        assert gxd.max_over_ranks(2.5, torch.device("cpu")) == 2.5
+        gxd.barrier()
+        senv = _StubShardEngine(0)
+        sr = gxd.ShardedReset(senv)
+        sr.reset()
+        assert senv.installed[-1][1].tolist() == [2]
+        q.put(("ok", None))
+        torch.distributed.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put(("fail", traceback.format_exc()))
+        raise
+
+
+@pytest.mark.timeout(300)
+def test_forced_collective_in_a_world_of_one_over_gloo():
+    """GX_FORCE_DIST=1: a one-rank group runs the N > 1 path as it is (collective issued, sampler "sharded" over the one
+    rank, close() joining the shard sampler) -- the CPU twin of tests/test_rccl_one_rank.py"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    tag, msg = q.get(timeout=240)
+    assert tag == "ok", msg
+    p.join(60)
+    assert p.exitcode == 0
