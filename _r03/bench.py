@@ -104,10 +104,16 @@ class RolloutHandoff:
                 s[0].wait()
 
 
+SHARDED_RESET = None   # guardx_amd.dist.ShardedReset when GX_SHARD_SAMPLER=1 (optional second collective, default off)
+
+
 def run_epochs(env, tapes, epochs, handoff):
     """`epochs` bench steps: reset() + one fused 200-pass rollout each (+ the async hand-off)."""
     for ep in range(epochs):
-        env.reset(check=False)           # the layout_size assert is checked once after the loop
+        if SHARDED_RESET is not None and SHARDED_RESET.env is env:
+            SHARDED_RESET.reset(check=False)
+        else:
+            env.reset(check=False)       # the layout_size assert is checked once after the loop
         acts = tapes[ep % len(tapes)]
         if isinstance(handoff, RolloutHandoff):
             handoff.submit(env.rollout(acts, packed=True)[4])
@@ -125,24 +131,10 @@ PRECONDITION_MS = 60.0
 
 def precondition_clocks(device, ms=PRECONDITION_MS):
     """Keep the GPU busy for `ms` with work that is NOT the workload (fp32 torch.mm), so that the firmware's clock /
-    power ramp is over when the W warm-up epochs start.  Measured on this pool (tools/history/debug/cold_start_probe.py,
+    power ramp is over when the W warm-up epochs start.  Measured on this pool (tools/debug/cold_start_probe.py,
     DESIGN.md section 6): after >= 50 ms of idle the first ~25 epochs (13 ms) run 10 % -> 0 % slower than the steady
     state whatever ran before the idle gap, and 30 ms of any sustained compute removes that.  The driver's region
-    (5 + 20 epochs = 13 ms) would otherwise sit entirely inside the ramp.  The line reports `cold_start` beside.
-    (GX_PRECONDITION=int / GX_PRECONDITION_MS: experiments with another kind and length of filler work.)"""
-    ms = float(os.environ.get("GX_PRECONDITION_MS", ms))
-    kind = os.environ.get("GX_PRECONDITION", "mm")
-    if kind == "int":
-        x = torch.arange(1 << 24, device=device, dtype=torch.int32)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n = 0
-        while (time.perf_counter() - t0) * 1e3 < ms:
-            for _ in range(8):
-                x.mul_(1664525).add_(1013904223)
-            n += 8
-            torch.cuda.synchronize()
-        return {"ms": round((time.perf_counter() - t0) * 1e3, 1), "work": f"{n} x int32 multiply-add over 2^24 elements (not the workload)"}
+    (5 + 20 epochs = 13 ms) would otherwise sit entirely inside the ramp.  The line reports `cold_start` beside."""
     a = torch.ones(4096, 4096, device=device)
     b = torch.ones(4096, 4096, device=device)
     c = a @ b                                            # library initialisation happens here, outside the busy loop
@@ -339,11 +331,7 @@ def cpu_baseline(epochs_all=8, epochs_1t=1):
     rng = np.random.RandomState(0)
     acts = rng.uniform(-1, 1, (EP_LEN, ENV_NUM, 2)).astype(np.float32)
     L = gxo.lib()
-    visible = int(L.gxo_get_threads())
-    share = cpu_share()
-    # a GPU box shows all of its host's hardware threads but grants this job a share of them (cgroup quota): more
-    # OpenMP threads than the share only time-slice (round 3 timed 128 threads on what was a 16-CPU share)
-    ncores = max(1, min(visible, share)) if share else visible
+    ncores = int(L.gxo_get_threads())
 
     def run(threads, epochs):
         L.gxo_set_threads(threads)
@@ -371,37 +359,11 @@ def cpu_baseline(epochs_all=8, epochs_1t=1):
             "stepping_only_all_cores": round(sa, 1), "stepping_only_1thread": round(s1, 1),
             "reset_s_all_cores": round(ra, 3), "reset_s_1thread": round(r1, 3),
             "threads": {"reset_phase": ncores, "step_phase": ncores},
-            "host": {"hardware_threads_visible": visible, "cpu_share_of_this_job": share},
             "sample": f"{epochs_all} epochs on {ncores} threads ({wa:.1f} s) and {epochs_1t} epoch on 1 thread "
                       f"({w1:.1f} s): {EP_LEN} steps x {ENV_NUM} envs incl. reset() over 1e6 layout candidates "
                       "and reset_done()",
             "note": "CPU restatement (oracle/, gcc -O2 -fopenmp), not the reference's XLA:CPU program; "
                     "a reported baseline, not the optimisation target"}
-
-
-def cpu_share():
-    """CPUs this process may actually use: the cgroup quota (v2 cpu.max, v1 cfs quota) and the affinity mask, or None"""
-    n = None
-    try:
-        n = len(os.sched_getaffinity(0))
-    except Exception:  # noqa: BLE001
-        pass
-    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: None if t.split()[0] == "max" else float(t.split()[0]) / float(t.split()[1])),
-                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", None)):
-        try:
-            txt = open(path).read().strip()
-            if parse is None:
-                q = float(txt)
-                per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip())
-                v = None if q <= 0 else q / per
-            else:
-                v = parse(txt)
-            if v:
-                n = int(min(n, max(1, round(v)))) if n else int(max(1, round(v)))
-            break
-        except Exception:  # noqa: BLE001
-            continue
-    return n
 
 
 def epoch_breakdown(device):
@@ -443,24 +405,23 @@ def valu_issue_floor():
     n, why = _evidence("epoch_valu_instructions")
     if n is None:
         return {"note": "no counter evidence: " + why}
-    ns = 1.73   # profiles/history/r02_probe_threefry_chain.log: 110 ns per 63.5-instruction Threefry block per SIMD
+    ns = 1.73   # profiles/r02_probe_threefry_chain.log: 110 ns per 63.5-instruction Threefry block per SIMD
     return {"wave_instructions_per_epoch": round(n), "ns_per_wave_instruction_per_simd": ns, "simds": 1024,
             "issue_floor_us": round(n * ns * 1e-9 / 1024 * 1e6, 1),
-            "note": "NOT measured in this run: SQ_INSTS_VALU of every kernel of one epoch (profiles/r04_sampler_pmc_SQ.csv, "
-                    "r04_rollout_N2000_T200_pmc_SQ.csv) x the measured issue cost of the sampler's own Threefry code / 1024 "
+            "note": "NOT measured in this run: SQ_INSTS_VALU of every kernel of one epoch (profiles/r03_sampler_pmc_SQ.csv, "
+                    "r03_rollout_N2000_T200_pmc_SQ.csv) x the measured issue cost of the sampler's own Threefry code / 1024 "
                     "SIMDs; compare with the headline ms_per_step"}
 
 
-def closed_loop_rate(device, epochs=50, hidden=64):
-    """reset() + rollout_policy per epoch: the (h, h)-tanh actor-critic of trpo_core.py:110-173 (random init) evaluated on
-    device.  h = 64 (the reference default): ONE launch per 200-step rollout; wider networks
-    (trpo.py:606 --hid): two launches per control step."""
+def closed_loop_rate(device, epochs=50):
+    """reset() + ONE rollout_policy launch per epoch: the (64,64)-tanh actor-critic of
+    trpo_core.py:110-173 (random init) evaluated inside the persistent kernel."""
     from guardx_amd import Engine
     env = make_engine(ENV_NUM, 0, 1)
     D = env.obs_flat_size
     torch.manual_seed(0)
-    mk = lambda out: torch.nn.Sequential(torch.nn.Linear(D, hidden), torch.nn.Tanh(), torch.nn.Linear(hidden, hidden),  # noqa: E731
-                                         torch.nn.Tanh(), torch.nn.Linear(hidden, out))
+    mk = lambda out: torch.nn.Sequential(torch.nn.Linear(D, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64),  # noqa: E731
+                                         torch.nn.Tanh(), torch.nn.Linear(64, out))
     params = Engine.pack_actor_critic(mu_net=mk(2), v_net=mk(1), log_std=torch.full((2,), -0.5)).to(device)
 
     def epoch():
@@ -510,30 +471,6 @@ def other_robots(device, epochs=50):
                      "ms_per_epoch": round(dt / epochs * 1e3, 4)}
         if label:
             out[name]["label"] = label
-        # the same epochs through the hand-off pipeline in a world of one: the observation pass of epoch k runs on the
-        # hand-off's stream during epoch k + 1 (packed rows one epoch late) instead of behind the dynamics pass -- what
-        # a rank of the multi-GPU run does; it pays where the dynamics chain, not the sampler, bounds the epoch
-        try:
-            from guardx_amd.dist import TapeHandoff
-            env = Engine(cfg)
-            h = TapeHandoff(env, EP_LEN, sharded_sampler=False)
-
-            def epoch_p():
-                env.reset(check=False)
-                h.step(tape)
-            epoch_p(); epoch_p()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(epochs):
-                epoch_p()
-            h.drain()
-            torch.cuda.synchronize()
-            dtp = time.perf_counter() - t0
-            env.check_layouts()
-            env.close()
-            out[name]["pipelined_env_steps_per_s"] = round(ENV_NUM * EP_LEN * epochs / dtp, 1)
-        except Exception as exc:  # noqa: BLE001
-            out[name]["pipelined_env_steps_per_s"] = f"{type(exc).__name__}: {exc}"[:120]
     return out
 
 
@@ -570,52 +507,6 @@ def reset_done_heavy(device, epochs=50):
             "config": "Goal_Point_8Hazards env_num=2000, goal_size=2.9, num_steps=60 (timeouts), 200-step epochs"}
 
 
-def multi_gpu_rehearsal(device, world=8, epochs=30):
-    """This GPU plays rank 0 of `world` in the default N > 1 epoch (tools/rehearse_rank.py): everything a rank does per
-    epoch -- 1/world of the layout sampler for a later reset, its dynamics pass, the install of every rank's export
-    block, the observation pass over all (or only its own) tapes -- with device copies standing in for the all-gather.
-    Measured GPU time of a rank's epoch + the link as arithmetic = the predicted weak-scaling efficiency (an 8-GPU node
-    is the driver's to run).  Run in a FRESH process, as a rank is: inside this one -- a dozen engines and their streams
-    created and destroyed by the other extras -- the same rehearsal measures 0.72-0.74 ms per epoch instead of 0.48
-    (HIP assigns streams to hardware queues in creation order; a rank process creates its engine and hand-off first)."""
-    import tempfile
-    with tempfile.TemporaryDirectory() as tmp:
-        out = os.path.join(tmp, "rehearsal.json")
-        env = dict(os.environ)
-        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
-            env.pop(k, None)
-        env["HIP_VISIBLE_DEVICES"] = env.get("HIP_VISIBLE_DEVICES", str(device.index if device.index is not None else 0))
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rehearse_rank.py"), "--world", str(world),
-                            "--epochs", str(epochs), "--json", out], env=env, capture_output=True, text=True, timeout=600)
-        if r.returncode != 0:
-            raise RuntimeError("tools/rehearse_rank.py failed: " + r.stderr[-300:])
-        with open(out) as f:
-            res = json.load(f)
-    res["note"] = ("NOT an 8-GPU measurement: one GPU playing rank 0 of 8 in a fresh process; the xGMI transfer enters as "
-                   "bytes / bandwidth (model)")
-    return res
-
-
-def in_fresh_process(what, device):
-    """run one of the supplementary measurements in a child process started from scratch (`bench.py --child-extra`)"""
-    import tempfile
-    with tempfile.TemporaryDirectory() as tmp:
-        out = os.path.join(tmp, what + ".json")
-        env = dict(os.environ)
-        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GX_FORCE_DIST"):
-            env.pop(k, None)
-        env["HIP_VISIBLE_DEVICES"] = env.get("HIP_VISIBLE_DEVICES", str(device.index if device.index is not None else 0))
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child-extra", what, "--child-out", out], env=env,
-                           capture_output=True, text=True, timeout=900)
-        if r.returncode != 0:
-            raise RuntimeError(f"bench.py --child-extra {what} failed: " + r.stderr[-300:])
-        with open(out) as f:
-            return json.load(f)
-
-
-CHILD_EXTRAS = {"other_robots": lambda device: dict(other_robots(device), process="fresh child process of bench.py")}
-
-
 def api_loop_rate(env, tape, steps):
     """Python-driven Engine.step()/reset_done() loop (what an unmodified learner drives)."""
     torch.cuda.synchronize()
@@ -629,117 +520,6 @@ def api_loop_rate(env, tape, steps):
             s += 1
     torch.cuda.synchronize()
     return env.env_num * steps / (time.perf_counter() - t0)
-
-
-def api_loop_summary(env, tape, reps=5, steps=2000):
-    """the default Engine (out_ring=0: step() outputs are never overwritten, engine.py:495) and the opt-in ring of 8
-    reused output sets, side by side"""
-    from guardx_amd import Engine
-    rates = sorted(api_loop_rate(env, tape, steps) for _ in range(reps))
-    ring = Engine(env._ctor_config, **dict(env._ctor_kwargs, out_ring=8))
-    ring.set_prefetch(EP_LEN)
-    r8 = sorted(api_loop_rate(ring, tape, steps) for _ in range(reps))
-    ring.close()
-    return {"value": round(rates[reps // 2], 1), "best": round(rates[-1], 1), "out_ring": 0,
-            "out_ring_8": {"value": round(r8[reps // 2], 1), "best": round(r8[-1], 1)},
-            "unit": "env-steps/s", "note": f"median (and best) of {reps} runs of {steps} step()+reset_done() pairs incl. "
-                                           "a reset() every 200"}
-
-
-def previous_round_values():
-    """What the newest committed driver record (BENCH_rNN.json at the repo root: `parsed` + the last 2000 characters of
-    the line in `tail`) and, for the keys the truncated tail no longer holds, the builder's own driver-style line of the
-    same round (profiles/rNN_bench_driver_style.json) say about the values this line reports.  -> (round, {key: (value,
-    source)})"""
-    import glob
-    import re
-    recs = sorted(glob.glob(os.path.join(ROOT, "BENCH_r[0-9][0-9].json")))
-    if not recs:
-        return None, {}
-    rec = recs[-1]
-    rnd = os.path.basename(rec)[6:9]
-    prev = {}
-    try:
-        with open(rec) as f:
-            d = json.load(f)
-        src = os.path.basename(rec)
-        if isinstance(d.get("parsed"), dict) and d["parsed"].get("value"):
-            prev["value"] = (float(d["parsed"]["value"]), src + ":parsed.value")
-        tail = d.get("tail") or ""
-        for name in ("Goal_Swimmer_8Hazards", "Goal_Ant_8Hazards", "Goal_Walker_8Hazards", "Ant_8Hazards_8Pillars_synthetic"):
-            m = re.search(r'"%s": \{"env_steps_per_s": ([0-9.]+)' % name, tail)
-            if m:
-                prev["other_robots." + name] = (float(m.group(1)), src + ":tail")
-    except (OSError, ValueError):
-        pass
-    own = os.path.join(ROOT, "profiles", f"{rnd}_bench_driver_style.json")
-    try:
-        with open(own) as f:
-            line = json.loads([ln for ln in f if ln.startswith("{")][0])
-        src = os.path.relpath(own, ROOT)
-        for key, val in _comparable_values(line).items():
-            prev.setdefault(key, (val, src))
-    except (OSError, ValueError, IndexError):
-        pass
-    return rnd, prev
-
-
-def _comparable_values(line):
-    """the rates of a bench line that are compared round over round"""
-    out = {}
-    if line.get("value"):
-        out["value"] = float(line["value"])
-    for name, v in (line.get("other_robots") or {}).items():
-        if isinstance(v, dict) and v.get("env_steps_per_s"):
-            out["other_robots." + name] = float(v["env_steps_per_s"])
-    api = line.get("api_step_loop_env_steps_per_s")
-    if isinstance(api, dict) and api.get("value"):
-        out["api_step_loop"] = float(api["value"])
-        if isinstance(api.get("out_ring_8"), dict) and api["out_ring_8"].get("value"):
-            out["api_step_loop.out_ring_8"] = float(api["out_ring_8"]["value"])
-    if isinstance(line.get("preconditioned"), dict) and line["preconditioned"].get("value"):
-        out["preconditioned"] = float(line["preconditioned"]["value"])
-    if isinstance(line.get("closed_loop_policy_env_steps_per_s"), (int, float)):
-        out["closed_loop_policy.hidden_64"] = float(line["closed_loop_policy_env_steps_per_s"])
-    for k, v in (line.get("closed_loop_policy_wider_env_steps_per_s") or {}).items():
-        if isinstance(v, (int, float)):
-            out["closed_loop_policy." + k] = float(v)
-    rh = line.get("reset_done_heavy")
-    if isinstance(rh, dict) and rh.get("env_steps_per_s"):
-        out["reset_done_heavy"] = float(rh["env_steps_per_s"])
-    return out
-
-
-def vs_previous_round(line, threshold=-0.02):
-    """every compared rate of this line beside the previous round's, and the list of those more than 2 % below it"""
-    rnd, prev = previous_round_values()
-    if not prev:
-        return {"previous": None, "note": "no BENCH_rNN.json in the tree"}
-    now = _comparable_values(line)
-    unlike = set()
-    if rnd <= "r04" and "value" in prev:
-        # rounds 2-4 reported ONE repetition behind a clock-warming prelude as `value`; from round 5 on it is the
-        # un-preconditioned median.  Like is compared with like: this line's `preconditioned` sibling against it.
-        unlike.add("value")
-        if isinstance(line.get("preconditioned"), dict):
-            now["preconditioned"] = float(line["preconditioned"]["value"])
-            prev["preconditioned"] = prev["value"]
-    rows, regress = {}, []
-    for key, val in now.items():
-        if key not in prev:
-            continue
-        p, src = prev[key]
-        rel = val / p - 1.0
-        rows[key] = {"now": round(val, 1), "previous": round(p, 1), "change": round(rel, 4), "source": src}
-        if key in unlike:
-            rows[key]["like_for_like"] = False
-        elif rel < threshold:
-            regress.append(key)
-    out = {"previous": rnd, "values": rows, "regressions": regress, "threshold": threshold}
-    if unlike:
-        out["note"] = ("the previous round's `value` was one repetition behind a clock-warming prelude; this round's is the "
-                       "un-preconditioned median: the like-for-like row is `preconditioned`")
-    return out
 
 
 def spawn_ranks(args):
@@ -788,21 +568,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--reps", type=int, default=5,
-                    help="repetitions of the [warm-up, timed] region; `value` is their median (default 5)")
     ap.add_argument("--no-precondition", action="store_true",
-                    help="skip the `preconditioned` sibling measurement (one repetition behind 60 ms of torch.mm)")
-    ap.add_argument("--child-extra", choices=sorted(CHILD_EXTRAS), help=argparse.SUPPRESS)
-    ap.add_argument("--child-out", help=argparse.SUPPRESS)
+                    help="skip the 60 ms of unrelated GPU work before the warm-up epochs (clock ramp, see precondition_clocks)")
     args = ap.parse_args()
-    if args.child_extra:
-        torch.cuda.set_device(0)
-        res = CHILD_EXTRAS[args.child_extra](torch.device("cuda", 0))
-        with open(args.child_out, "w") as f:
-            json.dump(res, f)
-        return
-    if args.steps < 1 or args.warmup < 0 or args.reps < 1:
-        ap.error("--steps >= 1, --warmup >= 0, --reps >= 1")
+    if args.steps < 1 or args.warmup < 0:
+        ap.error("--steps >= 1, --warmup >= 0")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
@@ -819,25 +589,30 @@ def main():
 
     env = make_engine(ENV_NUM, rank, world)
     env.set_prefetch(EP_LEN)
+    global SHARDED_RESET
+    if os.environ.get("GX_SHARD_SAMPLER") == "1":
+        # OPTIONAL, off by default: the 1e6-candidate layout sampler split over the ranks + one small all-gather of the
+        # valid layouts (a second collective; north_star names one).  Same pools, same results.
+        SHARDED_RESET = gxd.ShardedReset(env)
     tapes = [action_tape(EP_LEN, ENV_NUM, 1000 * rank + k, device) for k in range(4)]
-    import torch.distributed as tdist
-    forced = gxd.forced_dist() and tdist.is_initialized()   # GX_FORCE_DIST=1: the N > 1 path over a one-rank group
-    gather = world > 1 or forced
-    # the hand-off: "tape" (default) all-gathers the 40-B-per-env-step dynamics tape and expands it on every rank,
+    gather = world > 1
+    # the hand-off: "tape" (default) all-gathers the 48-B-per-env-step dynamics tape and expands it on every rank,
     # "packed" all-gathers the 192-B packed rows (what round 1 did; GX_HANDOFF=packed to compare)
     mode = os.environ.get("GX_HANDOFF", "tape")
-    if gather and mode == "tape":
-        env.reset()                      # sizes the export blocks of the sharded sampler (layout_size)
-
-    def make_handoff(sharded, expand):
-        if not gather:
-            return None
+    handoff = None
+    if gather:
+        if mode == "tape":
+            try:
+                handoff = gxd.TapeHandoff(env, EP_LEN)
+            except Exception as exc:  # noqa: BLE001 - same code on every rank, so every rank falls back together
+                print(f"bench.py: tape hand-off unavailable ({type(exc).__name__}: {exc}); using the packed rows",
+                      file=sys.stderr)
+                mode = "packed"
         if mode != "tape":
-            return RolloutHandoff(world)
-        return gxd.TapeHandoff(env, EP_LEN, sharded_sampler=sharded, expand=expand)
+            handoff = RolloutHandoff(world)
 
-    def timed_region(handoff, warmup):
-        run_epochs(env, tapes, warmup, handoff)
+    def timed_region():
+        run_epochs(env, tapes, args.warmup, handoff)
         gxd.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -846,53 +621,36 @@ def main():
         gxd.barrier()
         return gxd.max_over_ranks(time.perf_counter() - t0, device)
 
-    def leg(sharded, expand, warmup, reps=1):
-        """`reps` repetitions of [W warm-up epochs, barrier, K timed epochs, barrier] through one hand-off object;
-        returns the sorted-by-time middle one (the median for odd reps), all of them, and the hand-off"""
-        h = make_handoff(sharded, expand)
-        ts = [timed_region(h, warmup) for _ in range(reps)]
-        if hasattr(h, "close"):
-            h.close()                    # the engine samples for itself again
-        return sorted(ts)[len(ts) // 2], ts, h
-
-    # `value` at N > 1: the tape hand-off with the layout sampler sharded over the ranks (each rank samples 1/N of the
-    # candidates of the reset after next, the rows ride on the tape all-gather: still ONE collective per epoch) and every
-    # rank expanding every rank's tape
-    # `value` = the MEDIAN of --reps repetitions of the driver's region (W untimed warm-up epochs, then exactly K timed
-    # epochs between barrier + synchronize), started from whatever state the process start left the GPU in: no filler
-    # work in front of it.  The first repetition is the cold one (the firmware's clock ramp, ~13 ms on this pool, covers
-    # it); it is reported with the others, and min / max give the spread.
-    dt, dts, handoff = leg(True, "all", args.warmup, reps=args.reps)
+    precond = None if args.no_precondition else precondition_clocks(device)
+    dt = timed_region()
 
     env_steps = ENV_NUM * world * EP_LEN * args.steps
     value = env_steps / dt
     stepping_only = None
-    legs = None
     if gather:
-        w2 = max(4, args.warmup)         # a change of the layout source costs up to three inline samplers
-        W = env.obs_flat_size + 2 + 3
-
-        def rate(t):
-            return {"value": round(env_steps / t, 1), "unit": "env-steps/s", "ms_per_step": round(t / args.steps * 1e3, 6)}
         # the same epochs without the hand-off: what the sharded stepping alone sustains (no collective on the
-        # data path, every rank samples all candidates for itself)
-        dt1 = timed_region(None, w2)
-        stepping_only = dict(rate(dt1),
-                             handoff_ms_per_epoch_exposed=round((dt - dt1) / args.steps * 1e3, 6), handoff=mode,
-                             handoff_bytes_received_per_rank_per_epoch=int(
-                                 (world - 1) * (handoff.n if mode == "tape" else EP_LEN * ENV_NUM * W) * 4),
-                             packed_rows_bytes_per_rank_per_epoch=int(EP_LEN * ENV_NUM * W * 4),
-                             note="same epochs with the rollout hand-off switched off (two-kernel gx_rollout, every rank "
-                                  "samples all 1e6 layout candidates itself); `value` above includes the hand-off")
-        if mode == "tape":
-            dt2, _, _ = leg(False, "all", w2)
-            dt3, _, _ = leg(True, "local", w2)
-            legs = {"unsharded_sampler": dict(rate(dt2), note="the round-3 default: tape hand-off, every rank expands every "
-                                              "tape, every rank samples all 1e6 layout candidates itself"),
-                    "local_expand": dict(rate(dt3), note="as `value`, but a rank expands only its own tape; the other "
-                                         "ranks' tapes are held and expanded on demand (TapeHandoff.expand_rank)"),
-                    "warmup_epochs_each": w2,
-                    "note": "`value` = sharded sampler + expand all; all legs: same engine, same epochs, one collective per epoch"}
+        # data path), so the cost of the mandated all-gather can be read off the two numbers
+        gxd.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_epochs(env, tapes, args.steps, None)
+        torch.cuda.synchronize()
+        gxd.barrier()
+        dt1 = gxd.max_over_ranks(time.perf_counter() - t1, device)
+        W = env.obs_flat_size + 2 + 3
+        stepping_only = {"value": round(env_steps / dt1, 1), "unit": "env-steps/s",
+                         "ms_per_step": round(dt1 / args.steps * 1e3, 6),
+                         "handoff_ms_per_epoch_exposed": round((dt - dt1) / args.steps * 1e3, 6),
+                         "handoff": mode,
+                         "handoff_bytes_received_per_rank_per_epoch":
+                             int((world - 1) * (handoff.n if mode == "tape" else EP_LEN * ENV_NUM * W) * 4),
+                         "packed_rows_bytes_per_rank_per_epoch": int(EP_LEN * ENV_NUM * W * 4),
+                         "note": "same epochs with the rollout hand-off switched off (two-kernel gx_rollout); `value` "
+                                 "above includes the hand-off: asynchronous all-gather of the dynamics tape, 3 in "
+                                 "flight, and the observation pass over all ranks' tapes on every rank"
+                                 if mode == "tape" else
+                                 "same epochs with the rollout hand-off switched off; `value` above includes it "
+                                 "(asynchronous all-gather of the packed rows, 3 gathered buffers in flight)"}
     line = {
         "metric": "env-steps/sec", "value": round(value, 1), "unit": "env-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -912,54 +670,37 @@ def main():
                    "driver": "gx_rollout: two launches per 200-pass epoch (serial dynamics tape, then one thread per "
                              "(step, env) observation row), layout pool of the next epoch prefetched on a side stream",
                    "layout_candidates_per_reset": 1_000_000,
-                   "layout_sampler": ("sharded over the ranks: each samples 1/N of the candidates of the reset after next, the "
-                                      "valid rows ride in the tail of its tape shard (no second collective)"
-                                      if getattr(handoff, "sharded_used", False) else
-                                      "every rank samples all candidates (shared key)"),
+                   "layout_sampler": ("sharded over the ranks + all-gather of the valid layouts (GX_SHARD_SAMPLER=1)"
+                                      if SHARDED_RESET is not None else "every rank samples all candidates (shared key)"),
                    "point_actuators": "mjcf defaults inherited (DESIGN.md 0.1)"},
     }
     try:   # the 8-GPU hand-off as arithmetic (it cannot be measured on a one-GPU box): bytes on the wire vs the epoch
-        shard_bytes = int(handoff.n if hasattr(handoff, "n") else sum(env.tape_floats(EP_LEN))) * 4
+        shard_bytes = int(sum(env.tape_floats(EP_LEN))) * 4
         line["handoff_model"] = {
             "shard_bytes_per_rank_per_epoch": shard_bytes,
             "packed_rows_bytes_per_rank_per_epoch": int(EP_LEN * ENV_NUM * (env.obs_flat_size + 2 + 3) * 4),
             "received_per_rank_at_8_gpus_bytes": 7 * shard_bytes,
             "allgather_ms_at_8_gpus_310GBps": round(7 * shard_bytes / 310e9 * 1e3, 4),
-            "note_n1": "at N = 1 no hand-off runs; the shard here is the bare tape -- at N > 1 each rank's block of valid "
-                       "layouts (~0.5 MB) rides in its tail",
             "ms_per_step_this_run": round(dt / args.steps * 1e3, 4),
-            "note": "one async all-gather of the dynamics tape per epoch (40 B per env-step: qpos, qvel, action, done, "
-                    "two layout-row indices; at N > 1 plus the rank's export block of valid layouts, ~0.5 MB), overlapped "
-                    "with the following epoch; 310 GB/s = a realistic all-gather bus "
+            "note": "one async all-gather of the dynamics tape per epoch (48 B per env-step: qpos, qvel, action, done, "
+                    "two layout-row indices), overlapped with the following epoch; 310 GB/s = a realistic all-gather bus "
                     "bandwidth over 7 xGMI links (537 GB/s peak per direction); arithmetic, not a measurement"}
     except Exception as exc:  # noqa: BLE001
         line["handoff_model"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
-    line["repetitions"] = {
-        "n": len(dts), "values": [round(env_steps / t, 1) for t in dts],
-        "min": round(env_steps / max(dts), 1), "max": round(env_steps / min(dts), 1),
-        "first": round(env_steps / dts[0], 1),
-        "note": "`value` = the median of these: each repetition is W untimed warm-up epochs + K timed epochs between "
-                "barrier + synchronize (max over ranks), run back to back; the first starts from the idle GPU the "
-                "process start leaves (inside the firmware's clock ramp), no filler work precedes any of them"}
-    if not args.no_precondition:
-        # the round-2..4 headline, kept as a sibling: ONE repetition behind 60 ms of unrelated GPU work (torch.mm)
-        precond = precondition_clocks(device)
-        dtp, _, _ = leg(True, "all", args.warmup)
-        line["preconditioned"] = {"value": round(env_steps / dtp, 1), "unit": "env-steps/s",
-                                  "ms_per_step": round(dtp / args.steps * 1e3, 6), "prelude": precond,
-                                  "note": "one repetition started right behind unrelated GPU work that holds the clocks "
-                                          "up (what rounds 2-4 reported as `value`); NOT the headline any more"}
-    if forced:
-        line["forced_dist"] = {"backend": tdist.get_backend(), "world_size": world,
-                               "note": "GX_FORCE_DIST=1: the N > 1 path (process group, barrier, max-over-ranks, tape hand-off "
-                                       "with the collective issued, sharded sampler, all-tapes expansion) over a group of "
-                                       "this many ranks -- a code-path run, not a scaling measurement"}
+    line["clock_preconditioning"] = (dict(precond, note="unrelated GPU work before the W warm-up epochs so that the "
+                                          "firmware clock ramp (13 ms on this pool) is not inside the timed region; "
+                                          "`cold_start` below is the same W + K epochs after 1 s of idle without it")
+                                     if precond else None)
+    if precond and world == 1:
+        time.sleep(1.0)
+        dtc = timed_region()
+        line["cold_start"] = {"value": round(env_steps / dtc, 1), "unit": "env-steps/s",
+                              "ms_per_step": round(dtc / args.steps * 1e3, 6),
+                              "note": "same W warm-up + K timed epochs started from an idle GPU (1 s sleep), no preconditioning"}
     if dt < 0.010:
         line["warning"] = f"timed region {dt*1e3:.2f} ms < 10 ms: use more --steps for a meaningful rate"
     if stepping_only is not None:
         line["stepping_only"] = stepping_only
-    if legs is not None:
-        line["legs"] = legs
     if rank == 0:
         try:
             line["roofline"] = roofline_rollout(ENV_NUM, EP_LEN, 30, device)
@@ -976,36 +717,12 @@ def main():
             # bandwidth regime: the thread-per-env step kernel at 2^22 envs
             extra("roofline_large_batch", lambda: roofline_step(1 << 22, 30, device))
             extra("large_batch_fused", lambda: large_batch_fused(1 << 22, 32, device))
-            # host-bound (one ctypes call per step; the box's host cores are shared with other tenants): median of five
-            extra("api_step_loop_env_steps_per_s", lambda: api_loop_summary(env, tapes[0]))
+            # host-bound (one ctypes call per step): best of three, the box's host cores are shared with other tenants
+            extra("api_step_loop_env_steps_per_s", lambda: round(max(api_loop_rate(env, tapes[0], 2000) for _ in range(3)), 1))
             extra("epoch_breakdown", lambda: epoch_breakdown(device))
             extra("closed_loop_policy_env_steps_per_s", lambda: round(closed_loop_rate(device), 1))
-            extra("closed_loop_policy_wider_env_steps_per_s",
-                  lambda: {f"hidden_{h}": round(closed_loop_rate(device, 20, h), 1) for h in (128, 256)})
             extra("reset_done_heavy", lambda: reset_done_heavy(device))
-            extra("multi_gpu_rehearsal", lambda: multi_gpu_rehearsal(device))
-            mg = line.get("multi_gpu_rehearsal", {})
-            if "expand_all" in mg and isinstance(line.get("handoff_model"), dict):   # the prediction next to the byte count
-                line["handoff_model"]["predicted_at_8_gpus"] = {
-                    "rank_epoch_ms_measured_on_one_gpu": mg["expand_all"]["ms_per_epoch"],
-                    "one_gpu_epoch_ms": mg["one_gpu_own_sampler"]["ms_per_epoch"],
-                    "weak_scaling_efficiency_at_310GBps": mg["expand_all"]["model"]["at_310GBps"]["weak_scaling_efficiency"],
-                    "weak_scaling_efficiency_at_200GBps": mg["expand_all"]["model"]["at_200GBps"]["weak_scaling_efficiency"],
-                    "bytes_received_per_rank_per_epoch": mg["expand_all"]["bytes_received_per_epoch"],
-                    "link_bound_below_GBps": mg["expand_all"]["model"].get("link_bound_below_GBps"),
-                    "break_even_GBps": mg["expand_all"]["model"].get("break_even_GBps"),
-                    "efficiency_if_gpu_bound": mg["expand_all"]["model"].get("efficiency_if_gpu_bound"),
-                    "note": "from `multi_gpu_rehearsal` (this GPU playing rank 0 of 8 in the default N > 1 epoch, fresh "
-                            "process): GPU time of a rank's epoch measured, the link as bytes / bandwidth; efficiency = "
-                            "one-GPU epoch / max(rank epoch, all-gather time)"}
-            # in a fresh process, as each of these tasks would run on its own (same reason as multi_gpu_rehearsal: after the
-            # dozen engines and streams of the extras above, HIP's stream -> hardware-queue assignment costs ~3 %)
-            extra("other_robots", lambda: in_fresh_process("other_robots", device))
-        if world == 1:
-            try:
-                line["vs_previous_round"] = vs_previous_round(line)
-            except Exception as exc:  # noqa: BLE001
-                line["vs_previous_round"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            extra("other_robots", lambda: other_robots(device))
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline()
@@ -1014,8 +731,10 @@ def main():
         print(json.dumps(line), flush=True)
     gxd.barrier()
     env.close()
-    if tdist.is_initialized():
-        tdist.destroy_process_group()
+    if world > 1:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

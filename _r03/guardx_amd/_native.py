@@ -62,8 +62,6 @@ SYMBOLS = {
     "gx_layout_size_min": (C.c_int, [C.c_void_p, _I32P]),
     "gx_step": (C.c_int, [C.c_void_p, _FP, _FP, _FP, _FP, _FP, _FP, C.c_void_p]),
     "gx_step_rd": (C.c_int, [C.c_void_p, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _I32P, C.c_void_p]),
-    "gx_step_set_floats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
-    "gx_step_slab": (C.c_int, [C.c_void_p, _FP, _FP, C.c_int32, C.c_int32, _I32P, C.c_void_p]),
     "gx_reset_done_commit": (C.c_int, [C.c_void_p]),
     "gx_reset_done": (C.c_int, [C.c_void_p, _FP, _FP, C.c_void_p]),
     "gx_rollout_packed": (C.c_int, [C.c_void_p, C.c_int32, _FP, _FP, C.c_void_p]),
@@ -71,14 +69,8 @@ SYMBOLS = {
     "gx_tape_floats": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "gx_rollout_tape": (C.c_int, [C.c_void_p, C.c_int32, _FP, _FP, C.POINTER(C.c_int64), C.c_void_p]),
     "gx_expand_tape": (C.c_int, [C.c_void_p, C.c_int32, _FP, C.c_int64, _FP, C.c_void_p]),
-    "gx_expand_tapes": (C.c_int, [C.c_void_p, C.c_int32, _FP, C.c_int64, C.c_int32, C.c_int64, _FP, C.c_int64, C.c_void_p]),
     "gx_sample_shard": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _FP, C.c_int32, _FP, C.c_void_p]),
     "gx_reset_from_shards": (C.c_int, [C.c_void_p, _FP, _FP, C.c_int32, C.c_int32, _FP, C.c_void_p]),
-    "gx_set_layout_source": (C.c_int, [C.c_void_p, C.c_int32]),
-    "gx_shard_block_floats": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
-    "gx_sample_shard_ahead": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _FP, C.c_int32, C.POINTER(C.c_int64), C.c_void_p]),
-    "gx_shard_join": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "gx_install_shards": (C.c_int, [C.c_void_p, C.c_int64, _FP, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
     "gx_rollout": (C.c_int, [C.c_void_p, C.c_int32, _FP, _FP, _FP, _FP, _FP, C.c_void_p]),
     "gx_rollout_policy": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(GxPolicy)] + [_FP] * 12 + [C.c_void_p]),
     "gx_set_policy_impl": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -120,42 +112,17 @@ def load():
             raise ImportError(
                 f"{LIB_PATH} is missing or stale (sources {want}, library {_build.built_id()}) and could not be "
                 f"built with hipcc ({exc}); run `python -m guardx_amd.build` (guardx_amd has no CPU fallback)") from exc
-    path = LIB_PATH
-    if os.environ.get("GX_LIB") and os.environ.get("GX_LIB_EXPERIMENT") == "1":
-        # A/B experiments only (tools/build_variant.py): a variant built from the SAME sources with other flags
-        path = os.path.abspath(os.environ["GX_LIB"])
-    lib = C.CDLL(path)
+    lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the ABI drifted
         fn.restype = res
         fn.argtypes = args
     got = lib.gx_build_id().decode()
-    if got != want and path == LIB_PATH:
+    if got != want:
         raise ImportError(f"{LIB_PATH} was built from other sources (library {got}, tree {want}); "
                           "run `python -m guardx_amd.build`")
-    _warn_if_unprofiled_compiler(lib)
     _lib = lib
     return lib
-
-
-def _warn_if_unprofiled_compiler(lib):
-    """The parity soak and the committed profiles were taken on one hipcc (profiles/<round>_build_id.txt, line 2); the
-    lane-group kernels are known to be sensitive to the compiler (guardx_amd/build.py).  A library built by another one
-    is not refused -- the parity tests are the judge -- but it says so once."""
-    import glob
-    import warnings
-    ids = sorted(glob.glob(os.path.join(os.path.dirname(_HERE), "profiles", "r[0-9][0-9]_build_id.txt")))
-    if not ids:
-        return
-    try:
-        lines = open(ids[-1]).read().splitlines()
-    except OSError:
-        return
-    have = lib.gx_build_compiler().decode()
-    if len(lines) > 1 and lines[1].strip() and have != "unknown" and lines[1].strip() != have:
-        warnings.warn(f"libguardx_hip.so was built with [{have}]; the parity soak and profiles of {os.path.basename(ids[-1])} "
-                      f"were taken with [{lines[1].strip()}]: run `pytest -m gpu` and tests/soak_parity.py on this build",
-                      RuntimeWarning, stacklevel=3)
 
 
 class GxError(RuntimeError):

@@ -94,27 +94,6 @@ struct gx_engine {
     int keys_cap[kKeyRing];
     hipEvent_t keys_ev[kKeyRing];
     int keys_next;
-    // step-wise policy rollout (hidden widths beyond the fused kernel's): transposed weights, current observation
-    float* pol_wt = nullptr;
-    size_t pol_wt_cap = 0;
-    float* pol_cur = nullptr;
-    // ---- sharded layout sampling ----
-    // gx_sample_shard -> gx_reset_from_shards: the pool and key the last shard was sampled for (claim_pool done there)
-    bool rs_sampled = false;
-    int rs_pool = -1;
-    uint32_t rs_key[2] = {0, 0};
-    // piggy-backed form (gx_sample_shard_ahead / gx_install_shards): layout_source 1 = the pool of the next reset() is
-    // installed from the ranks' export blocks, gx_reset launches no prefetch sampler of its own
-    int layout_source = 0;
-    Pool shard_scratch;            // the shard sampler's own working pool (the ring's three are all in use)
-    bool shard_scratch_ok = false;
-    int shard_scratch_cap = 0;     // candidates it holds
-    hipEvent_t shard_dep = nullptr, shard_done = nullptr;
-    bool shard_inflight = false;
-    struct ShardJob { int64_t ticket; uint32_t k0, k1; int n_shards, cap; };
-    static const int kJobs = 4;
-    ShardJob jobs[kJobs];          // the last four gx_sample_shard_ahead calls, slot = ticket % kJobs
-    int64_t next_ticket = 1;
 };
 
 // the pending reset_done (if any) is consumed by the launch about to be made / dropped by reset()
@@ -127,20 +106,13 @@ static int take_commit(gx_engine* e)
 }
 
 // env_num at which the lane-group form of a step beats the thread-per-env form.  Measured crossovers of the two
-// families (fused step incl. reset_done, tools/history/debug/legs_large.py, round 3 -- after the legs' lanes stopped
+// families (fused step incl. reset_done, tools/debug/legs_large.py, round 3 -- after the legs' lanes stopped
 // replicating work): Point / Swimmer 16384 envs; Ant ~27 k (lane-group 38.6 us at 24576 against ~44 us of the serial
 // step); Walker ~16 k (61.6 us at 16384 against 60.7 us)
 static bool in_group_regime(const gx_engine* e)
 {
     const int limit = e->cfg.robot == AntRobot::kId ? 27000 : (e->cfg.robot == WalkerRobot::kId ? 16000 : 16384);
     return e->p.N <= limit;
-}
-
-// floats of the dynamics tape of a T-step rollout, rounded up so that what follows it in a shard buffer (the layout
-// snapshot, float4 planes) stays 16-byte aligned: a tape row is 10 floats for the Point
-static size_t tape_floats_padded(const gx_engine* e, int32_t T)
-{
-    return ((size_t)T * e->p.N * split_tape_width(e->p) + 3) / 4 * 4;
 }
 
 // fused rollouts at small env_num: two kernels (a serial dynamics tape, then one thread per
@@ -150,16 +122,6 @@ static bool use_split_rollout(const gx_engine* e, int T)
     if (e->path_mode == 1 || e->path_mode == 2) return false;
     if (!split_rollout_supported(e->p) || !in_group_regime(e)) return false;
     return e->path_mode == 3 || T >= 8;
-}
-
-// Is other work of this engine on the chip while a dynamics pass runs?  A prefetch sampler in flight, or -- the engine
-// is a rank of a multi-GPU run (layout_source 1: pools come from the ranks' export blocks) -- the rank's share of the
-// sampler and the expansion of the gathered tapes.  The dynamics pass then takes its compact form (Swimmer: one lane per
-// env; Ant / Walker: four envs per wave), which leaves SIMDs to the company; alone it takes the spread-out one.  Ant,
-// one GPU playing rank 0 of 8, every tape expanded: 1.73 ms per epoch with the spread-out form, 1.49 ms with the compact.
-static bool dyn_pass_has_company(const gx_engine* e)
-{
-    return (e->pf_valid && e->prefetch_steps != -1) || e->layout_source == 1;
 }
 
 static bool use_group_path(const gx_engine* e)
@@ -366,8 +328,6 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     e->keys_next = 0;
     for (int i = 0; i < gx_engine::kKeyRing; ++i) { e->h_keys[i] = nullptr; e->keys_cap[i] = 0; e->keys_ev[i] = nullptr; }
     memset(&e->b, 0, sizeof(e->b));
-    memset(&e->shard_scratch, 0, sizeof(e->shard_scratch));
-    memset(e->jobs, 0, sizeof(e->jobs));
 
     const size_t M = (size_t)sp.M;
     hipError_t err = hipSuccess;
@@ -439,23 +399,12 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     return GX_OK;
 }
 
-static void free_shard_scratch(gx_engine* e)
-{
-    Pool& pl = e->shard_scratch;
-    void* pb[] = {pl.cand_ok, pl.cand_xy, pl.blk_cnt, pl.cand_of, pl.layout_size, pl.n_surv, pl.surv, pl.surv0};
-    for (void* q : pb)
-        if (q) (void)hipFree(q);
-    memset(&pl, 0, sizeof(pl));
-    e->shard_scratch_ok = false;
-    e->shard_scratch_cap = 0;
-}
-
 extern "C" gx_status gx_destroy(gx_engine* e)
 {
     if (!e) return GX_OK;
     DeviceGuard guard(e->device);
     (void)hipDeviceSynchronize();
-    void* bufs[] = {e->b.dyn, e->b.obj, e->b.hist, e->b.rd_j, e->haz_bounds, e->tape, e->obj0, e->pol_wt, e->pol_cur};
+    void* bufs[] = {e->b.dyn, e->b.obj, e->b.hist, e->b.rd_j, e->haz_bounds, e->tape, e->obj0};
     for (void* q : bufs)
         if (q) (void)hipFree(q);
     for (int i = 0; i < gx_engine::kPools; ++i) {
@@ -476,9 +425,6 @@ extern "C" gx_status gx_destroy(gx_engine* e)
     if (e->h_layout_size) (void)hipHostFree(e->h_layout_size);
     if (e->layout_ev) (void)hipEventDestroy(e->layout_ev);
     if (e->pf_phase1) (void)hipEventDestroy(e->pf_phase1);
-    if (e->shard_dep) (void)hipEventDestroy(e->shard_dep);
-    if (e->shard_done) (void)hipEventDestroy(e->shard_done);
-    free_shard_scratch(e);
     delete e;
     return GX_OK;
 }
@@ -532,7 +478,7 @@ extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
         GX_HIP(claim_pool(e, e->cur, s));
         e->sp.k0 = e->key[0];
         e->sp.k1 = e->key[1];
-        // per-wave stamps of sample_phase2 (tools/history/debug/sampler_waves.py): only on request, the buffer must hold
+        // per-wave stamps of sample_phase2 (tools/debug/sampler_waves.py): only on request, the buffer must hold
         // 65536 + 4 * 16384 words -- the other stamp tools pass much smaller ones
         e->sp.dbg = (e->stamps && getenv("GX_SAMPLER_STAMPS")) ? e->stamps + 65536 : nullptr;
         GX_HIP(launch_sample(e->sp, e->pools[e->cur], s));
@@ -553,7 +499,7 @@ extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
     // step() (engine.py:431) -- independent of the data, so it can be computed now
     const int horizon = e->prefetch_steps == -2 ? (e->last_interval > 0 ? e->last_interval : e->cfg.num_steps)
                                                  : e->prefetch_steps;
-    if (horizon >= 0 && e->layout_source == 0) {
+    if (horizon >= 0) {
         uint32_t k0 = e->key[0], k1 = e->key[1];
         for (int t = 0; t < horizon; ++t) {
             uint32_t a0, a1, b0, b1;
@@ -602,7 +548,6 @@ extern "C" gx_status gx_sample_shard(gx_engine* e, int32_t shard, int32_t n_shar
     hipStream_t s = (hipStream_t)stream;
     const int tgt = shard_target_pool(e);
     GX_HIP(claim_pool(e, tgt, s));
-    e->rs_sampled = true; e->rs_pool = tgt; e->rs_key[0] = e->key[0]; e->rs_key[1] = e->key[1];
     SampleParams sp = e->sp;
     const long long M = e->sp.M;
     sp.c0 = (int)(M * shard / n_shards);
@@ -634,12 +579,6 @@ extern "C" gx_status gx_reset_from_shards(gx_engine* e, const float* d_rows_all,
     if (e->have_reset) e->last_interval = e->steps_since_reset;
     e->steps_since_reset = 0;
     const int tgt = shard_target_pool(e);
-    // normally this engine sampled one of the shards itself (gx_sample_shard claimed the pool: tokens of its old
-    // contents expired, the sampler ran behind the last expansion that read them).  If it did not -- or sampled for
-    // another key -- the pool is claimed here, so that an outstanding tape token never names rewritten rows
-    if (!(e->rs_sampled && e->rs_pool == tgt && e->rs_key[0] == e->key[0] && e->rs_key[1] == e->key[1]))
-        GX_HIP(claim_pool(e, tgt, s));
-    e->rs_sampled = false;
     if (e->have_reset) GX_HIP(hipEventRecord(e->pool_free[e->cur], s));
     e->cur = tgt;
     launch_pool_install(e->pools[tgt], e->nobj_total, n_shards, cap, reinterpret_cast<const float2*>(d_rows_all), d_counts,
@@ -654,155 +593,6 @@ extern "C" gx_status gx_reset_from_shards(gx_engine* e, const float* d_rows_all,
     GX_HIP(hipGetLastError());
     e->layout_pending = true;
     e->have_reset = true;
-    return GX_OK;
-}
-
-// ---- piggy-backed form: the shard of a LATER reset travels with the rollout hand-off ---------------------------------
-// The key of a later reset is known now (this key advanced by one split per step(), engine.py:431, the horizon being the
-// learned interval between resets).  The schedule (include/guardx.h spells it out; guardx_amd/dist.py:TapeHandoff runs
-// it): after epoch k's rollout rank r samples ITS share of the candidates of reset(k + 3) on the side stream
-// (resets_ahead = 3: the key advanced by 3 * horizon - steps_since_reset) into the tail of the buffer that carries epoch
-// k + 1's tape; that epoch's all-gather delivers every rank's block; during epoch k + 2 -- after gx_reset(k + 2), before
-// gx_reset(k + 3) -- gx_install_shards turns the blocks into the pool slot the NEXT gx_reset takes as a prefetch hit.
-// A reset whose key has no installed pool samples inline (all candidates), exactly as a prefetch miss does: results
-// never depend on any of this.
-extern "C" gx_status gx_set_layout_source(gx_engine* e, int32_t source)
-{
-    if (!e || source < 0 || source > 1) return fail(GX_ERR_ARG, "gx_set_layout_source: 0 = own sampler, 1 = installed shards");
-    e->layout_source = source;
-    return GX_OK;
-}
-
-static int shard_horizon(const gx_engine* e)
-{
-    return e->prefetch_steps == -2 ? (e->last_interval > 0 ? e->last_interval : e->cfg.num_steps) : e->prefetch_steps;
-}
-
-extern "C" gx_status gx_shard_block_floats(const gx_engine* e, int32_t cap, int64_t* floats)
-{
-    if (!e || cap < 1 || !floats) return fail(GX_ERR_ARG, "gx_shard_block_floats: bad argument");
-    *floats = 4 + (int64_t)cap * e->nobj_total * 2; // count, key, tag | rows: a multiple of 4 floats
-    return GX_OK;
-}
-
-extern "C" gx_status gx_sample_shard_ahead(gx_engine* e, int32_t shard, int32_t n_shards, int32_t resets_ahead,
-                                           float* d_block, int32_t cap, int64_t* ticket, void* stream)
-{
-    if (!e || !d_block || !ticket || n_shards < 1 || shard < 0 || shard >= n_shards || cap < 1 || resets_ahead < 1 || n_shards > 32767)
-        return fail(GX_ERR_ARG, "gx_sample_shard_ahead: bad argument");
-    if (reinterpret_cast<uintptr_t>(d_block) & 15u) return fail(GX_ERR_ARG, "gx_sample_shard_ahead: d_block must be 16-byte aligned");
-    if (!e->have_reset) return fail(GX_ERR_STATE, "gx_sample_shard_ahead before gx_reset");
-    if (e->layout_source != 1)
-        return fail(GX_ERR_STATE, "gx_sample_shard_ahead: gx_set_layout_source(e, 1) first (the engine's own prefetch "
-                                  "sampler and installed shards would fight over the next pool)");
-    const int horizon = shard_horizon(e);
-    if (horizon < 1) return fail(GX_ERR_STATE, "gx_sample_shard_ahead: needs a reset interval (gx_set_prefetch(e, -2) or a fixed one)");
-    const long long adv = (long long)resets_ahead * horizon - e->steps_since_reset;
-    if (adv < 0 || adv > (1 << 24)) return fail(GX_ERR_STATE, "gx_sample_shard_ahead: more steps since the last reset than the horizon covers");
-    DeviceGuard guard(e->device);
-    hipStream_t s = (hipStream_t)stream;
-    const long long M = e->sp.M;
-    SampleParams sp = e->sp;
-    sp.c0 = (int)(M * shard / n_shards);
-    sp.M = (int)(M * (shard + 1) / n_shards) - sp.c0;
-    sp.Mtot = (int)M;
-    sp.dbg = nullptr;
-    if (sp.M < 1) return fail(GX_ERR_ARG, "gx_sample_shard_ahead: more shards than candidates");
-    uint32_t k0 = e->key[0], k1 = e->key[1];
-    for (long long t = 0; t < adv; ++t) {
-        uint32_t a0, a1, b0, b1;
-        split2(k0, k1, a0, a1, b0, b1);
-        k0 = a0; k1 = a1;
-    }
-    sp.k0 = k0; sp.k1 = k1;
-    Pool& pl = e->shard_scratch;
-    if (!e->shard_scratch_ok || e->shard_scratch_cap < sp.M) {
-        // sized for THIS shard's candidates (1/n_shards of the list; ~35 MB instead of ~280 MB at 1e6 / 8), regrown when a
-        // later call samples a larger share (n_shards shrank)
-        if (e->shard_scratch_ok) {
-            GX_HIP(hipStreamSynchronize(e->side[0])); // the last shard sampler still runs on the old arrays
-            free_shard_scratch(e);
-        }
-        hipError_t err = hipSuccess;
-        auto alloc = [&](void** ptr, size_t bytes) {
-            if (err == hipSuccess) err = hipMalloc(ptr, bytes);
-            if (err == hipSuccess) err = hipMemset(*ptr, 0, bytes);
-        };
-        const size_t Mz = (size_t)sp.M, tile = (size_t)sample_compact_tile();
-        alloc((void**)&pl.cand_ok, (Mz + tile - 1) / tile * tile);
-        alloc((void**)&pl.cand_xy, sizeof(float2) * Mz * e->nobj_total);
-        alloc((void**)&pl.blk_cnt, sizeof(int) * ((Mz + tile - 1) / tile));
-        alloc((void**)&pl.cand_of, sizeof(int) * Mz);
-        alloc((void**)&pl.layout_size, sizeof(int));
-        alloc((void**)&pl.n_surv, 2 * sizeof(int));
-        alloc((void**)&pl.surv, sizeof(uint32_t) * 32 * Mz);
-        alloc((void**)&pl.surv0, sizeof(uint32_t) * 8 * Mz);
-        pl.fake = nullptr;
-        if (err == hipSuccess && !e->shard_dep) err = hipEventCreateWithFlags(&e->shard_dep, hipEventDisableTiming);
-        if (err == hipSuccess && !e->shard_done) err = hipEventCreateWithFlags(&e->shard_done, hipEventDisableTiming);
-        if (err != hipSuccess) {
-            free_shard_scratch(e); // whatever was allocated before the failure
-            return fail(GX_ERR_HIP, std::string("gx_sample_shard_ahead: ") + hipGetErrorString(err));
-        }
-        e->shard_scratch_ok = true;
-        e->shard_scratch_cap = sp.M;
-    }
-    hipStream_t side = e->side[0];
-    // behind everything queued on the caller's stream: the block may be the tail of a buffer an earlier collective
-    // read, and the caller ordered its own stream behind that
-    GX_HIP(hipEventRecord(e->shard_dep, s));
-    GX_HIP(hipStreamWaitEvent(side, e->shard_dep, 0));
-    const int tile = sample_compact_tile();
-    const int padded = (sp.M + tile - 1) / tile * tile;
-    if (padded > sp.M) GX_HIP(hipMemsetAsync(pl.cand_ok + sp.M, 0, (size_t)(padded - sp.M), side));
-    GX_HIP(launch_sample(sp, pl, side));
-    launch_pool_export(pl, e->nobj_total, reinterpret_cast<float2*>(d_block + 4), cap, reinterpret_cast<int*>(d_block), side,
-                       reinterpret_cast<uint32_t*>(d_block), k0, k1, (uint32_t)shard | ((uint32_t)n_shards << 16));
-    GX_HIP(hipEventRecord(e->shard_done, side));
-    GX_HIP(hipGetLastError());
-    e->shard_inflight = true;
-    gx_engine::ShardJob& j = e->jobs[e->next_ticket % gx_engine::kJobs];
-    j.ticket = e->next_ticket; j.k0 = k0; j.k1 = k1; j.n_shards = n_shards; j.cap = cap;
-    *ticket = e->next_ticket++;
-    return GX_OK;
-}
-
-// `stream` waits for the export block of the last gx_sample_shard_ahead (call it before handing the block to a collective)
-extern "C" gx_status gx_shard_join(gx_engine* e, void* stream)
-{
-    if (!e) return fail(GX_ERR_ARG, "null engine");
-    if (!e->shard_inflight) return GX_OK;
-    DeviceGuard guard(e->device);
-    GX_HIP(hipStreamWaitEvent((hipStream_t)stream, e->shard_done, 0));
-    return GX_OK;
-}
-
-extern "C" gx_status gx_install_shards(gx_engine* e, int64_t ticket, const float* d_blocks, int64_t stride_floats,
-                                       int32_t n_shards, int32_t cap, void* stream)
-{
-    if (!e || !d_blocks || n_shards < 1 || cap < 1 || stride_floats < 4 + (int64_t)cap * (e ? e->nobj_total : 0) * 2)
-        return fail(GX_ERR_ARG, "gx_install_shards: bad argument");
-    if ((reinterpret_cast<uintptr_t>(d_blocks) & 15u) || (stride_floats & 3))
-        return fail(GX_ERR_ARG, "gx_install_shards: blocks must be 16-byte aligned and a multiple of 4 floats apart");
-    if (!e->have_reset) return fail(GX_ERR_STATE, "gx_install_shards before gx_reset");
-    if (e->layout_source != 1) return fail(GX_ERR_STATE, "gx_install_shards: gx_set_layout_source(e, 1) first");
-    const gx_engine::ShardJob j = e->jobs[(ticket > 0 ? ticket : 0) % gx_engine::kJobs];
-    if (ticket < 1 || j.ticket != ticket)
-        return fail(GX_ERR_STATE, "gx_install_shards: unknown ticket (the engine remembers its last four gx_sample_shard_ahead calls)");
-    if (j.n_shards != n_shards || j.cap != cap)
-        return fail(GX_ERR_STATE, "gx_install_shards: n_shards / cap differ from the gx_sample_shard_ahead call of this ticket");
-    DeviceGuard guard(e->device);
-    hipStream_t s = (hipStream_t)stream;
-    const int tgt = (e->cur + 1) % gx_engine::kPools;
-    GX_HIP(hipStreamWaitEvent(s, e->pool_free[tgt], 0)); // the epoch that drew from this pool has been stepped
-    if (e->pf_valid) GX_HIP(hipStreamWaitEvent(s, e->pool_ready[tgt], 0)); // a sampler / install still writing it finishes first
-    GX_HIP(claim_pool(e, tgt, s));                       // tokens of its old rows expire; behind their last expansion
-    launch_pool_install_blocks(e->pools[tgt], e->nobj_total, n_shards, cap, d_blocks, stride_floats, j.k0, j.k1, e->sp.M, s);
-    launch_fake_table(e->p, e->pools[tgt], e->nobj_total, e->sp.M, s);
-    GX_HIP(hipEventRecord(e->pool_ready[tgt], s));
-    GX_HIP(hipGetLastError());
-    e->pf_valid = true; // the next gx_reset takes it if its key is this one, otherwise it samples inline
-    e->pf_key[0] = j.k0; e->pf_key[1] = j.k1;
     return GX_OK;
 }
 
@@ -921,32 +711,6 @@ extern "C" gx_status gx_step_rd(gx_engine* e, const float* d_action, float* d_ob
     return step_impl(e, d_action, d_obs, d_reward, d_cost, d_done, d_qacc, d_obs_rd, speculated, stream);
 }
 
-// ---- step() outputs addressed inside a caller-owned slab: one pointer + a slot index per call -------------------------
-// An unmodified learner drives Engine.step() once per control step (trpo.py:479-547) and must be handed tensors nobody
-// overwrites later (engine.py:495).  The Python host carves them out of one allocation per ~100 calls; passing SIX
-// addresses per call through ctypes is a third of that call's host time at env_num = 2000.  Layout of one output set
-// (floats; Dp = D rounded up to 4, Np = env_num rounded up to 4, every piece 16-byte aligned):
-//   obs [N][D] (at 0) | obs_rd [N][D] (at N*Dp) | reward [N] (at 2*N*Dp) | cost [N] (+Np) | done [N] (+2*Np) | qacc [N][nv] (+3*Np)
-extern "C" gx_status gx_step_set_floats(const gx_engine* e, int64_t* floats)
-{
-    if (!e || !floats) return fail(GX_ERR_ARG, "null argument");
-    const int64_t N = e->p.N, Dp = (e->p.D + 3) / 4 * 4, Np = (N + 3) / 4 * 4;
-    *floats = 2 * N * Dp + 3 * Np + Np * e->nv;
-    return GX_OK;
-}
-
-extern "C" gx_status gx_step_slab(gx_engine* e, const float* d_action, float* d_slab, int32_t slot, int32_t flags,
-                                  int32_t* speculated, void* stream)
-{
-    if (!e || !d_slab || slot < 0 || !speculated) return fail(GX_ERR_ARG, "gx_step_slab: bad argument");
-    if (reinterpret_cast<uintptr_t>(d_slab) & 15u) return fail(GX_ERR_ARG, "gx_step_slab: d_slab must be 16-byte aligned");
-    const int64_t N = e->p.N, Dp = (e->p.D + 3) / 4 * 4, Np = (N + 3) / 4 * 4;
-    float* b = d_slab + (size_t)slot * (size_t)(2 * N * Dp + 3 * Np + Np * e->nv);
-    float* rew = b + 2 * N * Dp;
-    return step_impl(e, d_action, b, rew, rew + Np, rew + 2 * Np, (flags & 1) ? rew + 3 * Np : nullptr,
-                     (flags & 2) ? b + N * Dp : nullptr, speculated, stream);
-}
-
 extern "C" gx_status gx_reset_done_commit(gx_engine* e)
 {
     if (!e) return fail(GX_ERR_ARG, "null engine");
@@ -1037,7 +801,7 @@ static gx_status rollout_impl(gx_engine* e, int32_t T, const float* d_actions, f
     r.act_out = d_act_out; r.obs_stride = obs_stride; r.sc_stride = sc_stride;
     e->last_policy = false;
     if (use_split_rollout(e, T)) { // light robots, small env_num: dynamics tape + one thread per (step, env) row
-        const size_t nt = tape_floats_padded(e, T);
+        const size_t nt = (size_t)T * e->p.N * split_tape_width(e->p);
         const size_t need = nt + (size_t)e->p.N * split_entry_width(e->p); // [tape | entry records]
         if (need > e->tape_cap) {
             GX_HIP(hipStreamSynchronize(s));            // an earlier launch may still read the old tape
@@ -1052,7 +816,7 @@ static gx_status rollout_impl(gx_engine* e, int32_t T, const float* d_actions, f
         hipEvent_t hold = nullptr;
         if (e->pf_phase1_pending && getenv("GX_NO_OBS_HOLD") == nullptr) { hold = e->pf_phase1; e->pf_phase1_pending = false; }
         // a prefetch sampler is in flight beside this rollout: the one-lane dynamics pass (see SwimmerRobot::kDynLanes)
-        const int lanes = dyn_pass_has_company(e) ? 1 : 4;
+        const int lanes = (e->pf_valid && e->prefetch_steps != -1) ? 1 : 4;
         GX_HIP(launch_split_rollout(e->p, r, e->tape, e->obj0, e->tape + nt, e->b, s, hold, 3, lanes));
     } else if (use_group_path(e)) {   // latency regime: 16 lanes per env
         r.commit = take_commit(e);
@@ -1090,7 +854,7 @@ extern "C" gx_status gx_rollout_packed(gx_engine* e, int32_t T, const float* d_a
 extern "C" int32_t gx_packed_width(const gx_engine* e) { return e ? e->p.D + e->na + 3 : -1; }
 
 // ---------------------------------------------------------------------------------------------------------------
-// tape hand-off: the rank that steps the envs runs only the serial dynamics pass and hands out its tape (40 B per
+// tape hand-off: the rank that steps the envs runs only the serial dynamics pass and hands out its tape (48 B per
 // env-step for the Point -- qpos, qvel, action, done, two layout-row indices -- instead of the 192 B packed row);
 // whoever needs the rollout -- every rank, after ONE all-gather of the tapes -- runs the observation pass on it, which
 // re-derives pose, ctrl and reward.  Every rank samples the same layout pools (the key is shared, engine.py:263), so
@@ -1102,7 +866,7 @@ extern "C" gx_status gx_tape_floats(const gx_engine* e, int32_t T, int64_t* tape
     if (!e || T < 1 || !tape || !obj0 || !entry) return fail(GX_ERR_ARG, "bad argument");
     if (!split_rollout_supported(e->p))
         return fail(GX_ERR_UNSUPPORTED, "tape hand-off: needs a task without observe_vel / observe_acc and one physics step per control step");
-    *tape = (int64_t)tape_floats_padded(e, T);
+    *tape = (int64_t)T * e->p.N * split_tape_width(e->p);
     *obj0 = (int64_t)e->p.P * e->p.Npad * 4;
     *entry = (int64_t)e->p.N * split_entry_width(e->p);
     return GX_OK;
@@ -1119,18 +883,18 @@ extern "C" gx_status gx_rollout_tape(gx_engine* e, int32_t T, const float* d_act
         return fail(GX_ERR_ARG, "d_actions must be 8-byte, d_shard 16-byte aligned");
     DeviceGuard guard(e->device);
     hipStream_t s = (hipStream_t)stream;
-    gx_status st = flush_pending(e, s); // (before a key slot is taken: nothing to undo)
-    if (st != GX_OK) return st;
     int slot; uint32_t k0, k1;
-    st = stage_rollout_keys(e, T, slot, k0, k1);
+    gx_status st = stage_rollout_keys(e, T, slot, k0, k1);
     if (st != GX_OK) return st;
     RolloutArgs r;
     fill_rollout_args(e, r, T, slot);
     r.act = d_actions;
     e->last_policy = false;
-    const size_t nt = tape_floats_padded(e, T), no = (size_t)e->p.P * e->p.Npad * 4;
+    st = flush_pending(e, s);
+    if (st != GX_OK) return st;
+    const size_t nt = (size_t)T * e->p.N * split_tape_width(e->p), no = (size_t)e->p.P * e->p.Npad * 4;
     GX_HIP(launch_split_rollout(e->p, r, d_shard, reinterpret_cast<float4*>(d_shard + nt), d_shard + nt + no, e->b, s,
-                                nullptr, 1, dyn_pass_has_company(e) ? 1 : 4));
+                                nullptr, 1, (e->pf_valid && e->prefetch_steps != -1) ? 1 : 4));
     GX_HIP(hipEventRecord(e->keys_ev[slot], s));
     GX_HIP(hipGetLastError());
     e->key[0] = k0; e->key[1] = k1;
@@ -1140,14 +904,13 @@ extern "C" gx_status gx_rollout_tape(gx_engine* e, int32_t T, const float* d_act
     return GX_OK;
 }
 
-static gx_status expand_impl(gx_engine* e, int32_t T, const float* d_shards, int64_t stride_floats, int32_t n_shards,
-                             int64_t token, float* d_packed, int64_t packed_stride_floats, void* stream)
+extern "C" gx_status gx_expand_tape(gx_engine* e, int32_t T, const float* d_shard, int64_t token, float* d_packed,
+                                    void* stream)
 {
-    if (!e || !d_shards || !d_packed || T < 1 || n_shards < 1 || n_shards > 65535) return fail(GX_ERR_ARG, "bad argument");
+    if (!e || !d_shard || !d_packed || T < 1) return fail(GX_ERR_ARG, "bad argument");
     if (!split_rollout_supported(e->p))
         return fail(GX_ERR_UNSUPPORTED, "tape hand-off: needs a task without observe_vel / observe_acc and one physics step per control step");
-    if ((reinterpret_cast<uintptr_t>(d_shards) & 15u) || (n_shards > 1 && (stride_floats & 3)))
-        return fail(GX_ERR_ARG, "d_shard must be 16-byte aligned (and the shards a multiple of 4 floats apart)");
+    if (reinterpret_cast<uintptr_t>(d_shard) & 15u) return fail(GX_ERR_ARG, "d_shard must be 16-byte aligned");
     const int pi = (int)(token & 0xff);
     if (pi < 0 || pi >= gx_engine::kPools || (uint32_t)(token >> 8) != e->pool_gen[pi])
         return fail(GX_ERR_STATE, "gx_expand_tape: the layout pool of this tape has been resampled (expand a tape "
@@ -1159,100 +922,19 @@ static gx_status expand_impl(gx_engine* e, int32_t T, const float* d_shards, int
     const int W = e->p.D + e->na + 3;
     r.T = T; r.do_reset = 1; r.nobj_total = e->nobj_total;
     r.cand_xy = e->pools[pi].cand_xy; r.n_rows = e->sp.M; r.fake = e->pools[pi].fake;
-    const size_t nt = tape_floats_padded(e, T), no = (size_t)e->p.P * e->p.Npad * 4;
-    if (n_shards > 1 && ((size_t)stride_floats < nt + no + (size_t)e->p.N * split_entry_width(e->p) ||
-                         (size_t)packed_stride_floats < (size_t)T * e->p.N * W))
-        return fail(GX_ERR_ARG, "gx_expand_tapes: the strides are smaller than one shard / one packed rollout");
+    const size_t nt = (size_t)T * e->p.N * split_tape_width(e->p), no = (size_t)e->p.P * e->p.Npad * 4;
     r.act = nullptr; // the tape rows carry the actions
     r.obs = d_packed; r.act_out = d_packed + e->p.D;
     r.rew = d_packed + e->p.D + e->na; r.cost = r.rew + 1; r.done = r.rew + 2;
     r.obs_stride = W; r.sc_stride = W;
     // the pool must be complete on this stream (it is when the tape's rank has stepped, but this may be another stream)
     GX_HIP(hipStreamWaitEvent(s, e->pool_ready[pi], 0));
-    GX_HIP(launch_split_rollout(e->p, r, const_cast<float*>(d_shards),
-                                reinterpret_cast<float4*>(const_cast<float*>(d_shards) + nt),
-                                const_cast<float*>(d_shards) + nt + no, e->b, s, nullptr, 2, 1, n_shards, stride_floats,
-                                packed_stride_floats));
+    GX_HIP(launch_split_rollout(e->p, r, const_cast<float*>(d_shard),
+                                reinterpret_cast<float4*>(const_cast<float*>(d_shard) + nt),
+                                const_cast<float*>(d_shard) + nt + no, e->b, s, nullptr, 2));
     GX_HIP(hipEventRecord(e->expand_ev[pi], s));
     e->expand_pending[pi] = true;
     GX_HIP(hipGetLastError());
-    return GX_OK;
-}
-
-extern "C" gx_status gx_expand_tape(gx_engine* e, int32_t T, const float* d_shard, int64_t token, float* d_packed,
-                                    void* stream)
-{
-    return expand_impl(e, T, d_shard, 0, 1, token, d_packed, 0, stream);
-}
-
-// the observation pass over the shards of ALL ranks in one launch (the all-gathered buffer as it is)
-extern "C" gx_status gx_expand_tapes(gx_engine* e, int32_t T, const float* d_shards, int64_t stride_floats, int32_t n_shards,
-                                     int64_t token, float* d_packed, int64_t packed_stride_floats, void* stream)
-{
-    return expand_impl(e, T, d_shards, stride_floats, n_shards, token, d_packed, packed_stride_floats, stream);
-}
-
-// Hidden widths whose weights do not fit the fused kernel's LDS (128, 256; also 64 with gx_set_policy_impl(e, 3), as a
-// cross-check): per control step one policy launch over all envs (gx_policy_step.hip) and the ordinary fused
-// step + reset_done launch -- the loop of oracle/gx_oracle.c:gxo_rollout_policy, the arithmetic of the fused kernel.
-static gx_status rollout_policy_stepwise(gx_engine* e, int32_t T, const gx_policy* pol, const float* d_obs0, float* d_obs_in,
-                                         float* d_act, float* d_logp, float* d_val, float* d_mu, float* d_reward,
-                                         float* d_cost, float* d_done, float* d_obs_last, float* d_val_last, float* d_logstd,
-                                         void* stream)
-{
-    const int H = pol->hidden;
-    if (!policy_step_supported(H))
-        return fail(GX_ERR_UNSUPPORTED, "gx_rollout_policy: hidden_sizes must be (64, 64), (128, 128), (192, 192) or (256, 256)");
-    if ((e->na & 1) || e->na > 16) return fail(GX_ERR_UNSUPPORTED, "gx_rollout_policy: needs an even action width <= 16");
-    if (reinterpret_cast<uintptr_t>(d_act) & 7u) return fail(GX_ERR_ARG, "gx_rollout_policy: d_act must be 8-byte aligned");
-    DeviceGuard guard(e->device);
-    hipStream_t s = (hipStream_t)stream;
-    const int N = e->p.N, D = e->p.D, A = e->na;
-    const size_t need = (size_t)policy_step_wt_floats(D, H);
-    if (need > e->pol_wt_cap) {
-        GX_HIP(hipStreamSynchronize(s));
-        if (e->pol_wt) (void)hipFree(e->pol_wt);
-        e->pol_wt = nullptr; e->pol_wt_cap = 0;
-        GX_HIP(hipMalloc((void**)&e->pol_wt, sizeof(float) * need));
-        e->pol_wt_cap = need;
-    }
-    if (!e->pol_cur) GX_HIP(hipMalloc((void**)&e->pol_cur, sizeof(float) * (size_t)N * D));
-    const bool group = use_group_path(e);
-    const bool valu = e->policy_impl == 1; // gx_set_policy_impl(e, 1): fmaf chains; otherwise the MFMA tiles
-    gx_status st = GX_OK;
-    if (!group) { st = flush_pending(e, s); if (st != GX_OK) return st; } // (before a key slot is taken: nothing to undo)
-    int slot; uint32_t k0, k1;
-    st = stage_rollout_keys(e, T, slot, k0, k1);
-    if (st != GX_OK) return st;
-    launch_policy_transpose(pol->d_params, e->pol_wt, D, A, H, s);
-    GX_HIP(hipMemcpyAsync(e->pol_cur, d_obs0, sizeof(float) * (size_t)N * D, hipMemcpyDeviceToDevice, s));
-    for (int32_t t = 0; t < T; ++t) {
-        const size_t tn = (size_t)t * N;
-        launch_policy_step(H, pol->d_params, e->pol_wt, e->pol_cur, pol->seed[0], pol->seed[1], e->policy_steps + (uint32_t)t, N, D,
-                           A, e->p.env_offset, 0, d_obs_in + tn * D, d_act + tn * A, d_mu + tn * A, d_logp + tn, d_val + tn,
-                           nullptr, d_logstd, s, valu);
-        RolloutArgs r;
-        fill_rollout_args(e, r, 1, slot);
-        r.keys = e->h_keys[slot] + t;          // this step's reset_done key (engine.py:431,447,500)
-        r.act = d_act + tn * A;
-        r.obs = e->pol_cur;                    // the post-reset_done observation feeds the next policy step (trpo.py:547)
-        r.rew = d_reward + tn; r.cost = d_cost + tn; r.done = d_done + tn; r.qacc = nullptr;
-        if (group) {
-            r.commit = t == 0 ? take_commit(e) : 0;
-            launch_group_rollout(e->p, r, e->b, s);
-        } else {
-            launch_thread_rollout(e->p, r, e->b, s);
-        }
-        if (e->hist < 2) e->hist++;
-    }
-    launch_policy_step(H, pol->d_params, e->pol_wt, e->pol_cur, pol->seed[0], pol->seed[1], 0u, N, D, A, e->p.env_offset, 1,
-                       nullptr, nullptr, nullptr, nullptr, d_val_last, d_obs_last, nullptr, s, valu);
-    e->last_policy = false; // (the open-loop kernels ran: the prefetch sampler keeps its back-to-back chain)
-    GX_HIP(hipEventRecord(e->keys_ev[slot], s));
-    GX_HIP(hipGetLastError());
-    e->key[0] = k0; e->key[1] = k1;
-    e->steps_since_reset += T;
-    e->policy_steps += (uint32_t)T;
     return GX_OK;
 }
 
@@ -1267,16 +949,11 @@ extern "C" gx_status gx_rollout_policy(gx_engine* e, int32_t T, const gx_policy*
     if (pol->struct_size != (int32_t)sizeof(gx_policy) || !pol->d_params)
         return fail(GX_ERR_ARG, "gx_policy.struct_size mismatch or null parameters");
     if (!e->have_reset) return fail(GX_ERR_STATE, "gx_rollout_policy before gx_reset");
-    // hidden_sizes (128, 128) in ONE launch (round 5: hidden-layer weights resident in registers, gx_policy.h) -- the
-    // default for the light robots' default-width observations; gx_set_policy_impl(e, 1 | 2 | 3) keeps the step-wise forms
-    const bool fused128 = pol->hidden == kPolHd2 && e->policy_impl == 0 && policy_fused128_supported(e->p) && !(e->na & 1) &&
-                          e->p.N <= 65536;
-    if ((pol->hidden != kPolHd && !fused128) || e->policy_impl == 3)
-        return rollout_policy_stepwise(e, T, pol, d_obs0, d_obs_in, d_act, d_logp, d_val, d_mu, d_reward, d_cost, d_done,
-                                       d_obs_last, d_val_last, d_logstd, stream);
+    if (pol->hidden != kPolHd)
+        return fail(GX_ERR_UNSUPPORTED, "gx_rollout_policy: hidden_sizes must be (64, 64) (the reference default)");
     if (!policy_rollout_supported(e->p) || (e->na & 1) || e->na > 16 || e->p.N > 65536)
         return fail(GX_ERR_UNSUPPORTED, "gx_rollout_policy: needs hazards_num <= 15, lidar_num_bins <= 16, env_num <= 65536");
-    const int impl = fused128 ? 3 : (e->policy_impl == 1 ? 1 : 2); // auto = MFMA
+    const int impl = e->policy_impl == 1 ? 1 : 2; // auto = MFMA
     if (policy_lds_bytes(e->p, impl) > 150 * 1024)
         return fail(GX_ERR_UNSUPPORTED, "gx_rollout_policy: observation too wide for the LDS-resident weights");
     DeviceGuard guard(e->device);
@@ -1306,7 +983,7 @@ extern "C" gx_status gx_rollout_policy(gx_engine* e, int32_t T, const gx_policy*
 
 extern "C" gx_status gx_set_policy_impl(gx_engine* e, int32_t impl)
 {
-    if (!e || impl < 0 || impl > 3) return fail(GX_ERR_ARG, "gx_set_policy_impl: 0 auto, 1 VALU, 2 MFMA, 3 step-wise");
+    if (!e || impl < 0 || impl > 2) return fail(GX_ERR_ARG, "gx_set_policy_impl: 0 auto, 1 VALU, 2 MFMA");
     e->policy_impl = impl;
     return GX_OK;
 }

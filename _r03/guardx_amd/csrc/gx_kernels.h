@@ -55,15 +55,9 @@ int sample_compact_tile(); // candidates per block of the ordered compaction: ca
 // returns the status of the event record it enqueues (ordering-critical: never dropped)
 hipError_t launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s, hipEvent_t after_phase1 = nullptr);
 // sharded layout sampling: a shard's valid layouts out (candidate order), the gathered shards in as the pool
-// `hdr`: null, or the 4-word header of a piggy-backed export block whose words 1..3 become (k0, k1, tag)
-void launch_pool_export(const Pool& pl, int nobj_total, float2* rows, int cap, int* count, hipStream_t s,
-                        uint32_t* hdr = nullptr, uint32_t k0 = 0, uint32_t k1 = 0, uint32_t tag = 0);
+void launch_pool_export(const Pool& pl, int nobj_total, float2* rows, int cap, int* count, hipStream_t s);
 void launch_pool_install(const Pool& pl, int nobj_total, int n_shards, int cap, const float2* rows_all, const int* counts,
                          int M, hipStream_t s);
-// the same from n_shards export blocks [count, k0, k1, shard | n_shards << 16 | rows] `stride_floats` apart (the tails of
-// the all-gathered tape shards); blocks sampled for another key / shard / world size are refused (layout_size < 0)
-void launch_pool_install_blocks(const Pool& pl, int nobj_total, int n_shards, int cap, const float* blocks,
-                                long long stride_floats, uint32_t k0, uint32_t k1, int M, hipStream_t s);
 void launch_reset_apply(const Params& p, const DevBuffers& b, int nobj_total, uint32_t k10,
                         uint32_t k11, uint32_t k20, uint32_t k21, float* obs, int* host_layout_size,
                         hipStream_t s);
@@ -113,11 +107,9 @@ int split_entry_width(const Params& p);  // floats per env of the entry record (
 // returns the status of the stream-ordering calls it makes (the kernels' own launch errors surface in hipGetLastError)
 // `lanes`: lanes per env in the dynamics pass where the robot has both forms (Swimmer: 4 = the quad form, faster alone;
 // 1 = faster beside a running layout sampler)
-// `n_shards` > 1 (observation pass only): one launch over n_shards shard buffers `shard_stride` floats apart (tape, obj0
-// and entry all move by it), packed outputs `out_stride` floats apart
 hipError_t launch_split_rollout(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, float* entry,
                                 const DevBuffers& b, hipStream_t s, hipEvent_t hold = nullptr, int which = 3,
-                                int lanes = 1, int n_shards = 1, long long shard_stride = 0, long long out_stride = 0);
+                                int lanes = 1);
 // install the reset_done recorded in b.rd_j (pending commit) for consumers other than the lane-group kernels
 void launch_commit_pending(const Params& p, const DevBuffers& b, int nobj_total, int n_rows, hipStream_t s);
 // fill Pool::fake for the valid layouts of a freshly sampled pool (no-op for robots whose rest state is a fixed point)
@@ -139,22 +131,11 @@ struct RobotLaunch {
     static void commit_pending(const Params& p, const DevBuffers& b, int nobj_total, int n_rows, hipStream_t s);
     static void fake_table(const Params& p, const Pool& pl, int nobj_total, int M, hipStream_t s);
     static hipError_t split(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, float* entry,
-                            const DevBuffers& b, hipStream_t s, hipEvent_t hold, int which, int lanes, int n_shards,
-                            long long shard_stride, long long out_stride);
+                            const DevBuffers& b, hipStream_t s, hipEvent_t hold, int which, int lanes);
     static int split_width();
     static int split_entry_width();
 };
-// step-wise policy (gx_policy_step.hip): hidden widths whose weights do not fit the LDS of the fused kernel
-bool policy_step_supported(int H);
-int policy_step_wt_floats(int D, int H);
-void launch_policy_transpose(const float* params, float* wt, int D, int A, int H, hipStream_t s);
-// valu: sequential fmaf chains on the vector ALUs instead of v_mfma_f32_16x16x4_f32 tiles (same bits)
-// mode 0: ac.step for one time step (obs -> obs_in, act, mu, logp, val); mode 1: critic only (val -> val_last, obs_last)
-void launch_policy_step(int H, const float* params, const float* wt, const float* obs, uint32_t seed0, uint32_t seed1,
-                        uint32_t tnoise, int N, int D, int A, int env_offset, int mode, float* obs_in, float* act, float* mu,
-                        float* logp, float* val, float* obs_last, float* logstd, hipStream_t s, bool valu = false);
 bool policy_rollout_supported(const Params& p);
-bool policy_fused128_supported(const Params& p);
 size_t policy_lds_bytes(const Params& p, int impl);
 void launch_math_probe2(int n, const float* x, float* lg, float* th, hipStream_t s);
 void launch_math_probe(int n, const float* x, const float* y, float* s_, float* c, float* at2,

@@ -394,18 +394,12 @@ __global__ __launch_bounds__(kSampleBlock) void scan_compact_kernel(int M, const
 // rank INSTALLS the concatenation -- shard after shard, i.e. in candidate order -- as its pool: the same rows in the
 // same order as the unsharded sampler's compacted list, so layout_size and every randint draw agree.
 // ---------------------------------------------------------------------------
-// `hdr`: null, or the 4-word header of a piggy-backed export block (gx_sample_shard_ahead): count, the key the shard was
-// sampled for, and (shard | n_shards << 16) -- the installer checks all of it
 __global__ void pool_export_kernel(int nobj_total, const int* __restrict__ layout_size, const int* __restrict__ cand_of,
                                    const float2* __restrict__ cand_xy, float2* __restrict__ rows, int cap,
-                                   int* __restrict__ count, uint32_t* __restrict__ hdr, uint32_t k0, uint32_t k1,
-                                   uint32_t tag)
+                                   int* __restrict__ count)
 {
     const int L = *layout_size;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        *count = L; // may exceed cap: the installer reports the overflow
-        if (hdr) { hdr[1] = k0; hdr[2] = k1; hdr[3] = tag; }
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count = L; // may exceed cap: the installer reports the overflow
     const int n = (L < cap ? L : cap) * nobj_total;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         const int row = k / nobj_total, o = k - row * nobj_total;
@@ -413,56 +407,39 @@ __global__ void pool_export_kernel(int nobj_total, const int* __restrict__ layou
     }
 }
 
-// Shard s: rows at rows_all + s * row_stride (float2 units), count at counts[s * cnt_stride].  `check`: the three words
-// behind each count must be (k0, k1, s | n_shards << 16) -- a block that was sampled for another key, by another rank
-// or for another world size is reported like an overflow (layout_size < 0), never installed.
 __global__ void pool_install_kernel(int nobj_total, int n_shards, int cap, const float2* __restrict__ rows_all,
-                                    long long row_stride, const int* __restrict__ counts, long long cnt_stride, int check,
-                                    uint32_t k0, uint32_t k1, int M, float2* __restrict__ cand_xy,
+                                    const int* __restrict__ counts, int M, float2* __restrict__ cand_xy,
                                     int* __restrict__ cand_of, int* __restrict__ layout_size)
 {
     // rows in front of shard s: the counts of the shards before it (a handful of them)
     const int s = blockIdx.y;
     int off = 0, total = 0, bad = 0;
     for (int q = 0; q < n_shards; ++q) {
-        const int* h = counts + (size_t)q * cnt_stride;
-        const int c = h[0];
+        const int c = counts[q];
         if (c > cap || c < 0) bad = q + 1;
-        else if (check && ((uint32_t)h[1] != k0 || (uint32_t)h[2] != k1 || (uint32_t)h[3] != ((uint32_t)q | ((uint32_t)n_shards << 16))))
-            bad = 1000 + q;
         if (q < s) off += c;
         total += c;
     }
-    if (!bad && total > M) bad = n_shards + 1;
-    if (blockIdx.x == 0 && s == 0 && threadIdx.x == 0) *layout_size = bad ? -bad : total; // < 0: an export overflowed / is foreign
+    if (total > M) bad = n_shards + 1;
+    if (blockIdx.x == 0 && s == 0 && threadIdx.x == 0) *layout_size = bad ? -bad : total; // < 0: an export overflowed
     if (bad) return;
-    const int n = counts[(size_t)s * cnt_stride] * nobj_total;
-    const float2* src = rows_all + (size_t)s * row_stride;
+    const int n = counts[s] * nobj_total;
+    const float2* src = rows_all + (size_t)s * cap * nobj_total;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         cand_xy[(size_t)off * nobj_total + k] = src[k];
         if (k % nobj_total == 0) cand_of[off + k / nobj_total] = off + k / nobj_total;
     }
 }
 
-void launch_pool_export(const Pool& pl, int nobj_total, float2* rows, int cap, int* count, hipStream_t s, uint32_t* hdr,
-                        uint32_t k0, uint32_t k1, uint32_t tag)
+void launch_pool_export(const Pool& pl, int nobj_total, float2* rows, int cap, int* count, hipStream_t s)
 {
-    hipLaunchKernelGGL(pool_export_kernel, dim3(256), dim3(256), 0, s, nobj_total, pl.layout_size, pl.cand_of, pl.cand_xy, rows, cap,
-                       count, hdr, k0, k1, tag);
+    hipLaunchKernelGGL(pool_export_kernel, dim3(256), dim3(256), 0, s, nobj_total, pl.layout_size, pl.cand_of, pl.cand_xy, rows, cap, count);
 }
 void launch_pool_install(const Pool& pl, int nobj_total, int n_shards, int cap, const float2* rows_all, const int* counts,
                          int M, hipStream_t s)
 {
-    hipLaunchKernelGGL(pool_install_kernel, dim3(64, n_shards), dim3(256), 0, s, nobj_total, n_shards, cap, rows_all,
-                       (long long)cap * nobj_total, counts, 1LL, 0, 0u, 0u, M, pl.cand_xy, pl.cand_of, pl.layout_size);
-}
-void launch_pool_install_blocks(const Pool& pl, int nobj_total, int n_shards, int cap, const float* blocks,
-                                long long stride_floats, uint32_t k0, uint32_t k1, int M, hipStream_t s)
-{
-    // block = [count, k0, k1, tag | rows cap x nobj_total x 2]: rows start 4 floats (2 float2) into the block
-    hipLaunchKernelGGL(pool_install_kernel, dim3(64, n_shards), dim3(256), 0, s, nobj_total, n_shards, cap,
-                       reinterpret_cast<const float2*>(blocks) + 2, stride_floats / 2, reinterpret_cast<const int*>(blocks),
-                       stride_floats, 1, k0, k1, M, pl.cand_xy, pl.cand_of, pl.layout_size);
+    hipLaunchKernelGGL(pool_install_kernel, dim3(64, n_shards), dim3(256), 0, s, nobj_total, n_shards, cap, rows_all, counts, M,
+                       pl.cand_xy, pl.cand_of, pl.layout_size);
 }
 
 // ---------------------------------------------------------------------------
@@ -604,14 +581,13 @@ int split_entry_width(const Params& p)
     return 0;
 }
 hipError_t launch_split_rollout(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, float* entry,
-                                const DevBuffers& b, hipStream_t s, hipEvent_t hold, int which, int lanes, int n_shards,
-                                long long shard_stride, long long out_stride)
+                                const DevBuffers& b, hipStream_t s, hipEvent_t hold, int which, int lanes)
 {
-    if (p.robot == SwimmerRobot::kId) return RobotLaunch<SwimmerRobot>::split(p, r, tape, obj0, entry, b, s, hold, which, lanes, n_shards, shard_stride, out_stride);
-    if (p.robot == PointBareRobot::kId) return RobotLaunch<PointBareRobot>::split(p, r, tape, obj0, entry, b, s, hold, which, lanes, n_shards, shard_stride, out_stride);
-    if (p.robot == PointRobot::kId) return RobotLaunch<PointRobot>::split(p, r, tape, obj0, entry, b, s, hold, which, lanes, n_shards, shard_stride, out_stride);
-    if (p.robot == AntRobot::kId) return RobotLaunch<AntRobot>::split(p, r, tape, obj0, entry, b, s, hold, which, lanes, n_shards, shard_stride, out_stride);
-    if (p.robot == WalkerRobot::kId) return RobotLaunch<WalkerRobot>::split(p, r, tape, obj0, entry, b, s, hold, which, lanes, n_shards, shard_stride, out_stride);
+    if (p.robot == SwimmerRobot::kId) return RobotLaunch<SwimmerRobot>::split(p, r, tape, obj0, entry, b, s, hold, which, lanes);
+    if (p.robot == PointBareRobot::kId) return RobotLaunch<PointBareRobot>::split(p, r, tape, obj0, entry, b, s, hold, which, lanes);
+    if (p.robot == PointRobot::kId) return RobotLaunch<PointRobot>::split(p, r, tape, obj0, entry, b, s, hold, which, lanes);
+    if (p.robot == AntRobot::kId) return RobotLaunch<AntRobot>::split(p, r, tape, obj0, entry, b, s, hold, which, lanes);
+    if (p.robot == WalkerRobot::kId) return RobotLaunch<WalkerRobot>::split(p, r, tape, obj0, entry, b, s, hold, which, lanes);
     return hipErrorNotSupported;
 }
 
@@ -634,16 +610,6 @@ int fake_table_width(const Params& p)
 }
 
 bool policy_rollout_supported(const Params& p) { return p.nobj <= 16 && p.bins <= 16; }
-// width 128 in one launch (group_rollout_kernel<.., 3>): the light robots, observation width = the default task's (padded to
-// fours: the first layer's k-steps are a compile-time constant there)
-bool policy_fused128_supported(const Params& p)
-{
-    int ddef = 0;
-    if (p.robot == PointRobot::kId || p.robot == PointBareRobot::kId) ddef = PointRobot::NQ + PointRobot::NV + PointRobot::NU + 34;
-    else if (p.robot == SwimmerRobot::kId) ddef = SwimmerRobot::NQ + SwimmerRobot::NV + SwimmerRobot::NU + 34;
-    else return false;
-    return policy_rollout_supported(p) && pad4(p.D) == pad4(ddef);
-}
 size_t policy_lds_bytes(const Params& p, int impl)
 {
     return sizeof(float) * (size_t)policy_lds_floats(p.D, p.robot == AntRobot::kId ? AntRobot::NA : (p.robot == WalkerRobot::kId ? WalkerRobot::NA : 2), impl);

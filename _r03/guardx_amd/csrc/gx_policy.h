@@ -249,136 +249,12 @@ GX_D void normal_pair(uint32_t s0, uint32_t s1, uint32_t env, uint32_t ctr, floa
 
 GX_HD int pad4(int n) { return (n + 3) & ~3; }
 
-// ---------------------------------------------------------------------------
-// Width 128 in ONE launch (round 5): hidden_sizes = (128, 128) kept ON CHIP across the whole rollout.
-// The two networks are 179 KB -- they do not fit the LDS -- but in the MFMA form a lane only ever needs ITS B operands:
-// wave w of the 4-wave workgroup owns network w / 2 and the unit tiles 4 (w % 2) .. + 3 (16 units each), i.e. per
-// k-step of four inputs ONE float per tile and lane: KS1 x 4 floats for the first layer (KS1 = pad4(D) / 4 k-steps: 11
-// for the Point's 43 observations) and 32 x 4 for the second -- 172 registers, loaded once before the step loop from the
-// torch-layout parameters.  A workgroup is alone on its CU (125 workgroups of 16 envs on 256 CUs at env_num = 2000), so
-// a wave has the whole 512-register file of its SIMD.  LDS holds what the 16-lane groups read: biases, output layers,
-// the observation rows and the hidden activations.  Per control step nothing but the env's own outputs moves.
-// The arithmetic is the step-wise kernel's (gx_policy_step.hip) and the checker's: every hidden unit one
-// v_mfma_f32_16x16x4_f32 chain over k ascending (= a sequential fmaf chain), the output layer 16 lane partials over the
-// units 64 c + 4 l + j folded by the same butterfly.
-// ---------------------------------------------------------------------------
-constexpr int kPolHd2 = 128;          // the width this form serves
-constexpr int kPolHS2 = kPolHd2 + 4;  // LDS row stride of its hidden activations
-constexpr int kPol2KS = kPolHd2 / 4;  // k-steps of the second layer
-
-// LDS image of one network's small parts: b1[128] b2[128] W3[Out][128] b3[Out]
-GX_HD int mlp2_head_floats(int Out) { return 2 * kPolHd2 + Out * kPolHd2 + Out; }
-GX_HD int mlp2_floats(int D, int Out) { return kPolHd2 * D + kPolHd2 + kPolHd2 * kPolHd2 + kPolHd2 + Out * kPolHd2 + Out; }
-struct Mlp2Head { const float *b1, *b2, *W3, *b3; };
-GX_D Mlp2Head mlp2_head_view(const float* base, int Out)
-{
-    Mlp2Head m;
-    m.b1 = base; m.b2 = m.b1 + kPolHd2; m.W3 = m.b2 + kPolHd2; m.b3 = m.W3 + Out * kPolHd2;
-    return m;
-}
-GX_D void mlp2_head_stage(float* lds, const float* __restrict__ g, int D, int Out, int tid, int nthreads)
-{
-    const float* gb1 = g + kPolHd2 * D; const float* gb2 = gb1 + kPolHd2 + kPolHd2 * kPolHd2;
-    const float* gW3 = gb2 + kPolHd2; const float* gb3 = gW3 + Out * kPolHd2;
-    float* b1 = lds; float* b2 = b1 + kPolHd2; float* W3 = b2 + kPolHd2; float* b3 = W3 + Out * kPolHd2;
-    for (int i = tid; i < kPolHd2; i += nthreads) { b1[i] = gb1[i]; b2[i] = gb2[i]; }
-    for (int i = tid; i < Out * kPolHd2; i += nthreads) W3[i] = gW3[i];
-    for (int i = tid; i < Out; i += nthreads) b3[i] = gb3[i];
-}
-
-// this lane's B operands and biases: [k-step][tile]
-template <int KS1>
-struct Pol2Regs { float w1[KS1][4], w2[kPol2KS][4], bias1[4], bias2[4]; };
-
-template <int KS1>
-GX_D void pol2_load(Pol2Regs<KS1>& W, const float* __restrict__ params, int D, int A, int wave, int lw)
-{
-    const int c16 = lw & 15, kq = lw >> 4, net = wave >> 1, ut0 = 4 * (wave & 1);
-    const float* g = params + (net ? mlp2_floats(D, A) : 0);
-    const float* W1 = g; const float* b1 = W1 + kPolHd2 * D; const float* W2 = b1 + kPolHd2; const float* b2 = W2 + kPolHd2 * kPolHd2;
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-        const int unit = 16 * (ut0 + tt) + c16;
-        W.bias1[tt] = b1[unit]; W.bias2[tt] = b2[unit];
-#pragma unroll
-        for (int s = 0; s < KS1; ++s) { const int k = 4 * s + kq; W.w1[s][tt] = k < D ? W1[(size_t)unit * D + k] : 0.0f; }
-#pragma unroll
-        for (int s = 0; s < kPol2KS; ++s) W.w2[s][tt] = W2[(size_t)unit * kPolHd2 + 4 * s + kq];
-    }
-}
-
-// both hidden layers for the 16 envs of the workgroup: X = [16][XS] observations (columns D .. 4 KS1 - 1 zero),
-// H1 / H2 = [2 nets][16][kPolHS2].  Whole-workgroup call (two barriers).
-template <int KS1>
-GX_D void pol2_hidden(const Pol2Regs<KS1>& W, const float* X, int XS, float* H1, float* H2, int wave, int lw)
-{
-    const int c16 = lw & 15, kq = lw >> 4, net = wave >> 1, ut0 = 4 * (wave & 1);
-    mfma_f4 acc[4];
-    {
-        float av[KS1];
-        const float* ap = X + c16 * XS + kq;
-#pragma unroll
-        for (int s = 0; s < KS1; ++s) av[s] = ap[4 * s];
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) acc[tt] = mfma_f4{W.bias1[tt], W.bias1[tt], W.bias1[tt], W.bias1[tt]};
-#pragma unroll
-        for (int s = 0; s < KS1; ++s)
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], W.w1[s][tt], acc[tt], 0, 0, 0);
-        float* o = H1 + (size_t)net * 16 * kPolHS2 + 16 * ut0 + c16;
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[(4 * kq + r) * kPolHS2 + 16 * tt] = tanh_f(acc[tt][r]);
-    }
-    __syncthreads();
-    {
-        float av[kPol2KS];
-        const float* ap = H1 + (size_t)net * 16 * kPolHS2 + c16 * kPolHS2 + kq;
-#pragma unroll
-        for (int s = 0; s < kPol2KS; ++s) av[s] = ap[4 * s];
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) acc[tt] = mfma_f4{W.bias2[tt], W.bias2[tt], W.bias2[tt], W.bias2[tt]};
-#pragma unroll
-        for (int s = 0; s < kPol2KS; ++s)
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], W.w2[s][tt], acc[tt], 0, 0, 0);
-        float* o = H2 + (size_t)net * 16 * kPolHS2 + 16 * ut0 + c16;
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[(4 * kq + r) * kPolHS2 + 16 * tt] = tanh_f(acc[tt][r]);
-    }
-    __syncthreads();
-}
-
-// output layer of the 128-wide networks: partial l over the units 64 c + 4 l + j (c = 0, 1), butterfly, + bias
-// (gx_policy_step.hip, oracle/gx_oracle.c:mlp_forward)
-GX_D float head2_out(const Mlp2Head& w, int o, int l, const float* h2row)
-{
-    float pp = 0.0f;
-#pragma unroll
-    for (int c = 0; c < kPolHd2 / 64; ++c) {
-        const float4 hv = *reinterpret_cast<const float4*>(h2row + 64 * c + 4 * l);
-        const float4 wv = *reinterpret_cast<const float4*>(w.W3 + o * kPolHd2 + 64 * c + 4 * l);
-        pp = fmaf(hv.x, wv.x, pp); pp = fmaf(hv.y, wv.y, pp); pp = fmaf(hv.z, wv.z, pp); pp = fmaf(hv.w, wv.w, pp);
-    }
-    pp = pp + __shfl_xor(pp, 8, 16);
-    pp = pp + __shfl_xor(pp, 4, 16);
-    pp = pp + __shfl_xor(pp, 2, 16);
-    pp = pp + __shfl_xor(pp, 1, 16);
-    return w.b3[o] + pp;
-}
-
 // dynamic LDS of the policy variants, in floats.
 //  VALU form (64 threads, 4 envs):   pi image | v image | log_std,std | hbuf[4][2][Hd] | xrow[4][pad4 D]
 //  MFMA form (256 threads, 16 envs): pi image | v image (Wt1 zero-padded to pad4 D rows) | log_std,std |
 //                                    X[16][pad4 D + 1] | H1[2][16][68] | H2[2][16][68]
 GX_HD int policy_lds_floats(int D, int A, int pol)
 {
-    if (pol == 3) // width 128, register-resident hidden weights: pi head | v head | log_std,std | X | H1 | H2
-        return pad4(mlp2_head_floats(A)) + pad4(mlp2_head_floats(1)) + pad4(2 * A) + 16 * (pad4(D) + 1) + 3 +
-               2 * 2 * 16 * kPolHS2;
     if (pol == 2)
         return pad4(mlp_lds_floats(pad4(D), A)) + pad4(mlp_lds_floats(pad4(D), 1)) + pad4(2 * A) +
                16 * (pad4(D) + 1) + 3 + 2 * 2 * 16 * kPolHS;

@@ -322,11 +322,6 @@ __global__ __launch_bounds__(BLOCK) void reset_apply_kernel(Params p, int nobj_t
 {
     extern __shared__ float4 tile4[];
     float* tile = reinterpret_cast<float*>(tile4);
-    // One wave per SIMD on 32 SIMDs, in the serial chain of the epoch (dyn(k) -> reset_apply(k + 1) -> dyn(k + 1)) and
-    // always beside the prefetch sampler's phase 2, whose waves fill every SIMD: without priority its ~2 k dependent
-    // instructions wait their turn in the oldest-first arbitration (37 us for the Point, 78 us for the Swimmer in the
-    // epoch's kernel trace against ~8 us alone).
-    __builtin_amdgcn_s_setprio(3);
     const int L = *layout_size;
     // len(idx) for the host-side assert (engine.py:442-444): written straight into mapped pinned
     // host memory, no copy kernel on the stream
@@ -837,20 +832,16 @@ GX_D float pick(const float (&a)[N], int k)
 }
 
 // kPol: 0 open loop (action tape), 1 policy evaluated with VALU fmaf chains (one wave per workgroup),
-//       2 policy evaluated with fp32 MFMA tiles (four waves = 16 envs per workgroup), width 64, weights in LDS
-//       3 the same for width 128: hidden-layer weights resident in REGISTERS as the lanes' MFMA B operands (gx_policy.h)
+//       2 policy evaluated with fp32 MFMA tiles (four waves = 16 envs per workgroup)
 template <class R, int OPL, int BPL, bool kQacc, bool kDef, int kPol>
-__global__ __launch_bounds__(kPol >= 2 ? 256 : 64) void group_rollout_kernel(Params p_in, RolloutArgs r,
+__global__ __launch_bounds__(kPol == 2 ? 256 : 64) void group_rollout_kernel(Params p_in, RolloutArgs r,
                                                                             PolicyArgs pol,
                                                                             float4* __restrict__ dyn,
                                                                             float4* __restrict__ obj,
                                                                             float4* __restrict__ hist)
 {
-    constexpr int BT = (kPol >= 2) ? 256 : 64;
+    constexpr int BT = (kPol == 2) ? 256 : 64;
     constexpr bool kPolicy = kPol != 0;
-    // k-steps of the first hidden layer in the register-resident form: the robot's default-task observation width
-    // (qpos, qvel, ctrl, compass, two 16-bin lidars), padded to fours -- the launcher checks that p.D matches
-    constexpr int KS1 = (R::NQ + R::NV + R::NU + 2 + 32 + 3) / 4;
     const Params p = fold_params<R, kDef>(p_in);
     stamp(r, 0);
     __shared__ GroupLds<OPL, BPL, BT> S;
@@ -864,38 +855,10 @@ __global__ __launch_bounds__(kPol >= 2 ? 256 : 64) void group_rollout_kernel(Par
     // ---- policy: weights into LDS, entry observation into this env's LDS row
     float* pol_lds = reinterpret_cast<float*>(pol_lds4);
     MlpLds wpi, wv;
-    Mlp2Head hpi, hvv;
-    Pol2Regs<kPol == 3 ? KS1 : 1> PW;
     float *xrow = nullptr, *hbuf = nullptr, *X = nullptr, *H1 = nullptr, *H2 = nullptr;
     int XS = 0;
     float pstd[R::NA], plstd[R::NA];
-    if constexpr (kPol == 3) {
-        const int D = p.D, A = R::NA;
-        float* pi_img = pol_lds;
-        float* v_img = pi_img + pad4(mlp2_head_floats(A));
-        float* ls_img = v_img + pad4(mlp2_head_floats(1));
-        XS = pad4(D) + 1;
-        X = ls_img + pad4(2 * A);
-        H1 = X + pad4(16 * XS);
-        H2 = H1 + 2 * 16 * kPolHS2;
-        xrow = X + (lane >> 4) * XS;
-        for (int i = lane; i < 16 * XS; i += BT) X[i] = 0.0f; // zero padding columns
-        pol2_load<KS1>(PW, pol.params, D, A, lane >> 6, lane & 63);
-        mlp2_head_stage(pi_img, pol.params, D, A, lane, BT);
-        mlp2_head_stage(v_img, pol.params + mlp2_floats(D, A), D, 1, lane, BT);
-        hpi = mlp2_head_view(pi_img, A);
-        hvv = mlp2_head_view(v_img, 1);
-        const float* gls = pol.params + mlp2_floats(D, A) + mlp2_floats(D, 1);
-#pragma unroll
-        for (int d = 0; d < A; ++d) {
-            pstd[d] = exp_f(gls[d]);      // std = exp(log_std)          trpo_core.py:123
-            plstd[d] = log_f(pstd[d]);    // torch.log(pi.stddev)        trpo_core.py:173
-            if (blockIdx.x == 0 && lane == d) pol.logstd[d] = plstd[d];
-        }
-        __syncthreads();
-        for (int k = l; k < D; k += kGL) xrow[k] = pol.obs0[(size_t)e * D + k];
-        __syncthreads();
-    } else if (kPolicy) {
+    if (kPolicy) {
         const int D = p.D, A = R::NA;
         const int rows = (kPol == 2) ? pad4(D) : D;
         float* pi_img = pol_lds;
@@ -990,13 +953,7 @@ __global__ __launch_bounds__(kPol >= 2 ? 256 : 64) void group_rollout_kernel(Par
             // ac.step(o): a ~ N(mu(o), std), logp, v(o)   trpo_core.py:166-173
             const size_t te = (size_t)t * p.N + env;
             float mu[R::NA], vv[1];
-            if constexpr (kPol == 3) {
-                pol2_hidden<KS1>(PW, X, XS, H1, H2, lane >> 6, lane & 63);
-                const float* h2p = H2 + (lane >> 4) * kPolHS2;
-#pragma unroll
-                for (int o = 0; o < R::NA; ++o) mu[o] = head2_out(hpi, o, l, h2p);
-                vv[0] = head2_out(hvv, 0, l, h2p + 16 * kPolHS2);
-            } else if (kPol == 2) {
+            if (kPol == 2) {
                 mfma_hidden(wpi, wv, X, XS, pad4(p.D), H1, H2, lane >> 6, lane & 63);
                 const float* h2p = H2 + (lane >> 4) * kPolHS + 4 * l;
                 const float4 hp = *reinterpret_cast<const float4*>(h2p);
@@ -1213,13 +1170,7 @@ __global__ __launch_bounds__(kPol >= 2 ? 256 : 64) void group_rollout_kernel(Par
     }
 
     if (kPolicy) { // bootstrap inputs: o_T and V(o_T)   trpo.py:523-529
-        float vlast;
-        if constexpr (kPol == 3) {
-            pol2_hidden<KS1>(PW, X, XS, H1, H2, lane >> 6, lane & 63);
-            vlast = head2_out(hvv, 0, l, H2 + (16 + (lane >> 4)) * kPolHS2);
-        } else {
-            vlast = critic_forward(wv, xrow, hbuf, p.D, l);
-        }
+        const float vlast = critic_forward(wv, xrow, hbuf, p.D, l);
         if (live) {
             for (int k = l; k < p.D; k += kGL) pol.obs_last[(size_t)env * p.D + k] = xrow[k];
             if (l == 0) pol.val_last[env] = vlast;
@@ -1336,7 +1287,7 @@ template <class R, int kPol>
 static void launch_policy_rp(const Params& p, const RolloutArgs& r, const PolicyArgs& pol, const DevBuffers& b,
                              hipStream_t s)
 {
-    constexpr int BT = (kPol >= 2) ? 256 : 64;
+    constexpr int BT = (kPol == 2) ? 256 : 64;
     const dim3 grid((p.N + BT / 16 - 1) / (BT / 16)), blk(BT);
     const size_t lds = sizeof(float) * (size_t)policy_lds_floats(p.D, R::NA, kPol);
     auto launch = [&](auto kern) {
@@ -1387,20 +1338,20 @@ void RobotLaunch<R>::fake_table(const Params& p, const Pool& pl, int nobj_total,
 
 template <class R>
 hipError_t RobotLaunch<R>::split(const Params& p, const RolloutArgs& r, float* tape, float4* obj0, float* entry,
-                                 const DevBuffers& b, hipStream_t s, hipEvent_t hold, int which, int lanes, int n_shards,
-                                 long long shard_stride, long long out_stride)
+                                 const DevBuffers& b, hipStream_t s, hipEvent_t hold, int which, int lanes)
 {
-    SplitArgs sa;
-    sa.tape = tape; sa.obj0 = obj0; sa.entry = entry; sa.lanes = lanes;
-    sa.shard_stride = shard_stride; sa.out_stride = out_stride;
     if constexpr (R::kRestFixed) {
-        if (p.P <= 5) return launch_split_p<R, 5>(p, r, sa, b, s, hold, which, n_shards);
-        if (p.P <= 9) return launch_split_p<R, 9>(p, r, sa, b, s, hold, which, n_shards);
-        return launch_split_p<R, 33>(p, r, sa, b, s, hold, which, n_shards);
+        SplitArgs sa;
+        sa.tape = tape; sa.obj0 = obj0; sa.entry = entry; sa.lanes = lanes;
+        if (p.P <= 5) return launch_split_p<R, 5>(p, r, sa, b, s, hold, which);
+        if (p.P <= 9) return launch_split_p<R, 9>(p, r, sa, b, s, hold, which);
+        return launch_split_p<R, 33>(p, r, sa, b, s, hold, which);
     } else { // Ant, Walker: the dynamics pass is the lane-group form of the step
-        if (p.P <= 5) return launch_split_group_p<R, 5>(p, r, sa, b, s, hold, which, n_shards);
-        if (p.P <= 9) return launch_split_group_p<R, 9>(p, r, sa, b, s, hold, which, n_shards);
-        return launch_split_group_p<R, 33>(p, r, sa, b, s, hold, which, n_shards);
+        SplitArgs sa;
+        sa.tape = tape; sa.obj0 = obj0; sa.entry = entry; sa.lanes = lanes;
+        if (p.P <= 5) return launch_split_group_p<R, 5>(p, r, sa, b, s, hold, which);
+        if (p.P <= 9) return launch_split_group_p<R, 9>(p, r, sa, b, s, hold, which);
+        return launch_split_group_p<R, 33>(p, r, sa, b, s, hold, which);
     }
 }
 template <class R>
@@ -1447,33 +1398,8 @@ template <class R>
 void RobotLaunch<R>::policy(const Params& p, const RolloutArgs& r, const PolicyArgs& pol, const DevBuffers& b,
                             int impl, hipStream_t s)
 {
-    if constexpr (R::kRestFixed) { // width 128 in one launch: the light robots (the Ant's / Walker's step needs the registers)
-        if (impl == 3) { launch_policy_rp<R, 3>(p, r, pol, b, s); return; }
-    }
     if (impl == 2) launch_policy_rp<R, 2>(p, r, pol, b, s);
     else launch_policy_rp<R, 1>(p, r, pol, b, s);
 }
 
 } // namespace gx
-
-// Explicit instantiation in two parts (guardx_amd/build.py compiles them with different scheduling strategies): the
-// two-kernel rollout -- whose dynamics pass is one wave per SIMD -- and everything else of a robot.
-#define GX_INSTANTIATE_SPLIT(R)                                                                                          \
-    template hipError_t RobotLaunch<R>::split(const Params&, const RolloutArgs&, float*, float4*, float*, const DevBuffers&, \
-                                              hipStream_t, hipEvent_t, int, int, int, long long, long long);          \
-    template int RobotLaunch<R>::split_width();                                                                          \
-    template int RobotLaunch<R>::split_entry_width();
-#define GX_INSTANTIATE_REST(R)                                                                                           \
-    template void RobotLaunch<R>::step(const Params&, const DevBuffers&, const float*, float*, float*, float*, float*,   \
-                                       float*, hipStream_t);                                                             \
-    template void RobotLaunch<R>::reset_apply(const Params&, const DevBuffers&, int, uint32_t, uint32_t, uint32_t,       \
-                                              uint32_t, float*, int*, hipStream_t);                                      \
-    template void RobotLaunch<R>::reset_done(const Params&, const DevBuffers&, int, uint32_t, uint32_t, uint32_t,        \
-                                             uint32_t, const float*, float*, hipStream_t);                               \
-    template void RobotLaunch<R>::group(const Params&, const RolloutArgs&, const DevBuffers&, hipStream_t);              \
-    template void RobotLaunch<R>::thread_rollout(const Params&, const RolloutArgs&, const DevBuffers&, hipStream_t);     \
-    template void RobotLaunch<R>::policy(const Params&, const RolloutArgs&, const PolicyArgs&, const DevBuffers&, int,   \
-                                         hipStream_t);                                                                   \
-    template void RobotLaunch<R>::commit_pending(const Params&, const DevBuffers&, int, int, hipStream_t);               \
-    template void RobotLaunch<R>::fake_table(const Params&, const Pool&, int, int, hipStream_t);
-

@@ -4,7 +4,7 @@
 //   pass 1  the serial chain: convert_action, mjx.step, done / NaN guard / timeout, reset_done (layout index draw +
 //           re-placement) -- everything the NEXT step depends on -- and one SLIM tape row per (step, env): qpos, qvel after
 //           the step, the action, done, the layout row in effect and the layout row a reset_done installed.
-//           dyn_tape_kernel (Point, Swimmer): one thread per env, 10 / 14 floats per row, ~170 instructions per Point step
+//           dyn_tape_kernel (Point, Swimmer): one thread per env, 12 / 16 floats per row, ~170 instructions per Point step
 //           (the Swimmer also as a quad of lanes per env, SwimmerRobot::substep_q).
 //           group_dyn_tape_kernel (Ant, Walker; round 3): the lane-group form of their step, 16 lanes per env, 36 / 40
 //           floats per row (+ the row of the pool's fake-step table a reset_done observation is read from).
@@ -32,21 +32,13 @@ namespace gx {
 
 template <class R>
 struct SplitTape {
-    // One row per (step, env): qpos | qvel after the step | the action | the layout row in effect (-1: the layout at
-    // entry) | kCode: done and reset_done in one word -- -1: the step did not finish the env; -2: it did, and no layout
-    // was installed (no reset_done in this launch, or an empty pool); j >= 0: it did, and reset_done installed layout row j
-    // | kFidx (Ant, Walker): row of Pool::fake (= index into the compacted layout list) of that layout.
-    // Round 4: `done` rode in a word of its own and the row was padded to 16 bytes (Point: 12 floats); now 10 floats =
-    // 40 B (Swimmer 14, Ant 34, Walker 40) -- this is what the multi-GPU hand-off puts on the wire, 400 000 rows per
-    // rank and epoch.  Rows are 8-byte aligned (kW is even).
-    static constexpr int kQ = 0, kV = kQ + R::NQ, kAct = kV + R::NV, kJcur = kAct + R::NA, kCode = kJcur + 1,
-                         kFidx = kCode + 1, kUsed = kFidx + (R::kRestFixed ? 0 : 1), kW = (kUsed + 1) / 2 * 2;
+    // kFidx (Ant, Walker): row of Pool::fake (= index into the compacted layout list) of the layout a reset_done installed
+    static constexpr int kQ = 0, kV = kQ + R::NQ, kAct = kV + R::NV, kDone = kAct + R::NA, kJcur = kDone + 1,
+                         kJaft = kJcur + 1, kFidx = kJaft + 1, kUsed = kFidx + (R::kRestFixed ? 0 : 1),
+                         kW = (kUsed + 3) / 4 * 4;
     // entry record of an env: qpos at entry | the stale pose (x, y, cos, sin) | done0 | number of step() calls so far
     static constexpr int kEQ = 0, kEPose = R::NQ, kEDone = kEPose + 4, kEHist = kEDone + 1, kE = (kEHist + 1 + 3) / 4 * 4;
     static_assert(!R::kRestFixed || kE == 12, "entry record of the light robots: 12 floats (include/guardx.h)");
-    GX_D static int code(float dn, int jaft) { return dn > 0.0f ? (jaft >= 0 ? jaft : -2) : -1; }
-    GX_D static float done_of(int c) { return c != -1 ? 1.0f : 0.0f; }
-    GX_D static int jaft_of(int c) { return c >= 0 ? c : -1; }
 };
 
 struct SplitArgs {
@@ -54,51 +46,26 @@ struct SplitArgs {
     float4* obj0;       // [P][Npad] snapshot of the layouts at entry (pass 2 reads it for rows with jcur < 0)
     float* entry;       // [N][kE] state at entry (pass 2 needs it for the rows of steps 0 and 1)
     int lanes;          // lanes per env in pass 1 where the robot offers a choice (R::kDynLanes): 1 or 4
-    // pass 2 over several shards in ONE launch (gx_expand_tapes; blockIdx.y = shard): floats between the buffers of
-    // consecutive shards (tape, obj0 and entry all move by it) and between their packed outputs
-    long long shard_stride, out_stride;
 };
 
 GX_D bool moderate(float x) { return fabsf(x) < 1e18f; } // false for NaN / Inf too
-// the dynamics pass's bound on the sum of |qpos|, |qvel| (and |action|) of a state a common step may start from: 2^24,
-// so that every angle in it is within the range the unguarded sincos_f<true> reduces exactly like the guarded one
-GX_D bool state_ok(float sum) { return fabsf(sum) < 16777216.0f; }
 constexpr int kActBlock = 16; // steps whose actions the dynamics pass fetches at once
-constexpr int kObsGridCap = 3072; // one-wave workgroups of a ONE-shard observation launch (measured: 47.1 -> 44.2 us at 400 000 rows; a launch over
-                                  // several shards is fastest uncapped: 32.5 us per shard at 8 shards)
 
-// rows of W floats, W even: 16-byte pieces and, for W % 4 == 2, one 8-byte piece.  Tape rows start on 8-byte boundaries
-// only (kW = 10 for the Point), so the 16-byte accesses are declared with 8-byte alignment (the hardware takes a dwordx4
-// at any dword address; the compiler must not be told more than is true); entry records are 16-byte aligned rows of 12.
-typedef float gx_f4u __attribute__((ext_vector_type(4), aligned(8)));
-typedef float gx_f2u __attribute__((ext_vector_type(2), aligned(8)));
 template <int W>
 GX_D void load_row(const float* __restrict__ p, float (&v)[W])
 {
-    static_assert(W % 2 == 0, "even row width");
 #pragma unroll
     for (int k = 0; k < W / 4; ++k) {
-        const gx_f4u t4 = *reinterpret_cast<const gx_f4u*>(p + 4 * k);
+        const float4 t4 = reinterpret_cast<const float4*>(p)[k];
         v[4 * k] = t4.x; v[4 * k + 1] = t4.y; v[4 * k + 2] = t4.z; v[4 * k + 3] = t4.w;
-    }
-    if (W % 4) {
-        const gx_f2u t2 = *reinterpret_cast<const gx_f2u*>(p + W - 2);
-        v[W - 2] = t2.x; v[W - 1] = t2.y;
     }
 }
 template <int W>
 GX_D void store_row(float* __restrict__ p, const float (&v)[W])
 {
-    static_assert(W % 2 == 0, "even row width");
 #pragma unroll
-    for (int k = 0; k < W / 4; ++k) {
-        gx_f4u t4; t4.x = v[4 * k]; t4.y = v[4 * k + 1]; t4.z = v[4 * k + 2]; t4.w = v[4 * k + 3];
-        *reinterpret_cast<gx_f4u*>(p + 4 * k) = t4;
-    }
-    if (W % 4) {
-        gx_f2u t2; t2.x = v[W - 2]; t2.y = v[W - 1];
-        *reinterpret_cast<gx_f2u*>(p + W - 2) = t2;
-    }
+    for (int k = 0; k < W / 4; ++k)
+        reinterpret_cast<float4*>(p)[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
 }
 
 template <class R, int BLOCK, int PMAX, bool kDef, int LPE = 1>
@@ -180,25 +147,15 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
     // results either way, the serial chain is ~45 instructions shorter.
     //   s_ok: qpos, qvel at the start of the step are finite and < 1e18 (so is the pose the step returns, and its
     //         velocity-servo term cannot be NaN);  p_ok: the stale pose's cos / sin are finite (ctrl = pose0 * action)
-    // (round 4: one flag for both -- a common step starts with it set and leaves it set, so the serial chain carries
-    // no flag updates at all; only the general step below recomputes it)
-    // WAVE MASKS, not per-lane bools: the flags live as 64-bit lane masks in scalar registers (one ballot each), the
-    // tests of a step are ballots ANDed on the scalar unit, and one scalar compare decides "every lane had a common
-    // step".  (As per-lane bools the compiler kept merging them under the exec mask at the end of every step: ~20
-    // scalar and vector instructions on the serial chain for flags that almost never change.)
-    typedef unsigned long long mask_t;
-    const mask_t live_m = __builtin_amdgcn_ballot_w64(true);
-    const int lane_id = tid & 63;
-    mask_t objs_m = __builtin_amdgcn_ballot_w64(objs_ok), sp_m;
+    bool s_ok, p_ok;
     {
         float m0 = fabsf(pose0[2]) + fabsf(pose0[3]), m1 = 0.f;
 #pragma unroll
         for (int k = 0; k < R::NQ; ++k) m1 = m1 + fabsf(q[k]);
 #pragma unroll
         for (int k = 0; k < R::NV; ++k) m1 = m1 + fabsf(v[k]);
-        sp_m = __builtin_amdgcn_ballot_w64(state_ok(m1)) & __builtin_amdgcn_ballot_w64(moderate(m0));
+        s_ok = moderate(m1); p_ok = moderate(m0);
     }
-    const mask_t phys1_m = p.physics_steps == 1 ? ~0ull : 0ull;
 #pragma unroll 1
     for (int tb = 0; tb < r.T; tb += kActBlock) { // blocks of kActBlock steps (two loops: the block's addresses are
                                                   // computed once per block, not carried through every step)
@@ -208,9 +165,8 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
             if (tb + kActBlock + k < r.T) load_action<R>(r.act, (size_t)(tb + kActBlock + k) * p.N + i, anx[k]);
     }
     const int kend = r.T - tb < kActBlock ? r.T - tb : kActBlock;
-    // (two steps per trip: the stepped state of the first is the start of the second in place -- a one-step loop copies
-    // every loop-carried register back at the end of each step, ~30 moves on the serial chain)
-    auto step1 = [&](const int kb) __attribute__((always_inline)) {
+#pragma unroll 1
+    for (int kb = 0; kb < kend; ++kb) {
         const int t = tb + kb;
         float a[R::NA];
 #pragma unroll
@@ -228,158 +184,104 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
         if constexpr (LPE == 4) R::template substep_q<true>(qf, vf, ctrl, pose, qacc, jq);
         else R::template substep<false, true>(qf, vf, ctrl, pose, qacc);
         world_pose(p, pose);
-        // sum of magnitudes of the stepped state and the action, as a tree (it only feeds a bound: any order will do,
-        // and the chain from the last velocity to the branch is three additions long instead of eight)
-        float mag;
-        {
-            float term[R::NQ + R::NV + R::NA];
+        float mag = 0.f;
 #pragma unroll
-            for (int k = 0; k < R::NQ; ++k) term[k] = fabsf(qf[k]);
+        for (int k = 0; k < R::NQ; ++k) mag = mag + fabsf(qf[k]);
 #pragma unroll
-            for (int k = 0; k < R::NV; ++k) term[R::NQ + k] = fabsf(vf[k]);
+        for (int k = 0; k < R::NV; ++k) mag = mag + fabsf(vf[k]);
 #pragma unroll
-            for (int k = 0; k < R::NA; ++k) term[R::NQ + R::NV + k] = fabsf(a[k]);
-            constexpr int n = R::NQ + R::NV + R::NA;
-#pragma unroll
-            for (int w = 1; w < n; w *= 2)
-#pragma unroll
-                for (int k = 0; k + w < n; k += 2 * w) term[k] = term[k] + term[k + w];
-            mag = term[0];
-        }
+        for (int k = 0; k < R::NA; ++k) mag = mag + fabsf(a[k]);
         const float mx = pose[0] - pose0[0], my = pose[1] - pose0[1];
         const float gdx = gx - pose[0], gdy = gy - pose[1];
         const float d2 = gdx * gdx + gdy * gdy;                 // dist2()'s radicand
-        // (five compares into scalar lane masks and scalar ANDs)
-        const mask_t ord_m = objs_m & sp_m & phys1_m & __builtin_amdgcn_ballot_w64(state_ok(mag)) &
-                             __builtin_amdgcn_ballot_w64((mx * mx + my * my) < 0.9f) & __builtin_amdgcn_ballot_w64(d2 < 1e8f);
-        // COMMON STEP vs GENERAL STEP (round 4).  Almost every step of almost every wave is ordinary, finishes no env
-        // (no goal reached, no timeout) and so re-initialises nothing.  The per-lane branches for the other cases -- the
-        // exact redo, done, the reset_done draw, the re-placement -- cost this serial chain an exec-mask save / restore
-        // and a taken jump over kilobytes of cold code each, every step (stubbing the dynamics showed 86 of the Point's
-        // 114 us per 200 steps in this wrapper, not in the step).  One wave-uniform test now selects a branch-free
-        // commit; any lane that needs more sends the whole wave through the general code below (same results).
-        const mask_t rare_m = (~ord_m & live_m) | __builtin_amdgcn_ballot_w64(d2 < p.goal_cut) |
-                              __builtin_amdgcn_ballot_w64(steps > p.num_steps_f);
-        if (__builtin_expect(rare_m == 0ull, 1)) {
+        const bool ordinary = objs_ok && s_ok && p_ok && p.physics_steps == 1 && moderate(mag) &&
+                              (mx * mx + my * my) < 0.9f && d2 < 1e8f;
+        float dn;
+        if (ordinary) {
 #pragma unroll
             for (int k = 0; k < R::NQ; ++k) q[k] = qf[k];
 #pragma unroll
             for (int k = 0; k < R::NV; ++k) v[k] = vf[k];
-            steps = steps + 1.0f;                       // :493 (done == 0); the flag masks stay as they are
-            float rowv[TP::kW];
-#pragma unroll
-            for (int k = 0; k < R::NQ; ++k) rowv[TP::kQ + k] = q[k];
-#pragma unroll
-            for (int k = 0; k < R::NV; ++k) rowv[TP::kV + k] = v[k];
-#pragma unroll
-            for (int k = 0; k < R::NA; ++k) rowv[TP::kAct + k] = a[k];
-            rowv[TP::kJcur] = __int_as_float(jcur); rowv[TP::kCode] = __int_as_float(-1);
-#pragma unroll
-            for (int k = TP::kUsed; k < TP::kW; ++k) rowv[k] = 0.f;
-            if (writer) store_row<TP::kW>(sa.tape + ((size_t)t * p.N + i) * TP::kW, rowv);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) pose0[k] = pose[k];
-            done0 = 0.0f;
-        } else {
-            const bool ordinary = (ord_m >> lane_id) & 1ull;
-            bool sp_ok;
-            objs_ok = (objs_m >> lane_id) & 1ull;
-            float dn;
-            if (ordinary) {
-#pragma unroll
-                for (int k = 0; k < R::NQ; ++k) q[k] = qf[k];
-#pragma unroll
-                for (int k = 0; k < R::NV; ++k) v[k] = vf[k];
-                dn = d2 < p.goal_cut ? 1.0f : 0.0f;
-                sp_ok = true;  // this step's pose: the kinematics of a moderate qpos; the state: moderate(mag)
-            } else { // rare: the step again, exactly (from the untouched q, v)
-                for (int k = 0; k < p.physics_steps; ++k) {
-                    if constexpr (LPE == 4) R::template substep_q<true>(q, v, ctrl, pose, qacc, jq);
-                    else R::template substep<false>(q, v, ctrl, pose, qacc);
-                }
-                world_pose(p, pose);
-                // NaN / Inf guard :696-699
-                float4 ob[PMAX];
-                if (jcur >= 0) { float rx_, ry_; load_layout<PMAX>(p, r.cand_xy, r.nobj_total, jcur, ob, rx_, ry_); }
-                else {
-#pragma unroll
-                    for (int k = 0; k < PMAX; ++k)
-                        ob[k] = (k < p.P) ? sa.obj0[(size_t)k * p.Npad + i] : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-                const bool bad = build_obs_row<R, PMAX>(p, row, pose, ob, ctrl, q, v, 0.f, 0.f, 0.f, 0.f);
-                // the done half of reward_done :787-802 (the reward itself is pass 2's)
-                const float dg = dist2(gx, gy, pose[0], pose[1]);
-                float last = dg;
-                if (have_last && !(last_done > 0.0f)) last = dist2(gx, gy, pose0[0], pose0[1]);
-                const float dd = last - dg;
-                dn = dg < p.goal_size ? 1.0f : 0.0f;
-                if (fabsf(dd) > 1.0f) dn = 1.0f;
-                if (bad) dn = 1.0f;                    // :696-699
-                float m1 = 0.f;
-#pragma unroll
-                for (int k = 0; k < R::NQ; ++k) m1 = m1 + fabsf(q[k]);
-#pragma unroll
-                for (int k = 0; k < R::NV; ++k) m1 = m1 + fabsf(v[k]);
-                sp_ok = (int)moderate(fabsf(pose[2]) + fabsf(pose[3])) & (int)state_ok(m1);
+            dn = d2 < p.goal_cut ? 1.0f : 0.0f;
+            p_ok = true;   // this step's pose: the kinematics of a moderate qpos
+            s_ok = true;   // moderate(mag)
+        } else { // rare: the step again, exactly (from the untouched q, v)
+            for (int k = 0; k < p.physics_steps; ++k) {
+                if constexpr (LPE == 4) R::template substep_q<true>(q, v, ctrl, pose, qacc, jq);
+                else R::template substep<false>(q, v, ctrl, pose, qacc);
             }
-            if (steps > p.num_steps_f) dn = 1.0f;      // :492
-            steps = dn > 0.0f ? 0.0f : steps + 1.0f;   // :493
-
-            // reset_done :497-505 for the env that just finished: the draw and the re-placement
-            int jaft = -1;
-            float nq0 = 0.f, nq1 = 0.f;
-            if (r.do_reset && dn > 0.0f && L > 0) {
-                const uint4 kk = r.keys ? r.keys[t] : r.key0;
-                const uint32_t idx = randint_at(kk.x, kk.y, kk.z, kk.w, (uint32_t)p.env_total, (uint32_t)L,
-                                                (uint32_t)(p.env_offset + i));
-                jaft = r.cand_of[idx];
-                const float2* rowp = r.cand_xy + (size_t)jaft * r.nobj_total;
-                const float2 g = rowp[0], rb = rowp[r.nobj_total - 1];
-                nq0 = rb.x; nq1 = rb.y;
-                gx = g.x; gy = g.y;
-                // The loads of this RARE branch must have landed before it ends: otherwise the compiler guards the next
-                // step's first touch of these registers with an s_waitcnt vmcnt(3) on the COMMON path -- and the memory
-                // counter is in order, so that wait also covers the tape stores of the step before the previous one: a
-                // store round trip on the serial chain of almost every step, for a load that almost never happened.
-                asm volatile("" : "+v"(nq0), "+v"(nq1), "+v"(gx), "+v"(gy));
+            world_pose(p, pose);
+            // NaN / Inf guard :696-699
+            float4 ob[PMAX];
+            if (jcur >= 0) { float rx_, ry_; load_layout<PMAX>(p, r.cand_xy, r.nobj_total, jcur, ob, rx_, ry_); }
+            else {
+#pragma unroll
+                for (int k = 0; k < PMAX; ++k)
+                    ob[k] = (k < p.P) ? sa.obj0[(size_t)k * p.Npad + i] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-
-            // tape row
-            float rowv[TP::kW];
+            const bool bad = build_obs_row<R, PMAX>(p, row, pose, ob, ctrl, q, v, 0.f, 0.f, 0.f, 0.f);
+            // the done half of reward_done :787-802 (the reward itself is pass 2's)
+            const float dg = dist2(gx, gy, pose[0], pose[1]);
+            float last = dg;
+            if (have_last && !(last_done > 0.0f)) last = dist2(gx, gy, pose0[0], pose0[1]);
+            const float dd = last - dg;
+            dn = dg < p.goal_size ? 1.0f : 0.0f;
+            if (fabsf(dd) > 1.0f) dn = 1.0f;
+            if (bad) dn = 1.0f;                    // :696-699
+            float m1 = 0.f;
 #pragma unroll
-            for (int k = 0; k < R::NQ; ++k) rowv[TP::kQ + k] = q[k];
+            for (int k = 0; k < R::NQ; ++k) m1 = m1 + fabsf(q[k]);
 #pragma unroll
-            for (int k = 0; k < R::NV; ++k) rowv[TP::kV + k] = v[k];
-#pragma unroll
-            for (int k = 0; k < R::NA; ++k) rowv[TP::kAct + k] = a[k];
-            rowv[TP::kJcur] = __int_as_float(jcur); rowv[TP::kCode] = __int_as_float(TP::code(dn, jaft));
-#pragma unroll
-            for (int k = TP::kUsed; k < TP::kW; ++k) rowv[k] = 0.f;
-            if (writer) store_row<TP::kW>(sa.tape + ((size_t)t * p.N + i) * TP::kW, rowv);
-
-            // commit the history, then the re-initialisation (the stale pose stays, :731)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) pose0[k] = pose[k];
-            done0 = dn;
-            if (jaft >= 0) {
-#pragma unroll
-                for (int k = 0; k < R::NQ; ++k) q[k] = 0.f;
-#pragma unroll
-                for (int k = 0; k < R::NV; ++k) v[k] = 0.f;
-                R::place(q, nq0, nq1);
-                jcur = jaft;
-                objs_ok = cfg_ok; // pool rows lie inside the placement extents
-                // ... and so does the robot, at rest; the stale pose is the one just checked
-                sp_ok = (int)moderate(fabsf(pose[2]) + fabsf(pose[3])) & (int)state_ok(fabsf(nq0) + fabsf(nq1));
-            }
-            objs_m = __builtin_amdgcn_ballot_w64(objs_ok);
-            sp_m = __builtin_amdgcn_ballot_w64(sp_ok);
+            for (int k = 0; k < R::NV; ++k) m1 = m1 + fabsf(v[k]);
+            p_ok = moderate(fabsf(pose[2]) + fabsf(pose[3]));
+            s_ok = moderate(m1);
         }
-    };
-    int kb = 0;
-#pragma unroll 1
-    for (; kb + 1 < kend; kb += 2) { step1(kb); step1(kb + 1); }
-    if (kb < kend) step1(kb);
+        if (steps > p.num_steps_f) dn = 1.0f;      // :492
+        steps = dn > 0.0f ? 0.0f : steps + 1.0f;   // :493
+
+        // reset_done :497-505 for the env that just finished: the draw and the re-placement
+        int jaft = -1;
+        float nq0 = 0.f, nq1 = 0.f;
+        if (r.do_reset && dn > 0.0f && L > 0) {
+            const uint4 kk = r.keys ? r.keys[t] : r.key0;
+            const uint32_t idx = randint_at(kk.x, kk.y, kk.z, kk.w, (uint32_t)p.env_total, (uint32_t)L,
+                                            (uint32_t)(p.env_offset + i));
+            jaft = r.cand_of[idx];
+            const float2* rowp = r.cand_xy + (size_t)jaft * r.nobj_total;
+            const float2 g = rowp[0], rb = rowp[r.nobj_total - 1];
+            nq0 = rb.x; nq1 = rb.y;
+            gx = g.x; gy = g.y;
+        }
+
+        // tape row
+        float rowv[TP::kW];
+#pragma unroll
+        for (int k = 0; k < R::NQ; ++k) rowv[TP::kQ + k] = q[k];
+#pragma unroll
+        for (int k = 0; k < R::NV; ++k) rowv[TP::kV + k] = v[k];
+#pragma unroll
+        for (int k = 0; k < R::NA; ++k) rowv[TP::kAct + k] = a[k];
+        rowv[TP::kDone] = dn;
+        rowv[TP::kJcur] = __int_as_float(jcur); rowv[TP::kJaft] = __int_as_float(jaft);
+#pragma unroll
+        for (int k = TP::kUsed; k < TP::kW; ++k) rowv[k] = 0.f;
+        if (writer) store_row<TP::kW>(sa.tape + ((size_t)t * p.N + i) * TP::kW, rowv);
+
+        // commit the history, then the re-initialisation (the stale pose stays, :731)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pose0[k] = pose[k];
+        done0 = dn;
+        if (jaft >= 0) {
+#pragma unroll
+            for (int k = 0; k < R::NQ; ++k) q[k] = 0.f;
+#pragma unroll
+            for (int k = 0; k < R::NV; ++k) v[k] = 0.f;
+            R::place(q, nq0, nq1);
+            jcur = jaft;
+            objs_ok = cfg_ok; // pool rows lie inside the placement extents
+            s_ok = true;      // ... and so does the robot, at rest
+        }
+    }
     abuf ^= 1; // park the next block's actions
 #pragma unroll
     for (int k = 0; k < kActBlock; ++k)
@@ -418,15 +320,9 @@ __global__ __launch_bounds__(64) void group_dyn_tape_kernel(Params p_in, Rollout
     __shared__ GroupLds<OPL, BPL, BT> S;
     __shared__ float actl[2][kActBlock][EPW][R::NA];
     const int lane = threadIdx.x, l = lane & (kGL - 1), g = lane >> 4;
-    // envs of this wave: 4, or -- sa.lanes = 1 | 2, chosen by the launcher while the waves still fit one per SIMD --
-    // fewer: the Newton loop of the step runs until the LAST env of the wave has converged, and the maximum over one or
-    // two envs is smaller than over four.  The other groups of lanes repeat the envs of the first (same data, same trip
-    // counts, no stores).
-    const int epw = (sa.lanes == 1 || sa.lanes == 2) ? sa.lanes : EPW;
-    const int env = blockIdx.x * epw + (g & (epw - 1));
-    const bool twin = env < p.N;            // computes (a group beyond epw repeats its twin's env, reset_done included)
-    const bool live = twin && g < epw;       // ... and stores
-    const int e = twin ? env : 0;
+    const int env = blockIdx.x * EPW + g;
+    const bool live = env < p.N;
+    const int e = live ? env : 0;
     const bool writer = live && l == 0;
 
     float q[R::NQ], v[R::NV], pose0[4], done0, steps;
@@ -557,7 +453,7 @@ __global__ __launch_bounds__(64) void group_dyn_tape_kernel(Params p_in, Rollout
         // reset_done :497-505 for the env that just finished: the draw and the re-placement
         int jaft = -1, fidx = 0;
         float nq0 = 0.f, nq1 = 0.f;
-        if (r.do_reset && twin && dn > 0.0f && L > 0) {
+        if (r.do_reset && live && dn > 0.0f && L > 0) {
             const uint4 kk = r.keys ? r.keys[t] : r.key0;
             const uint32_t idx = randint_at(kk.x, kk.y, kk.z, kk.w, (uint32_t)p.env_total, (uint32_t)L,
                                             (uint32_t)(p.env_offset + env));
@@ -576,7 +472,8 @@ __global__ __launch_bounds__(64) void group_dyn_tape_kernel(Params p_in, Rollout
             for (int k = 0; k < R::NV; ++k) rowv[TP::kV + k] = v[k];
 #pragma unroll
             for (int k = 0; k < R::NA; ++k) rowv[TP::kAct + k] = a[k];
-            rowv[TP::kJcur] = __int_as_float(jcur); rowv[TP::kCode] = __int_as_float(TP::code(dn, jaft));
+            rowv[TP::kDone] = dn;
+            rowv[TP::kJcur] = __int_as_float(jcur); rowv[TP::kJaft] = __int_as_float(jaft);
             rowv[TP::kFidx] = __int_as_float(fidx);
 #pragma unroll
             for (int k = TP::kUsed; k < TP::kW; ++k) rowv[k] = 0.f;
@@ -618,7 +515,7 @@ template <class R>
 GX_D void next_start(const float (&rowv)[SplitTape<R>::kW], const RolloutArgs& r, float (&s)[R::NQ])
 {
     using TP = SplitTape<R>;
-    const int jaft = TP::jaft_of(__float_as_int(rowv[TP::kCode]));
+    const int jaft = __float_as_int(rowv[TP::kJaft]);
     if (jaft >= 0 && jaft < r.n_rows) {
         const float2 rb = r.cand_xy[(size_t)jaft * r.nobj_total + r.nobj_total - 1];
 #pragma unroll
@@ -630,20 +527,6 @@ GX_D void next_start(const float (&rowv)[SplitTape<R>::kW], const RolloutArgs& r
     }
 }
 
-// LDS tile hand-over inside a workgroup: a single wave executes its LDS operations in program order, so only the
-// compiler has to keep the order (wave-scope fence over the LDS address space: no instruction, no wait for global stores)
-template <int BLOCK>
-GX_D void tile_sync()
-{
-    if (BLOCK == 64) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-    } else {
-        __syncthreads();
-    }
-}
-
 template <class R, int BLOCK, int PMAX, bool kDef>
 __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArgs r, SplitArgs sa)
 {
@@ -652,31 +535,18 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
     extern __shared__ float4 tile4[];
     float* tile = reinterpret_cast<float*>(tile4);
     const int tid = threadIdx.x;
-    if (blockIdx.y) { // another rank's shard of the gathered buffer (one launch expands them all)
-        const size_t so = (size_t)blockIdx.y * (size_t)sa.shard_stride;
-        sa.tape += so; sa.entry += so;
-        sa.obj0 = reinterpret_cast<float4*>(reinterpret_cast<float*>(sa.obj0) + so);
-        r.obs += (size_t)blockIdx.y * (size_t)sa.out_stride;
-    }
     const size_t G = (size_t)r.T * p.N;
+    const size_t g0 = (size_t)blockIdx.x * BLOCK, g = g0 + tid;
+    const bool live = g < G;
+    const size_t gg = live ? g : 0;
+    const int i = (int)(gg % (size_t)p.N);
+    const int t = (int)(gg / (size_t)p.N);
     const int RS = r.obs_stride;
     const bool packed = r.act_out != nullptr;
     // LDS row stride: RS + 1 when RS is a multiple of 4 floats (48 for the Point's packed rows: 64 rows on 4 banks,
     // 16-way conflicts on every row write); other widths conflict 2-way at worst and keep the contiguous tile
     const int LS = (RS & 3) ? RS : RS + 1;
     float* row = tile + tid * LS;
-    // GRID-STRIDE over the 64-row tiles (round 4).  With one tile per workgroup every wave of a launch goes through the same
-    // three phases at about the same time -- tape loads, ~1 800 VALU instructions, a 12 KB burst of row stores; with a
-    // capped grid (obs_grid) a wave's stores of tile k drain while it computes tile k + 1 (single-wave workgroups: the LDS
-    // tile is reused behind a wave-scope fence, which -- unlike __syncthreads -- does not wait for the stores to be
-    // acknowledged).  Measured gain at 400 000 rows: 6 % (47.1 -> 44.2 us with 3072 workgroups); a launch over several
-    // shards already has that overlap between its tiles and is fastest uncapped.
-    for (size_t g0 = (size_t)blockIdx.x * BLOCK; g0 < G; g0 += (size_t)gridDim.x * BLOCK) {
-    const size_t g = g0 + tid;
-    const bool live = g < G;
-    const size_t gg = live ? g : 0;
-    const int i = (int)(gg % (size_t)p.N);
-    const int t = (int)(gg / (size_t)p.N);
 
     float rowv[TP::kW], ev[TP::kE];
     load_row<TP::kW>(sa.tape + gg * TP::kW, rowv);
@@ -687,8 +557,8 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
     for (int k = 0; k < R::NV; ++k) v[k] = rowv[TP::kV + k];
 #pragma unroll
     for (int k = 0; k < R::NA; ++k) a[k] = rowv[TP::kAct + k];
-    const float dn = TP::done_of(__float_as_int(rowv[TP::kCode]));
-    const int jcur = __float_as_int(rowv[TP::kJcur]), jaft = TP::jaft_of(__float_as_int(rowv[TP::kCode]));
+    const float dn = rowv[TP::kDone];
+    const int jcur = __float_as_int(rowv[TP::kJcur]), jaft = __float_as_int(rowv[TP::kJaft]);
 
     // what the step started from (s), the stale pose it found (pose0) and the done flag before it
     float s[R::NQ], pose0[4], last_done, hist0;
@@ -703,7 +573,7 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
         float prev[TP::kW];
         load_row<TP::kW>(sa.tape + (gg - (size_t)p.N) * TP::kW, prev);
         next_start<R>(prev, r, s);
-        last_done = TP::done_of(__float_as_int(prev[TP::kCode]));
+        last_done = prev[TP::kDone];
         float sp[R::NQ]; // what the PREVIOUS step started from: its pose is this step's stale pose (reset_done keeps it, :731)
         if (t == 1) {
 #pragma unroll
@@ -776,7 +646,7 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
     } else if (live) {
         r.rew[g] = rw; r.cost[g] = cs; r.done[g] = dn;
     }
-    tile_sync<BLOCK>();
+    __syncthreads();
     const size_t left = G - g0;
     const int nrow = left < (size_t)BLOCK ? (int)left : BLOCK;
     if (LS == RS) flush_tile<BLOCK>(tile, r.obs + g0 * RS, nrow * RS);
@@ -784,39 +654,18 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
     else {
         for (int k = tid; k < nrow * RS; k += BLOCK) { const int rw_ = k / RS; r.obs[g0 * RS + k] = tile[rw_ * LS + (k - rw_ * RS)]; }
     }
-    tile_sync<BLOCK>(); // the tile is rewritten by the next iteration
-    }
-}
-
-// workgroups of the observation pass per shard.  ALONE on the chip: enough to fill it a few waves deep, few enough that
-// every wave takes several tiles in turn (kObsGridCap; the 6 % of the comment in obs_tape_kernel).  With COMPANY -- a
-// layout sampler of this engine in flight beside the rollout, or another rank's work -- one workgroup per tile: the
-// pass then competes with throughput kernels whose waves fill every SIMD, and its share of the issue slots is its share
-// of the resident waves.  Same-box A/B in the epoch (tools/ab_epoch.py, round 5): Swimmer, whose observation pass is on
-// the epoch's critical chain, 688 -> 720 M env-steps/s uncapped (this cap, introduced in round 4 after a standalone
-// A/B, was the Swimmer's round-3 -> round-4 regression, 706 -> 689 M on one box); Point 773 = 773, Ant 300 = 300.
-// (GX_OBS_GRID_CAP: experiments.)
-static unsigned obs_grid(size_t rows, int block, int n_shards, bool company)
-{
-    static const int forced = [] { const char* e = getenv("GX_OBS_GRID_CAP"); return e ? atoi(e) : 0; }();
-    const size_t tiles = (rows + block - 1) / block;
-    if (forced <= 0 && (n_shards > 1 || company)) return (unsigned)tiles;
-    size_t cap = forced > 0 ? (size_t)forced : (size_t)kObsGridCap;
-    cap = (cap + n_shards - 1) / n_shards;
-    if (cap < 1) cap = 1;
-    return (unsigned)(tiles < cap ? tiles : cap);
 }
 
 // which: bit 0 = the dynamics pass, bit 1 = the observation pass (gx_rollout: both; the tape hand-off runs them on
 // different ranks: gx_rollout_tape / gx_expand_tape)
 template <class R, int PMAX>
 static hipError_t launch_split_p(const Params& p, const RolloutArgs& r, const SplitArgs& sa, const DevBuffers& b, hipStream_t s,
-                                hipEvent_t hold, int which, int n_shards = 1)
+                                hipEvent_t hold, int which)
 {
     hipError_t st = hipSuccess; // of the wait that orders the observation pass behind the sampler: must not be dropped
     constexpr int B1 = 64, B2 = 64;
     const int lpe = (R::kDynLanes == 4 && sa.lanes == 4) ? 4 : 1;
-    const dim3 g1((p.N * lpe + B1 - 1) / B1), g2(obs_grid((size_t)r.T * p.N, B2, n_shards, sa.lanes != 4), n_shards);
+    const dim3 g1((p.N * lpe + B1 - 1) / B1), g2((unsigned)(((size_t)r.T * p.N + B2 - 1) / B2));
     const size_t lds1 = sizeof(float) * ((size_t)B1 * p.D + 2 * (size_t)kActBlock * B1 * R::NA); // obs rows + two action blocks
     const size_t lds2 = sizeof(float) * (size_t)B2 * (r.obs_stride | 1);
     const bool def = PMAX == 5 && is_default_layout<R>(p);
@@ -844,30 +693,15 @@ static hipError_t launch_split_p(const Params& p, const RolloutArgs& r, const Sp
 // the same for the robots whose dynamics pass is the lane-group kernel (Ant, Walker)
 template <class R, int PMAX>
 static hipError_t launch_split_group_p(const Params& p, const RolloutArgs& r, const SplitArgs& sa, const DevBuffers& b,
-                                       hipStream_t s, hipEvent_t hold, int which, int n_shards = 1)
+                                       hipStream_t s, hipEvent_t hold, int which)
 {
     hipError_t st = hipSuccess;
     constexpr int B2 = 64;
-    // Envs per wave: as few as still leave one wave per SIMD (1024 on the chip) -- one up to 1024 envs, two up to 2048,
-    // four beyond.  A wave runs the step's data-dependent loops (the active-set Newton iterations above all) until its
-    // LAST env is done, and it issues nearly every slot it gets (two waves on one SIMD take 1.97x the time of one), so
-    // fewer envs per wave is faster exactly as long as the waves do not have to share SIMDs.  Ant, 200 steps, round 4:
-    // 2000 envs 1262 us (4 per wave) -> 1205 us (2); 1000 envs 1131 us (1); Walker 2361 -> 2279 us.
-    // (GX_GROUP_EPW = 1 | 2 | 4: experiments.)
-    // ... and only ALONE on the chip (sa.lanes == 4: no layout sampler of this engine in flight, as for the Swimmer's
-    // quad form): beside the sampler the four-env waves leave it half of the SIMDs to itself -- Ant epoch 1.53 -> 1.46 ms
-    // (262 -> 274 M env-steps/s), the 18-object config 5 2.79 -> 2.67 ms with four.
-    static const int epw_forced = [] { const char* e = getenv("GX_GROUP_EPW"); return e ? atoi(e) : 0; }();
-    const int epw = epw_forced == 1 || epw_forced == 2 || epw_forced == 4
-                        ? epw_forced
-                        : (sa.lanes != 4 ? 4 : (p.N <= 1024 ? 1 : ((p.N + 1) / 2 <= 1024 ? 2 : 4)));
-    SplitArgs sg = sa;
-    sg.lanes = epw;
-    const dim3 g1((p.N + epw - 1) / epw), g2(obs_grid((size_t)r.T * p.N, B2, n_shards, sa.lanes != 4), n_shards);
+    const dim3 g1((p.N + 3) / 4), g2((unsigned)(((size_t)r.T * p.N + B2 - 1) / B2));
     const size_t lds2 = sizeof(float) * (size_t)B2 * (r.obs_stride | 1);
     if (which & 1) {
 #define GX_GDYN_LAUNCH(OPL, BPL, DEF) \
-    hipLaunchKernelGGL((group_dyn_tape_kernel<R, OPL, BPL, DEF>), g1, dim3(64), 0, s, p, r, sg, b.dyn, b.obj)
+    hipLaunchKernelGGL((group_dyn_tape_kernel<R, OPL, BPL, DEF>), g1, dim3(64), 0, s, p, r, sa, b.dyn, b.obj)
         if (is_default_layout<R>(p)) GX_GDYN_LAUNCH(1, 1, true);
         else if (p.nobj <= 16 && p.bins <= 16) GX_GDYN_LAUNCH(1, 1, false);
         else if (p.nobj <= 32 && p.bins <= 16) GX_GDYN_LAUNCH(2, 1, false);

@@ -57,8 +57,7 @@ class _LazyObsDict(dict):
             for k, s in slices.items():
                 dict.__setitem__(self, k, obs[:, s])
             if qacc is not None:
-                flat, i, lo, n, nv = qacc      # the step's qacc lives in the output slab: viewed only when asked for
-                dict.__setitem__(self, 'qacc', flat[i, lo:lo + n * nv].view(n, nv))
+                dict.__setitem__(self, 'qacc', qacc)
 
     def __getitem__(self, k):
         self._fill()
@@ -97,96 +96,6 @@ class _LazyObsDict(dict):
         return dict.__repr__(self)
 
 
-class _StepInfo(dict):
-    """The `info` dict of step() (engine.py:693-695: {'cost': ..., 'obs': {...}}).  'cost' is there from the start -- the
-    learners read it every step (trpo.py:484) --, 'obs' (the per-key views, which only render() reads) is built on first
-    use: step() + reset_done() is host bound at env_num = 2000 and every Python object made per call counts."""
-    __slots__ = ('_src',)
-
-    def _fill(self):
-        src = getattr(self, '_src', None)       # (an instance made any other way than by step() has no source)
-        if src is not None:
-            self._src = None
-            dict.__setitem__(self, 'obs', _LazyObsDict(*src))
-
-    # every entry point of dict that reads or removes entries goes through _fill() first, so the object behaves like
-    # the reference's plain {'cost': ..., 'obs': {...}} (engine.py:693-695) whatever the caller does with it
-    def copy(self):
-        self._fill()
-        return dict(self)
-
-    def pop(self, *a):
-        self._fill()
-        return dict.pop(self, *a)
-
-    def popitem(self):
-        self._fill()
-        return dict.popitem(self)
-
-    def setdefault(self, k, default=None):
-        self._fill()
-        return dict.setdefault(self, k, default)
-
-    def __or__(self, other):
-        self._fill()
-        return dict(self) | other
-
-    def __ror__(self, other):
-        self._fill()
-        return other | dict(self)
-
-    def __ior__(self, other):
-        self._fill()
-        dict.update(self, other)
-        return self
-
-    def __reversed__(self):
-        self._fill()
-        return dict.__reversed__(self)
-
-    def __missing__(self, k):
-        self._fill()
-        return dict.__getitem__(self, k)       # KeyError for anything but 'obs', as a plain dict
-
-    def __iter__(self):
-        self._fill()
-        return dict.__iter__(self)
-
-    def __len__(self):
-        self._fill()
-        return dict.__len__(self)
-
-    def __contains__(self, k):
-        self._fill()
-        return dict.__contains__(self, k)
-
-    def keys(self):
-        self._fill()
-        return dict.keys(self)
-
-    def items(self):
-        self._fill()
-        return dict.items(self)
-
-    def values(self):
-        self._fill()
-        return dict.values(self)
-
-    def get(self, k, default=None):
-        self._fill()
-        return dict.get(self, k, default)
-
-    def __repr__(self):
-        self._fill()
-        return dict.__repr__(self)
-
-    def __eq__(self, other):
-        self._fill()
-        return dict.__eq__(self, other)
-
-    __hash__ = None
-
-
 class Engine:
     """GUARD `Engine`: `env_num` independent Goal-task arenas stepped in lock-step.
 
@@ -198,8 +107,7 @@ class Engine:
       emit_qacc     fill info['obs']['qacc'] (engine.py:763-764); costs one more output array
       out_ring      0 (default): the tensors step() returns are never written again, as in the reference
                     (engine.py:495 hands out fresh buffers; trpo.py:529 mutates the obs it keeps in place) -- they
-                    are views of a slab of at most 64 MB (up to 256 calls' outputs) allocated in one piece and released
-                    when the last view dies.
+                    are views of a slab allocated once per 32 calls and released when the last view dies.
                     k > 0: opt-in ring of k preallocated output sets, a tensor is overwritten k step() calls
                     after it was returned (for callers that copy what they keep, trpo.py:58-64; saves the slab
                     allocations)
@@ -256,11 +164,7 @@ class Engine:
         'pillars_size': 0.2, 'observe_pillars': False,
     }
 
-    # step() outputs are carved out of one allocation per `k` calls, k sized by BYTES: as many output sets as fit
-    # _SLAB_BYTES, at most _SLAB_STEPS, at least one (env_num = 2000: 85 sets of 0.75 MB; 2^22 Point envs: one 1.6 GB set
-    # per call, as if every step allocated its own outputs).  A tensor a caller retains keeps at most one slab alive.
-    _SLAB_BYTES = 64 << 20
-    _SLAB_STEPS = 256
+    _SLAB_STEPS = 32     # step() outputs are carved out of one allocation per 32 calls
 
     def __init__(self, config={}, *, n_candidates=1_000_000, shard=None, emit_qacc=True, point_actuators='mjcf',
                  out_ring=0):
@@ -318,13 +222,10 @@ class Engine:
 
         self._act_shape = torch.Size((int(self.env_num), act_dim))
         self._out_ring = max(0, int(out_ring))
-        self._slab, self._slab_i = None, 0
-        self._per_set = self._slab_floats()
+        self._slab, self._slab_i = [], 0
         self._speculate = os.environ.get("GX_NO_SPECULATE", "0") != "1"
-        # bit 0: write qacc; bit 1: speculate reset_done in the step launch (off: two-launch form, debugging / A-B timing)
-        self._step_flags = (1 if self.emit_qacc else 0) | (2 if self._speculate else 0)
         # the per-step entry points, looked up once (step() + reset_done() is host-bound at env_num = 2000)
-        self._gx_step_slab = self._lib.gx_step_slab
+        self._gx_step_rd, self._gx_step = self._lib.gx_step_rd, self._lib.gx_step
         self._gx_commit = self._lib.gx_reset_done_commit
         self._raw_stream = torch._C._cuda_getCurrentRawStream
         self._dev_index = self.device.index
@@ -502,24 +403,13 @@ class Engine:
         self.layout_size = int(n.value)
         return self.layout_size
 
-    def _slab_floats(self):
-        """floats of one set of step() outputs (obs, obs_rd, reward, cost, done, qacc), every piece 16-byte aligned:
-        the layout gx_step_slab addresses (include/guardx.h)"""
-        n = C.c_int64()
-        _native.check(self._lib.gx_step_set_floats(self._h, C.byref(n)))
-        return int(n.value)
-
-    def _slab_steps(self):
-        return max(1, min(self._SLAB_STEPS, self._SLAB_BYTES // (4 * self._slab_floats())))
-
     def _out_slab(self, k):
-        """`k` sets of step() outputs carved out of ONE allocation: (obs, obs_rd, reward, cost, done, qacc) tuples of k
-        views each -- six unbind() calls, not 6 k slicing operations -- and the base address; the kernel addresses set i
-        itself (gx_step_slab), so no per-set pointer objects are made."""
+        """`k` sets of step() outputs carved out of ONE allocation: per set (obs, obs_rd, reward, cost, done, qacc,
+        device addresses).  The views of a slab are made with six unbind() calls, not 6 k slicing operations."""
         N, D, nv = self.env_num, self.obs_flat_size, self.robot.nv
         Dp = (D + 3) // 4 * 4                      # keep every piece 16-byte aligned
         Np = (N + 3) // 4 * 4
-        per = self._per_set
+        per = 2 * N * Dp + 3 * Np + Np * nv
         flat = torch.empty(k, per, dtype=torch.float32, device=self.device)
         o = 0
         obs = flat[:, o:o + N * D].view(k, N, D).unbind(0); o += N * Dp
@@ -527,9 +417,16 @@ class Engine:
         rew = flat[:, o:o + N].unbind(0); o += Np
         cost = flat[:, o:o + N].unbind(0); o += Np
         done = flat[:, o:o + N].unbind(0); o += Np
-        # qacc (engine.py:763-764; not part of the flat observation) is viewed on demand: (slab, set, offset, N, nv)
-        return (obs, obs_rd, rew, cost, done, (flat, o) if self.emit_qacc and self._qacc_in_info else None,
-                flat.data_ptr(), k)
+        qacc = flat[:, o:o + N * nv].view(k, N, nv).unbind(0) if self.emit_qacc else (None,) * k
+        base, off_rd, off_r, off_q = flat.data_ptr(), 4 * N * Dp, 8 * N * Dp, 4 * (2 * N * Dp + 3 * Np)
+        slots = []
+        vp = C.c_void_p       # ready-made ctypes arguments: no int -> c_void_p conversion per step() call
+        for i in range(k):
+            b = base + 4 * per * i
+            ptrs = (vp(b), vp(b + off_r), vp(b + off_r + 4 * Np), vp(b + off_r + 8 * Np),
+                    vp(b + off_q) if self.emit_qacc else None, vp(b + off_rd))
+            slots.append((obs[i], obs_rd[i], rew[i], cost[i], done[i], qacc[i], ptrs))
+        return slots
 
     def step(self, action):
         """One control step for every env (engine.py:469-495).  No auto-reset.  The same launch also
@@ -540,25 +437,25 @@ class Engine:
                 and a.device == self.device and a.is_contiguous() and not a.requires_grad):
             a = self._as_action(action)
         i = self._slab_i
-        slab = self._slab
-        if slab is None or i >= slab[7]:
+        if i >= len(self._slab):
             # out_ring == 0 (default): a NEW slab -- tensors already handed out are never written again
             # (engine.py:495 returns fresh buffers); out_ring > 0: wrap around and reuse the ring
-            if not self._out_ring or slab is None:
-                slab = self._slab = self._out_slab(self._out_ring or self._slab_steps())
+            if not self._out_ring or not self._slab:
+                self._slab = self._out_slab(self._out_ring or self._SLAB_STEPS)
             i = 0
         self._slab_i = i + 1
-        # (a CPython shim calling the same entry point with plain integers instead of ctypes was measured in round 4:
-        # 8.1 -> 8.0 us per call -- the cost is hipLaunchKernel's own ~3.5 us, not the argument conversion; not kept)
-        st = self._gx_step_slab(self._h, a.data_ptr(), slab[6], i, self._step_flags, self._spec_ref,
-                                self._raw_stream(self._dev_index))
+        obs, obs_rd, reward, cost, done, qacc, p = self._slab[i]
+        stream = self._raw_stream(self._dev_index)
+        if self._speculate:
+            st = self._gx_step_rd(self._h, a.data_ptr(), p[0], p[1], p[2], p[3], p[4], p[5], self._spec_ref, stream)
+        else:   # two-launch form (step, then reset_done on demand): debugging / A-B timing only
+            self._spec.value = 0
+            st = self._gx_step(self._h, a.data_ptr(), p[0], p[1], p[2], p[3], p[4], stream)
         if st:
             _native.check(st)
-        obs, reward, cost, done = slab[0][i], slab[2][i], slab[3][i], slab[4][i]
-        self._rd_obs = slab[1][i] if self._spec.value else None
-        info = _StepInfo(cost=cost)
-        q = slab[5]
-        info._src = (obs, self._obs_slices, None if q is None else (q[0], i, q[1], self.env_num, self.robot.nv))
+        self._rd_obs = obs_rd if self._spec.value else None
+        info = {'cost': cost,
+                'obs': _LazyObsDict(obs, self._obs_slices, qacc if self._qacc_in_info else None)}
         self._obs, self._reward, self._done, self._info = obs, reward, done, info
         return obs, reward, done, info
 
@@ -623,7 +520,7 @@ class Engine:
 
     def rollout_tape(self, actions, out=None):
         """The serial half of rollout(): T x (step -> reset_done) without building observations.  Returns
-        (shard, token): `shard` a flat float32 tensor [tape | layouts at entry | entry records] (40 B per env-step
+        (shard, token): `shard` a flat float32 tensor [tape | layouts at entry | entry records] (48 B per env-step
         for the Point against 192 B of packed rows) to all-gather as is, `token` naming the layout pool in effect.
         expand_tape(shard, token) -- here or on any rank's engine of the same configuration -- gives the packed
         (T, N, D + A + 3) rows of rollout(packed=True), bit for bit; call it before the second reset() after
@@ -654,17 +551,6 @@ class Engine:
         assert tuple(out.shape) == (int(T), N, W) and out.is_contiguous()
         _native.check(self._lib.gx_expand_tape(self._h, int(T), shard.data_ptr(), int(token), out.data_ptr(),
                                                self._stream()))
-        return out
-
-    def expand_tapes(self, shards, stride_floats, n_shards, token, T, out):
-        """expand_tape() over the shards of n_shards ranks in ONE launch: shard s at shards[s * stride_floats:] (the
-        all-gathered buffer as it is), its rows into out[s]; out is (n_shards, T, N, D + A + 3)."""
-        N, W, T = self.env_num, self.obs_flat_size + self.action_space.shape[0] + 3, int(T)
-        assert shards.is_contiguous() and shards.dtype == torch.float32 and shards.device == self.device
-        assert shards.numel() >= (int(n_shards) - 1) * int(stride_floats) + sum(self.tape_floats(T))
-        assert tuple(out.shape) == (int(n_shards), T, N, W) and out.is_contiguous() and out.device == self.device
-        _native.check(self._lib.gx_expand_tapes(self._h, T, shards.data_ptr(), int(stride_floats), int(n_shards),
-                                                int(token), out.data_ptr(), T * N * W, self._stream()))
         return out
 
     # ------------------------------------------------------------------
@@ -716,79 +602,30 @@ class Engine:
             _native.check(st)
         return obs
 
-    # ---- the same riding on the tape hand-off (one collective per epoch): guardx_amd.dist.TapeHandoff drives these ----
-    def set_layout_source(self, source):
-        """'own' (default): reset() samples / prefetches all candidates itself.  'shards': the pool of the next reset()
-        is installed from the ranks' export blocks (install_shards); a reset whose key has no installed pool samples
-        inline, so results never depend on the source."""
-        _native.check(self._lib.gx_set_layout_source(self._h, {'own': 0, 'shards': 1}[source]))
-
-    def shard_block_floats(self, cap):
-        n = C.c_int64()
-        _native.check(self._lib.gx_shard_block_floats(self._h, int(cap), C.byref(n)))
-        return int(n.value)
-
-    def sample_shard_ahead(self, shard, n_shards, block, cap, resets_ahead=2):
-        """Sample candidates [shard M / n, (shard + 1) M / n) of the reset() `resets_ahead` resets from now (its key is
-        this key advanced by the learned number of steps between resets) on the engine's side stream and export the
-        valid layouts into `block` (shard_block_floats(cap) floats: count, key, tag | rows).  Returns the ticket
-        install_shards() takes for the blocks of this call (the same number on every rank)."""
-        assert block.is_contiguous() and block.dtype == torch.float32 and block.device == self.device
-        assert block.numel() == self.shard_block_floats(cap)
-        ticket = C.c_int64()
-        _native.check(self._lib.gx_sample_shard_ahead(self._h, int(shard), int(n_shards), int(resets_ahead),
-                                                      block.data_ptr(), int(cap), C.byref(ticket), self._stream()))
-        return int(ticket.value)
-
-    def shard_join(self):
-        """the current stream waits for the block of the last sample_shard_ahead()"""
-        _native.check(self._lib.gx_shard_join(self._h, self._stream()))
-
-    def install_shards(self, ticket, blocks, stride_floats, n_shards, cap):
-        """Assemble the n_shards export blocks of sample_shard_ahead() call `ticket` (shard s at
-        blocks[s * stride_floats:]) into the pool of the reset() they were sampled for, on the current stream; that
-        reset() then takes it like a prefetched pool."""
-        assert blocks.is_contiguous() and blocks.dtype == torch.float32 and blocks.device == self.device
-        assert blocks.numel() >= (int(n_shards) - 1) * int(stride_floats) + self.shard_block_floats(cap)
-        _native.check(self._lib.gx_install_shards(self._h, int(ticket), blocks.data_ptr(), int(stride_floats),
-                                                  int(n_shards), int(cap), self._stream()))
-
     # ------------------------------------------------------------------
     # closed-loop fused rollout (policy evaluated inside the kernel)
     # ------------------------------------------------------------------
-    POLICY_HIDDEN = (64, 128, 192, 256)
-
     @staticmethod
     def pack_actor_critic(ac=None, *, mu_net=None, v_net=None, log_std=None, device=None):
-        """Flatten MLPActorCritic(hidden_sizes=(h, h), tanh) weights (trpo_core.py:110-164; h = 64 is the reference
-        default, trpo.py:606-607 --hid / --l) into the layout gx_rollout_policy expects.  `ac` needs .pi.mu_net,
-        .pi.log_std, .v.v_net (nn.Sequential of Linear/Tanh/Linear/Tanh/Linear[/Identity]); or pass the three pieces."""
+        """Flatten MLPActorCritic(hidden_sizes=(64,64), tanh) weights (trpo_core.py:110-164) into the
+        layout gx_rollout_policy expects.  `ac` needs .pi.mu_net, .pi.log_std, .v.v_net
+        (nn.Sequential of Linear/Tanh/Linear/Tanh/Linear[/Identity]); or pass the three pieces."""
         if ac is not None:
             mu_net, v_net, log_std = ac.pi.mu_net, ac.v.v_net, ac.pi.log_std
-        parts, widths = [], set()
+        parts = []
         for net in (mu_net, v_net):
             lin = [m for m in net if isinstance(m, torch.nn.Linear)]
-            if len(lin) != 3 or lin[0].out_features != lin[1].out_features or lin[1].in_features != lin[0].out_features:
-                raise NotImplementedError("rollout_policy supports two hidden layers of equal width (--l 2)")
-            widths.add(lin[0].out_features)
+            if len(lin) != 3 or lin[0].out_features != 64 or lin[1].out_features != 64:
+                raise NotImplementedError("rollout_policy supports hidden_sizes=(64, 64) (the reference default)")
             for m in lin:
                 parts += [m.weight.detach().reshape(-1), m.bias.detach().reshape(-1)]
-        if len(widths) != 1 or widths.pop() not in Engine.POLICY_HIDDEN:
-            raise NotImplementedError(f"rollout_policy supports hidden_sizes (h, h) with h in {Engine.POLICY_HIDDEN}, "
-                                      "the same for actor and critic")
         parts.append(torch.as_tensor(log_std).detach().reshape(-1))
         flat = torch.cat([t.to(torch.float32) for t in parts])
         return flat.to(device) if device is not None else flat
 
-    @staticmethod
-    def _policy_floats(D, A, h):
-        return 2 * (h * D + h + h * h + h) + (A + 1) * h + (A + 1) + A
-
     def rollout_policy(self, params, T, obs0=None, noise_seed=(0, 0)):
-        """T x (ac.step -> env.step -> reset_done) on device (trpo.py:466-547 with the actor-critic of
-        trpo_core.py:110-173 evaluated there).  `params` = pack_actor_critic(ac); the hidden width is read off its
-        size.  h = 64: ONE kernel launch for the whole rollout; h = 128 / 192 / 256 (the weights do not fit the fused
-        kernel's LDS): two launches per control step, same results.
+        """T x (ac.step -> env.step -> reset_done) in ONE kernel launch (trpo.py:466-547 with the
+        actor-critic of trpo_core.py:110-173 evaluated on device).  `params` = pack_actor_critic(ac).
         Returns a dict of time-major tensors: obs (T,N,D) [what the policy saw], act, mu (T,N,A),
         logp, val, rew, cost, done (T,N), plus obs_last (N,D), val_last (N,), logstd (A,)."""
         if obs0 is None:
@@ -799,19 +636,18 @@ class Engine:
         params = params.to(device=self.device, dtype=torch.float32).contiguous()
         obs0 = obs0.to(device=self.device, dtype=torch.float32).contiguous()
         assert tuple(obs0.shape) == (N, D)
-        hidden = next((h for h in self.POLICY_HIDDEN if self._policy_floats(D, A, h) == params.numel()), None)
-        if hidden is None:
-            raise ValueError(f"params has {params.numel()} floats; expected one of "
-                             f"{[self._policy_floats(D, A, h) for h in self.POLICY_HIDDEN]} (hidden {self.POLICY_HIDDEN})")
         self._rd_obs = None
         out = dict(obs=self._new(T, N, D), act=self._new(T, N, A), logp=self._new(T, N), val=self._new(T, N),
                    mu=self._new(T, N, A), rew=self._new(T, N), cost=self._new(T, N), done=self._new(T, N),
                    obs_last=self._new(N, D), val_last=self._new(N), logstd=self._new(A))
         pol = _native.GxPolicy()
         pol.struct_size = C.sizeof(_native.GxPolicy)
-        pol.hidden = hidden
+        pol.hidden = 64
         pol.d_params = params.data_ptr()
         pol.seed[0], pol.seed[1] = int(noise_seed[0]) & 0xFFFFFFFF, int(noise_seed[1]) & 0xFFFFFFFF
+        expect = 2 * (64 * D + 64 + 64 * 64 + 64) + (A + 1) * 64 + (A + 1) + A
+        if params.numel() != expect:
+            raise ValueError(f"params has {params.numel()} floats, expected {expect}")
         _native.check(self._lib.gx_rollout_policy(
             self._h, T, C.byref(pol), obs0.data_ptr(), out['obs'].data_ptr(), out['act'].data_ptr(),
             out['logp'].data_ptr(), out['val'].data_ptr(), out['mu'].data_ptr(), out['rew'].data_ptr(),
@@ -822,8 +658,7 @@ class Engine:
         return out
 
     def set_policy_impl(self, impl):
-        """rollout_policy hidden layers at width 64: 0 auto, 1 VALU fmaf chains, 2 fp32 MFMA tiles, 3 the step-wise form
-        the wider networks use (same bits)."""
+        """rollout_policy hidden layers: 0 auto, 1 VALU fmaf chains, 2 fp32 MFMA tiles (same bits)."""
         _native.check(self._lib.gx_set_policy_impl(self._h, int(impl)))
 
     def set_prefetch(self, steps):

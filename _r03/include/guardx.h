@@ -133,16 +133,6 @@ gx_status gx_step(gx_engine* e, const float* d_action, float* d_obs, float* d_re
  * thread-per-env kernels (env_num > 16384): d_obs_rd is then left unwritten and the caller uses gx_reset_done. */
 gx_status gx_step_rd(gx_engine* e, const float* d_action, float* d_obs, float* d_reward, float* d_cost,
                      float* d_done, float* d_qacc, float* d_obs_rd, int32_t* speculated, void* stream);
-/* gx_step / gx_step_rd with the outputs addressed inside ONE caller-owned allocation ("slab") of consecutive output sets:
- * set `slot` starts at d_slab + slot * gx_step_set_floats() floats (d_slab 16-byte aligned) and holds, every piece 16-byte
- * aligned (Dp = obs_dim rounded up to 4, Np = env_num rounded up to 4):
- *   obs [N][D] at 0 | obs_rd [N][D] at N*Dp | reward [N] at 2*N*Dp | cost [N] at +Np | done [N] at +2*Np | qacc [N][nv] at +3*Np
- * flags: bit 0 = write qacc, bit 1 = also evaluate obs_rd (= gx_step_rd; *speculated as there).  The host hands out
- * views of a set and never reuses it (engine.py:495 returns fresh buffers); one pointer and an index per call instead
- * of six addresses is what the learner-driven step()+reset_done() loop needs at env_num = 2000, where it is host bound. */
-gx_status gx_step_set_floats(const gx_engine* e, int64_t* floats);
-gx_status gx_step_slab(gx_engine* e, const float* d_action, float* d_slab, int32_t slot, int32_t flags,
-                       int32_t* speculated, void* stream);
 /* Engine.reset_done for the step just made through gx_step_rd (speculated == 1): host-only, idempotent.
  * GX_ERR_STATE if the last hot-path call was anything else. */
 gx_status gx_reset_done_commit(gx_engine* e);
@@ -173,11 +163,9 @@ int32_t gx_packed_width(const gx_engine* e);
  * tapes and gets the packed rows of gx_rollout_packed, bit for bit.  All ranks sample identical layout pools (shared
  * key, engine.py:263), so the pool rows a tape's reset_done events refer to are local on every rank.
  *   d_shard: gx_tape_floats() floats = [ tape | layouts at entry | entry records ], 16-byte aligned; all-gather it as
- *            is.  A tape row is qpos | qvel | action | layout row in effect | one word for done and the layout row
- *            reset_done installed (-1: not done, -2: done and nothing installed, j >= 0: done, row j installed):
- *            10 floats (40 B) per env-step for the Point, 14 for the Swimmer, 34 for the Ant and 40 for the Walker
- *            (including, for those two, the row of the pool's fake-step table a reset_done observation is read from); the
- *            tape is rounded up to a multiple of 4 floats so that the layouts behind it stay 16-byte aligned; the
+ *            is.  A tape row is qpos | qvel | action | done | layout row in effect | layout row reset_done installed:
+ *            12 floats (48 B) per env-step for the Point, 16 for the Swimmer, 36 for the Ant and 40 for the Walker
+ *            (plus, for those two, the row of the pool's fake-step table a reset_done observation is read from); the
  *            observation pass re-derives the pose, ctrl and the reward from consecutive rows.  One physics step per
  *            control step and no observe_vel / observe_acc only (GX_ERR_UNSUPPORTED otherwise).
  *   token:   names the layout pool in effect; gx_expand_tape (on any engine of the same configuration and key
@@ -189,12 +177,6 @@ gx_status gx_rollout_tape(gx_engine* e, int32_t T, const float* d_actions, float
                           void* stream);
 gx_status gx_expand_tape(gx_engine* e, int32_t T, const float* d_shard, int64_t token, float* d_packed,
                          void* stream);
-/* The same over the shards of n_shards ranks in ONE launch: shard s at d_shards + s * stride_floats (the all-gathered
- * buffer as it is; a multiple of 4 floats), its packed rows at d_packed + s * packed_stride_floats.  Eight separate
- * 400 000-row launches each pay their own ramp and tail; one 3.2 M-row launch runs at the rate of the large-batch
- * step kernel. */
-gx_status gx_expand_tapes(gx_engine* e, int32_t T, const float* d_shards, int64_t stride_floats, int32_t n_shards,
-                          int64_t token, float* d_packed, int64_t packed_stride_floats, void* stream);
 
 /* ---- sharded layout sampling (multi-GPU, OPTIONAL: a second collective on the reset path) -----------------
  * reset()'s rejection sampler (engine.py:433-444, 546-621) draws 1e6 independent candidates (candidate c from
@@ -212,49 +194,6 @@ gx_status gx_sample_shard(gx_engine* e, int32_t shard, int32_t n_shards, float* 
 gx_status gx_reset_from_shards(gx_engine* e, const float* d_rows_all, const int32_t* d_counts, int32_t n_shards,
                                int32_t cap, float* d_obs, void* stream);
 
-/* ---- the same riding on the rollout hand-off: ONE collective per epoch (the default multi-GPU path since round 4) --
- * The key of a later reset is known now: this key advanced by one split per step() (engine.py:431), the number of steps
- * between resets being the learned horizon of gx_set_prefetch.  The pipeline guardx_amd/dist.py:TapeHandoff runs
- * (epochs and resets counted from 0, epoch k = gx_reset(k) + its rollout):
- *   after epoch k's rollout, once its collective has been issued:
- *       gx_sample_shard_ahead(resets_ahead = 3) -- rank r samples ITS candidates of reset(k + 3) on the engine's side
- *       stream.  (resets_ahead counts from the LAST reset: the key is advanced by resets_ahead * horizon -
- *       steps_since_reset, i.e. by two horizons when called after the epoch's steps.  Called BEFORE an epoch's steps the
- *       same reset is resets_ahead = 2.)  The export block -- [count, key0, key1, shard | n_shards << 16 | rows cap x
- *       (goal, hazards.., pillars.., robot) x 2 floats] -- is the tail of the buffer that will carry epoch k + 1's tape.
- *   epoch k + 1: gx_shard_join, then the all-gather of [tape k + 1 | block] delivers every rank's block.
- *   epoch k + 2: gx_install_shards(ticket of that call), on the stream that waited for the collective, AFTER
- *       gx_reset(k + 2) and BEFORE gx_reset(k + 3): it writes the pool slot the NEXT gx_reset takes ((cur + 1) % 3), so
- *       exactly one install may lie between two consecutive resets -- an install made one reset early overwrites a
- *       pool that has not been taken yet, one made late lands in the wrong slot; either way the key check at the reset
- *       fails and that reset falls back to sampling inline (results unchanged, the sharing lost).
- *   gx_reset(k + 3) takes the installed pool exactly like a prefetch hit.
- * A reset whose key has no installed pool (the first three of a hand-off, a changed episode length) samples all
- * candidates inline like a prefetch miss: layouts, observations and every later draw are the reference's either way
- * (engine.py:433-452).  The sampler's work per GPU is 1/W of the reference's and no second collective exists.
- *   gx_set_layout_source(e, 1): gx_reset launches no prefetch sampler of its own; 0 (default) restores it.
- *   gx_shard_block_floats:  floats of one export block of capacity `cap` rows (a multiple of 4).
- *   gx_sample_shard_ahead:  resets_ahead >= 1 (3 in the pipeline above).  d_block 16-byte aligned.  GX_ERR_STATE when the
- *                           engine has no horizon (gx_set_prefetch(e, -1)) or more steps have been made since the last
- *                           reset than resets_ahead horizons cover: a state all ranks share -- skip the block on every
- *                           rank (TapeHandoff does), the reset it was meant for samples inline.  The sampler starts
- *                           behind everything already queued on `stream`; gx_shard_join makes `stream` wait for the block
- *                           (call it before the collective that sends it, and before freeing the buffer).
- *                           *ticket names the call: every rank makes the same calls in the same order, so the
- *                           ticket of the blocks that arrive with a collective is the local one of that epoch.
- *   gx_install_shards:      d_blocks = block of shard 0, shard s at d_blocks + s * stride_floats; `ticket` = the
- *                           gx_sample_shard_ahead call whose key / n_shards / cap these blocks belong to (the engine
- *                           remembers its last four; GX_ERR_STATE otherwise).  A block of another key, shard or world
- *                           size, or count > cap, leaves layout_size < 0: the reset that takes the pool fails its
- *                           layout check (engine.py:444) instead of using it. */
-gx_status gx_set_layout_source(gx_engine* e, int32_t source);
-gx_status gx_shard_block_floats(const gx_engine* e, int32_t cap, int64_t* floats);
-gx_status gx_sample_shard_ahead(gx_engine* e, int32_t shard, int32_t n_shards, int32_t resets_ahead, float* d_block,
-                                int32_t cap, int64_t* ticket, void* stream);
-gx_status gx_shard_join(gx_engine* e, void* stream);
-gx_status gx_install_shards(gx_engine* e, int64_t ticket, const float* d_blocks, int64_t stride_floats, int32_t n_shards,
-                            int32_t cap, void* stream);
-
 /* ---- closed-loop fused rollout with an on-device policy ------------------
  * `ac.step(o)` of MLPActorCritic(hidden_sizes=(64,64), tanh) (safe_rl_libX/trpo/trpo_core.py:110-173)
  * evaluated inside the persistent rollout kernel: per step  a ~ N(mu_net(o), exp(log_std)), logp,
@@ -266,9 +205,7 @@ gx_status gx_install_shards(gx_engine* e, int64_t ticket, const float* d_blocks,
  * d_obs_last[N][D], d_val_last[N] = o_T and V(o_T) for the bootstrap; d_logstd[A] = log(std). */
 typedef struct gx_policy {
     int32_t struct_size;   /* sizeof(gx_policy) */
-    int32_t hidden;        /* 64 (the reference default, trpo.py:606 --hid): one fused launch; 128, 192, 256: the weights
-                            * do not fit the fused kernel's LDS -- two launches per control step (policy over all envs,
-                            * then the fused step + reset_done), same arithmetic, same results as the checker */
+    int32_t hidden;        /* 64 */
     const float* d_params; /* device pointer, layout above */
     uint32_t seed[2];
 } gx_policy;
@@ -277,8 +214,7 @@ gx_status gx_rollout_policy(gx_engine* e, int32_t T, const gx_policy* pol, const
                             float* d_reward, float* d_cost, float* d_done, float* d_obs_last,
                             float* d_val_last, float* d_logstd, void* stream);
 /* How the two hidden layers are evaluated: 0 auto (= 2), 1 VALU fmaf chains with one wave per
- * workgroup, 2 v_mfma_f32_16x16x4_f32 tiles with 16 envs per workgroup, 3 the step-wise form the wider networks use
- * (two launches per control step; available at hidden = 64 as a cross-check).  Bit-identical results. */
+ * workgroup, 2 v_mfma_f32_16x16x4_f32 tiles with 16 envs per workgroup.  Bit-identical results. */
 gx_status gx_set_policy_impl(gx_engine* e, int32_t impl);
 gx_status gx_math_probe2(int32_t n, const float* d_x, float* d_log, float* d_tanh, void* stream);
 

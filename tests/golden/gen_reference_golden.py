@@ -93,10 +93,10 @@ def to_np(x):
 
 
 def key_data(key):
-    import jax
     try:
+        import jax
         return np.asarray(jax.random.key_data(key), np.uint32).reshape(-1)[-2:]
-    except Exception:  # noqa: BLE001 - raw uint32[2] keys
+    except Exception:  # noqa: BLE001 - raw uint32[2] keys (or no jax: the stand-in run of tests/test_pin_machinery.py)
         return np.asarray(key, np.uint32).reshape(-1)[-2:]
 
 

@@ -121,3 +121,26 @@ def test_observation_table_orders():
     e = _host_only(dict(configuration("Ant_8Hazards_8Pillars_synthetic")), 11, 11, 8)
     assert list(e._obs_slices) == ['ctrl', 'goal_compass', 'goal_lidar', 'hazards_lidar', 'pillars_lidar', 'qpos', 'qvel']
     assert e.obs_flat_size == 80
+
+
+def test_step_info_behaves_like_the_plain_dict_of_the_reference():
+    """info = {'cost': ..., 'obs': {...}} (engine.py:693-695): 'obs' is built lazily, but every dict entry point sees it."""
+    import torch
+    from guardx_amd.engine import _StepInfo
+
+    def make():
+        info = _StepInfo(cost=torch.ones(2))
+        info._src = (torch.arange(8.).reshape(2, 4), {'qpos': slice(0, 3), 'ctrl': slice(3, 4)}, None)
+        return info
+    assert set(make().copy()) == {'cost', 'obs'} and type(make().copy()) is dict
+    assert set(make().pop('obs')) == {'qpos', 'ctrl'}
+    assert make().setdefault('obs', None) is not None
+    assert set(make() | {'x': 1}) == {'cost', 'obs', 'x'} and set({'x': 1} | make()) == {'x', 'cost', 'obs'}
+    i = make(); i |= {'y': 2}
+    assert set(i) == {'cost', 'obs', 'y'}
+    assert make().popitem()[0] == 'obs' and list(reversed(make())) == ['obs', 'cost']
+    assert len(make()) == 2 and 'obs' in make() and make()['obs']['qpos'].shape == (2, 3)
+    with pytest.raises(KeyError):
+        make().pop('nope')
+    bare = _StepInfo(cost=1)                  # made without a source: an ordinary dict
+    assert bare.copy() == {'cost': 1} and 'obs' not in bare and len(bare) == 1

@@ -1051,7 +1051,7 @@ def test_bench_two_ranks_on_one_gpu_rehearsal(torch_cuda):
     What is checked is the plumbing the 8-GPU run depends on -- spawn, rendezvous, barrier, max-over-ranks timing, the
     tape hand-off ring with the layout sampler sharded over the two ranks (each samples half of the candidates of the
     reset after next, the rows ride on the tape all-gather, also over gloo), every leg the line reports at N > 1
-    (`value`, stepping_only, unsharded_sampler, local_expand, cold_start), the deferred layout check of every leg, ONE
+    (`value` as the median of --reps repetitions, stepping_only, unsharded_sampler, local_expand, preconditioned), the deferred layout check of every leg, ONE
     JSON line from rank 0 -- not the rate (gloo through host memory is two orders of magnitude slower than xGMI)."""
     import json
     import os
@@ -1062,7 +1062,7 @@ def test_bench_two_ranks_on_one_gpu_rehearsal(torch_cuda):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                          "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+                          "--reps", "3", "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -1072,7 +1072,9 @@ def test_bench_two_ranks_on_one_gpu_rehearsal(torch_cuda):
     so = line["stepping_only"]
     assert so["handoff"] == "tape" and so["value"] > line["value"]
     assert so["handoff_bytes_received_per_rank_per_epoch"] < so["packed_rows_bytes_per_rank_per_epoch"] / 2
-    assert "roofline" in line and line["cold_start"]["value"] > 0
+    assert "roofline" in line and line["preconditioned"]["value"] > 0
+    reps = line["repetitions"]
+    assert reps["n"] == 3 and reps["min"] <= line["value"] <= reps["max"] and line["value"] in reps["values"]
     assert line["config"]["layout_sampler"].startswith("sharded")
     assert line["legs"]["unsharded_sampler"]["value"] > 0 and line["legs"]["local_expand"]["value"] > 0
 

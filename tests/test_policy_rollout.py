@@ -125,14 +125,17 @@ def test_policy_rollout_parity(oracle, robot, impl):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("robot,hidden,impl", [("point", 128, "mfma"), ("point", 128, "valu"), ("point", 256, "mfma"),
+@pytest.mark.parametrize("robot,hidden,impl", [("point", 128, "mfma"), ("point", 128, "valu"), ("point", 128, "stepwise"),
+                                               ("swimmer", 128, "mfma"), ("point", 256, "mfma"),
                                                ("swimmer", 192, "mfma"), ("ant", 128, "mfma"), ("walker", 256, "valu"),
                                                ("walker", 256, "mfma"), ("point", 64, "mfma"), ("ant", 64, "mfma")])
 def test_policy_rollout_other_widths_parity(oracle, robot, hidden, impl):
-    """hidden_sizes (h, h) beyond the fused kernel's 64 (trpo.py:606-607 --hid): the step-wise form (two launches per
-    control step, gx_policy_step.hip; hidden layers as v_mfma_f32_16x16x4_f32 tiles by default, as fmaf chains with
-    gx_set_policy_impl(1)) equals the checker bit for bit -- every output, the state afterwards, a second call that
-    continues the noise stream; at h = 64 (gx_set_policy_impl(3)) it also equals the FUSED kernel's outputs."""
+    """hidden_sizes (h, h) beyond 64 (trpo.py:606-607 --hid).  h = 128 on the light robots ("mfma" = the default): ONE
+    launch with the hidden-layer weights resident in registers (group_rollout_kernel<.., 3>, gx_policy.h); everything
+    else: the step-wise form (two launches per control step, gx_policy_step.hip; hidden layers as v_mfma_f32_16x16x4_f32
+    tiles -- "stepwise" = gx_set_policy_impl(2) forces it at 128 -- or as fmaf chains with gx_set_policy_impl(1)).  Each
+    equals the checker bit for bit -- every output, the state afterwards, a second call that continues the noise stream;
+    at h = 64 (gx_set_policy_impl(3)) the step-wise form also equals the FUSED kernel's outputs."""
     import torch
     from guardx_amd import Engine
     N, T = 203, 40
@@ -143,6 +146,8 @@ def test_policy_rollout_other_widths_parity(oracle, robot, hidden, impl):
         E.set_policy_impl(3)
     elif impl == "valu":
         E.set_policy_impl(1)
+    elif impl == "stepwise":
+        E.set_policy_impl(2)
     O = oracle.OracleEngine(cfg, n_candidates=40000)
     og, oo = E.reset(), O.reset()
     np.testing.assert_array_equal(og.cpu().numpy(), oo)

@@ -113,8 +113,9 @@ def test_slow_link_delays_the_epochs_and_corrupts_nothing(W):
     t1.record()
     torch.cuda.synchronize()
     total_ms = t0.elapsed_time(t1)
-    # the link throttled the pipeline: every collective slept, and they are serial on the link
-    assert total_ms > 0.9 * EPOCHS * sleep_ms, (total_ms, sleep_ms)
+    # the link throttled the pipeline: every collective slept, and they are serial on the link (_sleep counts shader
+    # cycles and the calibration above ran on a colder clock than the loop: hence the margin)
+    assert total_ms > 0.6 * EPOCHS * sleep_ms, (total_ms, sleep_ms)
     n_rows = 0
     for kind, ep, r, x, want in got:
         if kind == "reset":

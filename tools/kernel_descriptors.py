@@ -52,7 +52,9 @@ def descriptors(elf):
             kd = elf[sec[4] + value - sec[3]:sec[4] + value - sec[3] + 64]
             lds, scratch = struct.unpack_from("<II", kd, 0)
             props, = struct.unpack_from("<H", kd, 56)
-            res[name[:-3]] = dict(lds=lds, scratch=scratch, dispatch_ptr=bool(props & 2), queue_ptr=bool(props & 4),
+            rsrc3, rsrc1 = struct.unpack_from("<II", kd, 44)
+            res[name[:-3]] = dict(lds=lds, scratch=scratch, vgprs=((rsrc1 & 63) + 1) * 8,   # unified VGPR+AGPR file, granule 8
+                                  accum_offset=((rsrc3 & 63) + 1) * 4, dispatch_ptr=bool(props & 2), queue_ptr=bool(props & 4),
                                   kernarg_ptr=bool(props & 8), dispatch_id=bool(props & 16))
     return res
 
@@ -73,3 +75,12 @@ if __name__ == "__main__":
     print(len(ks), "kernels;", len(bad), "read the AQL dispatch/queue packet")
     for k in bad:
         print("  ", k)
+    if len(sys.argv) > 2:                 # python tools/kernel_descriptors.py <lib> <substring>: resources of the matches
+        import subprocess
+        for k, v in sorted(ks.items()):
+            if sys.argv[2] in k:
+                try:
+                    dem = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", k], capture_output=True, text=True).stdout.strip()
+                except OSError:
+                    dem = k
+                print(f"vgprs {v['vgprs']:4d} (agpr from {v['accum_offset']:3d})  lds {v['lds']:6d}  scratch {v['scratch']:5d}  {dem[:150]}")

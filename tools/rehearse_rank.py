@@ -155,6 +155,12 @@ def model(one, rank, world, gbps=(310.0, 200.0)):
         out[f"at_{int(bw)}GBps"] = {"allgather_ms": round(t_link, 4), "epoch_ms": round(t, 4),
                                     "weak_scaling_efficiency": round(one["ms_per_epoch"] / t, 4),
                                     "env_steps_per_s_all_ranks": round(world * bench.ENV_NUM * bench.EP_LEN / (t * 1e-3), 1)}
+    # the bandwidths one SCALE run can be read against: below `link_bound_below_GBps` the all-gather, not the GPU, sets
+    # the rank's epoch; at `break_even_GBps` the sharded epoch equals the one-GPU epoch (weak-scaling efficiency 1.0)
+    nbytes = rank["bytes_received_per_epoch"]
+    out["link_bound_below_GBps"] = round(nbytes / (rank["ms_per_epoch"] * 1e-3) / 1e9, 1)
+    out["break_even_GBps"] = round(nbytes / (one["ms_per_epoch"] * 1e-3) / 1e9, 1)
+    out["efficiency_if_gpu_bound"] = round(one["ms_per_epoch"] / rank["ms_per_epoch"], 4)
     return out
 
 
