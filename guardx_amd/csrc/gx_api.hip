@@ -39,6 +39,7 @@ struct gx_engine {
     gx_config cfg;
     Params p;
     SampleParams sp;
+    float phase1_pass_estimate = 0.f; // of the candidates that reach phase 1 (gx_create: picks the sampler's form)
     DevBuffers b;
     int nobj_total;
     uint32_t key[2];
@@ -63,6 +64,7 @@ struct gx_engine {
     int cur;                 // pool the envs are drawn from
     hipStream_t side[kPools]; // prefetch samplers: pool i is sampled on side[i % n_side]
     int n_side;
+    hipStream_t aux = nullptr; // gx_aux_stream: a least-priority stream for the caller's throughput work beside the stepping
     hipEvent_t pool_ready[kPools]; // recorded on the sampling stream when pool i is complete
     hipEvent_t pool_free[kPools];  // recorded on the caller's stream when pool i is no longer read
     hipEvent_t expand_ev[kPools];  // recorded behind the last gx_expand_tape that read pool i
@@ -340,6 +342,29 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     for (int q = 0; q < 4; ++q)
         for (int t = 0; t < 4; ++t) sp.thr_sq[q][t] = sqrt_cutoff(sp.thr[q][t]);
     sp.min_rg_sq = sqrt_cutoff(sp.min_rg);
+    // Which form of the sampler (gx_kernels.hip, sample_phase2_kernel<kFused>)?  Phase 1 pays a whole walk of the key chain
+    // to reject the candidates none of whose ten robot tries can be min_rg away from the goal.  Its pass rate depends on
+    // the geometry only -- goal uniform in its rectangle, ten robot tries uniform in theirs -- and is estimated here by a
+    // fixed-seed Monte Carlo (a plain LCG: an estimate for a cost decision, not part of the sampler; both forms give the
+    // same pool).  Reference arena (4 m, min_rg 3.0): ~0.25 -> three phases; synthetic config 5 (6 m): ~0.9 -> fused.
+    {
+        uint64_t lcg = 0x9E3779B97F4A7C15ull;
+        auto u01 = [&]() { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return (double)(lcg >> 11) * (1.0 / 9007199254740992.0); };
+        int pass = 0;
+        const int trials = 4000;
+        for (int i = 0; i < trials; ++i) {
+            const double gx = sp.lo_x[0] + u01() * (sp.hi_x[0] - sp.lo_x[0]), gy = sp.lo_y[0] + u01() * (sp.hi_y[0] - sp.lo_y[0]);
+            bool far = false;
+            for (int t = 0; t < 10; ++t) {
+                const double rx = sp.lo_x[2] + u01() * (sp.hi_x[2] - sp.lo_x[2]), ry = sp.lo_y[2] + u01() * (sp.hi_y[2] - sp.lo_y[2]);
+                if ((rx - gx) * (rx - gx) + (ry - gy) * (ry - gy) >= (double)sp.min_rg * sp.min_rg) far = true;
+            }
+            pass += far ? 1 : 0;
+        }
+        e->phase1_pass_estimate = (float)pass / trials;
+        sp.fused = e->phase1_pass_estimate > 0.6f ? 1 : 0;
+        if (const char* ev = getenv("GX_SAMPLE_FUSED")) sp.fused = atoi(ev) ? 1 : 0; // experiments / tests
+    }
 
     // PRNGKey(seed)  engine.py:216
     e->key[0] = 0u;
@@ -469,6 +494,7 @@ extern "C" gx_status gx_destroy(gx_engine* e)
     }
     for (int i = 0; i < gx_engine::kPools; ++i)
         if (e->side[i]) (void)hipStreamDestroy(e->side[i]);
+    if (e->aux) (void)hipStreamDestroy(e->aux);
     for (int i = 0; i < gx_engine::kKeyRing; ++i) {
         if (e->h_keys[i]) (void)hipHostFree(e->h_keys[i]);
         if (e->keys_ev[i]) (void)hipEventDestroy(e->keys_ev[i]);
@@ -803,6 +829,26 @@ extern "C" gx_status gx_install_shards(gx_engine* e, int64_t ticket, const float
     GX_HIP(hipGetLastError());
     e->pf_valid = true; // the next gx_reset takes it if its key is this one, otherwise it samples inline
     e->pf_key[0] = j.k0; e->pf_key[1] = j.k1;
+    return GX_OK;
+}
+
+// A stream of the engine's device at the LEAST priority, owned by the engine (destroyed with it), for throughput work the
+// caller runs beside the stepping -- the tape hand-off's installs and expansions (guardx_amd/dist.py).  HIP multiplexes a
+// process's streams onto a few hardware queues PER PRIORITY LEVEL: a stream of another priority than the caller's can
+// never share a hardware queue with it, so the serial chain of the epoch (reset -> dynamics pass, on the caller's
+// stream) is never queued behind an expansion, however many streams the process has created (measured, round 5: one GPU
+// playing rank 0 of 8 took 0.70 ms per epoch with the expansion on a normal-priority stream that happened to share the
+// caller's queue, 0.46 ms in processes where it did not).
+extern "C" gx_status gx_aux_stream(gx_engine* e, void** stream)
+{
+    if (!e || !stream) return fail(GX_ERR_ARG, "gx_aux_stream: null argument");
+    if (!e->aux) {
+        DeviceGuard guard(e->device);
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi); // lo = least urgent
+        GX_HIP(hipStreamCreateWithPriority(&e->aux, hipStreamNonBlocking, lo));
+    }
+    *stream = (void*)e->aux;
     return GX_OK;
 }
 

@@ -21,6 +21,7 @@ struct SampleParams {
     float thr_sq[4][4]; // exact cutoffs: sqrtf(d2) < thr  <=>  d2 < thr_sq
     float min_rg_sq;
     uint32_t k0, k1; // engine key at reset time
+    int fused;       // 1: sparse arena -- phases 0 and 2 only, the robot drawn at the end of the ONE chain walk (gx_kernels.hip)
     unsigned long long* dbg; // null, or per phase-2 wave: s_memtime at entry / exit, HW_ID, XCC_ID (gx_debug_stamps)
 };
 

@@ -181,6 +181,16 @@ GX_D void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
+// kFused (round 5; sparse arenas): the survivors of phase 0 come straight here, phase 1 is not run.  Phase 1 exists to
+// reject, before any hazard is placed, the candidates none of whose ten robot tries can be 3.0 away from the goal -- 75 %
+// of them in the reference's 4 m arena -- at the price of walking the whole `rng, rng1 = split(rng)` chain (20 Threefry
+// blocks per object) once just to reach the robot's keys, and again here for the objects' try keys.  In a sparse arena
+// (the synthetic config 5: 6 m, 18 objects) it rejects 10 % and the chain is 320 blocks per walk: the second walk costs
+// more than the rejection saves.  This form walks the chain ONCE: objects first (no pruning by the robot's tries, which
+// are not known yet: a candidate only dies when an object fails all ten tries), then the robot's ten links and tries,
+// validated against everything placed (draw_placement :579-621: the last valid try wins; :570-571).  Same candidates
+// succeed with the same rows -- the sampler's result does not depend on the form (launch_sample picks by geometry).
+template <bool kFused>
 __global__ __launch_bounds__(kP2Block * kP2Waves) void sample_phase2_kernel(SampleParams sp,
                                                                  const int* __restrict__ n_surv,
                                                                  const uint32_t* __restrict__ surv,
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(kP2Block * kP2Waves) void sample_phase2_kernel(Samp
     for (int base = wave0 * kP2Block; base < NS; base += nwaves * kP2Block) { // wave-uniform
         const int i = base + lane;
         const bool live = i < NS;
-        const uint32_t* rec = surv + (size_t)(live ? i : 0) * kSurvWords;
+        const uint32_t* rec = surv + (size_t)(live ? i : 0) * (kFused ? 8 : kSurvWords); // phase-0 / phase-1 record
         const int j = (int)rec[0];
         uint32_t r0 = rec[1], r1 = rec[2];
         const float gx = u2f(rec[3]), gy = u2f(rec[4]);
@@ -222,7 +232,11 @@ __global__ __launch_bounds__(kP2Block * kP2Waves) void sample_phase2_kernel(Samp
         // hazard -- the late hazards, whose draws cost the most rounds, see a fifth of them.
         float cx[10], cy[10];
         unsigned rvalid = 0u, rfar = 0u; // bit t: try t conflicts with nothing placed so far / is far from the goal
-        {
+        if (kFused) {
+#pragma unroll
+            for (int t = 0; t < 10; ++t) { cx[t] = 0.f; cy[t] = 0.f; }
+            rvalid = rfar = 1u; // nothing is known about the robot yet: no pruning
+        } else {
             const float tgr = sp.thr_sq[0][2];
 #pragma unroll
             for (int t = 0; t < 10; ++t) {
@@ -306,7 +320,7 @@ __global__ __launch_bounds__(kP2Block * kP2Waves) void sample_phase2_kernel(Samp
                 wave_sync(); // owner / best are rewritten by the next round
             }
             placed[o * kP2Block + lane] = make_float2(px, py);
-            if (alive) { // the robot tries this object rules out
+            if (!kFused && alive) { // the robot tries this object rules out
                 const float thr = o <= sp.H ? sp.thr_sq[1][2] : sp.thr_sq[3][2];
 #pragma unroll
                 for (int t = 0; t < 10; ++t)
@@ -314,6 +328,28 @@ __global__ __launch_bounds__(kP2Block * kP2Waves) void sample_phase2_kernel(Samp
                 if (!(rvalid & rfar)) alive = false;
             }
             wave_sync();
+        }
+        if (kFused && alive) { // the robot's ten links and tries (phase 1's), against everything placed
+            rvalid = 0u; rfar = 0u;
+            const float tgr = sp.thr_sq[0][2], thz = sp.thr_sq[1][2], tpl = sp.thr_sq[3][2];
+#pragma unroll 1
+            for (int t = 0; t < 10; ++t) {
+                uint32_t n0, n1, g0, g1;
+                split2(r0, r1, n0, n1, g0, g1); r0 = n0; r1 = n1;
+                float tx, ty;
+                draw_xy(g0, g1, sp.lo_x[2], sp.hi_x[2], sp.lo_y[2], sp.hi_y[2], tx, ty);
+                const float d2 = dsq(tx, ty, gx, gy);
+                bool ok_t = !(d2 < tgr);
+                for (int q = 1; q < nobj - 1; ++q) {
+                    const float2 pq = placed[q * kP2Block + lane];
+                    if (dsq(tx, ty, pq.x, pq.y) < (q <= sp.H ? thz : tpl)) ok_t = false;
+                }
+                // (cx / cy are indexed by compile-time constants below: select instead of a dynamic index)
+#pragma unroll
+                for (int u = 0; u < 10; ++u) if (u == t) { cx[u] = tx; cy[u] = ty; }
+                if (ok_t) rvalid |= 1u << t;
+                if (!(d2 < sp.min_rg_sq)) rfar |= 1u << t;
+            }
         }
         bool success = alive;
         float px = -__builtin_inff(), py = -__builtin_inff();
@@ -517,8 +553,10 @@ hipError_t launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s, 
     int cap = 1 << 30;
     if (const char* ev = getenv("GX_SAMPLE_GRID_CAP")) cap = atoi(ev) > 0 ? atoi(ev) : cap;
     const int grid1 = grid < (cap < 3072 ? cap : 3072) ? grid : (cap < 3072 ? cap : 3072);
-    hipLaunchKernelGGL(sample_phase1_kernel<kSampleBlock>, dim3(grid1), dim3(kSampleBlock), 0, s, sp, pl.n_surv + 1,
-                       pl.surv0, pl.n_surv, pl.surv);
+    const bool fused = sp.fused != 0; // sparse arena: one walk of the chain (sample_phase2_kernel<true>), no phase 1
+    if (!fused)
+        hipLaunchKernelGGL(sample_phase1_kernel<kSampleBlock>, dim3(grid1), dim3(kSampleBlock), 0, s, sp, pl.n_surv + 1,
+                           pl.surv0, pl.n_surv, pl.surv);
     if (after_phase1) {
         const hipError_t st = hipEventRecord(after_phase1, s);
         if (st != hipSuccess) return st;
@@ -529,8 +567,12 @@ hipError_t launch_sample(const SampleParams& sp, const Pool& pl, hipStream_t s, 
     const int cap2 = cap < 8192 / wpb ? cap : 8192 / wpb;
     const int grid2 = wgs < cap2 ? wgs : cap2;
     const size_t lds2 = wpb * lds_wave;
-    hipLaunchKernelGGL(sample_phase2_kernel, dim3(grid2), dim3(kP2Block * wpb), lds2, s, sp, pl.n_surv, pl.surv,
-                       pl.cand_ok, pl.cand_xy, pl.blk_cnt);
+    if (fused)
+        hipLaunchKernelGGL(sample_phase2_kernel<true>, dim3(grid2), dim3(kP2Block * wpb), lds2, s, sp, pl.n_surv + 1, pl.surv0,
+                           pl.cand_ok, pl.cand_xy, pl.blk_cnt);
+    else
+        hipLaunchKernelGGL(sample_phase2_kernel<false>, dim3(grid2), dim3(kP2Block * wpb), lds2, s, sp, pl.n_surv, pl.surv,
+                           pl.cand_ok, pl.cand_xy, pl.blk_cnt);
     hipLaunchKernelGGL(scan_compact_kernel, dim3((M + kCompactTile - 1) / kCompactTile), dim3(kSampleBlock), 0, s, M,
                        pl.cand_ok, pl.blk_cnt, pl.cand_of, pl.layout_size, pl.n_surv);
     return hipSuccess;

@@ -154,7 +154,12 @@ class TapeHandoff:
         # the expansion runs on its own stream (a CPU stand-in engine, as in the gloo unit test, has none): ONE per device
         # and process, shared by successive hand-offs (bench.py makes one per leg) -- HIP multiplexes a process's
         # streams onto a few hardware queues in creation order, and every extra stream is a chance of an alias
-        self.stream = _handoff_stream(dev) if dev.type == "cuda" else None
+        if dev.type != "cuda":
+            self.stream = None
+        elif hasattr(env, "aux_stream") and os.environ.get("GX_HANDOFF_STREAM", "aux") == "aux":
+            self.stream = env.aux_stream()     # least priority: never on the hardware queue of the caller's stream
+        else:
+            self.stream = _handoff_stream(dev)
         self.pending = None            # (work, slot, token, ticket of the block it carries) of the epoch in flight
         self.last = None               # (gathered buffer on the device, token) of the last expanded epoch (expand_rank)
         self.k = 0
@@ -281,6 +286,9 @@ class TapeHandoff:
         return self.rollout[s]
 
     def drain(self):
+        if getattr(self.env, "_h", True) is None:      # the engine is closed (it synchronised the device): nothing in flight
+            self.pending = None
+            return
         self._expand_pending(install=False)
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)

@@ -740,6 +740,16 @@ class Engine:
                                                       block.data_ptr(), int(cap), C.byref(ticket), self._stream()))
         return int(ticket.value)
 
+    def aux_stream(self):
+        """A least-priority stream owned by the engine, as a torch stream (valid until close()): for throughput work beside
+        the stepping -- the hand-off's installs and expansions.  Streams of another priority than the caller's never share
+        a hardware queue with it (gx_aux_stream)."""
+        if getattr(self, "_aux", None) is None:
+            ptr = C.c_void_p()
+            _native.check(self._lib.gx_aux_stream(self._h, C.byref(ptr)))
+            self._aux = torch.cuda.ExternalStream(ptr.value, device=self.device)
+        return self._aux
+
     def shard_join(self):
         """the current stream waits for the block of the last sample_shard_ahead()"""
         _native.check(self._lib.gx_shard_join(self._h, self._stream()))
@@ -910,8 +920,9 @@ class Engine:
 
     def close(self):
         if getattr(self, '_h', None):
-            self._lib.gx_destroy(self._h)
+            self._lib.gx_destroy(self._h)       # (synchronises the device; the aux stream dies with the engine)
             self._h = None
+            self._aux = None
 
     def __del__(self):
         try:

@@ -247,6 +247,10 @@ gx_status gx_reset_from_shards(gx_engine* e, const float* d_rows_all, const int3
  *                           remembers its last four; GX_ERR_STATE otherwise).  A block of another key, shard or world
  *                           size, or count > cap, leaves layout_size < 0: the reset that takes the pool fails its
  *                           layout check (engine.py:444) instead of using it. */
+/* A least-priority stream of the engine's device, owned by the engine (valid until gx_destroy), for throughput work the
+ * caller runs beside the stepping: the hand-off's gx_install_shards / gx_expand_tapes.  Streams of different priority
+ * never share a hardware queue, so work on it cannot be queued in front of the caller's reset -> dynamics chain. */
+gx_status gx_aux_stream(gx_engine* e, void** stream);
 gx_status gx_set_layout_source(gx_engine* e, int32_t source);
 gx_status gx_shard_block_floats(const gx_engine* e, int32_t cap, int64_t* floats);
 gx_status gx_sample_shard_ahead(gx_engine* e, int32_t shard, int32_t n_shards, int32_t resets_ahead, float* d_block,

@@ -1045,6 +1045,29 @@ def test_sampler_grid_stride_iterations(torch_cuda, oracle, monkeypatch):
         E.close()
 
 
+@pytest.mark.parametrize("fused", ["0", "1"])
+@pytest.mark.parametrize("name", ["Goal_Point_8Hazards", "Ant_8Hazards_8Pillars_synthetic"])
+def test_both_forms_of_the_layout_sampler_give_the_checkers_pool(torch_cuda, oracle, monkeypatch, name, fused):
+    """The layout sampler has two forms (gx_kernels.hip): three phases (phase 1 walks the key chain to the robot's tries
+    and rejects the candidates that cannot end 3.0 from the goal before any hazard is placed) and the fused form for
+    sparse arenas (one walk: objects first, the robot's tries at the end).  gx_create picks by geometry; GX_SAMPLE_FUSED
+    forces either.  Both give the checker's pool -- size, rows, order -- in the reference's dense arena and in the sparse
+    synthetic one, over consecutive resets (prefetch hits), at a candidate count that takes several grid-stride rounds."""
+    torch = torch_cuda
+    from guardx_amd import configuration
+    monkeypatch.setenv("GX_SAMPLE_FUSED", fused)
+    monkeypatch.setenv("GX_SAMPLE_GRID_CAP", "64")
+    cfg = dict(configuration(name))
+    cfg.update(env_num=96, _seed=11, num_steps=50)
+    E, O = _engines(cfg, oracle, n_candidates=150_000)
+    for ep in range(3):
+        np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
+        assert E.layout_size == O.layout_size > 96
+        n = min(E.layout_size, 4000)
+        np.testing.assert_array_equal(E.get_pool(n), O.get_pool(n))
+    E.close()
+
+
 def test_bench_two_ranks_on_one_gpu_rehearsal(torch_cuda):
     """bench.py's N > 1 path end to end on this box: `--gpus 2` with no launcher starts two rank processes itself;
     both share GPU 0 and talk over gloo (RCCL refuses two ranks on one device), shards staged through host memory.

@@ -44,7 +44,7 @@ class _CopyWork:
 
 
 class RehearsalHandoff(TapeHandoff):
-    """TapeHandoff playing rank 0 of `world` on one GPU; `blocks[epoch][s]` = the export block rank s sends in `epoch`."""
+    """TapeHandoff playing rank 0 of `world` on one GPU; `blocks[epoch][s - 1]` = the export block rank s sends in `epoch`."""
 
     def __init__(self, env, T, world, blocks, expand):
         super().__init__(env, T, sharded_sampler=True, expand=expand, _play=(0, world))
@@ -52,14 +52,17 @@ class RehearsalHandoff(TapeHandoff):
         self.comm = torch.cuda.Stream(device=env.device)
 
     def _gather(self, i, buf):
+        # three copy launches per epoch, whatever the world size (a real collective is ONE call: the stand-in must not make
+        # the rank's epoch host-bound -- with one copy per shard and block, 16 launches at W = 8, it did on slow hosts)
         self.comm.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.comm):
-            recv = self.recv[i]
-            recv[:self.n].copy_(buf, non_blocking=True)
-            for s in range(1, self.world):
-                recv[s * self.n:s * self.n + self.n_tape].copy_(buf[:self.n_tape], non_blocking=True)
-                if self.blocks[self.epoch][s] is not None:
-                    recv[s * self.n + self.off_block:(s + 1) * self.n].copy_(self.blocks[self.epoch][s], non_blocking=True)
+            recv = self.recv[i].view(self.world, self.n)
+            recv[0].copy_(buf, non_blocking=True)
+            if self.world > 1:
+                recv[1:, :self.n_tape].copy_(buf[:self.n_tape].unsqueeze(0).expand(self.world - 1, self.n_tape), non_blocking=True)
+                blk = self.blocks[self.epoch]
+                if blk is not None:
+                    recv[1:, self.off_block:].copy_(blk, non_blocking=True)
             work = _CopyWork(self.comm)
         self.epoch += 1
         self.bytes_received += (self.world - 1) * self.n * 4
@@ -80,17 +83,15 @@ def other_ranks_blocks(world, robot, epochs, tapes, cap):
     twin.reset()
     twin.set_layout_source('shards')
     nb = twin.shard_block_floats(cap)
-    out = [[None] * world]            # epoch 0 carries no block (TapeHandoff samples the first one after its first tape)
+    out = [None]                      # epoch 0 carries no block (TapeHandoff samples the first one after its first tape)
     for ep in range(epochs):
         if ep:
             twin.reset(check=False)
         twin.rollout_tape(tapes[ep % len(tapes)])
-        row = [None]
+        row = torch.zeros(max(world - 1, 1), nb, device=twin.device)   # row s - 1: the block of rank s
         for s in range(1, world):     # what rank s samples at the end of its step(ep): travels with the tape of ep + 1
-            blk = torch.zeros(nb, device=twin.device)
-            twin.sample_shard_ahead(s, world, blk, cap, resets_ahead=3)
-            row.append(blk)
-        out.append(row)
+            twin.sample_shard_ahead(s, world, row[s - 1], cap, resets_ahead=3)
+        out.append(row if world > 1 else None)
     twin.shard_join()
     torch.cuda.synchronize()
     twin.check_layouts()
