@@ -1315,14 +1315,16 @@ extern "C" gx_status gx_rollout_policy(gx_engine* e, int32_t T, const gx_policy*
     if (!e->have_reset) return fail(GX_ERR_STATE, "gx_rollout_policy before gx_reset");
     // hidden_sizes (128, 128) in ONE launch (round 5: hidden-layer weights resident in registers, gx_policy.h) -- the
     // default for the light robots' default-width observations; gx_set_policy_impl(e, 1 | 2 | 3) keeps the step-wise forms
-    const bool fused128 = pol->hidden == kPolHd2 && e->policy_impl == 0 && policy_fused128_supported(e->p) && !(e->na & 1) &&
-                          e->p.N <= 65536;
-    if ((pol->hidden != kPolHd && !fused128) || e->policy_impl == 3)
+    // ... and (192, 192), (256, 256) with the hidden-layer weights streamed from their L2-resident transposed copy
+    const bool fusedw = (pol->hidden == kPolHd2 || pol->hidden == 192 || pol->hidden == 256) && e->policy_impl == 0 &&
+                        policy_fused128_supported(e->p) && !(e->na & 1) && e->p.N <= 65536;
+    const bool fused128 = fusedw && pol->hidden == kPolHd2;
+    if ((pol->hidden != kPolHd && !fusedw) || e->policy_impl == 3)
         return rollout_policy_stepwise(e, T, pol, d_obs0, d_obs_in, d_act, d_logp, d_val, d_mu, d_reward, d_cost, d_done,
                                        d_obs_last, d_val_last, d_logstd, stream);
     if (!policy_rollout_supported(e->p) || (e->na & 1) || e->na > 16 || e->p.N > 65536)
         return fail(GX_ERR_UNSUPPORTED, "gx_rollout_policy: needs hazards_num <= 15, lidar_num_bins <= 16, env_num <= 65536");
-    const int impl = fused128 ? 3 : (e->policy_impl == 1 ? 1 : 2); // auto = MFMA
+    const int impl = fused128 ? 3 : (fusedw ? pol->hidden : (e->policy_impl == 1 ? 1 : 2)); // auto = MFMA
     if (policy_lds_bytes(e->p, impl) > 150 * 1024)
         return fail(GX_ERR_UNSUPPORTED, "gx_rollout_policy: observation too wide for the LDS-resident weights");
     DeviceGuard guard(e->device);
@@ -1338,6 +1340,18 @@ extern "C" gx_status gx_rollout_policy(gx_engine* e, int32_t T, const gx_policy*
     pa.params = pol->d_params; pa.seed0 = pol->seed[0]; pa.seed1 = pol->seed[1]; pa.t0 = e->policy_steps;
     pa.obs0 = d_obs0; pa.obs_in = d_obs_in; pa.act = d_act; pa.logp = d_logp; pa.val = d_val; pa.mu = d_mu;
     pa.obs_last = d_obs_last; pa.val_last = d_val_last; pa.logstd = d_logstd;
+    if (fusedw && !fused128) { // the streaming form reads the [k][unit] transposed hidden layers (as the step-wise form does)
+        const size_t need = (size_t)policy_step_wt_floats(e->p.D, pol->hidden);
+        if (need > e->pol_wt_cap) {
+            GX_HIP(hipStreamSynchronize(s));
+            if (e->pol_wt) (void)hipFree(e->pol_wt);
+            e->pol_wt = nullptr; e->pol_wt_cap = 0;
+            GX_HIP(hipMalloc((void**)&e->pol_wt, sizeof(float) * need));
+            e->pol_wt_cap = need;
+        }
+        launch_policy_transpose(pol->d_params, e->pol_wt, e->p.D, e->na, pol->hidden, s);
+        pa.wt = e->pol_wt;
+    }
     r.commit = take_commit(e);
     launch_policy_rollout(e->p, r, pa, e->b, impl, s);
     e->last_policy = true;

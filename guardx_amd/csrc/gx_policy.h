@@ -17,6 +17,7 @@ constexpr int kPolHd = 64; // hidden width (the reference default --hid 64 --l 2
 
 struct PolicyArgs {
     const float* params;   // pi{W1[Hd][D] b1 W2[Hd][Hd] b2 W3[A][Hd] b3} v{.. W3[1][Hd] b3} log_std[A]
+    const float* wt;       // widths 192 / 256 (streaming form): the [k][unit] transposed hidden layers (policy_transpose_kernel)
     uint32_t seed0, seed1; // key of the action-noise stream
     uint32_t t0;           // policy steps taken before this launch (noise counter offset)
     const float* obs0;     // [N][D] observation at entry
@@ -267,22 +268,23 @@ constexpr int kPolHS2 = kPolHd2 + 4;  // LDS row stride of its hidden activation
 constexpr int kPol2KS = kPolHd2 / 4;  // k-steps of the second layer
 
 // LDS image of one network's small parts: b1[128] b2[128] W3[Out][128] b3[Out]
-GX_HD int mlp2_head_floats(int Out) { return 2 * kPolHd2 + Out * kPolHd2 + Out; }
-GX_HD int mlp2_floats(int D, int Out) { return kPolHd2 * D + kPolHd2 + kPolHd2 * kPolHd2 + kPolHd2 + Out * kPolHd2 + Out; }
+// (H = the hidden width: kPolHd2 for the register-resident form, 192 / 256 for the streaming form below)
+GX_HD int mlp2_head_floats(int Out, int H = kPolHd2) { return 2 * H + Out * H + Out; }
+GX_HD int mlp2_floats(int D, int Out, int H = kPolHd2) { return H * D + H + H * H + H + Out * H + Out; }
 struct Mlp2Head { const float *b1, *b2, *W3, *b3; };
-GX_D Mlp2Head mlp2_head_view(const float* base, int Out)
+GX_D Mlp2Head mlp2_head_view(const float* base, int Out, int H = kPolHd2)
 {
     Mlp2Head m;
-    m.b1 = base; m.b2 = m.b1 + kPolHd2; m.W3 = m.b2 + kPolHd2; m.b3 = m.W3 + Out * kPolHd2;
+    m.b1 = base; m.b2 = m.b1 + H; m.W3 = m.b2 + H; m.b3 = m.W3 + Out * H;
     return m;
 }
-GX_D void mlp2_head_stage(float* lds, const float* __restrict__ g, int D, int Out, int tid, int nthreads)
+GX_D void mlp2_head_stage(float* lds, const float* __restrict__ g, int D, int Out, int tid, int nthreads, int H = kPolHd2)
 {
-    const float* gb1 = g + kPolHd2 * D; const float* gb2 = gb1 + kPolHd2 + kPolHd2 * kPolHd2;
-    const float* gW3 = gb2 + kPolHd2; const float* gb3 = gW3 + Out * kPolHd2;
-    float* b1 = lds; float* b2 = b1 + kPolHd2; float* W3 = b2 + kPolHd2; float* b3 = W3 + Out * kPolHd2;
-    for (int i = tid; i < kPolHd2; i += nthreads) { b1[i] = gb1[i]; b2[i] = gb2[i]; }
-    for (int i = tid; i < Out * kPolHd2; i += nthreads) W3[i] = gW3[i];
+    const float* gb1 = g + H * D; const float* gb2 = gb1 + H + H * H;
+    const float* gW3 = gb2 + H; const float* gb3 = gW3 + Out * H;
+    float* b1 = lds; float* b2 = b1 + H; float* W3 = b2 + H; float* b3 = W3 + Out * H;
+    for (int i = tid; i < H; i += nthreads) { b1[i] = gb1[i]; b2[i] = gb2[i]; }
+    for (int i = tid; i < Out * H; i += nthreads) W3[i] = gW3[i];
     for (int i = tid; i < Out; i += nthreads) b3[i] = gb3[i];
 }
 
@@ -319,6 +321,7 @@ GX_D void pol2_hidden(const Pol2Regs<KS1>& W, const float* X, int XS, float* H1,
         const float* ap = X + c16 * XS + kq;
 #pragma unroll
         for (int s = 0; s < KS1; ++s) av[s] = ap[4 * s];
+        __builtin_amdgcn_sched_barrier(0); // (the scheduler otherwise sinks each ds_read to its MFMAs: an LDS round trip per 8)
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) acc[tt] = mfma_f4{W.bias1[tt], W.bias1[tt], W.bias1[tt], W.bias1[tt]};
 #pragma unroll
@@ -337,6 +340,7 @@ GX_D void pol2_hidden(const Pol2Regs<KS1>& W, const float* X, int XS, float* H1,
         const float* ap = H1 + (size_t)net * 16 * kPolHS2 + c16 * kPolHS2 + kq;
 #pragma unroll
         for (int s = 0; s < kPol2KS; ++s) av[s] = ap[4 * s];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) acc[tt] = mfma_f4{W.bias2[tt], W.bias2[tt], W.bias2[tt], W.bias2[tt]};
 #pragma unroll
@@ -352,15 +356,16 @@ GX_D void pol2_hidden(const Pol2Regs<KS1>& W, const float* X, int XS, float* H1,
     __syncthreads();
 }
 
-// output layer of the 128-wide networks: partial l over the units 64 c + 4 l + j (c = 0, 1), butterfly, + bias
+// output layer of the wide networks: partial l over the units 64 c + 4 l + j (c = 0 .. H / 64 - 1), butterfly, + bias
 // (gx_policy_step.hip, oracle/gx_oracle.c:mlp_forward)
+template <int H = kPolHd2>
 GX_D float head2_out(const Mlp2Head& w, int o, int l, const float* h2row)
 {
     float pp = 0.0f;
 #pragma unroll
-    for (int c = 0; c < kPolHd2 / 64; ++c) {
+    for (int c = 0; c < H / 64; ++c) {
         const float4 hv = *reinterpret_cast<const float4*>(h2row + 64 * c + 4 * l);
-        const float4 wv = *reinterpret_cast<const float4*>(w.W3 + o * kPolHd2 + 64 * c + 4 * l);
+        const float4 wv = *reinterpret_cast<const float4*>(w.W3 + o * H + 64 * c + 4 * l);
         pp = fmaf(hv.x, wv.x, pp); pp = fmaf(hv.y, wv.y, pp); pp = fmaf(hv.z, wv.z, pp); pp = fmaf(hv.w, wv.w, pp);
     }
     pp = pp + __shfl_xor(pp, 8, 16);
@@ -374,8 +379,127 @@ GX_D float head2_out(const Mlp2Head& w, int o, int l, const float* h2row)
 //  VALU form (64 threads, 4 envs):   pi image | v image | log_std,std | hbuf[4][2][Hd] | xrow[4][pad4 D]
 //  MFMA form (256 threads, 16 envs): pi image | v image (Wt1 zero-padded to pad4 D rows) | log_std,std |
 //                                    X[16][pad4 D + 1] | H1[2][16][68] | H2[2][16][68]
+// ---------------------------------------------------------------------------
+// Widths 192 and 256 in ONE launch (round 5): the hidden-layer weights (0.35 / 0.61 MB for both networks) fit neither
+// the LDS nor the registers, but every workgroup reads the SAME [k][unit] transposed copy (policy_transpose_kernel,
+// gx_policy_step.hip), which stays in the L2 of its XCD: each k-step's B operands are streamed from there, kSB k-steps
+// at a time and one block ahead of the MFMAs that consume them, while the A operands (observation rows, first hidden
+// layer) come from LDS.  What the step-wise form paid per control step -- two kernel launches, the observation's
+// round trip through global memory, a cold start of every wave -- is gone; the arithmetic (k ascending per unit) is the same.
+// Wave w of the 4-wave workgroup: network w / 2, unit tiles (H / 32) (w % 2) .. + H / 32 - 1.
+// ---------------------------------------------------------------------------
+constexpr int kSB = 8; // k-steps (of 4 inputs) whose operands are in flight together: 64 MFMAs at H = 256, about one L2 round trip
+// Tile tt of a wave holds the units col0 + TT c + tt (c = 0 .. 15): lane (kq, c) needs, per k-step, the TT CONSECUTIVE
+// floats Wt[k][col0 + TT c ..] -- two 16-byte loads at H = 256, three 8-byte loads at H = 192, and the 16 lanes of a k row
+// read one contiguous 512 / 384 bytes (tiles of 16 adjacent units would take TT 4-byte loads per k-step, 64 bytes per row
+// each).  Which unit sits in which tile slot changes nothing: every unit is its own accumulation chain.
+template <int TT>
+GX_D void polS_fetch(float (&av)[kSB], float (&bv)[kSB][TT], const float* ap, const float* bp, int H, int s0, int ns)
+{
+#pragma unroll
+    for (int i = 0; i < kSB; ++i) {
+        const int sidx = s0 + i;
+        if (sidx < ns) { // wave-uniform
+            av[i] = ap[4 * sidx];
+            const float* row = bp + (size_t)(4 * sidx) * H;
+            if constexpr (TT % 4 == 0) {
+#pragma unroll
+                for (int q = 0; q < TT / 4; ++q) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(row + 4 * q);
+                    bv[i][4 * q] = w4.x; bv[i][4 * q + 1] = w4.y; bv[i][4 * q + 2] = w4.z; bv[i][4 * q + 3] = w4.w;
+                }
+            } else {
+                static_assert(TT % 2 == 0, "even number of tiles per wave");
+#pragma unroll
+                for (int q = 0; q < TT / 2; ++q) {
+                    const float2 w2 = *reinterpret_cast<const float2*>(row + 2 * q);
+                    bv[i][2 * q] = w2.x; bv[i][2 * q + 1] = w2.y;
+                }
+            }
+        }
+    }
+}
+template <int TT>
+GX_D void polS_issue(mfma_f4 (&acc)[TT], const float (&av)[kSB], const float (&bv)[kSB][TT], int s0, int ns)
+{
+#pragma unroll
+    for (int i = 0; i < kSB; ++i)
+        if (s0 + i < ns) {
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i][tt], acc[tt], 0, 0, 0);
+        }
+}
+// acc[tile] += A[16 envs][K] Wt[K][units of the tile], k ascending
+template <int TT>
+GX_D void polS_chain(mfma_f4 (&acc)[TT], const float* __restrict__ wt, int H, int col0, const float* A, int AS, int K, int c16, int kq)
+{
+    const int ns = K >> 2;
+    const float* ap = A + c16 * AS + kq;
+    const float* bp = wt + (size_t)kq * H + col0 + TT * c16;
+    float a0[kSB], b0[kSB][TT], a1[kSB], b1[kSB][TT];
+    polS_fetch<TT>(a0, b0, ap, bp, H, 0, ns);
+    // (scheduling barriers: left alone, the machine scheduler sinks every load down to the MFMA that consumes it -- the
+    // kernel is short of registers -- and each group of MFMAs then waits an L2 round trip: s_waitcnt vmcnt(0) in front of it)
+#pragma unroll 1
+    for (int s0 = 0; s0 < ns; s0 += 2 * kSB) {
+        __builtin_amdgcn_sched_barrier(0);
+        polS_fetch<TT>(a1, b1, ap, bp, H, s0 + kSB, ns);
+        __builtin_amdgcn_sched_barrier(0);
+        polS_issue<TT>(acc, a0, b0, s0, ns);
+        __builtin_amdgcn_sched_barrier(0);
+        polS_fetch<TT>(a0, b0, ap, bp, H, s0 + 2 * kSB, ns);
+        __builtin_amdgcn_sched_barrier(0);
+        polS_issue<TT>(acc, a1, b1, s0 + kSB, ns);
+    }
+}
+// tanh of a wave's accumulators into the activation rows: lane (kq, c) holds envs 4 kq .. + 3 of the units col0 + TT c + tt
+template <int TT>
+GX_D void polS_store(const mfma_f4 (&acc)[TT], float* o, int HS, int c16, int kq)
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float* row = o + (4 * kq + r) * HS + TT * c16;
+        if constexpr (TT % 4 == 0) {
+#pragma unroll
+            for (int q = 0; q < TT / 4; ++q)
+                *reinterpret_cast<float4*>(row + 4 * q) = make_float4(tanh_f(acc[4 * q][r]), tanh_f(acc[4 * q + 1][r]),
+                                                                      tanh_f(acc[4 * q + 2][r]), tanh_f(acc[4 * q + 3][r]));
+        } else {
+#pragma unroll
+            for (int q = 0; q < TT / 2; ++q)
+                *reinterpret_cast<float2*>(row + 2 * q) = make_float2(tanh_f(acc[2 * q][r]), tanh_f(acc[2 * q + 1][r]));
+        }
+    }
+}
+// both hidden layers for the 16 envs of the workgroup.  wt = [pi Wt1 | pi Wt2 | v Wt1 | v Wt2] (Wt1 rows padded to Dp);
+// hp / hc = the LDS head images (biases).  X = [16][XS], H1 / H2 = [2][16][H + 4].  Whole-workgroup call.
+template <int H>
+GX_D void polS_hidden(const float* __restrict__ wt, const Mlp2Head& hp, const Mlp2Head& hc, const float* X, int XS, int Dp,
+                      float* H1, float* H2, int wave, int lw)
+{
+    constexpr int TT = H / 32, HS = H + 4;
+    const int c16 = lw & 15, kq = lw >> 4, net = wave >> 1, col0 = 16 * TT * (wave & 1);
+    const float* wt1 = wt + (size_t)net * (Dp * H + H * H);
+    const float* wt2 = wt1 + (size_t)Dp * H;
+    const Mlp2Head& hd = net ? hc : hp;
+    mfma_f4 acc[TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) { const float bb = hd.b1[col0 + TT * c16 + tt]; acc[tt] = mfma_f4{bb, bb, bb, bb}; }
+    polS_chain<TT>(acc, wt1, H, col0, X, XS, Dp, c16, kq);
+    polS_store<TT>(acc, H1 + (size_t)net * 16 * HS + col0, HS, c16, kq);
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) { const float bb = hd.b2[col0 + TT * c16 + tt]; acc[tt] = mfma_f4{bb, bb, bb, bb}; }
+    polS_chain<TT>(acc, wt2, H, col0, H1 + (size_t)net * 16 * HS, HS, H, c16, kq);
+    polS_store<TT>(acc, H2 + (size_t)net * 16 * HS + col0, HS, c16, kq);
+    __syncthreads();
+}
+
 GX_HD int policy_lds_floats(int D, int A, int pol)
 {
+    if (pol == 192 || pol == 256) // streaming form of that width: pi head | v head | log_std,std | X | H1 | H2
+        return pad4(mlp2_head_floats(A, pol)) + pad4(mlp2_head_floats(1, pol)) + pad4(2 * A) + 16 * (pad4(D) + 1) + 3 +
+               2 * 2 * 16 * (pol + 4);
     if (pol == 3) // width 128, register-resident hidden weights: pi head | v head | log_std,std | X | H1 | H2
         return pad4(mlp2_head_floats(A)) + pad4(mlp2_head_floats(1)) + pad4(2 * A) + 16 * (pad4(D) + 1) + 3 +
                2 * 2 * 16 * kPolHS2;

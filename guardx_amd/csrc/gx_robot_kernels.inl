@@ -839,6 +839,7 @@ GX_D float pick(const float (&a)[N], int k)
 // kPol: 0 open loop (action tape), 1 policy evaluated with VALU fmaf chains (one wave per workgroup),
 //       2 policy evaluated with fp32 MFMA tiles (four waves = 16 envs per workgroup), width 64, weights in LDS
 //       3 the same for width 128: hidden-layer weights resident in REGISTERS as the lanes' MFMA B operands (gx_policy.h)
+//       192 / 256 that width, hidden-layer weights STREAMED from the L2-resident transposed copy (gx_policy.h)
 template <class R, int OPL, int BPL, bool kQacc, bool kDef, int kPol>
 __global__ __launch_bounds__(kPol >= 2 ? 256 : 64) void group_rollout_kernel(Params p_in, RolloutArgs r,
                                                                             PolicyArgs pol,
@@ -851,6 +852,8 @@ __global__ __launch_bounds__(kPol >= 2 ? 256 : 64) void group_rollout_kernel(Par
     // k-steps of the first hidden layer in the register-resident form: the robot's default-task observation width
     // (qpos, qvel, ctrl, compass, two 16-bin lidars), padded to fours -- the launcher checks that p.D matches
     constexpr int KS1 = (R::NQ + R::NV + R::NU + 2 + 32 + 3) / 4;
+    constexpr bool kStream = kPol == 192 || kPol == 256;   // streaming form of that width
+    constexpr int HW = kStream ? kPol : kPolHd2, HWS = HW + 4;
     const Params p = fold_params<R, kDef>(p_in);
     stamp(r, 0);
     __shared__ GroupLds<OPL, BPL, BT> S;
@@ -869,23 +872,23 @@ __global__ __launch_bounds__(kPol >= 2 ? 256 : 64) void group_rollout_kernel(Par
     float *xrow = nullptr, *hbuf = nullptr, *X = nullptr, *H1 = nullptr, *H2 = nullptr;
     int XS = 0;
     float pstd[R::NA], plstd[R::NA];
-    if constexpr (kPol == 3) {
+    if constexpr (kPol == 3 || kStream) {
         const int D = p.D, A = R::NA;
         float* pi_img = pol_lds;
-        float* v_img = pi_img + pad4(mlp2_head_floats(A));
-        float* ls_img = v_img + pad4(mlp2_head_floats(1));
+        float* v_img = pi_img + pad4(mlp2_head_floats(A, HW));
+        float* ls_img = v_img + pad4(mlp2_head_floats(1, HW));
         XS = pad4(D) + 1;
         X = ls_img + pad4(2 * A);
         H1 = X + pad4(16 * XS);
-        H2 = H1 + 2 * 16 * kPolHS2;
+        H2 = H1 + 2 * 16 * HWS;
         xrow = X + (lane >> 4) * XS;
         for (int i = lane; i < 16 * XS; i += BT) X[i] = 0.0f; // zero padding columns
-        pol2_load<KS1>(PW, pol.params, D, A, lane >> 6, lane & 63);
-        mlp2_head_stage(pi_img, pol.params, D, A, lane, BT);
-        mlp2_head_stage(v_img, pol.params + mlp2_floats(D, A), D, 1, lane, BT);
-        hpi = mlp2_head_view(pi_img, A);
-        hvv = mlp2_head_view(v_img, 1);
-        const float* gls = pol.params + mlp2_floats(D, A) + mlp2_floats(D, 1);
+        if constexpr (kPol == 3) pol2_load<KS1>(PW, pol.params, D, A, lane >> 6, lane & 63);
+        mlp2_head_stage(pi_img, pol.params, D, A, lane, BT, HW);
+        mlp2_head_stage(v_img, pol.params + mlp2_floats(D, A, HW), D, 1, lane, BT, HW);
+        hpi = mlp2_head_view(pi_img, A, HW);
+        hvv = mlp2_head_view(v_img, 1, HW);
+        const float* gls = pol.params + mlp2_floats(D, A, HW) + mlp2_floats(D, 1, HW);
 #pragma unroll
         for (int d = 0; d < A; ++d) {
             pstd[d] = exp_f(gls[d]);      // std = exp(log_std)          trpo_core.py:123
@@ -990,12 +993,13 @@ __global__ __launch_bounds__(kPol >= 2 ? 256 : 64) void group_rollout_kernel(Par
             // ac.step(o): a ~ N(mu(o), std), logp, v(o)   trpo_core.py:166-173
             const size_t te = (size_t)t * p.N + env;
             float mu[R::NA], vv[1];
-            if constexpr (kPol == 3) {
-                pol2_hidden<KS1>(PW, X, XS, H1, H2, lane >> 6, lane & 63);
-                const float* h2p = H2 + (lane >> 4) * kPolHS2;
+            if constexpr (kPol == 3 || kStream) {
+                if constexpr (kPol == 3) pol2_hidden<KS1>(PW, X, XS, H1, H2, lane >> 6, lane & 63);
+                else polS_hidden<HW>(pol.wt, hpi, hvv, X, XS, pad4(p.D), H1, H2, lane >> 6, lane & 63);
+                const float* h2p = H2 + (lane >> 4) * HWS;
 #pragma unroll
-                for (int o = 0; o < R::NA; ++o) mu[o] = head2_out(hpi, o, l, h2p);
-                vv[0] = head2_out(hvv, 0, l, h2p + 16 * kPolHS2);
+                for (int o = 0; o < R::NA; ++o) mu[o] = head2_out<HW>(hpi, o, l, h2p);
+                vv[0] = head2_out<HW>(hvv, 0, l, h2p + 16 * HWS);
             } else if (kPol == 2) {
                 mfma_hidden(wpi, wv, X, XS, pad4(p.D), H1, H2, lane >> 6, lane & 63);
                 const float* h2p = H2 + (lane >> 4) * kPolHS + 4 * l;
@@ -1214,9 +1218,10 @@ __global__ __launch_bounds__(kPol >= 2 ? 256 : 64) void group_rollout_kernel(Par
 
     if (kPolicy) { // bootstrap inputs: o_T and V(o_T)   trpo.py:523-529
         float vlast;
-        if constexpr (kPol == 3) {
-            pol2_hidden<KS1>(PW, X, XS, H1, H2, lane >> 6, lane & 63);
-            vlast = head2_out(hvv, 0, l, H2 + (16 + (lane >> 4)) * kPolHS2);
+        if constexpr (kPol == 3 || kStream) {
+            if constexpr (kPol == 3) pol2_hidden<KS1>(PW, X, XS, H1, H2, lane >> 6, lane & 63);
+            else polS_hidden<HW>(pol.wt, hpi, hvv, X, XS, pad4(p.D), H1, H2, lane >> 6, lane & 63);
+            vlast = head2_out<HW>(hvv, 0, l, H2 + (16 + (lane >> 4)) * HWS);
         } else {
             vlast = critic_forward(wv, xrow, hbuf, p.D, l);
         }
@@ -1447,8 +1452,10 @@ template <class R>
 void RobotLaunch<R>::policy(const Params& p, const RolloutArgs& r, const PolicyArgs& pol, const DevBuffers& b,
                             int impl, hipStream_t s)
 {
-    if constexpr (R::kRestFixed) { // width 128 in one launch: the light robots (the Ant's / Walker's step needs the registers)
+    if constexpr (R::kRestFixed) { // widths 128, 192, 256 in one launch: the light robots (the Ant's / Walker's step needs the registers)
         if (impl == 3) { launch_policy_rp<R, 3>(p, r, pol, b, s); return; }
+        if (impl == 192) { launch_policy_rp<R, 192>(p, r, pol, b, s); return; }
+        if (impl == 256) { launch_policy_rp<R, 256>(p, r, pol, b, s); return; }
     }
     if (impl == 2) launch_policy_rp<R, 2>(p, r, pol, b, s);
     else launch_policy_rp<R, 1>(p, r, pol, b, s);

@@ -126,13 +126,15 @@ def test_policy_rollout_parity(oracle, robot, impl):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("robot,hidden,impl", [("point", 128, "mfma"), ("point", 128, "valu"), ("point", 128, "stepwise"),
-                                               ("swimmer", 128, "mfma"), ("point", 256, "mfma"),
-                                               ("swimmer", 192, "mfma"), ("ant", 128, "mfma"), ("walker", 256, "valu"),
+                                               ("swimmer", 128, "mfma"), ("point", 256, "mfma"), ("point", 256, "stepwise"),
+                                               ("swimmer", 192, "mfma"), ("point", 192, "mfma"), ("swimmer", 256, "mfma"),
+                                               ("swimmer", 192, "stepwise"), ("ant", 128, "mfma"), ("walker", 256, "valu"),
                                                ("walker", 256, "mfma"), ("point", 64, "mfma"), ("ant", 64, "mfma")])
 def test_policy_rollout_other_widths_parity(oracle, robot, hidden, impl):
-    """hidden_sizes (h, h) beyond 64 (trpo.py:606-607 --hid).  h = 128 on the light robots ("mfma" = the default): ONE
-    launch with the hidden-layer weights resident in registers (group_rollout_kernel<.., 3>, gx_policy.h); everything
-    else: the step-wise form (two launches per control step, gx_policy_step.hip; hidden layers as v_mfma_f32_16x16x4_f32
+    """hidden_sizes (h, h) beyond 64 (trpo.py:606-607 --hid).  On the light robots ("mfma" = the default) ONE launch:
+    h = 128 with the hidden-layer weights resident in registers (group_rollout_kernel<.., 3>), h = 192 / 256 with the
+    weights streamed from their L2-resident transposed copy (group_rollout_kernel<.., 192 / 256>, gx_policy.h); everything
+    else (Ant, Walker, other observation widths): the step-wise form (two launches per control step, gx_policy_step.hip; hidden layers as v_mfma_f32_16x16x4_f32
     tiles -- "stepwise" = gx_set_policy_impl(2) forces it at 128 -- or as fmaf chains with gx_set_policy_impl(1)).  Each
     equals the checker bit for bit -- every output, the state afterwards, a second call that continues the noise stream;
     at h = 64 (gx_set_policy_impl(3)) the step-wise form also equals the FUSED kernel's outputs."""

@@ -45,3 +45,14 @@ def test_bench_has_no_typed_in_profile_numbers():
     for lit in ("1742.6", "16662.1", "31500.0", "71875.0", "118.3", "33.8", "301e6"):
         assert lit not in src, lit
     assert "profile_evidence" in src and re.search(r"_evidence\(\"rollout_numbers\"\)", src)
+
+
+def test_readme_table_of_this_round_is_what_the_files_say():
+    """profiles/README.md's table for the current round is generated (python tools/profile_evidence.py --readme): build id,
+    kernel microseconds, PMC megabytes, roofline fraction, bench values, test counts are READ from the CSV / JSON / log
+    files -- the committed prose cannot go stale without this test failing."""
+    text = open(pe.README).read()
+    assert pe.BEGIN in text and pe.END in text, "run `python tools/profile_evidence.py --readme`"
+    have = text[text.index(pe.BEGIN):text.index(pe.END) + len(pe.END)]
+    assert have == pe.readme_block(), "profiles/README.md differs from the evidence files: run `python tools/profile_evidence.py --readme`"
+    assert f"`{pe.TAG}_build_id.txt`" in have and f"`{pe.TAG}_gputest_final.log`" in have

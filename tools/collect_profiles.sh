@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collect every rocprofv3 summary bench.py / DESIGN.md quote, on the GPU box (through gpurun, from the repo root):
-#   tools/collect_profiles.sh r04      -> gpurun_out/r04_*.csv, r04_build_id.txt  (copy them into profiles/)
+#   tools/collect_profiles.sh r05      -> gpurun_out/r05_*.csv, r05_build_id.txt  (copy them into profiles/)
 # Counter passes are separate runs with --pmc only (no --kernel-trace/--stats mixed in).
 set -e
-tag=${1:-r04}
+tag=${1:-r05}
 out=$PWD/gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
@@ -51,5 +51,9 @@ kt rehearsal_rank0_of_8 python3 tools/rehearse_rank.py --world 8 --epochs 30
 kt policy_widths python3 tools/bench_policy_widths.py
 kt sampler_config5 python3 tools/profile_reset.py --task Ant_8Hazards_8Pillars_synthetic
 pmc sampler_config5 SQ SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_BUSY_CYCLES -- python3 tools/profile_reset.py --task Ant_8Hazards_8Pillars_synthetic
+# round 5: the exhaustive reciprocal probe (tools/probes/rcp_exact_probe.hip), rank rehearsals of the Point and the Ant
+(cd tools/probes && hipcc -O3 -ffp-contract=off --offload-arch=gfx950 -o rcp_exact_probe rcp_exact_probe.hip) && ./tools/probes/rcp_exact_probe > $out/${tag}_rcp_exact_probe.log 2>&1
+python3 tools/rehearse_rank.py --world 8 --epochs 30 --json $out/${tag}_rehearsal_rank0_of_8.json > /dev/null 2>&1
+python3 tools/rehearse_rank.py --world 8 --epochs 30 --robot xmls/ant.xml --json $out/${tag}_rehearsal_rank0_of_8_ant.json > /dev/null 2>&1
 rm -f $out/${tag}_*_kt.log $out/${tag}_*_pmc_*.log
 ls $out/${tag}_* | wc -l

@@ -1,7 +1,7 @@
 #!/bin/bash
 # the round's run-time evidence on the final build (through gpurun, from the repo root; the rocprofv3 summaries come
-# from tools/collect_profiles.sh):   bash tools/final_gpu.sh r04 [soak|bench]   -> gpurun_out/r04_*  (copy into profiles/)
-tag=${1:-r04}; what=${2:-all}
+# from tools/collect_profiles.sh):   bash tools/final_gpu.sh r05 [soak|bench]   -> gpurun_out/r05_*  (copy into profiles/)
+tag=${1:-r05}; what=${2:-all}
 cd $GRAFT_REPO_ROOT
 if [ "$what" = "all" ] || [ "$what" = "soak" ]; then
   for rb in point swimmer ant walker; do
@@ -14,21 +14,25 @@ fi
 if [ "$what" = "all" ] || [ "$what" = "bench" ]; then
   python -m pytest tests -m gpu -q 2>&1 | tail -n 4 > gpurun_out/${tag}_gputest_final.log
   cat gpurun_out/${tag}_gputest_final.log
+  # the RCCL one-rank run leaves its report, RCCL's own log lines and the forced-dist bench line in gpurun_out/
+  cp gpurun_out/rccl_one_rank_report.json gpurun_out/${tag}_rccl_one_rank_report.json
+  grep "NCCL INFO" gpurun_out/rccl_one_rank.log | grep -v "NET/\|lugin" | head -120 > gpurun_out/${tag}_rccl_one_rank_nccl.log
+  cp gpurun_out/bench_force_dist_one_rank.json gpurun_out/${tag}_bench_force_dist_one_rank.json
   python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -n 1
   python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench_driver_style.json 2> gpurun_out/bench_err.log
   python bench.py > gpurun_out/${tag}_bench_full.json 2>> gpurun_out/bench_err.log
-  GX_BENCH_FORCE_DEVICE=0 GX_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 10 --warmup 5 --no-extras --no-cpu-baseline > gpurun_out/${tag}_rehearsal_2ranks_one_gpu_gloo.json 2>> gpurun_out/bench_err.log
+  GX_BENCH_FORCE_DEVICE=0 GX_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 10 --warmup 5 --reps 3 --no-extras --no-cpu-baseline > gpurun_out/${tag}_rehearsal_2ranks_one_gpu_gloo.json 2>> gpurun_out/bench_err.log
   python - <<PY
 import json
 for f in ("gpurun_out/${tag}_bench_driver_style.json", "gpurun_out/${tag}_bench_full.json"):
     l = json.loads(open(f).read().strip().splitlines()[-1])
-    print(f, round(l["value"]/1e6,1), l["ms_per_step"], l["roofline"]["frac"], l["roofline"].get("traffic"), round(l.get("cold_start",{}).get("value",0)/1e6,1),
+    print(f, round(l["value"]/1e6,1), l["ms_per_step"], l["roofline"]["frac"], l["roofline"].get("traffic"), l.get("repetitions",{}).get("values"), round(l.get("preconditioned",{}).get("value",0)/1e6,1), l.get("vs_previous_round",{}).get("regressions"),
           {k: round(v["env_steps_per_s"]/1e6,1) for k,v in l["other_robots"].items()}, round(l["reset_done_heavy"]["env_steps_per_s"]/1e6,1),
           l["api_step_loop_env_steps_per_s"], l.get("closed_loop_policy_env_steps_per_s"), l.get("closed_loop_policy_wider_env_steps_per_s"),
           {k: l.get("cpu_baseline",{}).get(k) for k in ("value","cores","value_1thread","host")})
     mg = l.get("multi_gpu_rehearsal", {})
     print("  rehearsal:", {k: (mg[k]["ms_per_epoch"], mg[k]["model"]["at_310GBps"]["weak_scaling_efficiency"]) for k in ("expand_all","expand_local") if k in mg}, mg.get("one_gpu_own_sampler"))
 l = json.loads(open("gpurun_out/${tag}_rehearsal_2ranks_one_gpu_gloo.json").read().strip().splitlines()[-1])
-print("2 ranks / gloo / one GPU:", round(l["value"]/1e6,1), {k: round(v["value"]/1e6,1) for k,v in l["legs"].items() if isinstance(v, dict)}, round(l["stepping_only"]["value"]/1e6,1), round(l["cold_start"]["value"]/1e6,1))
+print("2 ranks / gloo / one GPU:", round(l["value"]/1e6,1), {k: round(v["value"]/1e6,1) for k,v in l["legs"].items() if isinstance(v, dict)}, round(l["stepping_only"]["value"]/1e6,1), round(l["preconditioned"]["value"]/1e6,1))
 PY
 fi

@@ -10,7 +10,7 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROFILES = os.path.join(ROOT, "profiles")
-TAG = "r04"
+TAG = "r05"
 
 
 def path(name):
@@ -95,7 +95,205 @@ def epoch_valu_instructions():
     return sum(v for k, v in s.items() if k.endswith("_valu")) + r["dyn_valu"] + r["obs_valu"]
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# profiles/README.md: the round's table is GENERATED from the files (python tools/profile_evidence.py --readme), and
+# tests/test_profiles_evidence.py fails when the committed text differs from what the files say.
+# ---------------------------------------------------------------------------------------------------------------------
+README = os.path.join(PROFILES, "README.md")
+BEGIN, END = f"<!-- BEGIN GENERATED {TAG} (tools/profile_evidence.py --readme) -->", f"<!-- END GENERATED {TAG} -->"
+
+
+def _have(name):
+    return os.path.exists(path(name))
+
+
+def _json_line(name):
+    import json
+    with open(path(name)) as f:
+        return json.loads([ln for ln in f if ln.startswith("{")][-1])
+
+
+def _kt(csv_name, substr):
+    try:
+        return f"{kernel_avg_us(csv_name, substr)[0]:.1f}"
+    except (OSError, KeyError):
+        return "n/a"
+
+
+def _pmc(csv_name, substr, counter, scale=1.0, fmt="{:.1f}"):
+    try:
+        return fmt.format(pmc_mean(csv_name, substr, counter) * scale)
+    except (OSError, KeyError):
+        return "n/a"
+
+
+def _M(x):
+    return f"{x / 1e6:.1f} M"
+
+
+def readme_rows():
+    """[(files, command, what it shows)] for every evidence file of TAG that exists; every number is read from the file"""
+    rows = []
+    bid, comp = build_id()
+    if bid:
+        rows.append((f"`{TAG}_build_id.txt`", "`gx_build_id()` / `gx_build_compiler()` of the library the profiles were taken on",
+                     f"build `{bid}` ({comp.split(';')[0]}); must equal the tree's build (`tests/test_profiles_evidence.py`)"))
+    pre = "rollout_N2000_T200"
+    if _have(f"{pre}_kernel_stats.csv"):
+        r = rollout_numbers()
+        tot = r["dyn_bytes"] + r["obs_bytes"]
+        algo = 372 * 2000 * 200
+        rows.append((f"`{TAG}_{pre}_kernel_stats.csv`, `..._pmc_{{FETCH_SIZE,WRITE_SIZE,SQ}}.csv`",
+                     "`rocprofv3 --kernel-trace --stats` / `--pmc ...` `-- python3 tools/profile_step.py --mode rollout --env-num 2000 "
+                     "--launches 200 --repeat 20`",
+                     f"one `gx_rollout` call standalone: `dyn_tape_kernel` {r['dyn_us']:.1f} us ({r['dyn_waves']:.0f} waves, "
+                     f"{r['dyn_valu'] / r['dyn_waves'] / 200:.0f} VALU + {r['dyn_salu'] / r['dyn_waves'] / 200:.0f} SALU per step) + "
+                     f"`obs_tape_kernel` {r['obs_us']:.1f} us; PMC traffic 2 x FETCH + WRITE: dynamics pass "
+                     f"{r['dyn_bytes'] / 1e6:.1f} MB, observation pass {r['obs_bytes'] / 1e6:.1f} MB = {tot / 1e6:.1f} MB against "
+                     f"{algo / 1e6:.1f} MB algorithmic ({tot / algo:.2f}); `roofline.frac` from these two durations = "
+                     f"{algo / ((r['dyn_us'] + r['obs_us']) * 1e-6) / 8e12:.3f}"))
+    if _have("step_N4194304_kernel_stats.csv"):
+        st = step_large_numbers()
+        rows.append((f"`{TAG}_step_N4194304_*`, `{TAG}_thread_rollout_N4194304_K16_pmc_*`",
+                     "`... --mode step --env-num 4194304 --launches 20` / `--mode rollout --env-num 4194304 --launches 16`",
+                     f"bandwidth regime: `step_kernel` {st['us']:.1f} us under the profiler, {st['bytes_per_env']:.2f} B per env-step "
+                     f"(PMC) against 372 algorithmic = {372 * (1 << 22) / (st['us'] * 1e-6) / 8e12:.3f} of peak"))
+    parts = []
+    for rb, kern in (("swimmer", "dyn_tape_kernel"), ("ant", "group_dyn_tape_kernel"), ("walker", "group_dyn_tape_kernel")):
+        f = f"{rb}_rollout_N2000_T200_kernel_stats.csv"
+        if _have(f):
+            sq = f"{rb}_rollout_N2000_T200_pmc_SQ.csv"
+            parts.append(f"{rb.capitalize()} dynamics pass {_kt(f, kern)} us + observation pass {_kt(f, 'obs_tape_kernel')} us per 200 "
+                         f"steps ({_pmc(sq, kern, 'SQ_WAVES', 1, '{:.0f}')} waves, "
+                         f"{_pmc(sq, kern, 'SQ_INSTS_VALU', 1e-6)} M VALU wave-instructions)")
+    if parts:
+        rows.append((f"`{TAG}_{{swimmer,ant,walker}}_rollout_N2000_T200_{{kernel_stats,pmc_SQ}}.csv`",
+                     "`... --robot xmls/<robot>.xml --repeat 10`", "; ".join(parts)))
+    for name, task in (("sampler", "the reference's arena"), ("sampler_config5", "the synthetic config 5 (18 objects, 6 m)")):
+        f = f"{name}_kernel_stats.csv"
+        if _have(f):
+            ph = [(k, _kt(f, k)) for k in ("sample_phase0_kernel", "sample_phase1_kernel", "sample_phase2_kernel", "scan_compact_kernel")]
+            valu = [_pmc(f"{name}_pmc_SQ.csv", k, "SQ_INSTS_VALU", 1e-6) for k, _ in ph[:3]]
+            rows.append((f"`{TAG}_{name}_kernel_stats.csv`, `{TAG}_{name}_pmc_SQ.csv`",
+                         "`... -- python3 tools/profile_reset.py`" + (" `--task Ant_8Hazards_8Pillars_synthetic`" if "config5" in name else ""),
+                         f"inline `reset()`, {task}: phases 0 / 1 / 2 / compaction {' / '.join(u for _, u in ph)} us "
+                         f"(n/a = the form without that phase), {' / '.join(valu)} M VALU wave-instructions"))
+    if _have("bench_noextras_kernel_stats.csv"):
+        f = "bench_noextras_kernel_stats.csv"
+        rows.append((f"`{TAG}_{f}`", "`... -- python3 bench.py --no-cpu-baseline --no-extras`",
+                     f"the headline run under the profiler, per epoch: `sample_phase0/1/2` {_kt(f, 'sample_phase0')} / "
+                     f"{_kt(f, 'sample_phase1')} / {_kt(f, 'sample_phase2')} us on the side stream; `reset_apply` {_kt(f, 'reset_apply')}, "
+                     f"`dyn_tape` {_kt(f, 'dyn_tape_kernel')}, `obs_tape` {_kt(f, 'obs_tape_kernel')} us on the caller's stream beside them"))
+    if _have("policy_widths_kernel_stats.csv"):
+        f = "policy_widths_kernel_stats.csv"
+        rows.append((f"`{TAG}_{f}`", "`... -- python3 tools/bench_policy_widths.py`",
+                     f"closed-loop policy rollout by width: the fused kernels (one launch per 200 steps) `group_rollout_kernel<.., 2>` "
+                     f"(64) {_kt(f, 'ELi2EEE')} us, `<.., 3>` (128, weights in registers) {_kt(f, 'ELi3EEE')} us; step-wise "
+                     f"`policy_step_mfma_kernel<192 / 256>` {_kt(f, 'policy_step_mfma_kernelILi192')} / "
+                     f"{_kt(f, 'policy_step_mfma_kernelILi256')} us per control step"))
+    for name, cmd in (("bench_driver_style.json", "`python bench.py --steps 20 --warmup 5`"), ("bench_full.json", "`python bench.py`")):
+        if _have(name):
+            l = _json_line(name)
+            oth = l.get("other_robots", {})
+            reps = l.get("repetitions", {})
+            api = l.get("api_step_loop_env_steps_per_s", {})
+            wide = l.get("closed_loop_policy_wider_env_steps_per_s", {})
+            mg = l.get("multi_gpu_rehearsal", {})
+            txt = (f"`value` {_M(l['value'])} env-steps/s = the median of {reps.get('n')} un-preconditioned repetitions "
+                   f"(min {_M(reps.get('min', 0))}, max {_M(reps.get('max', 0))}, first {_M(reps.get('first', 0))}); "
+                   f"`preconditioned` {_M(l.get('preconditioned', {}).get('value', 0))}; `roofline.frac` {l['roofline'].get('frac')}; "
+                   f"other robots " + " / ".join(_M(v['env_steps_per_s']) for v in oth.values() if isinstance(v, dict)) +
+                   f"; api loop {_M(api.get('value', 0))} (ring of 8: {_M(api.get('out_ring_8', {}).get('value', 0))}); closed loop "
+                   f"{_M(l.get('closed_loop_policy_env_steps_per_s', 0))} (hidden 128 / 256: "
+                   f"{_M(wide.get('hidden_128', 0))} / {_M(wide.get('hidden_256', 0))}); rank rehearsal at W = 8: "
+                   f"{mg.get('expand_all', {}).get('ms_per_epoch')} ms per epoch; `vs_previous_round.regressions` = "
+                   f"{l.get('vs_previous_round', {}).get('regressions')}; `cpu_baseline` "
+                   f"{l.get('cpu_baseline', {}).get('value')} env-steps/s on {l.get('cpu_baseline', {}).get('cores')} cores")
+            rows.append((f"`{TAG}_{name}`", cmd, txt))
+    for name, lbl in (("rehearsal_rank0_of_8.json", "Point"), ("rehearsal_rank0_of_8_ant.json", "Ant")):
+        if _have(name):
+            import json
+            d = json.load(open(path(name)))
+            m = d["expand_all"]["model"]
+            rows.append((f"`{TAG}_{name}`", f"`python tools/rehearse_rank.py --world 8 --epochs 30" +
+                         (" --robot xmls/ant.xml" if lbl == "Ant" else "") + " --json ...`",
+                         f"one GPU playing rank 0 of 8, {lbl}: {d['expand_all']['ms_per_epoch']} ms per rank epoch (`expand=\"local\"`: "
+                         f"{d['expand_local']['ms_per_epoch']}) against {d['one_gpu_own_sampler']['ms_per_epoch']} ms on one GPU; "
+                         f"{d['expand_all']['bytes_received_per_epoch'] / 1e6:.1f} MB received per epoch: link-bound below "
+                         f"{m.get('link_bound_below_GBps')} GB/s, break-even with one GPU at {m.get('break_even_GBps')} GB/s (model, not a "
+                         f"measurement of the link)"))
+    if _have("rccl_one_rank_report.json"):
+        import json
+        d = json.load(open(path("rccl_one_rank_report.json")))
+        th = d.get("tape_handoff", {})
+        rows.append((f"`{TAG}_rccl_one_rank_report.json`, `{TAG}_rccl_one_rank_nccl.log`",
+                     "`pytest tests/test_rccl_one_rank.py` (child: `tests/rccl_one_rank_child.py`, `GX_FORCE_DIST=1`, `NCCL_DEBUG=INFO`)",
+                     f"the N > 1 path over a real one-rank RCCL {d.get('nccl_version')} group: {len(d.get('calls', []))} kinds of calls ran "
+                     f"(init, barrier, all_reduce, async all_gather_into_tensor on device receive rings, ShardedReset, destroy); "
+                     f"TapeHandoff {th.get('epochs')} epochs, {th.get('blocks_installed')} shard blocks installed, rows bit-equal to the "
+                     f"packed rollout and to the CPU checker"))
+    if _have("bench_force_dist_one_rank.json"):
+        l = _json_line("bench_force_dist_one_rank.json")
+        rows.append((f"`{TAG}_bench_force_dist_one_rank.json`", "`GX_FORCE_DIST=1 python bench.py --gpus 1 --steps 4 --warmup 2 --no-extras`",
+                     f"the N > 1 bench path over a one-rank `{l.get('forced_dist', {}).get('backend')}` group (a code-path run, not a "
+                     f"rate): all legs present -- `value` {_M(l['value'])}, stepping_only {_M(l['stepping_only']['value'])}, "
+                     f"unsharded_sampler {_M(l['legs']['unsharded_sampler']['value'])}, local_expand {_M(l['legs']['local_expand']['value'])}"))
+    if _have("gputest_final.log"):
+        last = [ln.strip() for ln in open(path("gputest_final.log")) if " passed" in ln or " failed" in ln]
+        rows.append((f"`{TAG}_gputest_final.log`", "`python -m pytest tests -m gpu -q`", last[-1] if last else "(no summary line)"))
+    soaks = []
+    for rb in ("point", "swimmer", "ant", "walker"):
+        for kind in ("soak", "soak_variants"):
+            f = f"{kind}_{rb}.log"
+            if _have(f):
+                lines = [ln.strip() for ln in open(path(f)) if ln.strip()]
+                soaks.append(f"{kind} {rb}: {lines[-1][:110] if lines else 'empty'}")
+    if soaks:
+        rows.append((f"`{TAG}_soak_{{point,swimmer,ant,walker}}.log`, `{TAG}_soak_variants_*.log`",
+                     "`python tests/soak_parity.py <robot> 300000 4096 400`, `python tests/soak_variants.py <robot> 2`",
+                     "HIP vs CPU restatement on the final build -- last line of each log: " + " | ".join(soaks)))
+    import glob
+    ab = sorted(os.path.basename(f) for f in glob.glob(path("ab_*.log")))
+    if ab:
+        rows.append((", ".join(f"`{f}`" for f in ab), "`tools/ab/*.sh` (same-box A/B runs of library variants / trees: `tools/build_variant.py`, `tools/ab_epoch.py`)",
+                     "the in-epoch A/B logs behind this round's decisions (DESIGN.md section 5): the Swimmer regression bisected to the "
+                     "capped observation grid, `reset_apply` at priority, the sampler's fused form, the hand-off stream"))
+    if _have("rcp_exact_probe.log"):
+        first = [ln.strip() for ln in open(path("rcp_exact_probe.log")) if ln.startswith("A ")]
+        rows.append((f"`{TAG}_rcp_exact_probe.log`", "`tools/probes/rcp_exact_probe` (all 2^32 inputs)", first[0] if first else ""))
+    return rows
+
+
+def readme_block():
+    lines = [BEGIN, "", "| file | command | what it shows |", "|---|---|---|"]
+    for files, cmd, what in readme_rows():
+        lines.append(f"| {files} | {cmd} | {what} |")
+    lines += ["", END]
+    return "\n".join(lines)
+
+
+def write_readme():
+    text = open(README).read()
+    block = readme_block()
+    if BEGIN in text and END in text:
+        a, b = text.index(BEGIN), text.index(END) + len(END)
+        text = text[:a] + block + text[b:]
+    else:
+        marker = "## Round 4"
+        head = f"## Round {int(TAG[1:])}\n\nEvery number in this table is read from the files by `tools/profile_evidence.py --readme`; " \
+               f"`tests/test_profiles_evidence.py` fails when this text and the files disagree.\n\n"
+        a = text.index(marker)
+        text = text[:a] + head + block + "\n\n" + text[a:]
+    with open(README, "w") as f:
+        f.write(text)
+
+
 if __name__ == "__main__":
+    import sys
+    if "--readme" in sys.argv:
+        write_readme()
+        print(readme_block())
+        sys.exit(0)
     import json
     print(json.dumps(dict(build=build_id(), rollout=rollout_numbers(), step_large=step_large_numbers(),
                           sampler=sampler_numbers(), epoch_valu=epoch_valu_instructions()), indent=1))
