@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -64,7 +65,6 @@ struct gx_engine {
     int cur;                 // pool the envs are drawn from
     hipStream_t side[kPools]; // prefetch samplers: pool i is sampled on side[i % n_side]
     int n_side;
-    hipStream_t aux = nullptr; // gx_aux_stream: a least-priority stream for the caller's throughput work beside the stepping
     hipEvent_t pool_ready[kPools]; // recorded on the sampling stream when pool i is complete
     hipEvent_t pool_free[kPools];  // recorded on the caller's stream when pool i is no longer read
     hipEvent_t expand_ev[kPools];  // recorded behind the last gx_expand_tape that read pool i
@@ -494,7 +494,6 @@ extern "C" gx_status gx_destroy(gx_engine* e)
     }
     for (int i = 0; i < gx_engine::kPools; ++i)
         if (e->side[i]) (void)hipStreamDestroy(e->side[i]);
-    if (e->aux) (void)hipStreamDestroy(e->aux);
     for (int i = 0; i < gx_engine::kKeyRing; ++i) {
         if (e->h_keys[i]) (void)hipHostFree(e->h_keys[i]);
         if (e->keys_ev[i]) (void)hipEventDestroy(e->keys_ev[i]);
@@ -832,23 +831,27 @@ extern "C" gx_status gx_install_shards(gx_engine* e, int64_t ticket, const float
     return GX_OK;
 }
 
-// A stream of the engine's device at the LEAST priority, owned by the engine (destroyed with it), for throughput work the
-// caller runs beside the stepping -- the tape hand-off's installs and expansions (guardx_amd/dist.py).  HIP multiplexes a
-// process's streams onto a few hardware queues PER PRIORITY LEVEL: a stream of another priority than the caller's can
-// never share a hardware queue with it, so the serial chain of the epoch (reset -> dynamics pass, on the caller's
-// stream) is never queued behind an expansion, however many streams the process has created (measured, round 5: one GPU
-// playing rank 0 of 8 took 0.70 ms per epoch with the expansion on a normal-priority stream that happened to share the
-// caller's queue, 0.46 ms in processes where it did not).
+// A stream of the engine's device at the LEAST priority, for throughput work the caller runs beside the stepping -- the
+// tape hand-off's installs and expansions (guardx_amd/dist.py).  HIP multiplexes a process's streams onto a few hardware
+// queues PER PRIORITY LEVEL: a stream of another priority than the caller's never shares a hardware queue with it, so the
+// serial chain of the epoch (reset -> dynamics pass, on the caller's stream) cannot be queued behind an expansion, however
+// many streams the process has created.  ONE per device and process, created on first use and never destroyed: the
+// caller's framework may keep per-stream state (torch's caching allocators do, for every stream memory was allocated or
+// copied on) that outlives any engine -- a stream that died with an engine crashed the interpreter at exit (round 5).
 extern "C" gx_status gx_aux_stream(gx_engine* e, void** stream)
 {
     if (!e || !stream) return fail(GX_ERR_ARG, "gx_aux_stream: null argument");
-    if (!e->aux) {
+    static std::mutex mu;
+    static hipStream_t per_device[64] = {};
+    if (e->device < 0 || e->device >= 64) return fail(GX_ERR_ARG, "gx_aux_stream: device index out of range");
+    std::lock_guard<std::mutex> lock(mu);
+    if (!per_device[e->device]) {
         DeviceGuard guard(e->device);
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi); // lo = least urgent
-        GX_HIP(hipStreamCreateWithPriority(&e->aux, hipStreamNonBlocking, lo));
+        GX_HIP(hipStreamCreateWithPriority(&per_device[e->device], hipStreamNonBlocking, lo));
     }
-    *stream = (void*)e->aux;
+    *stream = (void*)per_device[e->device];
     return GX_OK;
 }
 

@@ -90,7 +90,14 @@ struct AntGroup {
         M.A.J[4] = islim ? ((r == 1) ? lsg : 0.0f) : pj[4];
         M.A.aref = islim ? laref : paref;
         M.A.D = islim ? lD : foot_D;
+#ifdef GX_PROTO_ONE_ROW_PER_LANE
+        // COUNTING PROTOTYPE, never shipped (tools/ab/proto_one_row.sh): what would the Newton loop cost if a lane owned ONE
+        // row (the 32-lanes-per-env form)?  Row B is compiled out here -- wrong physics, right instruction count for the
+        // per-lane row work; the extra butterfly stage such a form needs is not included (it only adds).
+        M.B.present = false;
+#else
         M.B.present = islim && (foot_on != 0);
+#endif
 #pragma unroll
         for (int k = 0; k < 5; ++k) M.B.J[k] = pj[k];
         M.B.aref = paref;
@@ -110,7 +117,9 @@ struct AntGroup {
     {
         uint32_t m = 0;
         if (M.A.present && (dot5(M.A.J, ab, ah, abt) - M.A.aref < 0.0f)) m |= 1u << r;
+#ifndef GX_PROTO_ONE_ROW_PER_LANE
         if (M.B.present && (dot5(M.B.J, ab, ah, abt) - M.B.aref < 0.0f)) m |= 1u << (r + 4);
+#endif
         return quads_or(m);
     }
     GX_D static uint32_t gather_mask(uint32_t own)
@@ -292,7 +301,11 @@ struct AntGroup {
             uint32_t act = gather_mask(active_leg(MR, rq, ab, ah, abt));
             for (int it = 0; it < A::kIters; ++it) {
                 const uint32_t own = (act >> (6 * L)) & 63u;
+#ifdef GX_PROTO_ONE_ROW_PER_LANE
+                const bool onA = (own >> rq) & 1u, onB = false;
+#else
                 const bool onA = (own >> rq) & 1u, onB = (own >> (rq + 4)) & 1u; // (bit r + 4 is never set for r >= 2)
+#endif
                 // this lane's rows' products (+0 for a row outside the active set), in the order of AntRobot::newton_solve
                 const float DA = onA ? RA.D : 0.0f, DB = onB ? RB.D : 0.0f;
                 const float daA = DA * RA.aref, daB = DB * RB.aref;
@@ -332,7 +345,9 @@ struct AntGroup {
             float fA = 0.0f, fB = 0.0f;
             bool vA = false, vB = false;
             if (RA.present) { const float res = dot5(RA.J, ab, ah, abt) - RA.aref; if (res < 0.0f) { vA = true; fA = RA.D * (-res); } }
+#ifndef GX_PROTO_ONE_ROW_PER_LANE
             if (RB.present) { const float res = dot5(RB.J, ab, ah, abt) - RB.aref; if (res < 0.0f) { vB = true; fB = RB.D * (-res); } }
+#endif
             float Pf[3];
 #pragma unroll
             for (int b = 0; b < 3; ++b) Pf[b] = rows_sum(vA ? fA * RA.J[b] : -0.0f, vB ? fB * RB.J[b] : -0.0f);

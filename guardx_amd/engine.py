@@ -741,9 +741,9 @@ class Engine:
         return int(ticket.value)
 
     def aux_stream(self):
-        """A least-priority stream owned by the engine, as a torch stream (valid until close()): for throughput work beside
-        the stepping -- the hand-off's installs and expansions.  Streams of another priority than the caller's never share
-        a hardware queue with it (gx_aux_stream)."""
+        """The device's least-priority stream (one per device and process, never destroyed), as a torch stream: for throughput
+        work beside the stepping -- the hand-off's installs and expansions.  Streams of another priority than the caller's
+        never share a hardware queue with it (gx_aux_stream)."""
         if getattr(self, "_aux", None) is None:
             ptr = C.c_void_p()
             _native.check(self._lib.gx_aux_stream(self._h, C.byref(ptr)))
@@ -832,8 +832,9 @@ class Engine:
         return out
 
     def set_policy_impl(self, impl):
-        """rollout_policy hidden layers at width 64: 0 auto, 1 VALU fmaf chains, 2 fp32 MFMA tiles, 3 the step-wise form
-        the wider networks use (same bits)."""
+        """rollout_policy's form: 0 auto (one fused launch where there is one: every width on Point / Swimmer at the
+        default observation width, width 64 everywhere), 1 VALU fmaf chains, 2 fp32 MFMA tiles (width 64: fused; wider:
+        step-wise), 3 the step-wise form at every width (two launches per control step).  Same bits whichever runs."""
         _native.check(self._lib.gx_set_policy_impl(self._h, int(impl)))
 
     def set_prefetch(self, steps):
@@ -920,9 +921,8 @@ class Engine:
 
     def close(self):
         if getattr(self, '_h', None):
-            self._lib.gx_destroy(self._h)       # (synchronises the device; the aux stream dies with the engine)
+            self._lib.gx_destroy(self._h)       # (synchronises the device)
             self._h = None
-            self._aux = None
 
     def __del__(self):
         try:

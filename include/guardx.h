@@ -247,9 +247,10 @@ gx_status gx_reset_from_shards(gx_engine* e, const float* d_rows_all, const int3
  *                           remembers its last four; GX_ERR_STATE otherwise).  A block of another key, shard or world
  *                           size, or count > cap, leaves layout_size < 0: the reset that takes the pool fails its
  *                           layout check (engine.py:444) instead of using it. */
-/* A least-priority stream of the engine's device, owned by the engine (valid until gx_destroy), for throughput work the
- * caller runs beside the stepping: the hand-off's gx_install_shards / gx_expand_tapes.  Streams of different priority
- * never share a hardware queue, so work on it cannot be queued in front of the caller's reset -> dynamics chain. */
+/* A least-priority stream of the engine's device -- one per device and process, created on first use, never destroyed
+ * (valid for the life of the process) -- for throughput work the caller runs beside the stepping: the hand-off's
+ * gx_install_shards / gx_expand_tapes.  Streams of different priority never share a hardware queue, so work on it cannot
+ * be queued in front of the caller's reset -> dynamics chain. */
 gx_status gx_aux_stream(gx_engine* e, void** stream);
 gx_status gx_set_layout_source(gx_engine* e, int32_t source);
 gx_status gx_shard_block_floats(const gx_engine* e, int32_t cap, int64_t* floats);
@@ -270,9 +271,12 @@ gx_status gx_install_shards(gx_engine* e, int64_t ticket, const float* d_blocks,
  * d_obs_last[N][D], d_val_last[N] = o_T and V(o_T) for the bootstrap; d_logstd[A] = log(std). */
 typedef struct gx_policy {
     int32_t struct_size;   /* sizeof(gx_policy) */
-    int32_t hidden;        /* 64 (the reference default, trpo.py:606 --hid): one fused launch; 128, 192, 256: the weights
-                            * do not fit the fused kernel's LDS -- two launches per control step (policy over all envs,
-                            * then the fused step + reset_done), same arithmetic, same results as the checker */
+    int32_t hidden;        /* 64 (the reference default, trpo.py:606 --hid), 128, 192, 256.  One fused launch per call for
+                            * the light robots (Point, Swimmer) at their default observation width: 64 with the networks in
+                            * LDS, 128 with the hidden layers resident in registers as MFMA operands, 192 / 256 with them
+                            * streamed from an L2-resident transposed copy.  Otherwise (Ant, Walker, other observation widths,
+                            * gx_set_policy_impl 1 | 2 | 3) two launches per control step: policy over all envs, then the
+                            * fused step + reset_done.  Same arithmetic, same results as the checker, whichever runs. */
     const float* d_params; /* device pointer, layout above */
     uint32_t seed[2];
 } gx_policy;

@@ -18,6 +18,7 @@ ap.add_argument("--lib", default=os.path.join(os.path.dirname(os.path.dirname(os
                                               "libguardx_hip.so"))
 ap.add_argument("--dump")
 ap.add_argument("--all", action="store_true", help="every match (default: the first)")
+ap.add_argument("--loops", action="store_true", help="also list every loop (backward branch) of 100+ instructions with its size and VALU count")
 args = ap.parse_args()
 objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 pats = args.pattern.split("&")
@@ -51,6 +52,20 @@ with tempfile.TemporaryDirectory() as tmp:
                         if tgt < a and (best is None or a - tgt > best[1] - best[0]):
                             best = (tgt, a)
             print(n[:150])
+            if args.loops:
+                seen = set()
+                for a, op, ln in ins:
+                    if op.startswith("s_cbranch") or op == "s_branch":
+                        m = re.search(r"<[^>]*\+0x([0-9a-f]+)>", ln)
+                        if m:
+                            tgt = ins[0][0] + int(m.group(1), 16)
+                            body = [x for x in ins if tgt <= x[0] <= a]
+                            if tgt < a and len(body) >= 100 and (tgt) not in seen:
+                                seen.add(tgt)
+                                nv = sum(1 for x in body if x[1].startswith("v_"))
+                                nd = sum(1 for x in body if "dpp" in x[2] or "row_" in x[2] or "quad_perm" in x[2])
+                                print(f"  loop of {len(body)} instructions: {nv} VALU, of them {nd} DPP, "
+                                      f"{sum(1 for x in body if x[1].startswith('v_rcp'))} divisions")
             for label, sel in (("kernel", ins), ("largest loop", [x for x in ins if best and best[0] <= x[0] <= best[1]])):
                 c = collections.Counter()
                 for a, op, ln in sel:
