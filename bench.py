@@ -477,6 +477,9 @@ def closed_loop_rate(device, epochs=50, hidden=64):
     return ENV_NUM * EP_LEN * epochs / dt
 
 
+OTHER_WARMUP = 30   # untimed warm-up epochs per task in other_robots (17 ms for the Swimmer, 75 ms for the Walker)
+
+
 def other_robots(device, epochs=50):
     """the same epoch (reset + one 200-step rollout, env_num=2000) for the articulated robots: BASELINE config 3
     (Goal_Swimmer_8Hazards), Goal_Ant_8Hazards / Goal_Walker_8Hazards (contact + joint-limit solver), and BASELINE
@@ -497,7 +500,8 @@ def other_robots(device, epochs=50):
         def epoch():
             env.reset(check=False)
             env.rollout(tape)
-        epoch(); epoch()
+        for _ in range(OTHER_WARMUP):    # the process is fresh: the first ~15 ms of any load sit in the firmware's clock ramp
+            epoch()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(epochs):
@@ -521,7 +525,8 @@ def other_robots(device, epochs=50):
             def epoch_p():
                 env.reset(check=False)
                 h.step(tape)
-            epoch_p(); epoch_p()
+            for _ in range(4):
+                epoch_p()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(epochs):
@@ -710,6 +715,9 @@ def _comparable_values(line):
     return out
 
 
+HOST_BOUND_THRESHOLD = -0.10
+
+
 def vs_previous_round(line, threshold=-0.02):
     """every compared rate of this line beside the previous round's, and the list of those more than 2 % below it"""
     rnd, prev = previous_round_values()
@@ -731,9 +739,14 @@ def vs_previous_round(line, threshold=-0.02):
         p, src = prev[key]
         rel = val / p - 1.0
         rows[key] = {"now": round(val, 1), "previous": round(p, 1), "change": round(rel, 4), "source": src}
+        # the Python-driven loop is host-bound (one hipLaunchKernel per step): on one box, same library, consecutive medians
+        # of it differ by +-10 % (tools/ab_api.py, profiles/r05_ab_api.log) -- its bar is -10 %, and the row says so
+        thr = HOST_BOUND_THRESHOLD if key.startswith("api_step_loop") else threshold
+        if thr != threshold:
+            rows[key]["threshold"] = thr
         if key in unlike:
             rows[key]["like_for_like"] = False
-        elif rel < threshold:
+        elif rel < thr:
             regress.append(key)
     out = {"previous": rnd, "values": rows, "regressions": regress, "threshold": threshold}
     if unlike:

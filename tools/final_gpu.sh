@@ -27,7 +27,7 @@ import json
 for f in ("gpurun_out/${tag}_bench_driver_style.json", "gpurun_out/${tag}_bench_full.json"):
     l = json.loads(open(f).read().strip().splitlines()[-1])
     print(f, round(l["value"]/1e6,1), l["ms_per_step"], l["roofline"]["frac"], l["roofline"].get("traffic"), l.get("repetitions",{}).get("values"), round(l.get("preconditioned",{}).get("value",0)/1e6,1), l.get("vs_previous_round",{}).get("regressions"),
-          {k: round(v["env_steps_per_s"]/1e6,1) for k,v in l["other_robots"].items()}, round(l["reset_done_heavy"]["env_steps_per_s"]/1e6,1),
+          {k: round(v["env_steps_per_s"]/1e6,1) for k,v in l["other_robots"].items() if isinstance(v, dict)}, round(l["reset_done_heavy"]["env_steps_per_s"]/1e6,1),
           l["api_step_loop_env_steps_per_s"], l.get("closed_loop_policy_env_steps_per_s"), l.get("closed_loop_policy_wider_env_steps_per_s"),
           {k: l.get("cpu_baseline",{}).get(k) for k in ("value","cores","value_1thread","host")})
     mg = l.get("multi_gpu_rehearsal", {})
