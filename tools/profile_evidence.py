@@ -188,9 +188,8 @@ def readme_rows():
         f = "policy_widths_kernel_stats.csv"
         rows.append((f"`{TAG}_{f}`", "`... -- python3 tools/bench_policy_widths.py`",
                      f"closed-loop policy rollout by width: the fused kernels (one launch per 200 steps) `group_rollout_kernel<.., 2>` "
-                     f"(64) {_kt(f, 'ELi2EEE')} us, `<.., 3>` (128, weights in registers) {_kt(f, 'ELi3EEE')} us; step-wise "
-                     f"`policy_step_mfma_kernel<192 / 256>` {_kt(f, 'policy_step_mfma_kernelILi192')} / "
-                     f"{_kt(f, 'policy_step_mfma_kernelILi256')} us per control step"))
+                     f"(64, weights in LDS) {_kt(f, ', true, 2>(')} us, `<.., 3>` (128, weights in registers) {_kt(f, ', true, 3>(')} us, "
+                     f"`<.., 192>` / `<.., 256>` (weights streamed from L2) {_kt(f, ', true, 192>(')} / {_kt(f, ', true, 256>(')} us"))
     for name, cmd in (("bench_driver_style.json", "`python bench.py --steps 20 --warmup 5`"), ("bench_full.json", "`python bench.py`")):
         if _have(name):
             l = _json_line(name)
@@ -251,7 +250,7 @@ def readme_rows():
     if soaks:
         rows.append((f"`{TAG}_soak_{{point,swimmer,ant,walker}}.log`, `{TAG}_soak_variants_*.log`",
                      "`python tests/soak_parity.py <robot> 300000 4096 400`, `python tests/soak_variants.py <robot> 2`",
-                     "HIP vs CPU restatement on the final build -- last line of each log: " + " | ".join(soaks)))
+                     "HIP vs CPU restatement on the final build -- last line of each log: " + "; ".join(soaks)))
     import glob
     ab = sorted(os.path.basename(f) for f in glob.glob(path("ab_*.log")))
     if ab:
