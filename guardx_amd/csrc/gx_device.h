@@ -164,14 +164,35 @@ GX_D float log_f(float x)
     return fmaf(fe, 0.6931471824645996f, fmaf(fe, -1.9046542121259336e-09f, lnm));
 }
 
-// tanh through exp: sign(x) * (1 - 2 / (exp(2|x|) + 1)), saturating at |x| > 9
+// tanh through exp: sign(x) * (1 - 2 / (exp(2|x|) + 1)), saturating at |x| > 9.
+// The same values as the plain form (the CPU checker's), with two things taken off the policy kernels' chains (64 tanh per
+// lane and control step at hidden width 256):
+//  * exp_f's guards: the argument is in [0, 18], never NaN, never beyond +-87;
+//  * the IEEE division: d = exp(2|x|) + 1 lies in [2, 6.6e7], and for EVERY float d with 2^-126 <= |d| < 2^126 the short
+//    sequence y0 = v_rcp_f32(d), y1 = fma(fma(-d, y0, 1), y0, y0) is the correctly rounded 1 / d (all 2^32 inputs against
+//    the compiler's IEEE sequence, tools/probes/rcp_exact_probe.hip, profiles/r05_rcp_exact_probe.log); 2 / d = 2 * (1 / d)
+//    exactly (a power of two commutes with rounding away from the subnormals), so fl(1 - 2 / d) = fma(-2, y1, 1).
+// 3 + 1 instructions instead of the 11-instruction division and a subtraction.
 GX_D float tanh_f(float x)
 {
-    if (x != x) return x;
     const float ax = fabsf(x);
-    float t = 1.0f;
-    if (ax <= 9.0f) t = 1.0f - 2.0f / (exp_f(2.0f * ax) + 1.0f);
-    return (f2u(x) >> 31) ? -t : t;
+    const float a2 = ax > 9.0f ? 18.0f : 2.0f * ax;       // (keeps the core's argument in range on the lanes that saturate)
+    const float k = rintf(a2 * 1.4426950216293335f);      // exp_f's core, verbatim
+    float r = fmaf(-k, 0.6931471824645996f, a2);
+    r = fmaf(-k, -1.9046542121259336e-09f, r);
+    float q = fmaf(r, 0.001395172f, 0.008369599f);
+    q = fmaf(r, q, 0.041666187f);
+    q = fmaf(r, q, 0.16666512f);
+    q = fmaf(r, q, 0.5f);
+    const float e1 = 1.0f + fmaf(r * r, q, r);
+    const float ex = u2f(f2u(e1) + ((uint32_t)(int)k << 23));
+    const float d = ex + 1.0f;
+    const float y0 = __builtin_amdgcn_rcpf(d);
+    const float y1 = fmaf(fmaf(-d, y0, 1.0f), y0, y0);
+    float t = fmaf(-2.0f, y1, 1.0f);
+    if (!(ax <= 9.0f)) t = 1.0f;                           // saturated (and NaN, replaced below)
+    t = (f2u(x) >> 31) ? -t : t;
+    return x != x ? x : t;
 }
 
 // ---------------------------------------------------------------------------

@@ -10,6 +10,8 @@
 //   A: y0 = v_rcp_f32(x); e = fma(-x, y0, 1); y1 = fma(e, y0, y0); v_div_fixup(y1, x, 1)                  4 instructions
 //   B: A's y1, then e1 = fma(-x, y1, 1); y2 = fma(e1, y1, y1); fixup                                      6 instructions
 //   C: Markstein's final step on the numerator: q = y1; r = fma(-x, q, 1); q' = fma(r, y1, q); fixup       6 instructions
+//   D: A without the fixup (what tanh_f uses, gx_device.h: its divisor is in [2, 6.6e7])                                3 instructions
+//   E: 2 / x as 2 * D(x), compared with the IEEE quotient 2.0f / x (the numerator of tanh_f's division)
 // Reported per candidate: mismatches, and the binary exponents of x where they occur.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -44,6 +46,12 @@ __device__ __forceinline__ float rcp_C(float x)
     return __builtin_amdgcn_div_fixupf(q, x, 1.0f);
 }
 
+__device__ __forceinline__ float rcp_D(float x)
+{
+    const float y0 = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, y0, 1.0f), y0, y0);
+}
+
 __device__ __forceinline__ bool same(float a, float b)
 {
     if (a != a && b != b) return true;
@@ -58,12 +66,13 @@ __global__ void probe(unsigned long long* hist, uint32_t* example)
         const float x = __uint_as_float((uint32_t)b);
         const float ref = 1.0f / x;
         const int ex = (int)((b >> 23) & 255u);
-        const float c[3] = {rcp_A(x), rcp_B(x), rcp_C(x)};
+        const float c[5] = {rcp_A(x), rcp_B(x), rcp_C(x), rcp_D(x), 2.0f * rcp_D(x)};
+        const float refs[5] = {ref, ref, ref, ref, 2.0f / x};
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (!same(c[k], ref)) {
+        for (int k = 0; k < 5; ++k)
+            if (!same(c[k], refs[k])) {
                 const unsigned long long was = atomicAdd(&hist[k * 256 + ex], 1ull);
-                if (was == 0 && ex > 0 && ex < 255) { example[(k * 256 + ex) * 3] = (uint32_t)b; example[(k * 256 + ex) * 3 + 1] = __float_as_uint(c[k]); example[(k * 256 + ex) * 3 + 2] = __float_as_uint(ref); }
+                if (was == 0 && ex > 0 && ex < 255) { example[(k * 256 + ex) * 3] = (uint32_t)b; example[(k * 256 + ex) * 3 + 1] = __float_as_uint(c[k]); example[(k * 256 + ex) * 3 + 2] = __float_as_uint(refs[k]); }
             }
     }
 }
@@ -71,17 +80,18 @@ __global__ void probe(unsigned long long* hist, uint32_t* example)
 int main()
 {
     unsigned long long* d_hist; uint32_t* d_ex;
-    CK(hipMalloc(&d_hist, sizeof(unsigned long long) * 3 * 256));
-    CK(hipMalloc(&d_ex, sizeof(uint32_t) * 3 * 256 * 3));
-    CK(hipMemset(d_hist, 0, sizeof(unsigned long long) * 3 * 256));
-    CK(hipMemset(d_ex, 0, sizeof(uint32_t) * 3 * 256 * 3));
+    CK(hipMalloc(&d_hist, sizeof(unsigned long long) * 5 * 256));
+    CK(hipMalloc(&d_ex, sizeof(uint32_t) * 5 * 256 * 3));
+    CK(hipMemset(d_hist, 0, sizeof(unsigned long long) * 5 * 256));
+    CK(hipMemset(d_ex, 0, sizeof(uint32_t) * 5 * 256 * 3));
     hipLaunchKernelGGL(probe, dim3(8192), dim3(256), 0, 0, d_hist, d_ex);
     CK(hipDeviceSynchronize());
-    static unsigned long long h[3 * 256]; static uint32_t ex[3 * 256 * 3];
+    static unsigned long long h[5 * 256]; static uint32_t ex[5 * 256 * 3];
     CK(hipMemcpy(h, d_hist, sizeof h, hipMemcpyDeviceToHost));
     CK(hipMemcpy(ex, d_ex, sizeof ex, hipMemcpyDeviceToHost));
-    const char* names[3] = {"A rcp+1NR+fixup (4 instr)", "B rcp+2NR+fixup (6 instr)", "C rcp+NR+residual-correction+fixup (6 instr)"};
-    for (int k = 0; k < 3; ++k) {
+    const char* names[5] = {"A rcp+1NR+fixup (4 instr)", "B rcp+2NR+fixup (6 instr)", "C rcp+NR+residual-correction+fixup (6 instr)",
+                            "D rcp+1NR, no fixup (3 instr)", "E 2*D(x) vs 2.0f/x"};
+    for (int k = 0; k < 5; ++k) {
         unsigned long long tot = 0, normal = 0;
         int lo = 999, hi = -1;
         for (int e = 0; e < 256; ++e) {
