@@ -257,9 +257,13 @@ def readme_rows():
         rows.append((", ".join(f"`{f}`" for f in ab), "`tools/ab/*.sh` (same-box A/B runs of library variants / trees: `tools/build_variant.py`, `tools/ab_epoch.py`)",
                      "the in-epoch A/B logs behind this round's decisions (DESIGN.md section 5): the Swimmer regression bisected to the "
                      "capped observation grid, `reset_apply` at priority, the sampler's fused form, the hand-off stream"))
+    if _have("mfma_rate_probe.log"):
+        first = [ln.strip() for ln in open(path("mfma_rate_probe.log")) if ln.startswith("v_mfma")]
+        rows.append((f"`{TAG}_mfma_rate_probe.log`", "`tools/probes/mfma_rate_probe` (one wave per SIMD, independent accumulator chains)",
+                     first[0] if first else ""))
     if _have("rcp_exact_probe.log"):
-        first = [ln.strip() for ln in open(path("rcp_exact_probe.log")) if ln.startswith("A ")]
-        rows.append((f"`{TAG}_rcp_exact_probe.log`", "`tools/probes/rcp_exact_probe` (all 2^32 inputs)", first[0] if first else ""))
+        first = [ln.strip() for ln in open(path("rcp_exact_probe.log")) if ln.startswith(("A ", "D ", "E "))]
+        rows.append((f"`{TAG}_rcp_exact_probe.log`", "`tools/probes/rcp_exact_probe` (all 2^32 inputs)", "; ".join(first)))
     return rows
 
 
