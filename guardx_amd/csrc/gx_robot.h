@@ -45,6 +45,10 @@ struct PointRobotT {
     static constexpr float kH = 0.02f;
     static constexpr float kIo = 2.842182748581224e-05f; // inertia about the hinge axis (enters substep through kInvD3*)
     static constexpr int kDynLanes = 1; // lanes per env in the dynamics pass of the two-kernel rollout
+    // The observation pass of a ONE-shard rollout keeps its capped grid even beside the layout sampler: the Point's
+    // dynamics chain is short (~0.2 ms in the epoch), the sampler is the epoch's critical chain, and a pass that takes
+    // fewer issue slots from it wins (reset_done_heavy, same-box A/B: 746 M uncapped, 752 M capped = round 4's 753 M).
+    static constexpr bool kObsCapBesideSampler = true;
     // default Goal_Point_8Hazards observation: ctrl[0:3] compass[3:5] glidar[5:21] hlidar[21:37] qpos[37:40] qvel[40:43]
     static constexpr int kD = 43, kOffCtrl = 0, kOffComp = 3, kOffGl = 5, kOffHl = 21, kOffQpos = 37, kOffQvel = 40;
 

@@ -27,6 +27,7 @@
 // compass a sum of two products < 1e37), so that test decides almost every step; whenever it does not hold, pass 1
 // evaluates the observation exactly (build_obs_row into an LDS row) like the one-kernel paths.
 #pragma once
+#include <type_traits>
 
 namespace gx {
 
@@ -796,6 +797,10 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
 // the epoch's critical chain, 688 -> 720 M env-steps/s uncapped (this cap, introduced in round 4 after a standalone
 // A/B, was the Swimmer's round-3 -> round-4 regression, 706 -> 689 M on one box); Point 773 = 773, Ant 300 = 300.
 // (GX_OBS_GRID_CAP: experiments.)
+// (robots opt out of the uncapped form with `static constexpr bool kObsCapBesideSampler = true`: the Point)
+template <class R, class = void> struct ObsCapTrait { static constexpr bool value = false; };
+template <class R> struct ObsCapTrait<R, std::void_t<decltype(R::kObsCapBesideSampler)>> { static constexpr bool value = R::kObsCapBesideSampler; };
+template <class R> constexpr bool obs_cap_beside_sampler() { return ObsCapTrait<R>::value; }
 static unsigned obs_grid(size_t rows, int block, int n_shards, bool company)
 {
     static const int forced = [] { const char* e = getenv("GX_OBS_GRID_CAP"); return e ? atoi(e) : 0; }();
@@ -816,7 +821,7 @@ static hipError_t launch_split_p(const Params& p, const RolloutArgs& r, const Sp
     hipError_t st = hipSuccess; // of the wait that orders the observation pass behind the sampler: must not be dropped
     constexpr int B1 = 64, B2 = 64;
     const int lpe = (R::kDynLanes == 4 && sa.lanes == 4) ? 4 : 1;
-    const dim3 g1((p.N * lpe + B1 - 1) / B1), g2(obs_grid((size_t)r.T * p.N, B2, n_shards, sa.lanes != 4), n_shards);
+    const dim3 g1((p.N * lpe + B1 - 1) / B1), g2(obs_grid((size_t)r.T * p.N, B2, n_shards, sa.lanes != 4 && !obs_cap_beside_sampler<R>()), n_shards);
     const size_t lds1 = sizeof(float) * ((size_t)B1 * p.D + 2 * (size_t)kActBlock * B1 * R::NA); // obs rows + two action blocks
     const size_t lds2 = sizeof(float) * (size_t)B2 * (r.obs_stride | 1);
     const bool def = PMAX == 5 && is_default_layout<R>(p);
