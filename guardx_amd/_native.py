@@ -125,6 +125,9 @@ def load():
     if os.environ.get("GX_LIB") and os.environ.get("GX_LIB_EXPERIMENT") == "1":
         # A/B experiments only (tools/build_variant.py): a variant built from the SAME sources with other flags
         path = os.path.abspath(os.environ["GX_LIB"])
+        import warnings
+        warnings.warn(f"guardx_amd: loading the EXPERIMENTAL library {path} (GX_LIB + GX_LIB_EXPERIMENT=1); its build id is not "
+                      "checked against the tree", RuntimeWarning, stacklevel=3)
     lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the ABI drifted
