@@ -129,7 +129,8 @@ def test_policy_rollout_parity(oracle, robot, impl):
                                                ("swimmer", 128, "mfma"), ("point", 256, "mfma"), ("point", 256, "stepwise"),
                                                ("swimmer", 192, "mfma"), ("point", 192, "mfma"), ("swimmer", 256, "mfma"),
                                                ("swimmer", 192, "stepwise"), ("ant", 128, "mfma"), ("walker", 256, "valu"),
-                                               ("walker", 256, "mfma"), ("point", 64, "mfma"), ("ant", 64, "mfma")])
+                                               ("walker", 256, "mfma"), ("point", 64, "mfma"), ("ant", 64, "mfma"),
+                                               ("point-narrow", 128, "mfma"), ("point-narrow", 256, "mfma")])
 def test_policy_rollout_other_widths_parity(oracle, robot, hidden, impl):
     """hidden_sizes (h, h) beyond 64 (trpo.py:606-607 --hid).  On the light robots ("mfma" = the default) ONE launch:
     h = 128 with the hidden-layer weights resident in registers (group_rollout_kernel<.., 3>), h = 192 / 256 with the
@@ -141,7 +142,9 @@ def test_policy_rollout_other_widths_parity(oracle, robot, hidden, impl):
     import torch
     from guardx_amd import Engine
     N, T = 203, 40
-    extra = {"point": {}, "swimmer": SWIMMER, "ant": ANT, "walker": WALKER}[robot]
+    # "point-narrow": an observation width other than the default task's (8 lidar bins: D = 27) -- the one-launch forms
+    # of the wide networks have the first layer's k-steps compiled in, so this takes the step-wise form
+    extra = {"point": {}, "point-narrow": {"lidar_num_bins": 8}, "swimmer": SWIMMER, "ant": ANT, "walker": WALKER}[robot]
     cfg = task_config(N, seed=3, num_steps=25, goal_size=0.9, **extra)
     E = Engine(cfg, n_candidates=40000)
     if hidden == 64:
