@@ -257,6 +257,16 @@ def readme_rows():
         rows.append((", ".join(f"`{f}`" for f in ab), "`tools/ab/*.sh` (same-box A/B runs of library variants / trees: `tools/build_variant.py`, `tools/ab_epoch.py`)",
                      "the in-epoch A/B logs behind this round's decisions (DESIGN.md section 5): the Swimmer regression bisected to the "
                      "capped observation grid, `reset_apply` at priority, the sampler's fused form, the hand-off stream"))
+    for h in (128, 256):
+        f = f"example_ppo_fused_hid{h}.log"
+        if _have(f):
+            rows_ = [ln.split() for ln in open(path(f)) if ln.strip() and ln.split()[0].isdigit()]
+            if rows_:
+                a, b = rows_[0], rows_[-1]
+                rows.append((f"`{TAG}_{f}`", f"`python examples/train_ppo_fused.py --epochs 25 --hid {h}`",
+                             f"PPO-clip with ({h},{h}) actor and critic, the collection phase one fused launch per 400k-step epoch "
+                             f"({b[5]} ms): return {a[1]} -> {b[1]}, episode length {a[3]} -> {b[3]}, goals reached per env per epoch "
+                             f"{a[4]} -> {b[4]} in {len(rows_)} epochs"))
     if _have("mfma_rate_probe.log"):
         first = [ln.strip() for ln in open(path("mfma_rate_probe.log")) if ln.startswith("v_mfma")]
         rows.append((f"`{TAG}_mfma_rate_probe.log`", "`tools/probes/mfma_rate_probe` (one wave per SIMD, independent accumulator chains)",
