@@ -171,6 +171,60 @@ static bool use_group_path(const gx_engine* e)
     return in_group_regime(e); // latency regime (path_mode 3: rollouts split, steps here)
 }
 
+// ---- does a new stream share the hardware queue of the default stream? ---------------------------------------------
+// HIP multiplexes a process's streams onto a few hardware queues.  Rounds 3-4 blamed several slow-downs on a sampler /
+// hand-off stream that "aliased" the queue the caller steps on.  This test decides it: a kernel that spins for ~0.3 ms goes
+// onto the device's default stream, a marker kernel onto the candidate; if the marker completes while the spinner still
+// runs, the two are on different queues.  Measured in round 5 (GX_STREAM_CHECK=1 GX_STREAM_CHECK_VERBOSE=1
+// tools/probes/many_engines.py: 24 engines created and destroyed in one process, 1-3 sampler streams each plus the aux
+// stream, with 0-5 other torch streams alive): NOT ONE least-priority stream ever shared the default stream's queue.  The
+// slow-downs were contention (two samplers in flight beside a chain that is the epoch) and a host-bound harness, not
+// aliasing.  The test stays available (GX_STREAM_CHECK=1: a candidate that fails is kept alive until the search is over,
+// so that the next one gets another queue, six tries); it is OFF by default.
+__global__ void gx_spin_kernel(unsigned long long ticks_100mhz)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks_100mhz) __builtin_amdgcn_s_sleep(32);
+}
+__global__ void gx_mark_kernel() {}
+
+static bool stream_runs_beside_default(hipStream_t s)
+{
+    hipEvent_t e_spin = nullptr, e_mark = nullptr;
+    if (hipEventCreateWithFlags(&e_spin, hipEventDisableTiming) != hipSuccess) return true;
+    if (hipEventCreateWithFlags(&e_mark, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(e_spin); return true; }
+    hipLaunchKernelGGL(gx_spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)0, 30000ull);
+    (void)hipEventRecord(e_spin, (hipStream_t)0);
+    hipLaunchKernelGGL(gx_mark_kernel, dim3(1), dim3(64), 0, s);
+    (void)hipEventRecord(e_mark, s);
+    (void)hipEventSynchronize(e_mark);
+    const bool beside = hipEventQuery(e_spin) == hipErrorNotReady; // the marker finished while the spinner was still running
+    (void)hipEventSynchronize(e_spin);
+    (void)hipGetLastError();
+    (void)hipEventDestroy(e_spin); (void)hipEventDestroy(e_mark);
+    return beside;
+}
+
+static hipError_t create_side_stream(hipStream_t* out, int prio)
+{
+    static const bool check = [] { const char* e = getenv("GX_STREAM_CHECK"); return e && atoi(e) != 0; }();
+    hipStream_t rejected[6];
+    int nrej = 0;
+    hipStream_t s = nullptr;
+    hipError_t err = hipSuccess;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        err = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio);
+        if (err != hipSuccess) break;
+        if (!check || attempt == 5 || stream_runs_beside_default(s)) break;
+        if (getenv("GX_STREAM_CHECK_VERBOSE")) fprintf(stderr, "guardx: stream candidate %d shares the default stream's queue: rejected\n", attempt);
+        rejected[nrej++] = s;
+        s = nullptr;
+    }
+    for (int i = 0; i < nrej; ++i) (void)hipStreamDestroy(rejected[i]);
+    *out = s;
+    return err;
+}
+
 struct DeviceGuard {
     int prev = -1;
     bool changed = false;
@@ -440,7 +494,7 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
         e->n_side = 1;
         if (const char* ev = getenv("GX_SIDE_STREAMS")) e->n_side = atoi(ev) >= 1 && atoi(ev) <= gx_engine::kPools ? atoi(ev) : e->n_side; // experiments
         for (int i = 0; i < e->n_side && err == hipSuccess; ++i)
-            err = hipStreamCreateWithPriority(&e->side[i], hipStreamNonBlocking, prio);
+            err = create_side_stream(&e->side[i], prio);
     }
     e->cur = 0;
     e->b.pool = e->pools[0];
@@ -832,12 +886,10 @@ extern "C" gx_status gx_install_shards(gx_engine* e, int64_t ticket, const float
 }
 
 // A stream of the engine's device at the LEAST priority, for throughput work the caller runs beside the stepping -- the
-// tape hand-off's installs and expansions (guardx_amd/dist.py).  HIP multiplexes a process's streams onto a few hardware
-// queues PER PRIORITY LEVEL: a stream of another priority than the caller's never shares a hardware queue with it, so the
-// serial chain of the epoch (reset -> dynamics pass, on the caller's stream) cannot be queued behind an expansion, however
-// many streams the process has created.  ONE per device and process, created on first use and never destroyed: the
-// caller's framework may keep per-stream state (torch's caching allocators do, for every stream memory was allocated or
-// copied on) that outlives any engine -- a stream that died with an engine crashed the interpreter at exit (round 5).
+// tape hand-off's installs and expansions (guardx_amd/dist.py).  ONE per device and process, created on first use and never
+// destroyed: the caller's framework may keep per-stream state (torch's caching allocators do, for every stream memory was
+// allocated or copied on) that outlives any engine -- a stream that died with an engine crashed the interpreter at exit
+// (round 5).
 extern "C" gx_status gx_aux_stream(gx_engine* e, void** stream)
 {
     if (!e || !stream) return fail(GX_ERR_ARG, "gx_aux_stream: null argument");
@@ -849,7 +901,7 @@ extern "C" gx_status gx_aux_stream(gx_engine* e, void** stream)
         DeviceGuard guard(e->device);
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi); // lo = least urgent
-        GX_HIP(hipStreamCreateWithPriority(&per_device[e->device], hipStreamNonBlocking, lo));
+        GX_HIP(create_side_stream(&per_device[e->device], lo));
     }
     *stream = (void*)per_device[e->device];
     return GX_OK;

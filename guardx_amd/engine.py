@@ -742,8 +742,7 @@ class Engine:
 
     def aux_stream(self):
         """The device's least-priority stream (one per device and process, never destroyed), as a torch stream: for throughput
-        work beside the stepping -- the hand-off's installs and expansions.  Streams of another priority than the caller's
-        never share a hardware queue with it (gx_aux_stream)."""
+        work beside the stepping -- the hand-off's installs and expansions (gx_aux_stream)."""
         if getattr(self, "_aux", None) is None:
             ptr = C.c_void_p()
             _native.check(self._lib.gx_aux_stream(self._h, C.byref(ptr)))

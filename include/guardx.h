@@ -249,8 +249,8 @@ gx_status gx_reset_from_shards(gx_engine* e, const float* d_rows_all, const int3
  *                           layout check (engine.py:444) instead of using it. */
 /* A least-priority stream of the engine's device -- one per device and process, created on first use, never destroyed
  * (valid for the life of the process) -- for throughput work the caller runs beside the stepping: the hand-off's
- * gx_install_shards / gx_expand_tapes.  Streams of different priority never share a hardware queue, so work on it cannot
- * be queued in front of the caller's reset -> dynamics chain. */
+ * gx_install_shards / gx_expand_tapes.  (Least-priority streams were never observed on the default stream's hardware queue:
+ * GX_STREAM_CHECK=1 tests every new stream for it) */
 gx_status gx_aux_stream(gx_engine* e, void** stream);
 gx_status gx_set_layout_source(gx_engine* e, int32_t source);
 gx_status gx_shard_block_floats(const gx_engine* e, int32_t cap, int64_t* floats);
