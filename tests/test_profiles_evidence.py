@@ -56,3 +56,11 @@ def test_readme_table_of_this_round_is_what_the_files_say():
     have = text[text.index(pe.BEGIN):text.index(pe.END) + len(pe.END)]
     assert have == pe.readme_block(), "profiles/README.md differs from the evidence files: run `python tools/profile_evidence.py --readme`"
     assert f"`{pe.TAG}_build_id.txt`" in have and f"`{pe.TAG}_gputest_final.log`" in have
+
+
+def test_design_epoch_table_is_what_the_bench_line_says():
+    """DESIGN.md section 5's table of epoch rates is generated from profiles/<round>_bench_driver_style.json too"""
+    text = open(pe.DESIGN).read()
+    assert pe.D_BEGIN in text and pe.D_END in text
+    have = text[text.index(pe.D_BEGIN):text.index(pe.D_END) + len(pe.D_END)]
+    assert have == pe.design_epoch_table(), "DESIGN.md section 5 differs from the bench line: run `python tools/profile_evidence.py --readme`"

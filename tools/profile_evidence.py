@@ -285,6 +285,51 @@ def readme_block():
     return "\n".join(lines)
 
 
+DESIGN = os.path.join(ROOT, "DESIGN.md")
+D_BEGIN, D_END = "<!-- BEGIN GENERATED epoch table (tools/profile_evidence.py --readme) -->", "<!-- END GENERATED epoch table -->"
+
+
+def design_epoch_table():
+    """DESIGN.md section 5's table of epoch rates, from the committed driver-style bench line and the previous round's record"""
+    import json
+    l = _json_line("bench_driver_style.json")
+    vp = l.get("vs_previous_round", {}).get("values", {})
+
+    def prev(key):
+        return f"{vp[key]['previous'] / 1e6:.1f} M" if key in vp else "n/a"
+    reps = l["repetitions"]
+    rows = [D_BEGIN, "",
+            f"| per 200-step epoch at env_num = 2000 (`profiles/{TAG}_bench_driver_style.json`: `value` and, in a fresh child process "
+            f"after 30 warm-up epochs, `other_robots`) | ms | env-steps/s | round {int(l['vs_previous_round']['previous'][1:])} (driver record) |",
+            "|---|---|---|---|",
+            f"| Goal_Point_8Hazards (`value`: median of {reps['n']} repetitions, {reps['min'] / 1e6:.0f} … {reps['max'] / 1e6:.0f} M; "
+            f"`preconditioned` {l['preconditioned']['value'] / 1e6:.0f} M) | {l['ms_per_step']:.3f} | **{l['value'] / 1e6:.1f} M** | "
+            f"{prev('value')} (preconditioned) |"]
+    for name, v in l["other_robots"].items():
+        if isinstance(v, dict):
+            rows.append(f"| {name} | {v['ms_per_epoch']:.3f} | {v['env_steps_per_s'] / 1e6:.1f} M | {prev('other_robots.' + name)} |")
+    rh = l["reset_done_heavy"]
+    rows.append(f"| Point, every env re-initialised ≈ 3 times per epoch (`reset_done_heavy`) | {rh['ms_per_epoch']:.3f} | "
+                f"{rh['env_steps_per_s'] / 1e6:.1f} M | {prev('reset_done_heavy')} (builder's line) |")
+    api = l["api_step_loop_env_steps_per_s"]
+    wide = l["closed_loop_policy_wider_env_steps_per_s"]
+    rows += ["", f"(`vs_previous_round.regressions` of that line: {l['vs_previous_round']['regressions']}. The Python-driven "
+                 f"`step()+reset_done()` loop: {api['value'] / 1e6:.0f} M, ring of 8: {api['out_ring_8']['value'] / 1e6:.0f} M — host-bound, "
+                 f"± 10 % between consecutive medians of one library on one box, `profiles/{TAG}_ab_api.log`. Closed loop, hidden 64 / 128 / "
+                 f"256: {l['closed_loop_policy_env_steps_per_s'] / 1e6:.0f} / {wide['hidden_128'] / 1e6:.0f} / {wide['hidden_256'] / 1e6:.0f} M.)",
+             "", D_END]
+    return "\n".join(rows)
+
+
+def write_design():
+    text = open(DESIGN).read()
+    if D_BEGIN in text and D_END in text:
+        a, b = text.index(D_BEGIN), text.index(D_END) + len(D_END)
+        text = text[:a] + design_epoch_table() + text[b:]
+        with open(DESIGN, "w") as f:
+            f.write(text)
+
+
 def write_readme():
     text = open(README).read()
     block = readme_block()
@@ -305,6 +350,7 @@ if __name__ == "__main__":
     import sys
     if "--readme" in sys.argv:
         write_readme()
+        write_design()
         print(readme_block())
         sys.exit(0)
     import json
