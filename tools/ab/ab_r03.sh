@@ -1,3 +1,6 @@
+# Same-box A/B of whole trees.  The baselines are rebuilt from git when needed (they are not kept in the tree):
+#   mkdir -p _r03 && git archive f93ab85 guardx_amd include bench.py | tar -x -C _r03 && (cd _r03 && python -m guardx_amd.build) && cp tools/ab_epoch.py _r03/tools/
+#   (round 4: 3a50373 into _r04; bisection: one directory per commit under _bis/)
 set -e
 for t in Goal_Swimmer_8Hazards Goal_Point_8Hazards; do
 for i in 1 2; do
