@@ -15,6 +15,18 @@ namespace gx {
 
 constexpr int kPolHd = 64; // hidden width (the reference default --hid 64 --l 2)
 
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() is a release / acquire fence over ALL address
+// spaces: the compiler puts s_waitcnt vmcnt(0) in front of the barrier, i.e. every wave first waits until the global
+// stores of its step outputs (observation row, action, mu, logp, value, reward, cost, done) have been acknowledged -- an L2
+// round trip per barrier, several barriers per control step.  What the waves of a policy workgroup hand each other
+// (observation rows, hidden activations) lives in LDS; nothing written to global memory is read again in the kernel.
+GX_D void wg_sync_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 struct PolicyArgs {
     const float* params;   // pi{W1[Hd][D] b1 W2[Hd][Hd] b2 W3[A][Hd] b3} v{.. W3[1][Hd] b3} log_std[A]
     const float* wt;       // widths 192 / 256 (streaming form): the [k][unit] transposed hidden layers (policy_transpose_kernel)
@@ -229,9 +241,9 @@ GX_D void mfma_hidden(const MlpLds& wp, const MlpLds& wc, const float* X, int XS
     else if (Kp == 64) mfma_layer<16>(wp, wc, false, X, XS, 0, Kp, H1, wave, lw);
     else if (Kp == 72) mfma_layer<18>(wp, wc, false, X, XS, 0, Kp, H1, wave, lw);
     else mfma_layer<0>(wp, wc, false, X, XS, 0, Kp, H1, wave, lw);
-    __syncthreads();
+    wg_sync_lds();
     mfma_layer<kPolHd / 4>(wp, wc, true, H1, kPolHS, 16 * kPolHS, kPolHd, H2, wave, lw);
-    __syncthreads();
+    wg_sync_lds();
 }
 
 // two standard normals from one Threefry block keyed by `seed`, counter (global env, step*16+pair)
@@ -334,7 +346,7 @@ GX_D void pol2_hidden(const Pol2Regs<KS1>& W, const float* X, int XS, float* H1,
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[(4 * kq + r) * kPolHS2 + 16 * tt] = tanh_f(acc[tt][r]);
     }
-    __syncthreads();
+    wg_sync_lds();
     {
         float av[kPol2KS];
         const float* ap = H1 + (size_t)net * 16 * kPolHS2 + c16 * kPolHS2 + kq;
@@ -353,7 +365,7 @@ GX_D void pol2_hidden(const Pol2Regs<KS1>& W, const float* X, int XS, float* H1,
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[(4 * kq + r) * kPolHS2 + 16 * tt] = tanh_f(acc[tt][r]);
     }
-    __syncthreads();
+    wg_sync_lds();
 }
 
 // output layer of the wide networks: partial l over the units 64 c + 4 l + j (c = 0 .. H / 64 - 1), butterfly, + bias
@@ -487,12 +499,12 @@ GX_D void polS_hidden(const float* __restrict__ wt, const Mlp2Head& hp, const Ml
     for (int tt = 0; tt < TT; ++tt) { const float bb = hd.b1[col0 + TT * c16 + tt]; acc[tt] = mfma_f4{bb, bb, bb, bb}; }
     polS_chain<TT>(acc, wt1, H, col0, X, XS, Dp, c16, kq);
     polS_store<TT>(acc, H1 + (size_t)net * 16 * HS + col0, HS, c16, kq);
-    __syncthreads();
+    wg_sync_lds();
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) { const float bb = hd.b2[col0 + TT * c16 + tt]; acc[tt] = mfma_f4{bb, bb, bb, bb}; }
     polS_chain<TT>(acc, wt2, H, col0, H1 + (size_t)net * 16 * HS, HS, H, c16, kq);
     polS_store<TT>(acc, H2 + (size_t)net * 16 * HS + col0, HS, c16, kq);
-    __syncthreads();
+    wg_sync_lds();
 }
 
 GX_HD int policy_lds_floats(int D, int A, int pol)

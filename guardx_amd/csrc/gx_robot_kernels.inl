@@ -290,6 +290,20 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(Params p_in, const float* _
     flush_tile<BLOCK>(tile, obs + (size_t)env0 * p.D, nenv * p.D);
 }
 
+// synchronise the workgroup's LDS traffic only (one-wave workgroups: the wave's LDS operations execute in program
+// order, a compiler-only fence; larger ones: s_waitcnt lgkmcnt(0) + s_barrier) -- no wait for outstanding global stores
+template <int BLOCK>
+GX_D void lds_sync()
+{
+    if (BLOCK == 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    } else {
+        wg_sync_lds();
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Engine.reset (engine.py:454-467): get_layout + mjx_reset for every env
 // ---------------------------------------------------------------------------
@@ -568,9 +582,11 @@ void thread_rollout_kernel(Params p_in, RolloutArgs r,
                 touched_layout = true;
             }
         }
-        __syncthreads();
+        // (LDS-only synchronisation: __syncthreads() would make every wave wait, twice per step, until the tile's global
+        // stores of the step before have been acknowledged -- s_waitcnt vmcnt(0) of its all-address-space fence)
+        lds_sync<BLOCK>();
         flush_tile<BLOCK>(tile, r.obs + ((size_t)t * p.N + env0) * RS, nenv * RS);
-        __syncthreads(); // the tile is rewritten by the next step
+        lds_sync<BLOCK>(); // the tile is rewritten by the next step
     }
 
     if (live) {
@@ -670,6 +686,15 @@ __global__ __launch_bounds__(BLOCK) void fake_table_kernel(Params p, int nobj_to
 
 constexpr int kGL = 16; // lanes per environment
 
+// Stamps INSIDE the step loop of the lane-group kernel (3: step begins, 4: dynamics done, 5: observation done, 6: step
+// ends) are compiled in only with -DGX_LOOP_STAMPS: the store of a stamp sits behind a branch, and at the merge point the
+// compiler waits for it whether it happened or not -- an s_waitcnt vmcnt(0) per stamp and step, i.e. every step of the
+// closed-loop kernels waited for its own output stores (found in round 5 in the ISA of group_rollout_kernel<.., 2>).
+#ifdef GX_LOOP_STAMPS
+constexpr bool kLoopStamps = true;
+#else
+constexpr bool kLoopStamps = false;
+#endif
 // profiling aid: shader-clock stamp k of this workgroup (RolloutArgs::stamps, normally null)
 GX_D void stamp(const RolloutArgs& r, int k)
 {
@@ -686,10 +711,12 @@ GX_D void stamp(const RolloutArgs& r, int k)
 template <int BT, bool kWave>
 GX_D void group_sync()
 {
-    if (BT == 64 && kWave) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // (any workgroup size: what is exchanged here belongs to ONE env = 16 lanes of one wave; the policy kernels' four-wave
+    // workgroups took __syncthreads() -- an s_waitcnt vmcnt(0) on the step's output stores -- five times per step until round 5)
+    if (kWave) { // LDS-only fences: a fence over all address spaces, even at wave scope, makes the compiler wait for vmcnt(0)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     } else {
         __syncthreads();
     }
@@ -697,7 +724,7 @@ GX_D void group_sync()
 template <int BT, bool kWave>
 GX_D bool group_any(bool v)
 {
-    if (BT == 64 && kWave) return __ballot(v) != 0ull;
+    if (kWave) return __ballot(v) != 0ull;
     return __syncthreads_or(v ? 1 : 0) != 0;
 }
 
@@ -981,9 +1008,24 @@ __global__ __launch_bounds__(kPol >= 2 ? 256 : 64) void group_rollout_kernel(Par
         asm volatile("" ::"v"(s_));
         stamp(r, 2);
     }
+    if (kPolicy) {
+        // Everything loaded before the step loop is consumed HERE once.  Left to the compiler, the wait for a value first
+        // used inside the loop (the goal, the objects) is placed at that use -- inside the loop, as s_waitcnt vmcnt(0), where
+        // from the second step on it only waits for the previous step's output STORES (loads and stores share the counter).
+        float s_ = (float)L + gx + gy + done0 + steps + P1x + P1y + done1;
+#pragma unroll
+        for (int k = 0; k < R::NQ; ++k) s_ += q[k];
+#pragma unroll
+        for (int k = 0; k < R::NV; ++k) s_ += v[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_ += pose0[k];
+#pragma unroll
+        for (int j = 0; j < OPL; ++j) s_ += ox[j] + oy[j];
+        asm volatile("" ::"v"(s_));
+    }
     const int tstar = r.T > 100 ? 100 : r.T - 1; // the step whose phases are stamped (profiling aid)
     for (int t = 0; t < r.T; ++t) {
-        if (t == tstar) stamp(r, 3);
+        if (kLoopStamps && t == tstar) stamp(r, 3);
         float a[R::NA];
 #pragma unroll
         for (int d = 0; d < R::NA; ++d) a[d] = a_next[d];
@@ -1034,7 +1076,7 @@ __global__ __launch_bounds__(kPol >= 2 ? 256 : 64) void group_rollout_kernel(Par
                 }
                 if (l == 0) { pol.logp[te] = lp; pol.val[te] = vv[0]; }
             }
-            __syncthreads(); // xrow is rewritten at the end of this step
+            wg_sync_lds(); // xrow is rewritten at the end of this step
         }
         const bool have_last = (r.hist0 + t) >= 1, have_last_last = (r.hist0 + t) >= 2;
 
@@ -1052,7 +1094,7 @@ __global__ __launch_bounds__(kPol >= 2 ? 256 : 64) void group_rollout_kernel(Par
         for (int k = 0; k < R::NV; ++k) qacc[k] = 0.f;
         for (int k = 0; k < p.physics_steps; ++k) group_substep<R, kQacc>(q, v, ctrl, pose, qacc, l);
         world_pose(p, pose);
-        if (r.stamps && t == tstar) { asm volatile("" ::"v"(pose[0] + pose[3] + q[2])); stamp(r, 4); }
+        if (kLoopStamps && r.stamps && t == tstar) { asm volatile("" ::"v"(pose[0] + pose[3] + q[2])); stamp(r, 4); }
 
         float vel0 = 0.f, vel1 = 0.f, acc0 = 0.f, acc1 = 0.f;
         if (p.hist_on)
@@ -1060,7 +1102,7 @@ __global__ __launch_bounds__(kPol >= 2 ? 256 : 64) void group_rollout_kernel(Par
                         acc0, acc1);
 
         GroupObs<OPL, BPL> ob = group_observe<OPL, BPL, BT, R::kRestFixed>(p, S, lane, pose, gx, gy, ox, oy);
-        if (r.stamps && t == tstar) { asm volatile("" ::"v"(ob.gl[0] + ob.hl[0] + ob.cost)); stamp(r, 5); }
+        if (kLoopStamps && r.stamps && t == tstar) { asm volatile("" ::"v"(ob.gl[0] + ob.hl[0] + ob.cost)); stamp(r, 5); }
         bool bad = ob.bad;
         if (p.off_acc >= 0) bad = bad || notfinite(acc0) || notfinite(acc1);
         if (p.off_ctrl >= 0) {
@@ -1212,8 +1254,8 @@ __global__ __launch_bounds__(kPol >= 2 ? 256 : 64) void group_rollout_kernel(Par
             float* row = kPolicy ? xrow : (r.do_reset == 2 ? r.obs_rd + (size_t)env * p.D : r.obs + te * r.obs_stride);
             write_row(row, ob);
         }
-        if (kPolicy) __syncthreads();
-        if (t == tstar) stamp(r, 6);
+        if (kPolicy) wg_sync_lds();
+        if (kLoopStamps && t == tstar) stamp(r, 6);
     }
 
     if (kPolicy) { // bootstrap inputs: o_T and V(o_T)   trpo.py:523-529
