@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -63,7 +64,13 @@ struct gx_engine {
     static const int kPools = 3;
     Pool pools[kPools];
     int cur;                 // pool the envs are drawn from
-    hipStream_t side[kPools]; // prefetch samplers: pool i is sampled on side[i % n_side]
+    hipStream_t side[kPools]; // prefetch samplers: pool i is sampled on side[i % n_side] (least priority)
+    // the sampler's stream while the engine works beside a tape hand-off (its own aux stream in use, or layouts coming
+    // from the ranks' shards): ORDINARY priority -- see side_stream_priority()
+    hipStream_t side_ord = nullptr;
+    hipEvent_t side_switch = nullptr;
+    bool aux_in_use = false;
+    int sampler_class = 0;    // 0: the last sampler went onto side[], 1: onto side_ord
     int n_side;
     hipEvent_t pool_ready[kPools]; // recorded on the sampling stream when pool i is complete
     hipEvent_t pool_free[kPools];  // recorded on the caller's stream when pool i is no longer read
@@ -90,12 +97,13 @@ struct gx_engine {
     bool pf_phase1_pending = false;
     bool spec_valid = false;
     bool pending_commit = false;
-    // per-step layout keys for the fused rollout: ring of pinned staging + device buffers
-    static const int kKeyRing = 4;
-    uint4* h_keys[kKeyRing];
-    int keys_cap[kKeyRing];
-    hipEvent_t keys_ev[kKeyRing];
-    int keys_next;
+    // per-step layout keys of the fused rollouts: a ring of staging slots in ONE pinned, device-visible allocation
+    // (stage_rollout_keys)
+    uint4* h_keys = nullptr;
+    int keys_cap = 0;               // keys (steps) per slot
+    int keys_slots = 0;
+    int keys_next = 0;
+    std::vector<hipStream_t> keys_streams; // streams that were handed a slot in the current lap of the ring
     // step-wise policy rollout (hidden widths beyond the fused kernel's): transposed weights, current observation
     float* pol_wt = nullptr;
     size_t pol_wt_cap = 0;
@@ -205,9 +213,33 @@ static bool stream_runs_beside_default(hipStream_t s)
     return beside;
 }
 
+// Priority of the engine's own streams.  Rounds 3-5 created all of them at the LEAST priority: they carry throughput work
+// (the layout sampler, the hand-off's installs and expansions) beside a chain that is the epoch.  Who issues on a shared
+// SIMD is decided by the waves' own priority (s_setprio in the chain's kernels), though, and with the tape hand-off's
+// streams in flight a queue of another priority class costs far more than it gives on this stack: one GPU playing rank 0
+// of 8 (tools/rehearse_rank.py, profiles/r05_ab_stream_priorities.log), everything queued behind the dynamics pass
+// started 85-135 us late unless the sampler's AND the hand-off's queue were of the ordinary class -- Ant rank epoch
+// 1.57 -> 1.32 ms, Swimmer 0.71 -> 0.48, Point 0.485 -> 0.43 with every rank's tape expanded; bench.py --gpus 1 over a
+// one-rank RCCL group (GX_FORCE_DIST=1) 480 -> 644 M env-steps/s.  The one-GPU epochs do not care, but the per-call
+// Engine.step loop (host-bound, small launches) loses 6 % to an ordinary-priority sampler.  Hence two classes: the
+// sampler runs on a least-priority stream while the engine is on its own, and on an ordinary one (like the hand-off's
+// stream) from the moment it works beside a hand-off.  (GX_SIDE_PRIORITY / GX_AUX_PRIORITY = -1 | 0 | 1: least, ordinary,
+// highest, for the first / the second class -- experiments.)
+static int side_stream_priority(const char* env, int dflt, int lo, int hi)
+{
+    const char* ev = getenv(env);
+    const int v = ev ? atoi(ev) : dflt;
+    return v > 0 ? hi : (v == 0 ? (lo + hi) / 2 : lo);
+}
+
 static hipError_t create_side_stream(hipStream_t* out, int prio)
 {
-    static const bool check = [] { const char* e = getenv("GX_STREAM_CHECK"); return e && atoi(e) != 0; }();
+    // a stream of ordinary priority may share the default stream's queue: checked unless GX_STREAM_CHECK=0; the
+    // least-priority ones never did (above): checked only with GX_STREAM_CHECK=1
+    static const int check_env = [] { const char* e = getenv("GX_STREAM_CHECK"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+    int lo_ = 0, hi_ = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo_, &hi_);
+    const bool check = check_env >= 0 ? check_env == 1 : prio != lo_;
     hipStream_t rejected[6];
     int nrej = 0;
     hipStream_t s = nullptr;
@@ -442,8 +474,6 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
         e->pool_ready[i] = nullptr; e->pool_free[i] = nullptr; e->expand_ev[i] = nullptr;
         e->expand_pending[i] = false; e->pool_gen[i] = 0;
     }
-    e->keys_next = 0;
-    for (int i = 0; i < gx_engine::kKeyRing; ++i) { e->h_keys[i] = nullptr; e->keys_cap[i] = 0; e->keys_ev[i] = nullptr; }
     memset(&e->b, 0, sizeof(e->b));
     memset(&e->shard_scratch, 0, sizeof(e->shard_scratch));
     memset(e->jobs, 0, sizeof(e->jobs));
@@ -484,8 +514,7 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
     if (err == hipSuccess) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi); // lo = least urgent
-        int prio = lo;
-        if (const char* ev = getenv("GX_SIDE_PRIORITY")) prio = (atoi(ev) > 0) ? hi : (atoi(ev) == 0 ? (lo + hi) / 2 : lo); // experiments
+        int prio = side_stream_priority("GX_SIDE_PRIORITY", -1, lo, hi);
         // ONE side stream by default.  One per pool lets consecutive samplers overlap their tails (+1.8 % on the
         // headline epoch), but HIP multiplexes streams onto 4 hardware queues: with the caller's stream, the tape
         // hand-off's expansion stream and RCCL's own stream -- or a second engine in the process -- a fourth and
@@ -495,6 +524,7 @@ extern "C" gx_status gx_create(const gx_config* cfg, gx_engine** out)
         if (const char* ev = getenv("GX_SIDE_STREAMS")) e->n_side = atoi(ev) >= 1 && atoi(ev) <= gx_engine::kPools ? atoi(ev) : e->n_side; // experiments
         for (int i = 0; i < e->n_side && err == hipSuccess; ++i)
             err = create_side_stream(&e->side[i], prio);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&e->side_switch, hipEventDisableTiming);
     }
     e->cur = 0;
     e->b.pool = e->pools[0];
@@ -548,10 +578,9 @@ extern "C" gx_status gx_destroy(gx_engine* e)
     }
     for (int i = 0; i < gx_engine::kPools; ++i)
         if (e->side[i]) (void)hipStreamDestroy(e->side[i]);
-    for (int i = 0; i < gx_engine::kKeyRing; ++i) {
-        if (e->h_keys[i]) (void)hipHostFree(e->h_keys[i]);
-        if (e->keys_ev[i]) (void)hipEventDestroy(e->keys_ev[i]);
-    }
+    if (e->side_ord) (void)hipStreamDestroy(e->side_ord);
+    if (e->side_switch) (void)hipEventDestroy(e->side_switch);
+    if (e->h_keys) (void)hipHostFree(e->h_keys);
     if (e->h_layout_size) (void)hipHostFree(e->h_layout_size);
     if (e->layout_ev) (void)hipEventDestroy(e->layout_ev);
     if (e->pf_phase1) (void)hipEventDestroy(e->pf_phase1);
@@ -586,6 +615,47 @@ static void layout_keys(const gx_engine* e, uint32_t (&k)[4])
 {
     // get_layout: randint(key, ...) splits the key once  engine.py:447
     split2(e->key[0], e->key[1], k[0], k[1], k[2], k[3]);
+}
+
+// The second-class sampler stream exists from the moment the engine is told about a hand-off (gx_aux_stream: before the
+// caller creates its collective's streams) -- an engine on its own keeps the streams, and hardware queues, it always had.
+// HIP maps a process's streams of one priority onto a few hardware queues in creation order; created later (at the first
+// sampler launch, after the rehearsal's copy stream) this stream shared that stream's queue and the sampler queued behind
+// the "collective" it should overlap (profiles/r05_ab_stream_priorities.log).
+static hipError_t ensure_side_ord(gx_engine* e)
+{
+    if (e->side_ord) return hipSuccess;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    return create_side_stream(&e->side_ord, side_stream_priority("GX_AUX_PRIORITY", 0, lo, hi));
+}
+
+// the stream the next layout sampler goes onto; a change of class is ordered behind the samplers of the other class (they
+// share scratch arrays and the pool ring)
+static hipError_t sampler_stream(gx_engine* e, int pool, hipStream_t* out)
+{
+    const int cls = (e->aux_in_use || e->layout_source == 1) ? 1 : 0;
+    if (cls) {
+        const hipError_t err = ensure_side_ord(e);
+        if (err != hipSuccess) return err;
+    }
+    hipStream_t want = cls ? e->side_ord : e->side[pool % e->n_side];
+    if (cls != e->sampler_class) {
+        hipError_t err = hipSuccess;
+        if (cls) {
+            for (int i = 0; i < e->n_side && err == hipSuccess; ++i) {
+                err = hipEventRecord(e->side_switch, e->side[i]);
+                if (err == hipSuccess) err = hipStreamWaitEvent(e->side_ord, e->side_switch, 0);
+            }
+        } else {
+            err = hipEventRecord(e->side_switch, e->side_ord);
+            for (int i = 0; i < e->n_side && err == hipSuccess; ++i) err = hipStreamWaitEvent(e->side[i], e->side_switch, 0);
+        }
+        if (err != hipSuccess) return err;
+        e->sampler_class = cls;
+    }
+    *out = want;
+    return hipSuccess;
 }
 
 extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
@@ -640,7 +710,8 @@ extern "C" gx_status gx_reset(gx_engine* e, float* d_obs, void* stream)
             k0 = a0; k1 = a1;
         }
         const int tgt = (e->cur + 1) % gx_engine::kPools;
-        hipStream_t side = e->side[tgt % e->n_side];
+        hipStream_t side = nullptr;
+        GX_HIP(sampler_stream(e, tgt, &side));
         if (!first) GX_HIP(hipStreamWaitEvent(side, e->pool_free[tgt], 0));
         GX_HIP(claim_pool(e, tgt, side));
         // The closed-loop policy kernel (256-thread workgroups holding ~150 KB of LDS each) loses ~15 % when the
@@ -799,7 +870,7 @@ extern "C" gx_status gx_sample_shard_ahead(gx_engine* e, int32_t shard, int32_t 
         // sized for THIS shard's candidates (1/n_shards of the list; ~35 MB instead of ~280 MB at 1e6 / 8), regrown when a
         // later call samples a larger share (n_shards shrank)
         if (e->shard_scratch_ok) {
-            GX_HIP(hipStreamSynchronize(e->side[0])); // the last shard sampler still runs on the old arrays
+            GX_HIP(hipStreamSynchronize(e->sampler_class ? e->side_ord : e->side[0])); // the last shard sampler still runs on the old arrays
             free_shard_scratch(e);
         }
         hipError_t err = hipSuccess;
@@ -826,7 +897,8 @@ extern "C" gx_status gx_sample_shard_ahead(gx_engine* e, int32_t shard, int32_t 
         e->shard_scratch_ok = true;
         e->shard_scratch_cap = sp.M;
     }
-    hipStream_t side = e->side[0];
+    hipStream_t side = nullptr;
+    GX_HIP(sampler_stream(e, 0, &side));
     // behind everything queued on the caller's stream: the block may be the tail of a buffer an earlier collective
     // read, and the caller ordered its own stream behind that
     GX_HIP(hipEventRecord(e->shard_dep, s));
@@ -901,9 +973,11 @@ extern "C" gx_status gx_aux_stream(gx_engine* e, void** stream)
         DeviceGuard guard(e->device);
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi); // lo = least urgent
-        GX_HIP(create_side_stream(&per_device[e->device], lo));
+        GX_HIP(create_side_stream(&per_device[e->device], side_stream_priority("GX_AUX_PRIORITY", 0, lo, hi)));
     }
     *stream = (void*)per_device[e->device];
+    e->aux_in_use = true; // from now on the sampler runs at the hand-off's priority (side_stream_priority)
+    GX_HIP(ensure_side_ord(e));
     return GX_OK;
 }
 
@@ -1077,24 +1151,45 @@ extern "C" gx_status gx_reset_done(gx_engine* e, const float* d_obs_in, float* d
     return GX_OK;
 }
 
-// Per-step layout keys of a T-step fused rollout, staged in pinned device-visible host memory:
-// step t advances the key (engine.py:431), the reset_done that follows draws randint with that
-// key (engine.py:447,500).  Returns the slot; the caller records keys_ev[slot] after its launch.
-static gx_status stage_rollout_keys(gx_engine* e, int32_t T, int& slot_out, uint32_t& k0_out, uint32_t& k1_out)
+// Per-step layout keys of a T-step fused rollout, staged in pinned device-visible host memory: step t advances the key
+// (engine.py:431), the reset_done that follows draws randint with that key (engine.py:447,500).  Returns the slot.
+//
+// When may a slot be written again?  Rounds 1-4 kept four slots and an event per slot, recorded behind the launch that read
+// it, and had the host wait for the event of the slot it was about to reuse -- four launches old, so "never a wait".  On
+// this ROCm (7.2) that wait is one: hipEventQuery answers hipErrorNotReady for EVERY such event, however old (timing
+// enabled or not), and hipEventSynchronize then returns when everything queued on the stream so far has run -- measured in
+// round 5 (tools/ab/profile_rehearsal_host.py, -DGX_HOST_TIMING): 1.1-1.4 ms per call inside an Ant epoch, the host a whole
+// dynamics pass behind the GPU in every epoch; with one stream that costs a launch latency per epoch, with the tape
+// hand-off's several streams (the N > 1 configuration) it left the GPU idle for 140-340 us per epoch.  So: no events.  The
+// ring is long (up to 1024 slots, 8 MB), and the host synchronises the streams it handed slots to ONCE PER LAP.
+static gx_status stage_rollout_keys(gx_engine* e, int32_t T, hipStream_t s, int& slot_out, uint32_t& k0_out, uint32_t& k1_out)
 {
-    const int slot = e->keys_next;
-    e->keys_next = (slot + 1) % gx_engine::kKeyRing;
-    if (e->keys_cap[slot] < T) {
-        if (e->keys_ev[slot]) GX_HIP(hipEventSynchronize(e->keys_ev[slot]));
-        if (e->h_keys[slot]) (void)hipHostFree(e->h_keys[slot]);
-        e->h_keys[slot] = nullptr;
+    auto drain = [&]() -> hipError_t {
+        hipError_t err = hipSuccess;
+        for (hipStream_t q : e->keys_streams)
+            if (err == hipSuccess) err = hipStreamSynchronize(q);
+        e->keys_streams.clear();
+        return err;
+    };
+    if (e->keys_cap < T) {
+        GX_HIP(drain()); // launches still reading the old ring
+        if (e->h_keys) (void)hipHostFree(e->h_keys);
+        e->h_keys = nullptr; e->keys_cap = 0; e->keys_slots = 0; e->keys_next = 0;
         const int cap = T > 256 ? T : 256;
-        GX_HIP(hipHostMalloc((void**)&e->h_keys[slot], sizeof(uint4) * cap, hipHostMallocMapped));
-        e->keys_cap[slot] = cap;
-        if (!e->keys_ev[slot]) GX_HIP(hipEventCreateWithFlags(&e->keys_ev[slot], hipEventDisableTiming));
-    } else {
-        GX_HIP(hipEventSynchronize(e->keys_ev[slot])); // staging free again?
+        size_t slots = ((size_t)8 << 20) / (sizeof(uint4) * (size_t)cap);
+        const char* fv = getenv("GX_KEY_RING"); // experiments / tests (read at every allocation: they are rare)
+        const int forced = fv ? atoi(fv) : 0;
+        slots = forced >= 2 ? (size_t)forced : (slots < 16 ? 16 : (slots > 1024 ? 1024 : slots));
+        GX_HIP(hipHostMalloc((void**)&e->h_keys, sizeof(uint4) * (size_t)cap * slots, hipHostMallocMapped));
+        e->keys_cap = cap; e->keys_slots = (int)slots;
     }
+    const int slot = e->keys_next;
+    if (slot == 0) GX_HIP(drain()); // a lap is over: every launch that read the ring has to be
+    e->keys_next = (slot + 1) % e->keys_slots;
+    bool known = false;
+    for (hipStream_t q : e->keys_streams) known = known || q == s;
+    if (!known) e->keys_streams.push_back(s);
+    uint4* keys = e->h_keys + (size_t)slot * e->keys_cap;
     uint32_t k0 = e->key[0], k1 = e->key[1];
     for (int32_t t = 0; t < T; ++t) {
         uint32_t a0, a1, b0, b1;
@@ -1102,7 +1197,7 @@ static gx_status stage_rollout_keys(gx_engine* e, int32_t T, int& slot_out, uint
         k0 = a0; k1 = a1;
         uint4 kk;
         split2(k0, k1, kk.x, kk.y, kk.z, kk.w);
-        e->h_keys[slot][t] = kk;
+        keys[t] = kk;
     }
     slot_out = slot; k0_out = k0; k1_out = k1;
     return GX_OK;
@@ -1113,7 +1208,7 @@ static void fill_rollout_args(gx_engine* e, RolloutArgs& r, int32_t T, int slot)
     memset(&r, 0, sizeof r);
     r.T = T; r.do_reset = 1; r.nobj_total = e->nobj_total; r.hist0 = e->hist;
     r.obs_stride = e->p.D; r.sc_stride = 1; r.rd_j = e->b.rd_j;
-    r.keys = e->h_keys[slot]; // pinned + device-visible: read over the host link only on a reset
+    r.keys = e->h_keys + (size_t)slot * e->keys_cap; // pinned + device-visible: read over the host link only on a reset
     r.layout_size = e->b.pool.layout_size; r.cand_of = e->b.pool.cand_of; r.cand_xy = e->b.pool.cand_xy;
     r.n_rows = e->sp.M; r.stamps = e->stamps; r.fake = e->b.pool.fake;
     e->p.have_last = e->hist >= 1;
@@ -1129,7 +1224,7 @@ static gx_status rollout_impl(gx_engine* e, int32_t T, const float* d_actions, f
     DeviceGuard guard(e->device);
     hipStream_t s = (hipStream_t)stream;
     int slot; uint32_t k0, k1;
-    gx_status st = stage_rollout_keys(e, T, slot, k0, k1);
+    gx_status st = stage_rollout_keys(e, T, s, slot, k0, k1);
     if (st != GX_OK) return st;
     RolloutArgs r;
     fill_rollout_args(e, r, T, slot);
@@ -1163,7 +1258,6 @@ static gx_status rollout_impl(gx_engine* e, int32_t T, const float* d_actions, f
         if (st != GX_OK) return st;
         launch_thread_rollout(e->p, r, e->b, s);
     }
-    GX_HIP(hipEventRecord(e->keys_ev[slot], s)); // staging reusable once this launch is done
     GX_HIP(hipGetLastError());
     e->key[0] = k0; e->key[1] = k1;
     e->steps_since_reset += T;
@@ -1220,11 +1314,20 @@ extern "C" gx_status gx_rollout_tape(gx_engine* e, int32_t T, const float* d_act
         return fail(GX_ERR_ARG, "d_actions must be 8-byte, d_shard 16-byte aligned");
     DeviceGuard guard(e->device);
     hipStream_t s = (hipStream_t)stream;
+#ifdef GX_HOST_TIMING
+    auto t_0 = std::chrono::steady_clock::now();
+#endif
     gx_status st = flush_pending(e, s); // (before a key slot is taken: nothing to undo)
     if (st != GX_OK) return st;
     int slot; uint32_t k0, k1;
-    st = stage_rollout_keys(e, T, slot, k0, k1);
+#ifdef GX_HOST_TIMING
+    auto t_1 = std::chrono::steady_clock::now();
+#endif
+    st = stage_rollout_keys(e, T, s, slot, k0, k1);
     if (st != GX_OK) return st;
+#ifdef GX_HOST_TIMING
+    auto t_2 = std::chrono::steady_clock::now();
+#endif
     RolloutArgs r;
     fill_rollout_args(e, r, T, slot);
     r.act = d_actions;
@@ -1232,7 +1335,13 @@ extern "C" gx_status gx_rollout_tape(gx_engine* e, int32_t T, const float* d_act
     const size_t nt = tape_floats_padded(e, T), no = (size_t)e->p.P * e->p.Npad * 4;
     GX_HIP(launch_split_rollout(e->p, r, d_shard, reinterpret_cast<float4*>(d_shard + nt), d_shard + nt + no, e->b, s,
                                 nullptr, 1, dyn_pass_has_company(e) ? 1 : 4));
-    GX_HIP(hipEventRecord(e->keys_ev[slot], s));
+#ifdef GX_HOST_TIMING // (a variant build: GX_EXTRA_FLAGS_gx_api="-DGX_HOST_TIMING" python tools/build_variant.py hosttiming)
+    {
+        auto t_3 = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+        fprintf(stderr, "gx_rollout_tape host us: flush %ld keys %ld launch %ld\n", us(t_0, t_1), us(t_1, t_2), us(t_2, t_3));
+    }
+#endif
     GX_HIP(hipGetLastError());
     e->key[0] = k0; e->key[1] = k1;
     e->steps_since_reset += T;
@@ -1323,7 +1432,7 @@ static gx_status rollout_policy_stepwise(gx_engine* e, int32_t T, const gx_polic
     gx_status st = GX_OK;
     if (!group) { st = flush_pending(e, s); if (st != GX_OK) return st; } // (before a key slot is taken: nothing to undo)
     int slot; uint32_t k0, k1;
-    st = stage_rollout_keys(e, T, slot, k0, k1);
+    st = stage_rollout_keys(e, T, s, slot, k0, k1);
     if (st != GX_OK) return st;
     launch_policy_transpose(pol->d_params, e->pol_wt, D, A, H, s);
     GX_HIP(hipMemcpyAsync(e->pol_cur, d_obs0, sizeof(float) * (size_t)N * D, hipMemcpyDeviceToDevice, s));
@@ -1334,7 +1443,7 @@ static gx_status rollout_policy_stepwise(gx_engine* e, int32_t T, const gx_polic
                            nullptr, d_logstd, s, valu);
         RolloutArgs r;
         fill_rollout_args(e, r, 1, slot);
-        r.keys = e->h_keys[slot] + t;          // this step's reset_done key (engine.py:431,447,500)
+        r.keys = e->h_keys + (size_t)slot * e->keys_cap + t; // this step's reset_done key (engine.py:431,447,500)
         r.act = d_act + tn * A;
         r.obs = e->pol_cur;                    // the post-reset_done observation feeds the next policy step (trpo.py:547)
         r.rew = d_reward + tn; r.cost = d_cost + tn; r.done = d_done + tn; r.qacc = nullptr;
@@ -1349,7 +1458,6 @@ static gx_status rollout_policy_stepwise(gx_engine* e, int32_t T, const gx_polic
     launch_policy_step(H, pol->d_params, e->pol_wt, e->pol_cur, pol->seed[0], pol->seed[1], 0u, N, D, A, e->p.env_offset, 1,
                        nullptr, nullptr, nullptr, nullptr, d_val_last, d_obs_last, nullptr, s, valu);
     e->last_policy = false; // (the open-loop kernels ran: the prefetch sampler keeps its back-to-back chain)
-    GX_HIP(hipEventRecord(e->keys_ev[slot], s));
     GX_HIP(hipGetLastError());
     e->key[0] = k0; e->key[1] = k1;
     e->steps_since_reset += T;
@@ -1385,7 +1493,7 @@ extern "C" gx_status gx_rollout_policy(gx_engine* e, int32_t T, const gx_policy*
     DeviceGuard guard(e->device);
     hipStream_t s = (hipStream_t)stream;
     int slot; uint32_t k0, k1;
-    gx_status st = stage_rollout_keys(e, T, slot, k0, k1);
+    gx_status st = stage_rollout_keys(e, T, s, slot, k0, k1);
     if (st != GX_OK) return st;
     RolloutArgs r;
     fill_rollout_args(e, r, T, slot);
@@ -1410,7 +1518,6 @@ extern "C" gx_status gx_rollout_policy(gx_engine* e, int32_t T, const gx_policy*
     r.commit = take_commit(e);
     launch_policy_rollout(e->p, r, pa, e->b, impl, s);
     e->last_policy = true;
-    GX_HIP(hipEventRecord(e->keys_ev[slot], s));
     GX_HIP(hipGetLastError());
     e->key[0] = k0; e->key[1] = k1;
     e->steps_since_reset += T;

@@ -157,7 +157,7 @@ class TapeHandoff:
         if dev.type != "cuda":
             self.stream = None
         elif hasattr(env, "aux_stream") and os.environ.get("GX_HANDOFF_STREAM", "aux") == "aux":
-            self.stream = env.aux_stream()     # least priority: never on the hardware queue of the caller's stream
+            self.stream = env.aux_stream()     # one per device and process; checked against the default stream's queue
         else:
             self.stream = _handoff_stream(dev)
         self.pending = None            # (work, slot, token, ticket of the block it carries) of the epoch in flight

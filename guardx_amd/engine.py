@@ -741,8 +741,9 @@ class Engine:
         return int(ticket.value)
 
     def aux_stream(self):
-        """The device's least-priority stream (one per device and process, never destroyed), as a torch stream: for throughput
-        work beside the stepping -- the hand-off's installs and expansions (gx_aux_stream)."""
+        """The engine's stream for throughput work beside the stepping -- the hand-off's installs and expansions -- as a
+        torch stream: one per device and process, never destroyed, ordinary priority (gx_aux_stream).  Asking for it tells
+        the engine that it works beside a hand-off: its layout sampler moves to a stream of the same priority class."""
         if getattr(self, "_aux", None) is None:
             ptr = C.c_void_p()
             _native.check(self._lib.gx_aux_stream(self._h, C.byref(ptr)))

@@ -247,10 +247,13 @@ gx_status gx_reset_from_shards(gx_engine* e, const float* d_rows_all, const int3
  *                           remembers its last four; GX_ERR_STATE otherwise).  A block of another key, shard or world
  *                           size, or count > cap, leaves layout_size < 0: the reset that takes the pool fails its
  *                           layout check (engine.py:444) instead of using it. */
-/* A least-priority stream of the engine's device -- one per device and process, created on first use, never destroyed
- * (valid for the life of the process) -- for throughput work the caller runs beside the stepping: the hand-off's
- * gx_install_shards / gx_expand_tapes.  (Least-priority streams were never observed on the default stream's hardware queue:
- * GX_STREAM_CHECK=1 tests every new stream for it) */
+/* A stream of the engine's device -- one per device and process, created on first use, never destroyed (valid for the
+ * life of the process) -- for throughput work the caller runs beside the stepping: the hand-off's gx_install_shards /
+ * gx_expand_tapes.  Ordinary priority (round 5: with the hand-off's streams in flight a queue of another priority class
+ * delayed everything behind the dynamics pass by ~100 us per epoch); tested at creation not to share
+ * the default stream's hardware queue (GX_STREAM_CHECK=0 skips the test).  The call also tells the engine that it now
+ * works beside a hand-off: from here on its layout sampler runs on a stream of the same priority class (created now, before
+ * the caller makes its collective's streams) instead of its least-priority one. */
 gx_status gx_aux_stream(gx_engine* e, void** stream);
 gx_status gx_set_layout_source(gx_engine* e, int32_t source);
 gx_status gx_shard_block_floats(const gx_engine* e, int32_t cap, int64_t* floats);

@@ -1354,6 +1354,51 @@ def test_step_reset_done_rollout_on_a_side_stream(torch_cuda, oracle):
     E.close()
 
 
+def test_key_staging_ring_wraps_without_reusing_a_slot_in_flight(torch_cuda, oracle, monkeypatch):
+    """The per-step reset_done keys of a fused rollout are staged in a ring of pinned slots that the kernels read while
+    they run (gx_api.hip:stage_rollout_keys): a lap of the ring ends with the host waiting for the streams it handed
+    slots to.  With a ring of THREE slots (GX_KEY_RING, read when the ring is allocated) and rollouts issued back to back
+    on two streams without any synchronisation, eleven rollouts -- three and a half laps, every kind of launch that takes
+    a slot -- still draw the checker's layouts at every reset_done (goal_size 2.9: an env finishes every few steps), and a
+    longer rollout than the ring was sized for regrows it."""
+    torch = torch_cuda
+    monkeypatch.setenv("GX_KEY_RING", "3")
+    N, T = 192, 24
+    cfg = task_config(N, seed=77, num_steps=1000, goal_size=2.9)
+    E, O = _engines(cfg, oracle, n_candidates=60000)
+    np.testing.assert_array_equal(E.reset().cpu().numpy(), O.reset())
+    rng = np.random.default_rng(3)
+    side = torch.cuda.Stream()
+    pending = []
+
+    def check():
+        for (og, rg, cg, dg), acts in pending:
+            for t in range(acts.shape[0]):
+                oo, ro, do, io = O.step(acts[t])
+                o2 = O.reset_done()
+                np.testing.assert_array_equal(og[t].cpu().numpy(), o2)
+                np.testing.assert_array_equal(dg[t].cpu().numpy(), do)
+                np.testing.assert_array_equal(rg[t].cpu().numpy(), ro)
+        pending.clear()
+
+    for k in range(11):
+        acts = rng.uniform(-1, 1, (T, N, 2)).astype(np.float32)
+        if k % 3 == 2:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                pending.append((E.rollout(torch.from_numpy(acts).to('cuda', non_blocking=True)), acts))
+            torch.cuda.current_stream().wait_stream(side)
+        else:
+            pending.append((E.rollout(torch.from_numpy(acts).to('cuda', non_blocking=True)), acts))
+    check()
+    acts = rng.uniform(-1, 1, (300, N, 2)).astype(np.float32)         # longer than a slot (256 keys): the ring regrows
+    pending.append((E.rollout(torch.from_numpy(acts).cuda()), acts))
+    acts = rng.uniform(-1, 1, (T, N, 2)).astype(np.float32)
+    pending.append((E.rollout(torch.from_numpy(acts).cuda()), acts))
+    check()
+    E.close()
+
+
 def test_two_engines_interleaved_on_two_streams(torch_cuda, oracle):
     """Two engines (different seeds) in one process, each driven on its own stream, calls interleaved on the host, three
     epochs with prefetch hits: per engine the pool ring (in use | being prefetched | referenced by a tape in flight), its
