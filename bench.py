@@ -895,6 +895,7 @@ def main():
                              handoff_bytes_received_per_rank_per_epoch=int(
                                  (world - 1) * (handoff.n if mode == "tape" else EP_LEN * ENV_NUM * W) * 4),
                              packed_rows_bytes_per_rank_per_epoch=int(EP_LEN * ENV_NUM * W * 4),
+                             handoff_queue_probe=getattr(handoff, "queue_probe", None),
                              note="same epochs with the rollout hand-off switched off (two-kernel gx_rollout, every rank "
                                   "samples all 1e6 layout candidates itself); `value` above includes the hand-off")
         if mode == "tape":

@@ -76,6 +76,7 @@ SYMBOLS = {
     "gx_reset_from_shards": (C.c_int, [C.c_void_p, _FP, _FP, C.c_int32, C.c_int32, _FP, C.c_void_p]),
     "gx_set_layout_source": (C.c_int, [C.c_void_p, C.c_int32]),
     "gx_aux_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "gx_aux_stream_renew": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "gx_shard_block_floats": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "gx_sample_shard_ahead": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _FP, C.c_int32, C.POINTER(C.c_int64), C.c_void_p]),
     "gx_shard_join": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -957,29 +957,35 @@ extern "C" gx_status gx_install_shards(gx_engine* e, int64_t ticket, const float
     return GX_OK;
 }
 
-// A stream of the engine's device at the LEAST priority, for throughput work the caller runs beside the stepping -- the
-// tape hand-off's installs and expansions (guardx_amd/dist.py).  ONE per device and process, created on first use and never
-// destroyed: the caller's framework may keep per-stream state (torch's caching allocators do, for every stream memory was
-// allocated or copied on) that outlives any engine -- a stream that died with an engine crashed the interpreter at exit
-// (round 5).
-extern "C" gx_status gx_aux_stream(gx_engine* e, void** stream)
+// A stream of the engine's device (ordinary priority: side_stream_priority) for throughput work the caller runs beside
+// the stepping -- the tape hand-off's installs and expansions (guardx_amd/dist.py).  ONE per device and process, created on
+// first use and never destroyed: the caller's framework may keep per-stream state (torch's caching allocators do, for every
+// stream memory was allocated or copied on) that outlives any engine -- a stream that died with an engine crashed the
+// interpreter at exit (round 5).  renew: replace the device's stream by a new one (the old one stays alive, so the new one
+// gets another hardware queue) -- for a caller that found it sharing a queue with its collective's stream.
+static gx_status aux_stream_impl(gx_engine* e, void** stream, bool renew)
 {
     if (!e || !stream) return fail(GX_ERR_ARG, "gx_aux_stream: null argument");
     static std::mutex mu;
     static hipStream_t per_device[64] = {};
     if (e->device < 0 || e->device >= 64) return fail(GX_ERR_ARG, "gx_aux_stream: device index out of range");
     std::lock_guard<std::mutex> lock(mu);
-    if (!per_device[e->device]) {
+    if (!per_device[e->device] || renew) {
         DeviceGuard guard(e->device);
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi); // lo = least urgent
-        GX_HIP(create_side_stream(&per_device[e->device], side_stream_priority("GX_AUX_PRIORITY", 0, lo, hi)));
+        hipStream_t fresh = nullptr;
+        GX_HIP(create_side_stream(&fresh, side_stream_priority("GX_AUX_PRIORITY", 0, lo, hi)));
+        per_device[e->device] = fresh;
     }
     *stream = (void*)per_device[e->device];
     e->aux_in_use = true; // from now on the sampler runs at the hand-off's priority (side_stream_priority)
     GX_HIP(ensure_side_ord(e));
     return GX_OK;
 }
+
+extern "C" gx_status gx_aux_stream(gx_engine* e, void** stream) { return aux_stream_impl(e, stream, false); }
+extern "C" gx_status gx_aux_stream_renew(gx_engine* e, void** stream) { return aux_stream_impl(e, stream, true); }
 
 extern "C" gx_status gx_set_prefetch(gx_engine* e, int32_t steps)
 {

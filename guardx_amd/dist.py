@@ -8,6 +8,7 @@ The reference has no counterpart: it runs on a single device (engine.py:100,
 trpo.py:21)."""
 import contextlib
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -160,6 +161,10 @@ class TapeHandoff:
             self.stream = env.aux_stream()     # one per device and process; checked against the default stream's queue
         else:
             self.stream = _handoff_stream(dev)
+        self.queue_probe = []          # per probe round: (spin ms, collective ms, shared a queue?)
+        if self.collective and not self.host and self.stream is not None and dist.is_initialized() \
+                and os.environ.get("GX_HANDOFF_QUEUE_PROBE", "0") == "1":
+            self._probe_collective_queue()
         self.pending = None            # (work, slot, token, ticket of the block it carries) of the epoch in flight
         self.last = None               # (gathered buffer on the device, token) of the last expanded epoch (expand_rank)
         self.k = 0
@@ -171,6 +176,47 @@ class TapeHandoff:
         self.next_ticket = None        # ticket of the block being sampled into the next send buffer's tail
         self.shard_skips = 0           # epochs whose block was not sampled (the engine refused: see step())
         self.closed = False
+
+    PROBE_ROUNDS = 4
+    PROBE_SPIN_CYCLES = 3_000_000      # torch.cuda._sleep: ~1.2-1.5 ms
+
+    def _probe_collective_queue(self):
+        """Does the hand-off's stream share a hardware queue with the stream the collectives run on?  HIP maps a process's
+        streams of one priority onto a few hardware queues; RCCL's stream is torch's, made at the first collective.  On a
+        shared queue the epoch still computes the same thing, but collective k + 1 queues behind expansion k, and when the
+        link is the bound it idles for an expansion per epoch.  The test: a spinner (~1.3 ms) goes onto the hand-off's
+        stream, a four-float all-gather is issued and awaited -- if the host sees it complete only after the spinner, the
+        two share a queue and the engine is asked for another stream (gx_aux_stream_renew; the old one stays alive, so the
+        next lands elsewhere).  PROBE_ROUNDS rounds on EVERY rank, whatever each finds: the rounds are collectives.
+        OFF by default (GX_HANDOFF_QUEUE_PROBE=1 runs it): on the one GPU this project can measure on, a one-rank group, the
+        two streams DO share a queue (the probe finds it in round 2 and the third stream runs beside the collective:
+        0.06-0.11 ms against a 1.26 ms spinner) -- and bench.py --gpus 1 is slower afterwards, 590-596 M env-steps/s against
+        645-654 M (profiles/r05_ab_handoff_queue_probe.log): with a collective that is one local copy the shared queue costs
+        nothing and the stream the hand-off moves to shares its queue with something else.  Whether it pays when the link
+        is the bound needs the 8-GPU node."""
+        dev = self.env.device
+        x = torch.zeros(4, dtype=torch.float32, device=dev)
+        y = torch.zeros(4 * self.world, dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(y, x)                  # the first collective builds the communicator and its stream
+        torch.cuda.synchronize(dev)
+        cur = torch.cuda.current_stream(dev)
+        for rnd in range(self.PROBE_ROUNDS):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(self.stream):
+                e0.record()
+                torch.cuda._sleep(self.PROBE_SPIN_CYCLES)
+                e1.record()
+            t0 = time.perf_counter()
+            work = dist.all_gather_into_tensor(y, x, async_op=True)
+            work.wait()                                    # the current stream waits for the collective's stream ...
+            cur.synchronize()                              # ... and the host for the current stream: not for the spinner
+            ms = (time.perf_counter() - t0) * 1e3
+            torch.cuda.synchronize(dev)
+            spin = e0.elapsed_time(e1)
+            shared = ms > 0.7 * spin
+            self.queue_probe.append((round(spin, 3), round(ms, 3), bool(shared)))
+            if shared and rnd + 1 < self.PROBE_ROUNDS and hasattr(self.env, "aux_stream"):
+                self.stream = self.env.aux_stream(renew=True)
 
     def close(self):
         """Give the layout sampling back to the engine (its own prefetch) and order the CURRENT stream behind everything

@@ -740,13 +740,14 @@ class Engine:
                                                       block.data_ptr(), int(cap), C.byref(ticket), self._stream()))
         return int(ticket.value)
 
-    def aux_stream(self):
+    def aux_stream(self, renew=False):
         """The engine's stream for throughput work beside the stepping -- the hand-off's installs and expansions -- as a
         torch stream: one per device and process, never destroyed, ordinary priority (gx_aux_stream).  Asking for it tells
-        the engine that it works beside a hand-off: its layout sampler moves to a stream of the same priority class."""
-        if getattr(self, "_aux", None) is None:
-            ptr = C.c_void_p()
-            _native.check(self._lib.gx_aux_stream(self._h, C.byref(ptr)))
+        the engine that it works beside a hand-off: its layout sampler moves to a stream of the same priority class.
+        renew=True replaces the device's stream by a new one first (gx_aux_stream_renew)."""
+        ptr = C.c_void_p()
+        _native.check((self._lib.gx_aux_stream_renew if renew else self._lib.gx_aux_stream)(self._h, C.byref(ptr)))
+        if getattr(self, "_aux", None) is None or self._aux.cuda_stream != ptr.value:   # (another engine may have renewed it)
             self._aux = torch.cuda.ExternalStream(ptr.value, device=self.device)
         return self._aux
 

@@ -255,6 +255,10 @@ gx_status gx_reset_from_shards(gx_engine* e, const float* d_rows_all, const int3
  * works beside a hand-off: from here on its layout sampler runs on a stream of the same priority class (created now, before
  * the caller makes its collective's streams) instead of its least-priority one. */
 gx_status gx_aux_stream(gx_engine* e, void** stream);
+/* The same, but the device's stream is REPLACED by a new one first (the old one stays alive for the life of the process, so
+ * the new one lands on another hardware queue): for a caller that measured the stream sharing a queue with the stream of
+ * its collective (guardx_amd.dist.TapeHandoff probes this once, at construction). */
+gx_status gx_aux_stream_renew(gx_engine* e, void** stream);
 gx_status gx_set_layout_source(gx_engine* e, int32_t source);
 gx_status gx_shard_block_floats(const gx_engine* e, int32_t cap, int64_t* floats);
 gx_status gx_sample_shard_ahead(gx_engine* e, int32_t shard, int32_t n_shards, int32_t resets_ahead, float* d_block,

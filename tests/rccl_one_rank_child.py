@@ -71,8 +71,13 @@ def main(report_path):
     assert torch.equal(o0, b.reset())
     np.testing.assert_array_equal(o0.cpu().numpy(), O.reset())
     a.set_prefetch(T); b.set_prefetch(T)
+    os.environ["GX_HANDOFF_QUEUE_PROBE"] = "1"      # (off by default: see TapeHandoff._probe_collective_queue)
     h = gxd.TapeHandoff(a, T)
+    del os.environ["GX_HANDOFF_QUEUE_PROBE"]
     assert h.collective and h.sharded and not h.host and h.world == 1
+    # the probe of the collective's hardware queue ran its rounds; the last stream it settled on runs beside the collective
+    assert len(h.queue_probe) == h.PROBE_ROUNDS and not h.queue_probe[-1][2], h.queue_probe
+    report["queue_probe"] = h.queue_probe
     assert all(r.device.type == "cuda" for r in h.recv) and h.recv[0].data_ptr() != h.send[0].data_ptr()
     rng = np.random.default_rng(21)
     prev = None
