@@ -55,5 +55,8 @@ pmc sampler_config5 SQ SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_W
 (cd tools/probes && hipcc -O3 -ffp-contract=off --offload-arch=gfx950 -o rcp_exact_probe rcp_exact_probe.hip) && ./tools/probes/rcp_exact_probe > $out/${tag}_rcp_exact_probe.log 2>&1
 python3 tools/rehearse_rank.py --world 8 --epochs 30 --json $out/${tag}_rehearsal_rank0_of_8.json > /dev/null 2>&1
 python3 tools/rehearse_rank.py --world 8 --epochs 30 --robot xmls/ant.xml --json $out/${tag}_rehearsal_rank0_of_8_ant.json > /dev/null 2>&1
+python3 tools/rehearse_rank.py --world 8 --epochs 30 --robot xmls/swimmer.xml --json $out/${tag}_rehearsal_rank0_of_8_swimmer.json > /dev/null 2>&1
+python3 tools/rehearse_rank.py --world 8 --epochs 20 --robot xmls/walker.xml --json $out/${tag}_rehearsal_rank0_of_8_walker.json > /dev/null 2>&1
+(cd tools/probes && hipcc -O3 --offload-arch=gfx950 -o mfma_rate_probe mfma_rate_probe.hip) && ./tools/probes/mfma_rate_probe > $out/${tag}_mfma_rate_probe.log 2>&1
 rm -f $out/${tag}_*_kt.log $out/${tag}_*_pmc_*.log
 ls $out/${tag}_* | wc -l
