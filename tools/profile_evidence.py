@@ -209,18 +209,19 @@ def readme_rows():
                    f"{l.get('vs_previous_round', {}).get('regressions')}; `cpu_baseline` "
                    f"{l.get('cpu_baseline', {}).get('value')} env-steps/s on {l.get('cpu_baseline', {}).get('cores')} cores")
             rows.append((f"`{TAG}_{name}`", cmd, txt))
-    for name, lbl in (("rehearsal_rank0_of_8.json", "Point"), ("rehearsal_rank0_of_8_ant.json", "Ant")):
+    for name, lbl in (("rehearsal_rank0_of_8.json", "Point"), ("rehearsal_rank0_of_8_swimmer.json", "Swimmer"),
+                      ("rehearsal_rank0_of_8_ant.json", "Ant"), ("rehearsal_rank0_of_8_walker.json", "Walker")):
         if _have(name):
             import json
             d = json.load(open(path(name)))
             m = d["expand_all"]["model"]
             rows.append((f"`{TAG}_{name}`", f"`python tools/rehearse_rank.py --world 8 --epochs 30" +
-                         (" --robot xmls/ant.xml" if lbl == "Ant" else "") + " --json ...`",
+                         ("" if lbl == "Point" else f" --robot xmls/{lbl.lower()}.xml") + " --json ...`",
                          f"one GPU playing rank 0 of 8, {lbl}: {d['expand_all']['ms_per_epoch']} ms per rank epoch (`expand=\"local\"`: "
                          f"{d['expand_local']['ms_per_epoch']}) against {d['one_gpu_own_sampler']['ms_per_epoch']} ms on one GPU; "
                          f"{d['expand_all']['bytes_received_per_epoch'] / 1e6:.1f} MB received per epoch: link-bound below "
                          f"{m.get('link_bound_below_GBps')} GB/s, break-even with one GPU at {m.get('break_even_GBps')} GB/s (model, not a "
-                         f"measurement of the link)"))
+                         f"measurement of the link); the other ranks' slots: {d.get('link_stand_in', 'device copies')}"))
     if _have("rccl_one_rank_report.json"):
         import json
         d = json.load(open(path("rccl_one_rank_report.json")))
