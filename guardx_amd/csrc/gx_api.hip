@@ -1175,6 +1175,10 @@ static gx_status stage_rollout_keys(gx_engine* e, int32_t T, hipStream_t s, int&
         for (hipStream_t q : e->keys_streams)
             if (err == hipSuccess) err = hipStreamSynchronize(q);
         e->keys_streams.clear();
+        if (err != hipSuccess) { // a stream the caller has destroyed since (its work is done or gone with it): the device, then
+            (void)hipGetLastError();
+            err = hipDeviceSynchronize();
+        }
         return err;
     };
     if (e->keys_cap < T) {

@@ -247,20 +247,17 @@ class TapeHandoff:
     def step(self, actions):
         i = self.k % self.depth
         buf = self.send[i]
-        shard, token = self.env.rollout_tape(actions, out=buf[:self.n_tape])
         ticket, self.next_ticket = self.next_ticket, None   # the block sampled into this buffer's tail during the last step
         if ticket is not None:
             self.env.shard_join()      # the collective below must see the block (it was finished long ago)
-        self._expand_pending()         # epoch k-1: its collective has had a whole epoch
-        work = self._gather(i, buf)
-        self.works[i] = work
-        self.pending = (work, i, token, ticket)
-        self.k += 1
         if self.sharded:
             # The block that will travel with the NEXT epoch's tape: this rank's candidates of the reset three resets
-            # from now, sampled from here on -- beside this epoch's collective and the expansions, not beside the next
-            # dynamics pass (the serial chain of the epoch) and never in front of a collective that has to wait for it.
-            j = self.k % self.depth
+            # after the last one.  Launched FIRST, behind the reset that is already queued: the sampler then runs beside this
+            # epoch's dynamics pass and has until the next epoch's collective -- a whole epoch.  (Rounds 4-5 launched it
+            # after this epoch's collective was issued; queued behind the caller's stream it could only start when the
+            # dynamics pass had ENDED and had to be finished one dynamics pass later: at W = 2, where a rank's share of
+            # the sampler is as long as its dynamics pass, the next collective waited for it.)
+            j = (self.k + 1) % self.depth
             if self.works[j] is not None:
                 self.works[j].wait()   # the collective that last read send[j] (two epochs ago)
             try:
@@ -269,12 +266,18 @@ class TapeHandoff:
             except RuntimeError as exc:
                 # The engine has no horizon to sample for (prefetch switched off, or more steps since the last reset
                 # than three intervals cover): a state every rank shares, so every rank skips this block alike and the
-                # reset it was meant for samples inline.  Raising here -- after this epoch's collective was issued --
-                # would leave the other ranks waiting in the next one.
+                # reset it was meant for samples inline.  Raising here would leave the other ranks waiting in this
+                # epoch's collective.
                 if getattr(exc, "status", None) != _GX_ERR_STATE:
                     raise
                 self.next_ticket = None
                 self.shard_skips += 1
+        shard, token = self.env.rollout_tape(actions, out=buf[:self.n_tape])
+        self._expand_pending()         # epoch k-1: its collective has had a whole epoch
+        work = self._gather(i, buf)
+        self.works[i] = work
+        self.pending = (work, i, token, ticket)
+        self.k += 1
 
     def _gather(self, i, buf):
         """the ONE collective of the epoch: every rank's [tape | layouts | entry records | shard block] into recv[i]"""

@@ -216,11 +216,13 @@ gx_status gx_reset_from_shards(gx_engine* e, const float* d_rows_all, const int3
  * The key of a later reset is known now: this key advanced by one split per step() (engine.py:431), the number of steps
  * between resets being the learned horizon of gx_set_prefetch.  The pipeline guardx_amd/dist.py:TapeHandoff runs
  * (epochs and resets counted from 0, epoch k = gx_reset(k) + its rollout):
- *   after epoch k's rollout, once its collective has been issued:
+ *   epoch k, right after gx_reset(k) and BEFORE its rollout is launched (since round 5; rounds 4-5: after the epoch's
+ *   collective had been issued -- same keys, same blocks, but the sampler could then only start once the dynamics pass
+ *   had ended):
  *       gx_sample_shard_ahead(resets_ahead = 3) -- rank r samples ITS candidates of reset(k + 3) on the engine's side
- *       stream.  (resets_ahead counts from the LAST reset: the key is advanced by resets_ahead * horizon -
- *       steps_since_reset, i.e. by two horizons when called after the epoch's steps.  Called BEFORE an epoch's steps the
- *       same reset is resets_ahead = 2.)  The export block -- [count, key0, key1, shard | n_shards << 16 | rows cap x
+ *       stream, beside epoch k's dynamics pass.  (resets_ahead counts from the LAST reset: the key is advanced by
+ *       resets_ahead * horizon - steps_since_reset: three horizons when called before the epoch's steps, two when called
+ *       after them -- the same reset either way.)  The export block -- [count, key0, key1, shard | n_shards << 16 | rows cap x
  *       (goal, hazards.., pillars.., robot) x 2 floats] -- is the tail of the buffer that will carry epoch k + 1's tape.
  *   epoch k + 1: gx_shard_join, then the all-gather of [tape k + 1 | block] delivers every rank's block.
  *   epoch k + 2: gx_install_shards(ticket of that call), on the stream that waited for the collective, AFTER
