@@ -836,7 +836,7 @@ def main():
     import torch.distributed as tdist
     forced = gxd.forced_dist() and tdist.is_initialized()   # GX_FORCE_DIST=1: the N > 1 path over a one-rank group
     gather = world > 1 or forced
-    # the hand-off: "tape" (default) all-gathers the 40-B-per-env-step dynamics tape and expands it on every rank,
+    # the hand-off: "tape" (default) all-gathers the 36-B-per-env-step dynamics tape and expands it on every rank,
     # "packed" all-gathers the 192-B packed rows (what round 1 did; GX_HANDOFF=packed to compare)
     mode = os.environ.get("GX_HANDOFF", "tape")
     if gather and mode == "tape":
@@ -942,8 +942,8 @@ def main():
             "note_n1": "at N = 1 no hand-off runs; the shard here is the bare tape -- at N > 1 each rank's block of valid "
                        "layouts (~0.5 MB) rides in its tail",
             "ms_per_step_this_run": round(dt / args.steps * 1e3, 4),
-            "note": "one async all-gather of the dynamics tape per epoch (40 B per env-step: qpos, qvel, action, done, "
-                    "two layout-row indices; at N > 1 plus the rank's export block of valid layouts, ~0.5 MB), overlapped "
+            "note": "one async all-gather of the dynamics tape per epoch (36 B per env-step: qpos, qvel, action, one word for "
+                    "done and the layout rows; at N > 1 plus the rank's export block of valid layouts, ~0.5 MB), overlapped "
                     "with the following epoch; 310 GB/s = a realistic all-gather bus "
                     "bandwidth over 7 xGMI links (537 GB/s peak per direction); arithmetic, not a measurement"}
     except Exception as exc:  # noqa: BLE001

@@ -4,10 +4,10 @@
 //   pass 1  the serial chain: convert_action, mjx.step, done / NaN guard / timeout, reset_done (layout index draw +
 //           re-placement) -- everything the NEXT step depends on -- and one SLIM tape row per (step, env): qpos, qvel after
 //           the step, the action, done, the layout row in effect and the layout row a reset_done installed.
-//           dyn_tape_kernel (Point, Swimmer): one thread per env, 10 / 14 floats per row, ~170 instructions per Point step
+//           dyn_tape_kernel (Point, Swimmer): one thread per env, 9 / 13 floats per row, ~170 instructions per Point step
 //           (the Swimmer also as a quad of lanes per env, SwimmerRobot::substep_q).
-//           group_dyn_tape_kernel (Ant, Walker; round 3): the lane-group form of their step, 16 lanes per env, 36 / 40
-//           floats per row (+ the row of the pool's fake-step table a reset_done observation is read from).
+//           group_dyn_tape_kernel (Ant, Walker; round 3): the lane-group form of their step, 16 lanes per env, 32 / 38
+//           floats per row (incl. the row of the pool's fake-step table a reset_done observation is read from).
 //           (Rounds 1-2 also wrote the stepped pose, ctrl and the reward into the row.)
 //   pass 2  obs_tape_kernel   one thread per (step, env) tape row: re-derives what pass 1 no longer writes -- the pose
 //           the step returned (kinematics of the qpos the step STARTED from: the previous row's qpos, or the robot
@@ -33,21 +33,38 @@ namespace gx {
 
 template <class R>
 struct SplitTape {
-    // One row per (step, env): qpos | qvel after the step | the action | the layout row in effect (-1: the layout at
-    // entry) | kCode: done and reset_done in one word -- -1: the step did not finish the env; -2: it did, and no layout
-    // was installed (no reset_done in this launch, or an empty pool); j >= 0: it did, and reset_done installed layout row j
-    // | kFidx (Ant, Walker): row of Pool::fake (= index into the compacted layout list) of that layout.
-    // Round 4: `done` rode in a word of its own and the row was padded to 16 bytes (Point: 12 floats); now 10 floats =
-    // 40 B (Swimmer 14, Ant 34, Walker 40) -- this is what the multi-GPU hand-off puts on the wire, 400 000 rows per
-    // rank and epoch.  Rows are 8-byte aligned (kW is even).
-    static constexpr int kQ = 0, kV = kQ + R::NQ, kAct = kV + R::NV, kJcur = kAct + R::NA, kCode = kJcur + 1,
-                         kFidx = kCode + 1, kUsed = kFidx + (R::kRestFixed ? 0 : 1), kW = (kUsed + 1) / 2 * 2;
+    // One row per (step, env): qpos | qvel after the step | the action | kCode: ONE word for done, the layout row in effect
+    // and the layout row a reset_done installed | kFidx (Ant, Walker): row of Pool::fake (= index into the compacted layout
+    // list) of the installed layout.
+    //   kCode >= 0: the step did not finish the env; the layout in effect is row kCode - 1 of the pool (0: the layout at
+    //               entry);
+    //   kCode == -1: it did, and no layout was installed (no reset_done in this launch, or an empty pool);
+    //   kCode <= -2: it did, and reset_done installed layout row -(kCode + 2).
+    // The layout in effect during a step that DID finish the env is what the rows before it say (jcur_before): the row
+    // in front of it, almost always -- pass 2 has loaded that one anyway.
+    // Rounds 3-4 carried `done`, the layout in effect and the installed one in words of their own and padded the row to
+    // 16, then 8 bytes (Point: 12, then 10 floats); now 9 floats = 36 B (Swimmer 13, Ant 32, Walker 38) -- this is what the
+    // multi-GPU hand-off puts on the wire, 400 000 rows per rank and epoch, and at W = 8 the link is the bound.  Rows are
+    // 4-byte aligned only.
+    static constexpr int kQ = 0, kV = kQ + R::NQ, kAct = kV + R::NV, kCode = kAct + R::NA,
+                         kFidx = kCode + 1, kUsed = kFidx + (R::kRestFixed ? 0 : 1), kW = kUsed;
     // entry record of an env: qpos at entry | the stale pose (x, y, cos, sin) | done0 | number of step() calls so far
     static constexpr int kEQ = 0, kEPose = R::NQ, kEDone = kEPose + 4, kEHist = kEDone + 1, kE = (kEHist + 1 + 3) / 4 * 4;
     static_assert(!R::kRestFixed || kE == 12, "entry record of the light robots: 12 floats (include/guardx.h)");
-    GX_D static int code(float dn, int jaft) { return dn > 0.0f ? (jaft >= 0 ? jaft : -2) : -1; }
-    GX_D static float done_of(int c) { return c != -1 ? 1.0f : 0.0f; }
-    GX_D static int jaft_of(int c) { return c >= 0 ? c : -1; }
+    GX_D static int code(int jcur, float dn, int jaft) { return dn > 0.0f ? (jaft >= 0 ? -(jaft + 2) : -1) : jcur + 1; }
+    GX_D static float done_of(int c) { return c < 0 ? 1.0f : 0.0f; }
+    GX_D static int jaft_of(int c) { return c <= -2 ? -(c + 2) : -1; }
+    // the layout row in effect when step t of the env behind tape row gg starts (-1: the layout at entry), read off the
+    // rows before it: the last one that names a layout (a finished step without an install names none)
+    GX_D static int jcur_before(const float* __restrict__ tape, size_t gg, size_t N, int t)
+    {
+        for (int k = 1; k <= t; ++k) {
+            const int c = __float_as_int(tape[(gg - (size_t)k * N) * kW + kCode]);
+            if (c >= 0) return c - 1;
+            if (c <= -2) return -(c + 2);
+        }
+        return -1;
+    }
 };
 
 struct SplitArgs {
@@ -68,38 +85,40 @@ constexpr int kActBlock = 16; // steps whose actions the dynamics pass fetches a
 constexpr int kObsGridCap = 3072; // one-wave workgroups of a ONE-shard observation launch (measured: 47.1 -> 44.2 us at 400 000 rows; a launch over
                                   // several shards is fastest uncapped: 32.5 us per shard at 8 shards)
 
-// rows of W floats, W even: 16-byte pieces and, for W % 4 == 2, one 8-byte piece.  Tape rows start on 8-byte boundaries
-// only (kW = 10 for the Point), so the 16-byte accesses are declared with 8-byte alignment (the hardware takes a dwordx4
-// at any dword address; the compiler must not be told more than is true); entry records are 16-byte aligned rows of 12.
-typedef float gx_f4u __attribute__((ext_vector_type(4), aligned(8)));
-typedef float gx_f2u __attribute__((ext_vector_type(2), aligned(8)));
+// rows of W floats: 16-byte pieces, then an 8-byte and / or a 4-byte one.  Tape rows start on 4-byte boundaries only
+// (kW = 9 for the Point), so the wide accesses are declared with 4-byte alignment (the hardware takes a dwordx4 at any
+// dword address; the compiler must not be told more than is true); entry records are 16-byte aligned rows of 12.
+typedef float gx_f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float gx_f2u __attribute__((ext_vector_type(2), aligned(4)));
 template <int W>
 GX_D void load_row(const float* __restrict__ p, float (&v)[W])
 {
-    static_assert(W % 2 == 0, "even row width");
 #pragma unroll
     for (int k = 0; k < W / 4; ++k) {
         const gx_f4u t4 = *reinterpret_cast<const gx_f4u*>(p + 4 * k);
         v[4 * k] = t4.x; v[4 * k + 1] = t4.y; v[4 * k + 2] = t4.z; v[4 * k + 3] = t4.w;
     }
-    if (W % 4) {
-        const gx_f2u t2 = *reinterpret_cast<const gx_f2u*>(p + W - 2);
-        v[W - 2] = t2.x; v[W - 1] = t2.y;
+    constexpr int B = W / 4 * 4;
+    if (W % 4 >= 2) {
+        const gx_f2u t2 = *reinterpret_cast<const gx_f2u*>(p + B);
+        v[B] = t2.x; v[B + 1] = t2.y;
     }
+    if (W % 2) v[W - 1] = p[W - 1];
 }
 template <int W>
 GX_D void store_row(float* __restrict__ p, const float (&v)[W])
 {
-    static_assert(W % 2 == 0, "even row width");
 #pragma unroll
     for (int k = 0; k < W / 4; ++k) {
         gx_f4u t4; t4.x = v[4 * k]; t4.y = v[4 * k + 1]; t4.z = v[4 * k + 2]; t4.w = v[4 * k + 3];
         *reinterpret_cast<gx_f4u*>(p + 4 * k) = t4;
     }
-    if (W % 4) {
-        gx_f2u t2; t2.x = v[W - 2]; t2.y = v[W - 1];
-        *reinterpret_cast<gx_f2u*>(p + W - 2) = t2;
+    constexpr int B = W / 4 * 4;
+    if (W % 4 >= 2) {
+        gx_f2u t2; t2.x = v[B]; t2.y = v[B + 1];
+        *reinterpret_cast<gx_f2u*>(p + B) = t2;
     }
+    if (W % 2) p[W - 1] = v[W - 1];
 }
 
 template <class R, int BLOCK, int PMAX, bool kDef, int LPE = 1>
@@ -274,7 +293,7 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
             for (int k = 0; k < R::NV; ++k) rowv[TP::kV + k] = v[k];
 #pragma unroll
             for (int k = 0; k < R::NA; ++k) rowv[TP::kAct + k] = a[k];
-            rowv[TP::kJcur] = __int_as_float(jcur); rowv[TP::kCode] = __int_as_float(-1);
+            rowv[TP::kCode] = __int_as_float(TP::code(jcur, 0.0f, -1));
 #pragma unroll
             for (int k = TP::kUsed; k < TP::kW; ++k) rowv[k] = 0.f;
             if (writer) store_row<TP::kW>(sa.tape + ((size_t)t * p.N + i) * TP::kW, rowv);
@@ -353,7 +372,7 @@ __global__ __launch_bounds__(BLOCK) void dyn_tape_kernel(Params p_in, RolloutArg
             for (int k = 0; k < R::NV; ++k) rowv[TP::kV + k] = v[k];
 #pragma unroll
             for (int k = 0; k < R::NA; ++k) rowv[TP::kAct + k] = a[k];
-            rowv[TP::kJcur] = __int_as_float(jcur); rowv[TP::kCode] = __int_as_float(TP::code(dn, jaft));
+            rowv[TP::kCode] = __int_as_float(TP::code(jcur, dn, jaft));
 #pragma unroll
             for (int k = TP::kUsed; k < TP::kW; ++k) rowv[k] = 0.f;
             if (writer) store_row<TP::kW>(sa.tape + ((size_t)t * p.N + i) * TP::kW, rowv);
@@ -577,7 +596,7 @@ __global__ __launch_bounds__(64) void group_dyn_tape_kernel(Params p_in, Rollout
             for (int k = 0; k < R::NV; ++k) rowv[TP::kV + k] = v[k];
 #pragma unroll
             for (int k = 0; k < R::NA; ++k) rowv[TP::kAct + k] = a[k];
-            rowv[TP::kJcur] = __int_as_float(jcur); rowv[TP::kCode] = __int_as_float(TP::code(dn, jaft));
+            rowv[TP::kCode] = __int_as_float(TP::code(jcur, dn, jaft));
             rowv[TP::kFidx] = __int_as_float(fidx);
 #pragma unroll
             for (int k = TP::kUsed; k < TP::kW; ++k) rowv[k] = 0.f;
@@ -688,8 +707,11 @@ __global__ __launch_bounds__(BLOCK) void obs_tape_kernel(Params p_in, RolloutArg
     for (int k = 0; k < R::NV; ++k) v[k] = rowv[TP::kV + k];
 #pragma unroll
     for (int k = 0; k < R::NA; ++k) a[k] = rowv[TP::kAct + k];
-    const float dn = TP::done_of(__float_as_int(rowv[TP::kCode]));
-    const int jcur = __float_as_int(rowv[TP::kJcur]), jaft = TP::jaft_of(__float_as_int(rowv[TP::kCode]));
+    const int code = __float_as_int(rowv[TP::kCode]);
+    const float dn = TP::done_of(code);
+    const int jaft = TP::jaft_of(code);
+    // the layout the step was made in: in the word itself, or -- the step finished the env -- what the rows before say
+    const int jcur = code >= 0 ? code - 1 : TP::jcur_before(sa.tape, gg, (size_t)p.N, t);
 
     // what the step started from (s), the stale pose it found (pose0) and the done flag before it
     float s[R::NQ], pose0[4], last_done, hist0;

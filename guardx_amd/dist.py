@@ -91,7 +91,7 @@ class TapeHandoff:
                                                    #   PREVIOUS epoch's gathered tapes on a side stream
         h.drain(); h.rollout                       # (world, T, N, obs+act+3): the last expanded epoch
 
-    The rank that steps writes 40 B per env-step (Point: qpos, qvel, action, the layout row in effect, done + the layout row a reset_done installed) instead of
+    The rank that steps writes 36 B per env-step (Point: qpos, qvel, action, one word for done + the layout row in effect + the layout row a reset_done installed) instead of
     the 192-B packed row; ONE
     all_gather_into_tensor per epoch moves the shards as they are; every rank runs the observation pass
     (Engine.expand_tape) over all `world` tapes and so holds the same rows rollout(packed=True) + an all-gather of

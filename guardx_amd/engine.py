@@ -623,7 +623,7 @@ class Engine:
 
     def rollout_tape(self, actions, out=None):
         """The serial half of rollout(): T x (step -> reset_done) without building observations.  Returns
-        (shard, token): `shard` a flat float32 tensor [tape | layouts at entry | entry records] (40 B per env-step
+        (shard, token): `shard` a flat float32 tensor [tape | layouts at entry | entry records] (36 B per env-step
         for the Point against 192 B of packed rows) to all-gather as is, `token` naming the layout pool in effect.
         expand_tape(shard, token) -- here or on any rank's engine of the same configuration -- gives the packed
         (T, N, D + A + 3) rows of rollout(packed=True), bit for bit; call it before the second reset() after

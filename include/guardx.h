@@ -173,10 +173,13 @@ int32_t gx_packed_width(const gx_engine* e);
  * tapes and gets the packed rows of gx_rollout_packed, bit for bit.  All ranks sample identical layout pools (shared
  * key, engine.py:263), so the pool rows a tape's reset_done events refer to are local on every rank.
  *   d_shard: gx_tape_floats() floats = [ tape | layouts at entry | entry records ], 16-byte aligned; all-gather it as
- *            is.  A tape row is qpos | qvel | action | layout row in effect | one word for done and the layout row
- *            reset_done installed (-1: not done, -2: done and nothing installed, j >= 0: done, row j installed):
- *            10 floats (40 B) per env-step for the Point, 14 for the Swimmer, 34 for the Ant and 40 for the Walker
- *            (including, for those two, the row of the pool's fake-step table a reset_done observation is read from); the
+ *            is.  A tape row is qpos | qvel | action | ONE word for done, the layout row in effect and the layout row
+ *            reset_done installed (c >= 0: not done, layout row c - 1 of the pool in effect -- 0: the layout at entry;
+ *            -1: done and nothing installed; c <= -2: done, row -(c + 2) installed; the layout in effect during a step
+ *            that finished the env is what the rows before it say):
+ *            9 floats (36 B) per env-step for the Point, 13 for the Swimmer, 32 for the Ant and 38 for the Walker
+ *            (including, for those two, the row of the pool's fake-step table a reset_done observation is read from);
+ *            rows are 4-byte aligned only; the
  *            tape is rounded up to a multiple of 4 floats so that the layouts behind it stay 16-byte aligned; the
  *            observation pass re-derives the pose, ctrl and the reward from consecutive rows.  One physics step per
  *            control step and no observe_vel / observe_acc only (GX_ERR_UNSUPPORTED otherwise).

@@ -1566,8 +1566,8 @@ def test_config4_default_path_eight_ranks_full_size(torch_cuda, oracle):
 
 @pytest.mark.parametrize("robot,N,T", [("point", 37, 9), ("swimmer", 51, 7), ("ant", 13, 5), ("walker", 9, 3)])
 def test_tape_rows_odd_sizes(torch_cuda, robot, N, T):
-    """Tape rows are 10 / 14 / 34 / 40 floats (8-byte aligned, not 16): with an odd number of rows the tape is rounded up
-    to a multiple of 4 floats so that the layout snapshot behind it stays 16-byte aligned.  rollout_tape + expand_tape
+    """Tape rows are 9 / 13 / 32 / 38 floats (4-byte aligned, not 16): the tape is rounded up to a multiple of 4 floats so
+    that the layout snapshot behind it stays 16-byte aligned.  rollout_tape + expand_tape
     (own stream, one and three "ranks" in one launch) equal rollout(packed=True) bit for bit at such sizes."""
     torch = torch_cuda
     from guardx_amd import Engine
@@ -1577,7 +1577,7 @@ def test_tape_rows_odd_sizes(torch_cuda, robot, N, T):
     A = a.action_space.shape[0]
     assert (N * T) % 2 == 1
     tape, lay, ent = a.tape_floats(T)
-    width = {"point": 10, "swimmer": 14, "ant": 34, "walker": 40}[robot]
+    width = {"point": 9, "swimmer": 13, "ant": 32, "walker": 38}[robot]
     assert tape == (N * T * width + 3) // 4 * 4 and tape % 4 == 0
     rng = np.random.default_rng(3)
     for ep in range(2):
