@@ -316,7 +316,9 @@ def design_epoch_table():
     wide = l["closed_loop_policy_wider_env_steps_per_s"]
     rows += ["", f"(`vs_previous_round.regressions` of that line: {l['vs_previous_round']['regressions']}. The Python-driven "
                  f"`step()+reset_done()` loop: {api['value'] / 1e6:.0f} M, ring of 8: {api['out_ring_8']['value'] / 1e6:.0f} M — host-bound, "
-                 f"± 10 % between consecutive medians of one library on one box, `profiles/{TAG}_ab_api.log`. Closed loop, hidden 64 / 128 / "
+                 f"± 10 % between consecutive medians of one library on one box, `profiles/{TAG}_ab_api.log`; `reset_done_heavy` moves ± 2 % "
+                 f"from box to box (712–730 M over the round's lines) and not at all between builds on one box, "
+                 f"`profiles/{TAG}_ab_rdh_final.log`. Closed loop, hidden 64 / 128 / "
                  f"256: {l['closed_loop_policy_env_steps_per_s'] / 1e6:.0f} / {wide['hidden_128'] / 1e6:.0f} / {wide['hidden_256'] / 1e6:.0f} M.)",
              "", D_END]
     return "\n".join(rows)
