@@ -12,6 +12,11 @@
 //   C: Markstein's final step on the numerator: q = y1; r = fma(-x, q, 1); q' = fma(r, y1, q); fixup       6 instructions
 //   D: A without the fixup (what tanh_f uses, gx_device.h: its divisor is in [2, 6.6e7])                                3 instructions
 //   E: 2 / x as 2 * D(x), compared with the IEEE quotient 2.0f / x (the numerator of tanh_f's division)
+//   F: D, ACCEPTED only when its result is a normal number (one v_cmp_class): "F accepted" counts accepted results that
+//      differ from the IEEE quotient, "F rejected" the inputs a caller would have to send through the IEEE sequence.
+//      Result: 0 accepted results differ; rejected are exactly the inputs outside 2^-126 <= |x| <= 2^126 -- a bit-safe
+//      short reciprocal exists.  The two forms of the Ant's / Walker's solves built on it (round 5) both lost to the
+//      plain IEEE division in situ: profiles/r05_ab_short_rcp.log, DESIGN.md section 10.
 // Reported per candidate: mismatches, and the binary exponents of x where they occur.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -68,6 +73,8 @@ __global__ void probe(unsigned long long* hist, uint32_t* example)
         const int ex = (int)((b >> 23) & 255u);
         const float c[5] = {rcp_A(x), rcp_B(x), rcp_C(x), rcp_D(x), 2.0f * rcp_D(x)};
         const float refs[5] = {ref, ref, ref, ref, 2.0f / x};
+        if (__builtin_isnormal(c[3])) { if (!same(c[3], ref)) atomicAdd(&hist[5 * 256 + ex], 1ull); }
+        else atomicAdd(&hist[6 * 256 + ex], 1ull);
 #pragma unroll
         for (int k = 0; k < 5; ++k)
             if (!same(c[k], refs[k])) {
@@ -80,13 +87,13 @@ __global__ void probe(unsigned long long* hist, uint32_t* example)
 int main()
 {
     unsigned long long* d_hist; uint32_t* d_ex;
-    CK(hipMalloc(&d_hist, sizeof(unsigned long long) * 5 * 256));
+    CK(hipMalloc(&d_hist, sizeof(unsigned long long) * 7 * 256));
     CK(hipMalloc(&d_ex, sizeof(uint32_t) * 5 * 256 * 3));
-    CK(hipMemset(d_hist, 0, sizeof(unsigned long long) * 5 * 256));
+    CK(hipMemset(d_hist, 0, sizeof(unsigned long long) * 7 * 256));
     CK(hipMemset(d_ex, 0, sizeof(uint32_t) * 5 * 256 * 3));
     hipLaunchKernelGGL(probe, dim3(8192), dim3(256), 0, 0, d_hist, d_ex);
     CK(hipDeviceSynchronize());
-    static unsigned long long h[5 * 256]; static uint32_t ex[5 * 256 * 3];
+    static unsigned long long h[7 * 256]; static uint32_t ex[5 * 256 * 3];
     CK(hipMemcpy(h, d_hist, sizeof h, hipMemcpyDeviceToHost));
     CK(hipMemcpy(ex, d_ex, sizeof ex, hipMemcpyDeviceToHost));
     const char* names[5] = {"A rcp+1NR+fixup (4 instr)", "B rcp+2NR+fixup (6 instr)", "C rcp+NR+residual-correction+fixup (6 instr)",
@@ -107,6 +114,19 @@ int main()
                 float x, c, r; memcpy(&x, &ex[(k * 256 + e) * 3], 4); memcpy(&c, &ex[(k * 256 + e) * 3 + 1], 4); memcpy(&r, &ex[(k * 256 + e) * 3 + 2], 4);
                 printf("   exp %3d (2^%d): %llu   e.g. x=%a got %a want %a\n", e, e - 127, h[k * 256 + e], x, c, r);
             }
+    }
+    for (int k = 5; k < 7; ++k) {
+        unsigned long long tot = 0, normal = 0;
+        int lo = 999, hi = -1;
+        for (int e = 0; e < 256; ++e) {
+            tot += h[k * 256 + e];
+            if (e > 0 && e < 255 && h[k * 256 + e]) { normal += h[k * 256 + e]; if (e < lo) lo = e; if (e > hi) hi = e; }
+        }
+        printf("%s: %llu of 2^32 (zero/denormal inputs: %llu, inf/nan inputs: %llu, normal inputs: %llu",
+               k == 5 ? "F accepted (result a normal number) but not the IEEE quotient" : "F rejected (result not a normal number: the caller falls back)",
+               tot, h[k * 256], h[k * 256 + 255], normal);
+        if (normal) printf("; biased exponents %d..%d", lo, hi);
+        printf(")\n");
     }
     return 0;
 }

@@ -273,7 +273,7 @@ def readme_rows():
         rows.append((f"`{TAG}_mfma_rate_probe.log`", "`tools/probes/mfma_rate_probe` (one wave per SIMD, independent accumulator chains)",
                      first[0] if first else ""))
     if _have("rcp_exact_probe.log"):
-        first = [ln.strip() for ln in open(path("rcp_exact_probe.log")) if ln.startswith(("A ", "D ", "E "))]
+        first = [ln.strip() for ln in open(path("rcp_exact_probe.log")) if ln.startswith(("A ", "D ", "E ", "F "))]
         rows.append((f"`{TAG}_rcp_exact_probe.log`", "`tools/probes/rcp_exact_probe` (all 2^32 inputs)", "; ".join(first)))
     return rows
 
