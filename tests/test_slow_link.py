@@ -17,10 +17,10 @@ pytestmark = pytest.mark.gpu
 SLEEP_CYCLES = 30_000_000          # torch.cuda._sleep: ~12-15 ms at the shader clock, many epochs' worth of these sizes
 
 
-def _harness(torch, W, N, T, M, seed, sleep_cycles, lag=1):
+def _harness(torch, W, N, T, M, seed, sleep_cycles, lag=1, extra=None):
     from guardx_amd import Engine
     from guardx_amd.dist import TapeHandoff
-    kw = dict(seed=seed, num_steps=T, goal_size=2.9)
+    kw = dict(seed=seed, num_steps=T, goal_size=2.9, **(extra or {}))
     full = Engine(task_config(N * W, **kw), n_candidates=M)
     ranks = [Engine(task_config(N, **kw), n_candidates=M, shard=(r, W)) for r in range(W)]
     o_full = full.reset()

@@ -10,6 +10,17 @@ if [ "$what" = "all" ] || [ "$what" = "soak" ]; then
     timeout -k 10 400 python tests/soak_variants.py $rb 2 > gpurun_out/${tag}_soak_variants_$rb.log 2>&1 || echo "soak variants $rb FAILED"
     tail -n 1 gpurun_out/${tag}_soak_variants_$rb.log
   done
+  # the N > 1 epoch: W ranks in one process, every expanded row of every rank against one engine of W x N envs
+  for rb in point swimmer ant walker; do
+    timeout -k 10 300 python tests/soak_handoff.py $rb 4 150 256 40 > gpurun_out/${tag}_soak_handoff_$rb.log 2>&1 || echo "soak handoff $rb FAILED"
+    tail -n 1 gpurun_out/${tag}_soak_handoff_$rb.log
+  done
+  for rb in point ant; do
+    timeout -k 10 300 python tests/soak_handoff.py $rb 8 60 384 24 > gpurun_out/${tag}_soak_handoff_${rb}_w8.log 2>&1 || echo "soak handoff $rb W=8 FAILED"
+    tail -n 1 gpurun_out/${tag}_soak_handoff_${rb}_w8.log
+  done
+  timeout -k 10 300 python tests/soak_handoff.py point 2 100 2000 200 > gpurun_out/${tag}_soak_handoff_point_w2_full.log 2>&1 || echo "soak handoff point W=2 full size FAILED"
+  tail -n 1 gpurun_out/${tag}_soak_handoff_point_w2_full.log
 fi
 if [ "$what" = "all" ] || [ "$what" = "bench" ]; then
   python -m pytest tests -m gpu -q 2>&1 | tail -n 4 > gpurun_out/${tag}_gputest_final.log

@@ -253,6 +253,16 @@ def readme_rows():
                      "`python tests/soak_parity.py <robot> 300000 4096 400`, `python tests/soak_variants.py <robot> 2`",
                      "HIP vs CPU restatement on the final build -- last line of each log: " + "; ".join(soaks)))
     import glob
+    hs = sorted(glob.glob(path("soak_handoff_*.log")))
+    if hs:
+        res = []
+        for f in hs:
+            lines = [ln.strip() for ln in open(f) if ln.strip()]
+            head = [ln for ln in lines if ln.startswith("soak_handoff ")]
+            res.append((head[-1].split(":")[0].replace("soak_handoff ", "") if head else os.path.basename(f)) + ": " + (lines[-1] if lines else "empty"))
+        rows.append((f"`{TAG}_soak_handoff_*.log`", "`python tests/soak_handoff.py <robot> <W> <epochs> <N> <T>`",
+                     "the N > 1 epoch (sharded sampler, every rank expands every tape; W ranks in one process, the collective played by a "
+                     "stream) against ONE engine of W x N envs, every expanded row, reset observation and pool -- " + "; ".join(res)))
     ab = sorted(os.path.basename(f) for f in glob.glob(path("ab_*.log")))
     if ab:
         rows.append((", ".join(f"`{f}`" for f in ab), "`tools/ab/*.sh` (same-box A/B runs of library variants / trees: `tools/build_variant.py`, `tools/ab_epoch.py`)",
