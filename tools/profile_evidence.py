@@ -209,15 +209,17 @@ def readme_rows():
                    f"{l.get('vs_previous_round', {}).get('regressions')}; `cpu_baseline` "
                    f"{l.get('cpu_baseline', {}).get('value')} env-steps/s on {l.get('cpu_baseline', {}).get('cores')} cores")
             rows.append((f"`{TAG}_{name}`", cmd, txt))
-    for name, lbl in (("rehearsal_rank0_of_8.json", "Point"), ("rehearsal_rank0_of_8_swimmer.json", "Swimmer"),
-                      ("rehearsal_rank0_of_8_ant.json", "Ant"), ("rehearsal_rank0_of_8_walker.json", "Walker")):
+    for name, lbl, W in (("rehearsal_rank0_of_8.json", "Point", 8), ("rehearsal_rank0_of_8_swimmer.json", "Swimmer", 8),
+                         ("rehearsal_rank0_of_8_ant.json", "Ant", 8), ("rehearsal_rank0_of_8_walker.json", "Walker", 8),
+                         ("rehearsal_rank0_of_4.json", "Point", 4), ("rehearsal_rank0_of_4_ant.json", "Ant", 4),
+                         ("rehearsal_rank0_of_2.json", "Point", 2), ("rehearsal_rank0_of_2_ant.json", "Ant", 2)):
         if _have(name):
             import json
             d = json.load(open(path(name)))
             m = d["expand_all"]["model"]
-            rows.append((f"`{TAG}_{name}`", f"`python tools/rehearse_rank.py --world 8 --epochs 30" +
+            rows.append((f"`{TAG}_{name}`", f"`python tools/rehearse_rank.py --world {W} --epochs 30" +
                          ("" if lbl == "Point" else f" --robot xmls/{lbl.lower()}.xml") + " --json ...`",
-                         f"one GPU playing rank 0 of 8, {lbl}: {d['expand_all']['ms_per_epoch']} ms per rank epoch (`expand=\"local\"`: "
+                         f"one GPU playing rank 0 of {W}, {lbl}: {d['expand_all']['ms_per_epoch']} ms per rank epoch (`expand=\"local\"`: "
                          f"{d['expand_local']['ms_per_epoch']}) against {d['one_gpu_own_sampler']['ms_per_epoch']} ms on one GPU; "
                          f"{d['expand_all']['bytes_received_per_epoch'] / 1e6:.1f} MB received per epoch: link-bound below "
                          f"{m.get('link_bound_below_GBps')} GB/s, break-even with one GPU at {m.get('break_even_GBps')} GB/s (model, not a "
