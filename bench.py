@@ -711,11 +711,14 @@ def _comparable_values(line):
     for name, v in (line.get("other_robots") or {}).items():
         if isinstance(v, dict) and v.get("env_steps_per_s"):
             out["other_robots." + name] = float(v["env_steps_per_s"])
+    # the Python-driven loop is host-bound and the host is shared: of its five repetitions the BEST is the one least
+    # disturbed by the box's other tenants (one run of round 5: 211 M median, 251 M best; the next: 251 / 259) -- round over
+    # round the best is compared with the best
     api = line.get("api_step_loop_env_steps_per_s")
     if isinstance(api, dict) and api.get("value"):
-        out["api_step_loop"] = float(api["value"])
+        out["api_step_loop"] = float(api.get("best") or api["value"])
         if isinstance(api.get("out_ring_8"), dict) and api["out_ring_8"].get("value"):
-            out["api_step_loop.out_ring_8"] = float(api["out_ring_8"]["value"])
+            out["api_step_loop.out_ring_8"] = float(api["out_ring_8"].get("best") or api["out_ring_8"]["value"])
     if isinstance(line.get("preconditioned"), dict) and line["preconditioned"].get("value"):
         out["preconditioned"] = float(line["preconditioned"]["value"])
     if isinstance(line.get("closed_loop_policy_env_steps_per_s"), (int, float)):
@@ -758,6 +761,7 @@ def vs_previous_round(line, threshold=-0.02):
         thr = HOST_BOUND_THRESHOLD if key.startswith("api_step_loop") else threshold
         if thr != threshold:
             rows[key]["threshold"] = thr
+            rows[key]["statistic"] = "best of the repetitions"
         if key in unlike:
             rows[key]["like_for_like"] = False
         elif rel < thr:
