@@ -326,9 +326,22 @@ def design_epoch_table():
                 f"{rh['env_steps_per_s'] / 1e6:.1f} M | {prev('reset_done_heavy')} (builder's line) |")
     api = l["api_step_loop_env_steps_per_s"]
     wide = l["closed_loop_policy_wider_env_steps_per_s"]
+    ab_api = ""
+    if _have("ab_api.log"):
+        import json
+        best = {}
+        for ln in open(path("ab_api.log")):
+            try:
+                d = json.loads(ln)
+                best.setdefault(d["tag"], []).append(d["best_M"])
+            except (ValueError, KeyError):
+                pass
+        if "r04" in best and "new" in best:
+            ab_api = (" (same box, the round-4 tree against this round's: best of seven " + " / ".join(f"{v:.1f}" for v in best["r04"]) +
+                      " M vs " + " / ".join(f"{v:.1f}" for v in best["new"]) + " M: what the line compares with is another box's host)")
     rows += ["", f"(`vs_previous_round.regressions` of that line: {l['vs_previous_round']['regressions']}. The Python-driven "
                  f"`step()+reset_done()` loop: {api['value'] / 1e6:.0f} M, ring of 8: {api['out_ring_8']['value'] / 1e6:.0f} M — host-bound, "
-                 f"± 10 % between consecutive medians of one library on one box, `profiles/{TAG}_ab_api.log`; `reset_done_heavy` moves ± 2 % "
+                 f"± 10 % between consecutive medians of one library on one box, `profiles/{TAG}_ab_api.log`{ab_api}; `reset_done_heavy` moves ± 2 % "
                  f"from box to box (712–730 M over the round's lines) and not at all between builds on one box, "
                  f"`profiles/{TAG}_ab_rdh_final.log`. Closed loop, hidden 64 / 128 / "
                  f"256: {l['closed_loop_policy_env_steps_per_s'] / 1e6:.0f} / {wide['hidden_128'] / 1e6:.0f} / {wide['hidden_256'] / 1e6:.0f} M.)",
