@@ -196,6 +196,32 @@ GX_D float tanh_f(float x)
 }
 
 // ---------------------------------------------------------------------------
+// 1 / d for the pivots and 2x2 determinants of the Ant's / Walker's solves: the IEEE division WITHOUT its scaling steps.
+// The compiler's sequence for 1.0f / d is v_div_scale x2, v_rcp, a Newton step on the reciprocal, a multiply and two
+// residual corrections on the (scaled) quotient, v_div_fmas, v_div_fixup -- eleven dependent instructions on a chain that
+// pays for every instruction it issues.  The scaling only matters when d or 1 / d leaves the normal range; without it,
+//     y0 = v_rcp_f32(d);  y1 = fma(fma(-d, y0, 1), y0, y0);  v_div_fixup_f32(y1, d, 1.0f)
+// has the bits of 1.0f / d for EVERY d that is +-0, +-inf, NaN (v_div_fixup decides those from d alone, as in the IEEE
+// sequence) or a normal number with 2^-126 <= |d| <= 2^126 -- all 2^32 inputs checked against the compiler's sequence,
+// tools/probes/rcp_exact_probe.hip variant A (profiles/r05_rcp_exact_probe.log); it differs only for denormal d and for
+// |d| > 2^126 = 8.5e37.  The pivots it is used for cannot be there: each is a difference / sum of terms built from the
+// model's constants (masses, inertias, armatures: 1e-4 ... 1e1), sines and cosines, and D J^2 terms with D <= 19 / invw
+// -- a finite state puts them within 1e-7 ... 1e10, a cancellation leaves 0 (exact above) or a multiple of the operands'
+// ulp (>= 1e-13), and a non-finite state makes them NaN (exact above).  -DGX_RCP_DOMAIN_CHECK turns any d outside the
+// domain into a NaN result, which the parity soaks would report as mismatches (tests/soak_parity.py, soak_variants.py
+// under such a variant build: profiles/r05_rcp_domain_soak.log: none).  Four instructions instead of eleven.
+GX_D float rcp_unscaled(float d)
+{
+#ifdef GX_RCP_DOMAIN_CHECK
+    const float ad = fabsf(d);
+    if ((ad != 0.0f && ad < 1.17549435e-38f) || (ad > 8.50705917e37f && ad < __builtin_inff())) return __builtin_nanf("");
+#endif
+    const float y0 = __builtin_amdgcn_rcpf(d);
+    const float y1 = fmaf(fmaf(-d, y0, 1.0f), y0, y0);
+    return __builtin_amdgcn_div_fixupf(y1, d, 1.0f);
+}
+
+// ---------------------------------------------------------------------------
 // jax.random on threefry2x32 (published algorithm: Salmon et al. 2011 /
 // jax/_src/prng.py).  Used on host for the per-step key chain and on device
 // for layout sampling and layout index draws.

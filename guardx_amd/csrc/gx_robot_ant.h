@@ -152,15 +152,15 @@ struct AntRobot {
 
     GX_D static void ldl_factor(const float (&S)[3][3], Ldl3& f)
     {
-        f.rd0 = 1.0f / S[0][0];
+        f.rd0 = rcp_unscaled(S[0][0]);
         f.l10 = S[1][0] * f.rd0;
         f.l20 = S[2][0] * f.rd0;
         const float d1 = S[1][1] - f.l10 * S[1][0];
-        f.rd1 = 1.0f / d1;
+        f.rd1 = rcp_unscaled(d1);
         const float t21 = S[2][1] - f.l20 * S[1][0];
         f.l21 = t21 * f.rd1;
         const float d2 = (S[2][2] - f.l20 * S[2][0]) - f.l21 * t21;
-        f.rd2 = 1.0f / d2;
+        f.rd2 = rcp_unscaled(d2);
     }
     GX_D static void ldl_solve(const Ldl3& f, const float (&b)[3], float (&x)[3])
     {
@@ -185,7 +185,7 @@ struct AntRobot {
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
             const float det = A.Lhh[l] * A.Lbb[l] - A.Lhb[l] * A.Lhb[l];
-            const float rdet = 1.0f / det;
+            const float rdet = rcp_unscaled(det);
             i00[l] = A.Lbb[l] * rdet; i01[l] = -(A.Lhb[l] * rdet); i11[l] = A.Lhh[l] * rdet;
             float W[3][2];
 #pragma unroll

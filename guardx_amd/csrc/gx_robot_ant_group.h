@@ -134,7 +134,7 @@ struct AntGroup {
                                  float (&xb)[3], float& xh, float& xbt)
     {
         const float det = K.Lhh * K.Lbb - K.Lhb * K.Lhb;
-        const float rdet = 1.0f / det;
+        const float rdet = rcp_unscaled(det);
         const float i00 = K.Lbb * rdet, i01 = -(K.Lhb * rdet), i11 = K.Lhh * rdet;
         float W[3][2];
 #pragma unroll

@@ -90,7 +90,7 @@ struct WalkerGroup {
             float s = B.L[i][i];
 #pragma unroll
             for (int m = 0; m < i; ++m) s = s - u[i][m] * l[i][m];
-            rd[i] = 1.0f / s;
+            rd[i] = rcp_unscaled(s);
         }
         float x[K];
 #pragma unroll
