@@ -255,6 +255,15 @@ def readme_rows():
                      "`python tests/soak_parity.py <robot> 300000 4096 400`, `python tests/soak_variants.py <robot> 2`",
                      "HIP vs CPU restatement on the final build -- last line of each log: " + "; ".join(soaks)))
     import glob
+    longs = sorted(glob.glob(path("soak_long_*.log")))
+    if longs:
+        res = []
+        for f in longs:
+            lines = [ln.strip() for ln in open(f) if ln.strip()]
+            res.append(os.path.basename(f).replace(TAG + "_soak_long_", "").replace(".log", "") + ": " + (lines[-1] if lines else "empty"))
+        rows.append((f"`{TAG}_soak_long_*.log`", "`python tests/soak_parity.py <robot> 1500000 8192 600`",
+                     "the same soak, five times the states and twice the envs, for the robots whose solves changed last (the "
+                     "pivots' reciprocals) -- " + "; ".join(res)))
     hs = sorted(glob.glob(path("soak_handoff_*.log")))
     if hs:
         res = []
