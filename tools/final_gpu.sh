@@ -15,9 +15,13 @@ if [ "$what" = "all" ] || [ "$what" = "soak" ]; then
     timeout -k 10 300 python tests/soak_handoff.py $rb 4 150 256 40 > gpurun_out/${tag}_soak_handoff_$rb.log 2>&1 || echo "soak handoff $rb FAILED"
     tail -n 1 gpurun_out/${tag}_soak_handoff_$rb.log
   done
-  for rb in point ant; do
+  for rb in point ant swimmer walker; do
     timeout -k 10 300 python tests/soak_handoff.py $rb 8 60 384 24 > gpurun_out/${tag}_soak_handoff_${rb}_w8.log 2>&1 || echo "soak handoff $rb W=8 FAILED"
     tail -n 1 gpurun_out/${tag}_soak_handoff_${rb}_w8.log
+  done
+  for rb in ant walker; do   # the robots whose solves changed last (round 5: the pivots' reciprocals): a longer soak
+    timeout -k 10 500 python tests/soak_parity.py $rb 1500000 8192 600 > gpurun_out/${tag}_soak_long_$rb.log 2>&1 || echo "long soak $rb FAILED"
+    tail -n 1 gpurun_out/${tag}_soak_long_$rb.log
   done
   timeout -k 10 300 python tests/soak_handoff.py point 2 100 2000 200 > gpurun_out/${tag}_soak_handoff_point_w2_full.log 2>&1 || echo "soak handoff point W=2 full size FAILED"
   tail -n 1 gpurun_out/${tag}_soak_handoff_point_w2_full.log
